@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by IMPORTING the reference's Python QP twin.
+
+Runs only in the build container (needs /root/reference).  Nothing from the
+reference is copied: this script imports `network/utils/min_traj_opt.py`
+(MinTrajOpt.update -> Q,A,b,G1,h1,G2,h2; reference lines :68-178, :377-697) and
+`network/utils/trajectory.py` (Trajectory.get_pos/get_vel/get_acc, :47-98), feeds them
+seeded inputs and stores inputs + outputs as .npz data.
+
+The reference module imports `cvxpy`, `osqp` and `memory_profiler` at module top
+(min_traj_opt.py:3,12,16).  None is installed here and none is touched by the assembly
+code path, so inert placeholder modules are registered for the import to succeed.  They
+carry no arithmetic.
+
+Extra derived vectors (computed with numpy from the REFERENCE-ASSEMBLED matrices, so they
+pin the solve against the reference's own formulation):
+  z_eq / e_eq        : solution + 0.5 z'Qz of the equality-constrained QP (reference Q: m_34=1400)
+  z_wp_* / e_wp_*    : same with waypoint rows appended (the rows the reference keeps commented
+                       out at min_traj_opt.py:434-437) and Q patched to the true integral
+                       (1440) -> this is what a MINCO solve must reproduce.
+                       *_c3: only p,v,a fixed at the ends (reference convention)
+                       *_cs: p,v,a,(j) fixed at the ends (MINCO convention; extra rows appended)
+"""
+import os, sys, types, io, contextlib
+import numpy as np
+
+REF = "/root/reference/network"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    for name in ("cvxpy", "osqp", "memory_profiler"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "memory_profiler":
+                m.profile = lambda f: f
+            if name == "osqp":
+                m.OSQP = object
+            sys.modules[name] = m
+    sys.path.insert(0, REF)
+    import torch  # noqa
+    from utils.min_traj_opt import MinTrajOpt
+    from utils.trajectory import Trajectory
+    return MinTrajOpt, Trajectory
+
+
+def make_params(order, res, vmax=5.0, amax=7.0, vmax1=5.0, amax1=8.0):
+    return {
+        "physical_limits": {"max_vel": vmax, "max_acc": amax, "max_jerk": 12.0},
+        "phase1_physical_limits": {"max_vel": vmax1, "max_acc": amax1, "max_jerk": 10.0,
+                                   "inf_dis": 0.1},
+        "planning": {"order": order, "state_dim": 3, "dim": 3, "res": res, "seg": 5,
+                     "var_num": 120, "use_time_factor": False},
+    }
+
+
+def synth_problem(rng, N, M_max=12, rest=True):
+    """Random-walk waypoints + box-ish corridors in a.x<=b form (normalised rows)."""
+    pts = [np.array([0.0, 0.0, 1.0])]
+    for _ in range(N):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        p = pts[-1] + d * rng.uniform(1.0, 3.0)
+        p[2] = min(max(p[2], 0.0), 5.0)
+        pts.append(p)
+    pts = np.array(pts)
+    T = rng.uniform(0.5, 2.0, size=N)
+    state = np.zeros((9, 2))
+    state[0::3, 0] = pts[0]
+    state[0::3, 1] = pts[-1]
+    if not rest:
+        state[1::3, 0] = rng.normal(size=3) * 0.5
+        state[2::3, 0] = rng.normal(size=3) * 0.3
+        state[1::3, 1] = rng.normal(size=3) * 0.5
+        state[2::3, 1] = rng.normal(size=3) * 0.3
+    hpolys = np.zeros((50, 4, N))
+    for i in range(N):
+        lo = np.minimum(pts[i], pts[i + 1]) - rng.uniform(0.5, 3.0, size=3)
+        hi = np.maximum(pts[i], pts[i + 1]) + rng.uniform(0.5, 3.0, size=3)
+        rows = []
+        for ax in range(3):
+            e = np.zeros(3); e[ax] = 1.0
+            rows.append(np.r_[e, hi[ax]])
+            rows.append(np.r_[-e, -lo[ax]])
+        k = int(rng.integers(0, M_max - 6 + 1))
+        mid = 0.5 * (pts[i] + pts[i + 1])
+        for _ in range(k):
+            a = rng.normal(size=3); a /= np.linalg.norm(a)
+            rows.append(np.r_[a, a @ mid + rng.uniform(1.0, 3.0)])
+        rows = np.array(rows)
+        hpolys[: rows.shape[0], :, i] = rows
+    return state, hpolys, T, pts
+
+
+def kkt_solve(Q, A, b):
+    n, m = Q.shape[0], A.shape[0]
+    K = np.block([[Q, A.T], [A, np.zeros((m, m))]])
+    rhs = np.r_[np.zeros(n), b]
+    sol = np.linalg.solve(K, rhs)
+    z = sol[:n]
+    res = np.linalg.norm(K @ sol - rhs, np.inf)
+    return z, 0.5 * z @ Q @ z, res, np.linalg.cond(K)
+
+
+def main():
+    import torch
+    MinTrajOpt, Trajectory = _import_reference()
+    cases = [
+        # name, order, N, res, seed, rest, phase
+        ("snap_n5_r20", 4, 5, 20, 11, True, 2),
+        ("snap_n8_r5", 4, 8, 5, 12, False, 2),
+        ("snap_n8_r20", 4, 8, 20, 13, True, 1),
+        ("jerk_n5_r20", 3, 5, 20, 14, False, 2),
+        ("jerk_n16_r4", 3, 16, 4, 15, True, 1),
+        ("snap_n1_r4", 4, 1, 4, 16, False, 2),
+        ("jerk_n2_r3", 3, 2, 3, 17, False, 2),
+    ]
+    for name, order, N, res, seed, rest, phase in cases:
+        rng = np.random.default_rng(seed)
+        state, hpolys, T, pts = synth_problem(rng, N, rest=rest)
+        D = 2 * order
+        opt = MinTrajOpt(make_params(order, res))
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt.update(torch.tensor(state), torch.tensor(hpolys), torch.tensor(T),
+                       phase=phase, seq_len=N)
+        Q, A, b, G1, h1, G2, h2 = [p.detach().numpy().astype(np.float64) for p in opt.params]
+        assert opt.seg == N
+        n = 3 * D * N
+        assert Q.shape == (n, n) and A.shape[1] == n
+        # compact inequality storage: per row keep only the piece's 3*D columns
+        m_rows = [int(np.sum(np.linalg.norm(hpolys[:, :, i], axis=1) > 0)) for i in range(N)]
+        G1c = np.zeros((G1.shape[0], 3 * D)); G2c = np.zeros((G2.shape[0], D))
+        r = 0
+        for i in range(N):
+            for _ in range(res):
+                blk = G1[r:r + m_rows[i]]
+                G1c[r:r + m_rows[i]] = blk[:, i * 3 * D:(i + 1) * 3 * D]
+                z = blk.copy(); z[:, i * 3 * D:(i + 1) * 3 * D] = 0
+                assert not z.any()
+                r += m_rows[i]
+        assert r == G1.shape[0]
+        r = 0
+        for i in range(N):
+            for _ in range(res):
+                for j in range(3):
+                    blk = G2[r:r + 4]
+                    c0 = i * 3 * D + j * D
+                    G2c[r:r + 4] = blk[:, c0:c0 + D]
+                    z = blk.copy(); z[:, c0:c0 + D] = 0
+                    assert not z.any()
+                    r += 4
+        assert r == G2.shape[0]
+
+        out = dict(order=order, N=N, res=res, phase=phase, state=state,
+                   hpolys=hpolys[:16], m_rows=np.array(m_rows), T=T, pts=pts,
+                   Q=Q, A=A, b=b, G1c=G1c, h1=h1, G2c=G2c, h2=h2,
+                   G1_sum=G1.sum(), G2_sum=G2.sum(),
+                   path_length=float(opt.path_length))
+        assert not hpolys[16:].any()
+
+        # (1) equality-constrained QP with the reference's own Q (1400)
+        z, e, resid, cond = kkt_solve(Q, A, b)
+        out.update(z_eq=z, e_eq=e, kkt_resid=resid, kkt_cond=cond)
+
+        # (2) waypoint-pinned problems on the reference-assembled A,b (Q -> true integral)
+        Q2 = Q.copy()
+        if order == 4:
+            for blk in range(3 * N):
+                c0 = blk * D
+                Q2[c0 + 2, c0 + 3] *= 1440.0 / 1400.0
+                Q2[c0 + 3, c0 + 2] *= 1440.0 / 1400.0
+        rows, rhs = [], []
+        for i in range(1, N):          # start position of piece i == waypoint i
+            for ax in range(3):
+                rw = np.zeros(n); rw[i * 3 * D + ax * D + D - 1] = 1.0
+                rows.append(rw); rhs.append(pts[i, ax])
+        Aw = np.vstack([A] + rows) if rows else A
+        bw = np.r_[b, rhs] if rows else b
+        z3, e3, r3, _ = kkt_solve(Q2, Aw, bw)
+        out.update(z_wp_c3=z3, e_wp_c3=e3, wp_resid_c3=r3)
+        if order == 4:                 # MINCO convention: jerk also fixed (=0) at both ends
+            rows2, rhs2 = [], []
+            jh = rng.normal(size=3) * (0.0 if rest else 0.4)
+            jt = rng.normal(size=3) * (0.0 if rest else 0.4)
+            TN = T[-1]
+            for ax in range(3):
+                rw = np.zeros(n); rw[ax * D + 4] = 6.0
+                rows2.append(rw); rhs2.append(jh[ax])
+                rw = np.zeros(n); c0 = (N - 1) * 3 * D + ax * D
+                rw[c0:c0 + 5] = [210 * TN**4, 120 * TN**3, 60 * TN**2, 24 * TN, 6.0]
+                rows2.append(rw); rhs2.append(jt[ax])
+            As = np.vstack([Aw] + rows2); bs = np.r_[bw, rhs2]
+            zs, es, rs, _ = kkt_solve(Q2, As, bs)
+            out.update(z_wp_cs=zs, e_wp_cs=es, wp_resid_cs=rs, jerk_head=jh, jerk_tail=jt)
+
+        # (3) reference trajectory.py evaluation of z_eq
+        coeffs = [z.reshape(N, 3, D)[i] for i in range(N)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            traj = Trajectory(coeffs, list(T))
+            ts = np.linspace(0.0, float(np.sum(T)) * 0.999, 17)
+            pos = np.array([traj.get_pos(t) for t in ts])
+            vel = np.array([traj.get_vel(t) for t in ts])
+            acc = np.array([traj.get_acc(t) for t in ts])
+        out.update(eval_t=ts, eval_pos=pos, eval_vel=vel, eval_acc=acc)
+
+        path = os.path.join(OUT, f"qp_{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: n={n} me={A.shape[0]} mg={G1.shape[0]}+{G2.shape[0]} "
+              f"kkt_resid={resid:.1e} cond={cond:.1e} e_eq={e:.6g} e_wp_c3={e3:.6g} "
+              f"size={os.path.getsize(path)/1024:.0f}KB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+"""Numpy prototype of the reduced (Hermite / block-tridiagonal SPD) MINCO algorithm that the
+HIP kernels implement.  Design aid + cross-check only; not shipped in the product path."""
+import numpy as np
+from math import factorial
+from fractions import Fraction
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from minco_tables import tables
+
+
+def consts(s):
+    B, M, _ = tables(s)
+    return np.array(B, dtype=float), np.array(M, dtype=float)
+
+
+def piece_W(s, T, Mc):
+    D = 2 * s
+    W = np.zeros((D, D)); dW = np.zeros((D, D))
+    for a in range(D):
+        for b in range(D):
+            e = 1 - 2 * s + (a % s) + (b % s)
+            W[a, b] = Mc[a, b] * T ** e
+            dW[a, b] = Mc[a, b] * e * T ** (e - 1)
+    return W, dW
+
+
+def piece_Phi(s, T, Bc):
+    """c (highest first, D) = Phi @ [x_i; x_{i+1}],  and dPhi/dT."""
+    D = 2 * s
+    Phi = np.zeros((D, D)); dPhi = np.zeros((D, D))
+    for k in range(D):            # ascending power k -> output column D-1-k
+        for a in range(D):
+            e = (a % s) - k
+            Phi[D - 1 - k, a] = Bc[k, a] * T ** e
+            dPhi[D - 1 - k, a] = Bc[k, a] * e * T ** (e - 1)
+    return Phi, dPhi
+
+
+def assemble(s, T, c, Mc):
+    N = len(T); m = s - 1
+    Ws = [piece_W(s, T[i], Mc) for i in range(N)]
+    Kd = np.zeros((N + 1, m, m)); Ko = np.zeros((N, m, m))
+    for i in range(N):
+        W = Ws[i][0]
+        Kd[i] += W[1:s, 1:s]
+        Kd[i + 1] += W[s + 1:, s + 1:]
+        Ko[i] = W[1:s, s + 1:]
+    fixed = np.zeros((N + 1, m), dtype=bool)
+    fixed[0, :c - 1] = True; fixed[N, :c - 1] = True
+    return Ws, Kd, Ko, fixed
+
+
+def block_solve(Kd, Ko, fixed, rhs):
+    """Solve the block tridiagonal system with fixed entries pinned (rhs holds their values)."""
+    N1, m, _ = Kd.shape
+    Kd = Kd.copy(); Ko = Ko.copy(); rhs = rhs.copy()
+    # eliminate fixed entries symmetrically
+    pinned = rhs.copy()
+    for k in range(N1):
+        for j in range(m):
+            if fixed[k, j]:
+                v = pinned[k, j].copy()
+                rhs[k] -= np.outer(Kd[k][:, j], v)
+                if k + 1 < N1:
+                    rhs[k + 1] -= np.outer(Ko[k][j, :], v)
+                    Ko[k][j, :] = 0
+                if k > 0:
+                    rhs[k - 1] -= np.outer(Ko[k - 1][:, j], v)
+                    Ko[k - 1][:, j] = 0
+                Kd[k][:, j] = 0; Kd[k][j, :] = 0; Kd[k][j, j] = 1
+    for k in range(N1):
+        for j in range(m):
+            if fixed[k, j]:
+                rhs[k, j] = pinned[k, j]
+    Dk = [None] * N1; y = [None] * N1
+    Dk[0] = Kd[0]; y[0] = rhs[0]
+    for k in range(1, N1):
+        L = np.linalg.solve(Dk[k - 1], Ko[k - 1]).T      # Ko' D^-1  (D symmetric)
+        Dk[k] = Kd[k] - L @ Ko[k - 1]
+        y[k] = rhs[k] - L @ y[k - 1]
+    x = [None] * N1
+    x[N1 - 1] = np.linalg.solve(Dk[N1 - 1], y[N1 - 1])
+    for k in range(N1 - 2, -1, -1):
+        x[k] = np.linalg.solve(Dk[k], y[k] - Ko[k] @ x[k + 1])
+    return np.array(x)
+
+
+def solve(s, head, tail, wps, T):
+    """Returns coeffs (N,3,D highest-first), energy (int snap^2, no 1/2), node states X (N+1,s,3)."""
+    Bc, Mc = consts(s)
+    N = len(T); m = s - 1; c = head.shape[1]
+    Ws, Kd, Ko, fixed = assemble(s, T, c, Mc)
+    P = np.zeros((N + 1, 3)); P[0] = head[:, 0]; P[N] = tail[:, 0]
+    if N > 1:
+        P[1:N] = wps.T
+    rhs = np.zeros((N + 1, m, 3))
+    for i in range(N):
+        W = Ws[i][0]
+        rhs[i] -= np.outer(W[1:s, 0], P[i]) + np.outer(W[1:s, s], P[i + 1])
+        rhs[i + 1] -= np.outer(W[s + 1:, 0], P[i]) + np.outer(W[s + 1:, s], P[i + 1])
+    for j in range(1, c):
+        rhs[0, j - 1] = head[:, j]; rhs[N, j - 1] = tail[:, j]
+    d = block_solve(Kd, Ko, fixed, rhs)
+    X = np.zeros((N + 1, s, 3)); X[:, 0] = P; X[:, 1:] = d
+    coeffs = np.zeros((N, 3, 2 * s)); energy = 0.0
+    for i in range(N):
+        xx = np.vstack([X[i], X[i + 1]])            # 2s x 3
+        Phi, _ = piece_Phi(s, T[i], Bc)
+        coeffs[i] = (Phi @ xx).T
+        energy += np.einsum("ak,ab,bk->", xx, Ws[i][0], xx)
+    return coeffs, energy, X
+
+
+def propagate(s, head, tail, wps, T, gdC, gdT):
+    """Adjoint: given partial grads gdC (N,3,D) and gdT (N) of a scalar J(c,T), return
+    total grads wrt waypoints (3,N-1) and times (N) with c = c(wps,T)."""
+    Bc, Mc = consts(s)
+    N = len(T); m = s - 1; c = head.shape[1]
+    coeffs, energy, X = solve(s, head, tail, wps, T)
+    Ws, Kd, Ko, fixed = assemble(s, T, c, Mc)
+    gX = np.zeros((N + 1, s, 3)); gT = np.array(gdT, dtype=float).copy()
+    for i in range(N):
+        xx = np.vstack([X[i], X[i + 1]])
+        Phi, dPhi = piece_Phi(s, T[i], Bc)
+        g = Phi.T @ gdC[i].T                         # 2s x 3
+        gX[i] += g[:s]; gX[i + 1] += g[s:]
+        gT[i] += np.sum(gdC[i].T * (dPhi @ xx))
+    rhs = gX[:, 1:, :].copy()
+    rhs[0, :c - 1] = 0; rhs[N, :c - 1] = 0
+    lam = block_solve(Kd, Ko, fixed, rhs)           # fixed entries -> 0
+    Lh = np.zeros((N + 1, s, 3)); Lh[:, 1:] = lam
+    gP = gX[:, 0, :].copy()
+    for i in range(N):
+        xx = np.vstack([X[i], X[i + 1]]); ll = np.vstack([Lh[i], Lh[i + 1]])
+        W, dW = Ws[i]
+        wl = W @ ll
+        gP[i] -= wl[0]; gP[i + 1] -= wl[s]
+        gT[i] -= np.einsum("ak,ab,bk->", ll, dW, xx)
+    return gP[1:N].T, gT
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, "/root/repo")
+    from oracle import minco_np as o
+    rng = np.random.default_rng(0)
+    for s, c, N in [(4, 3, 8), (4, 4, 8), (3, 3, 16), (3, 3, 1), (4, 3, 1), (4, 4, 2), (2, 2, 5), (4, 2, 3)]:
+        head = rng.normal(size=(3, c)); tail = rng.normal(size=(3, c)) + 5
+        wps = np.cumsum(rng.normal(size=(3, max(N - 1, 0))), axis=1)
+        T = rng.uniform(0.5, 2.0, size=N)
+        if s == 2:
+            co0 = None
+        co, e, X = solve(s, head, tail, wps, T)
+        if s > 2:
+            co0, e0, Md, info, sol = o.minco_dense_solve(s, head, tail, wps, T)
+            print(s, c, N, "coeff rel", np.abs(co - co0).max() / np.abs(co0).max(), "energy rel", abs(e - e0) / e0)
+        # gradient check for J = energy + random linear functional of c + sum T^2
+        Gc = rng.normal(size=co.shape)
+        def J(wps_, T_):
+            co_, e_, _ = solve(s, head, tail, wps_, T_)
+            return e_ + np.sum(Gc * co_) + np.sum(T_ ** 2)
+        # partials of energy wrt c and T via oracle cost blocks (true integral)
+        def energy_partials(co_, T_):
+            gC = np.zeros_like(co_); gT_ = np.zeros(N)
+            for i in range(N):
+                t = T_[i]
+                for ax in range(3):
+                    # generic: d/dc of int (p^(s))^2 ; build Q via quadrature-free formula
+                    pass
+            return gC, gT_
+        # use envelope-free approach: J = E(c,T) with E from exact poly integral
+        def E_of(co_, T_):
+            tot = 0.0
+            for i in range(N):
+                for ax in range(3):
+                    p = np.poly1d(co_[i, ax]); q = np.polyder(p, s); tot += np.polyval(np.polyint(q * q), T_[i])
+            return tot
+        h = 1e-6
+        gC = np.zeros_like(co); gTp = np.zeros(N)
+        for idx in np.ndindex(co.shape):
+            cp = co.copy(); cp[idx] += h; cm = co.copy(); cm[idx] -= h
+            gC[idx] = (E_of(cp, T) - E_of(cm, T)) / (2 * h)
+        for i in range(N):
+            Tp = T.copy(); Tp[i] += h; Tm = T.copy(); Tm[i] -= h
+            gTp[i] = (E_of(co, Tp) - E_of(co, Tm)) / (2 * h)
+        gP, gT = propagate(s, head, tail, wps, T, gC + Gc, gTp + 2 * T)
+        # finite differences of total J
+        fP = np.zeros_like(wps); fT = np.zeros(N)
+        for idx in np.ndindex(wps.shape):
+            wp = wps.copy(); wp[idx] += h; wm = wps.copy(); wm[idx] -= h
+            fP[idx] = (J(wp, T) - J(wm, T)) / (2 * h)
+        for i in range(N):
+            Tp = T.copy(); Tp[i] += h; Tm = T.copy(); Tm[i] -= h
+            fT[i] = (J(wps, Tp) - J(wps, Tm)) / (2 * h)
+        print("   gradP rel", (np.abs(gP - fP).max() / max(1e-9, np.abs(fP).max())) if N > 1 else 0.0,
+              "gradT rel", np.abs(gT - fT).max() / np.abs(fT).max())
