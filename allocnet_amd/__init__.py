@@ -1,0 +1,10 @@
+"""allocnet_amd -- MI355X-native batched MINCO / min-jerk / min-snap trajectory solver.
+
+Host-side mirror (Python) of the reference's operator surface for the hot path; all arithmetic
+runs in hand-written HIP kernels behind the C ABI in include/allocnet_amd.h.
+"""
+from ._lib import AnetError, load, LIB_PATH  # noqa: F401
+from .context import Context, default_context  # noqa: F401
+from .minco import MINCO, MINCO_S2NU, MINCO_S3NU, MINCO_S4NU, minco_solve, minco_solve_dev  # noqa: F401
+
+__version__ = "0.1.0"

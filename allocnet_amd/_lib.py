@@ -1,0 +1,66 @@
+"""ctypes binding of include/allocnet_amd.h.  The library is the product; there is no Python or
+CPU fallback: if the .so is missing or no GPU is visible, calls fail loudly."""
+import ctypes
+import os
+from ctypes import c_int, c_int64, c_void_p, c_char_p, c_double, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liballocnet_amd.so")
+
+ANET_OK = 0
+ANET_ERR_INVALID = -1
+ANET_ERR_HIP = -2
+ANET_ERR_UNSUPPORTED = -3
+ANET_ERR_NOMEM = -4
+ANET_ERR_NODEVICE = -5
+
+_dp = POINTER(c_double)
+
+# name -> (restype, argtypes); must list every symbol include/allocnet_amd.h declares
+PROTOTYPES = {
+    "anet_abi_version": (c_int, []),
+    "anet_device_count": (c_int, []),
+    "anet_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "anet_destroy": (None, [c_void_p]),
+    "anet_last_error": (c_char_p, [c_void_p]),
+    "anet_stream": (c_void_p, [c_void_p]),
+    "anet_synchronize": (c_int, [c_void_p]),
+    "anet_to_batch_minor_dev": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "anet_to_traj_major_dev": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "anet_minco_solve_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anet_minco_solve": (c_int, [c_void_p, c_int, c_int, c_int, c_int64,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class AnetError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"allocnet_amd error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load the shared library (building is a separate, explicit step: allocnet_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -m allocnet_amd.build` (hipcc, gfx950). "
+            "allocnet_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx, rc):
+    if rc != ANET_OK:
+        msg = load().anet_last_error(ctx)
+        raise AnetError(rc, msg.decode() if msg else "?")

@@ -1,0 +1,328 @@
+// Per-lane MINCO machinery for gfx950: one trajectory per lane, batch-minor (SoA) global layout
+// so that every global access of a wave is one contiguous 512-B segment.
+//
+// Algorithm (derived; `minco.hpp` is not in the reference tree -- SURVEY.md section 0):
+// in normalised time each piece is a Hermite interpolant of its two end states
+// x_k = (p, p', .., p^(s-1)) and its control effort is  r^(2s-1) u' M u  with a CONSTANT integer
+// matrix M (minco_tables.h), r = 1/T, u = diag(T^deg)[x_k; x_k+1].  Minimising over the free
+// node derivatives gives a symmetric positive definite block-tridiagonal system with (s-1)x(s-1)
+// blocks, shared by the three axes.  It is factorised once per trajectory (block LDL^T, no
+// pivoting needed, no square roots) and each axis is a forward/backward sweep.  This is ~4x
+// fewer FP64 operations than the 2sN x 2sN banded collocation LU and needs no pivoting, which
+// is what lets one lane own one trajectory with the factor resident in registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "minco_tables.h"
+
+namespace anet {
+
+// 1/d to full double precision: v_rcp_f64 + two Newton steps (no div_scale/div_fixup chain).
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+  x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+  return x;
+}
+
+// Optimisation barrier.  The sweeps below deliberately RECOMPUTE the cheap per-piece quantities
+// (powers of r, the coupling block Y = L^-1 Ko) instead of keeping them: left alone the compiler
+// would CSE/hoist them across the sweeps and hold ~150 doubles live, which spills.  Laundering
+// r through an empty asm makes each sweep's copy a distinct value.
+__device__ __forceinline__ double launder(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+template <int S>
+struct Pw {  // r^1 .. r^(2S-1)
+  double v[2 * S];
+  __device__ __forceinline__ explicit Pw(double r) {
+    v[0] = 1.0;
+    v[1] = r;
+#pragma unroll
+    for (int e = 2; e < 2 * S; ++e) v[e] = v[e - 1] * r;
+  }
+  __device__ __forceinline__ double operator[](int e) const { return v[e]; }
+};
+
+// Block-tridiagonal SPD factor, one trajectory.  Node k in [0, N]; unknown j in [0, m) is the
+// derivative of order j+1 at that node.  `np` = c-1 derivatives are pinned at nodes 0 and N.
+template <int S, int NB>
+struct Factor {
+  static constexpr int m = S - 1;
+  static constexpr int nl = m * (m - 1) / 2;
+  double L[NB + 1][nl > 0 ? nl : 1];  // strict lower of the unit-lower LDL^T factor, row-major
+  double dinv[NB + 1][m];
+  double r[NB];  // 1/T per piece
+
+  __device__ __forceinline__ static int li(int i, int j) { return i * (i - 1) / 2 + j; }  // i>j
+
+  // Off-diagonal block of piece i: Ko(j,l) couples unknown j of node i with unknown l of node i+1.
+  __device__ __forceinline__ void build_Ko(int i, int N, int np, const Pw<S> &p,
+                                           double Ko[m][m]) const {
+#pragma unroll
+    for (int j = 0; j < m; ++j)
+#pragma unroll
+      for (int l = 0; l < m; ++l) {
+        double v = Tab<S>::M[1 + j][S + 1 + l] * p[2 * S - 3 - j - l];
+        if ((i == 0 && j < np) || (i == N - 1 && l < np)) v = 0.0;
+        Ko[j][l] = v;
+      }
+  }
+  // Y = L_k^-1 Ko (column-wise unit-lower forward substitution)
+  __device__ __forceinline__ void apply_Linv(int k, double Y[m][m]) const {
+#pragma unroll
+    for (int col = 0; col < m; ++col)
+#pragma unroll
+      for (int i = 1; i < m; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) Y[i][col] = __builtin_fma(-L[k][li(i, j)], Y[j][col], Y[i][col]);
+  }
+
+  __device__ __forceinline__ void factorize(int N, int np) {
+    double Dk[m][m];
+#pragma unroll
+    for (int j = 0; j < m; ++j)
+#pragma unroll
+      for (int l = 0; l < m; ++l) Dk[j][l] = 0.0;
+#pragma unroll
+    for (int k = 0; k <= NB; ++k) {
+      if (k <= N) {
+        // --- assemble the diagonal block of node k (Schur part from node k-1 already in Dk)
+        if (k < N) {
+          Pw<S> p(r[k]);
+#pragma unroll
+          for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int l = 0; l < m; ++l)
+              Dk[j][l] = __builtin_fma(Tab<S>::M[1 + j][1 + l], p[2 * S - 3 - j - l], Dk[j][l]);
+        }
+        if (k > 0) {
+          Pw<S> p(r[k - 1]);
+#pragma unroll
+          for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int l = 0; l < m; ++l)
+              Dk[j][l] =
+                  __builtin_fma(Tab<S>::M[S + 1 + j][S + 1 + l], p[2 * S - 3 - j - l], Dk[j][l]);
+        }
+        if (k == 0 || k == N) {
+#pragma unroll
+          for (int j = 0; j < m; ++j)
+#pragma unroll
+            for (int l = 0; l < m; ++l)
+              if (j < np || l < np) Dk[j][l] = (j == l) ? 1.0 : 0.0;
+        }
+        // --- LDL^T of the m x m block
+        double d[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+          double dj = Dk[j][j];
+#pragma unroll
+          for (int q = 0; q < j; ++q) dj = __builtin_fma(-L[k][li(j, q)] * d[q], L[k][li(j, q)], dj);
+          d[j] = dj;
+          dinv[k][j] = fast_rcp(dj);
+#pragma unroll
+          for (int i = j + 1; i < m; ++i) {
+            double v = Dk[i][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) v = __builtin_fma(-L[k][li(i, q)] * d[q], L[k][li(j, q)], v);
+            L[k][li(i, j)] = v * dinv[k][j];
+          }
+        }
+        // --- Schur complement seed for node k+1:  -Ko' D_k^-1 Ko
+        if (k < N) {
+          Pw<S> p(r[k]);
+          double Y[m][m];
+          build_Ko(k, N, np, p, Y);
+          apply_Linv(k, Y);
+#pragma unroll
+          for (int a = 0; a < m; ++a)
+#pragma unroll
+            for (int b = 0; b < m; ++b) {
+              double acc = 0.0;
+#pragma unroll
+              for (int j = 0; j < m; ++j) acc = __builtin_fma(-Y[j][a] * dinv[k][j], Y[j][b], acc);
+              Dk[a][b] = acc;
+            }
+        }
+      }
+    }
+  }
+};
+
+// One axis: forward sweep, backward sweep, emit coefficients (highest power first) and the
+// axis' share of int (p^(s))^2.  `emit(piece, col, value)` receives the D coefficients.
+//   P[k]   : node positions (k = 0..N), hv/tv : pinned head/tail derivatives (orders 1..np)
+template <int S, int NB, class Emit>
+__device__ __forceinline__ double solve_axis(const Factor<S, NB> &F, int N, int np,
+                                             const double (&P)[NB + 1], const double (&hv)[S - 1],
+                                             const double (&tv)[S - 1], double (&X)[NB + 1][S - 1],
+                                             Emit &&emit) {
+  constexpr int m = S - 1;
+  double rr[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
+  // ---- forward: w_k = L_k^-1 (rhs_k - Ko_{k-1}' D_{k-1}^-1 y_{k-1}) stored in X
+#pragma unroll
+  for (int k = 0; k <= NB; ++k) {
+    if (k <= N) {
+      double y[m];
+#pragma unroll
+      for (int l = 0; l < m; ++l) y[l] = 0.0;
+      if (k < N) {  // piece k, node k is its start
+        Pw<S> p(rr[k]);
+        const double dl = P[k + 1] - P[k];
+#pragma unroll
+        for (int l = 0; l < m; ++l) y[l] = Tab<S>::M[1 + l][0] * p[2 * S - 2 - l] * dl;
+        if (k == N - 1) {  // pinned tail derivatives couple into node N-1 through piece N-1
+#pragma unroll
+          for (int l = 0; l < m; ++l)
+#pragma unroll
+            for (int j = 0; j < m; ++j)
+              if (j < np)
+                y[l] = __builtin_fma(-Tab<S>::M[1 + l][S + 1 + j] * p[2 * S - 3 - l - j], tv[j], y[l]);
+        }
+      }
+      if (k > 0) {  // piece k-1, node k is its end
+        Pw<S> p(rr[k - 1]);
+        const double dl = P[k] - P[k - 1];
+#pragma unroll
+        for (int l = 0; l < m; ++l)
+          y[l] = __builtin_fma(Tab<S>::M[S + 1 + l][0] * p[2 * S - 2 - l], dl, y[l]);
+        if (k == 1) {  // pinned head derivatives couple into node 1 through piece 0
+#pragma unroll
+          for (int l = 0; l < m; ++l)
+#pragma unroll
+            for (int j = 0; j < m; ++j)
+              if (j < np)
+                y[l] = __builtin_fma(-Tab<S>::M[1 + j][S + 1 + l] * p[2 * S - 3 - l - j], hv[j], y[l]);
+        }
+      }
+      if (k == 0 || k == N) {
+        // unknowns of an end node also see that node's own pinned derivatives
+        if (k == 0 && N > 0) {
+          Pw<S> p(rr[0]);
+#pragma unroll
+          for (int l = 0; l < m; ++l)
+#pragma unroll
+            for (int j = 0; j < m; ++j)
+              if (j < np && l >= np)
+                y[l] = __builtin_fma(-Tab<S>::M[1 + l][1 + j] * p[2 * S - 3 - l - j], hv[j], y[l]);
+        }
+        if (k == N) {
+          Pw<S> p(rr[N - 1]);
+#pragma unroll
+          for (int l = 0; l < m; ++l)
+#pragma unroll
+            for (int j = 0; j < m; ++j)
+              if (j < np && l >= np)
+                y[l] = __builtin_fma(-Tab<S>::M[S + 1 + l][S + 1 + j] * p[2 * S - 3 - l - j], tv[j],
+                                     y[l]);
+        }
+#pragma unroll
+        for (int l = 0; l < m; ++l)
+          if (l < np) y[l] = (k == 0) ? hv[l] : tv[l];
+      }
+      if (k > 0) {
+        Pw<S> p(rr[k - 1]);
+        double Y[m][m];
+        F.build_Ko(k - 1, N, np, p, Y);
+        F.apply_Linv(k - 1, Y);
+#pragma unroll
+        for (int l = 0; l < m; ++l)
+#pragma unroll
+          for (int j = 0; j < m; ++j)
+            y[l] = __builtin_fma(-Y[j][l] * F.dinv[k - 1][j], X[k - 1][j], y[l]);
+      }
+      // w_k = L_k^-1 y
+#pragma unroll
+      for (int i = 1; i < m; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+          y[i] = __builtin_fma(-F.L[k][Factor<S, NB>::li(i, j)], y[j], y[i]);
+#pragma unroll
+      for (int l = 0; l < m; ++l) X[k][l] = y[l];
+    }
+  }
+  // ---- backward: x_k = L_k^-T dinv (w_k - Y_k x_{k+1}); emit piece k as soon as x_k is known
+  double energy = 0.0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
+#pragma unroll
+  for (int k = NB; k >= 0; --k) {
+    if (k <= N) {
+      double x[m];
+#pragma unroll
+      for (int l = 0; l < m; ++l) x[l] = X[k][l];
+      if (k < N) {
+        Pw<S> p(rr[k]);
+        double Y[m][m];
+        F.build_Ko(k, N, np, p, Y);
+        F.apply_Linv(k, Y);
+#pragma unroll
+        for (int l = 0; l < m; ++l)
+#pragma unroll
+          for (int j = 0; j < m; ++j) x[l] = __builtin_fma(-Y[l][j], X[k + 1][j], x[l]);
+      }
+#pragma unroll
+      for (int l = 0; l < m; ++l) x[l] *= F.dinv[k][l];
+#pragma unroll
+      for (int i = m - 2; i >= 0; --i)
+#pragma unroll
+        for (int j = i + 1; j < m; ++j)
+          x[i] = __builtin_fma(-F.L[k][Factor<S, NB>::li(j, i)], x[j], x[i]);
+#pragma unroll
+      for (int l = 0; l < m; ++l) X[k][l] = x[l];
+
+      if (k < N) {  // piece k: states (P[k], X[k]) -> (P[k+1], X[k+1])
+        Pw<S> p(rr[k]);
+        // v_b = x_b r^(S-1-deg b);  g_i = sum_b BHI[i][b] v_b (= T a_{S+i} r^S);
+        // c_{S+i} = r^(i+1) g_i;  piece energy = r g' QB g.   Only non-negative powers of r.
+        double v[2 * S];
+        v[0] = P[k] * p[S - 1];
+        v[S] = P[k + 1] * p[S - 1];
+#pragma unroll
+        for (int j = 1; j < S; ++j) {
+          v[j] = X[k][j - 1] * p[S - 1 - j];
+          v[S + j] = X[k + 1][j - 1] * p[S - 1 - j];
+        }
+        double g[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          // BHI[i][0] = -BHI[i][S]: use the position difference
+          double acc = Tab<S>::BHI[i][S] * (v[S] - v[0]);
+#pragma unroll
+          for (int b = 1; b < S; ++b) {
+            acc = __builtin_fma(Tab<S>::BHI[i][b], v[b], acc);
+            acc = __builtin_fma(Tab<S>::BHI[i][S + b], v[S + b], acc);
+          }
+          g[i] = acc;
+        }
+        double e = 0.0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          double t = Tab<S>::QB[i][i] * g[i];
+#pragma unroll
+          for (int j = i + 1; j < S; ++j) t = __builtin_fma(2.0 * Tab<S>::QB[i][j], g[j], t);
+          e = __builtin_fma(t, g[i], e);
+        }
+        energy = __builtin_fma(e, p[1], energy);
+        // low coefficients: c_j = x^(j)/j!
+        double fact = 1.0;
+        emit(k, 2 * S - 1, P[k]);
+#pragma unroll
+        for (int j = 1; j < S; ++j) {
+          fact *= (double)j;
+          emit(k, 2 * S - 1 - j, X[k][j - 1] * (1.0 / fact));
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) emit(k, S - 1 - i, g[i] * p[i + 1]);
+      }
+    }
+  }
+  return energy;
+}
+
+}  // namespace anet

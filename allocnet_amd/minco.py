@@ -1,0 +1,125 @@
+"""MINCO host mirror.
+
+`minco.hpp` is not in the reference tree; the class below follows the
+upstream GCOPTER method names the north star asks for -- setConditions / setParameters /
+getCoeffs / getEnergy -- batched over B independent trajectories.  Data conventions are the
+reference's (see include/allocnet_amd.h).  S3 = min-jerk (degree 5), S4 = min-snap (degree 7),
+the reference's own order numbering (planner.yaml:23, learning_planner.hpp:203-233).
+"""
+import ctypes
+import numpy as np
+
+from .context import default_context
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _f64c(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def minco_solve(head, tail, wps, T, s, want_coeffs=True, ctx=None):
+    """Host (numpy, trajectory-major) entry point -> anet_minco_solve.
+
+    head, tail : (B, 3, c);  wps : (B, N-1, 3);  T : (B, N)
+    returns coeffs (B, N, 3, 2s) [or None] and energy (B,)
+    """
+    ctx = ctx or default_context()
+    head = _f64c(head)
+    B, three, c = head.shape
+    if three != 3:
+        raise ValueError("head must be (B, 3, c)")
+    tail = _f64c(tail, (B, 3, c))
+    T = _f64c(T)
+    N = T.shape[1]
+    if T.shape != (B, N):
+        raise ValueError("T must be (B, N)")
+    wps = _f64c(wps if wps is not None else np.zeros((B, 0, 3)), (B, N - 1, 3))
+    coeffs = np.empty((B, N, 3, 2 * s)) if want_coeffs else None
+    energy = np.empty(B)
+    ctx.check(ctx.lib.anet_minco_solve(ctx.handle, s, c, N, B, _ptr(head), _ptr(tail), _ptr(wps),
+                                       _ptr(T), _ptr(coeffs), _ptr(energy)))
+    return coeffs, energy
+
+
+def minco_solve_dev(head, tail, wps, T, s, c, N, B, coeffs=None, energy=None, stream=None, ctx=None):
+    """Device entry point -> anet_minco_solve_dev.  All arguments are torch CUDA float64 tensors in
+    the batch-minor layout (rows = per-trajectory fields, columns = batch, row stride ld):
+    head/tail (3c, ld), wps ((N-1)*3, ld), T (N, ld), coeffs (N*3*2s, ld), energy (>=B,)."""
+    import torch
+    ctx = ctx or default_context(T.device.index or 0)
+    ld = T.stride(0) if T.dim() == 2 else T.shape[-1]
+    for t in (head, tail, T) + ((wps,) if N > 1 else ()) + ((coeffs,) if coeffs is not None else ()):
+        if t.dtype != torch.float64 or not t.is_cuda or t.stride(-1) != 1 or (t.dim() == 2 and t.stride(0) != ld):
+            raise ValueError("batch-minor float64 CUDA tensors with a common row stride expected")
+    if stream is None:
+        stream = torch.cuda.current_stream(T.device).cuda_stream
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    ctx.check(ctx.lib.anet_minco_solve_dev(ctx.handle, s, c, N, B, ld, p(head), p(tail),
+                                           p(wps) if N > 1 else None, p(T), p(coeffs), p(energy),
+                                           ctypes.c_void_p(stream)))
+    return coeffs, energy
+
+
+class MINCO:
+    """Batched MINCO_S{s}NU mirror: setConditions -> setParameters -> getCoeffs/getEnergy."""
+
+    def __init__(self, s, ctx=None):
+        if s not in (2, 3, 4):
+            raise ValueError("order s must be 2, 3 or 4")
+        self.s = s
+        self.ctx = ctx
+        self.N = None
+        self._coeffs = self._energy = None
+
+    def setConditions(self, headState, tailState, pieceNum):
+        """headState/tailState: (B, 3, c) or (3, c) (row = axis, cols p,v,a[,j])."""
+        h = np.asarray(headState, dtype=np.float64)
+        t = np.asarray(tailState, dtype=np.float64)
+        self._single = h.ndim == 2
+        if self._single:
+            h, t = h[None], t[None]
+        if h.shape != t.shape or h.shape[1] != 3 or not (1 <= h.shape[2] <= self.s):
+            raise ValueError("boundary states must be (B,3,c) with 1 <= c <= s")
+        self.head, self.tail, self.N = h, t, int(pieceNum)
+
+    def setParameters(self, inPs, ts):
+        """inPs: (B, N-1, 3) interior waypoints; ts: (B, N) durations."""
+        if self.N is None:
+            raise RuntimeError("setConditions first")
+        ts = np.asarray(ts, dtype=np.float64)
+        inPs = np.asarray(inPs, dtype=np.float64)
+        if self._single:
+            ts, inPs = ts[None], inPs[None]
+        B = self.head.shape[0]
+        if ts.shape != (B, self.N):
+            raise ValueError("ts must be (B, N)")
+        self.T = ts
+        self._coeffs, self._energy = minco_solve(self.head, self.tail, inPs.reshape(B, self.N - 1, 3),
+                                                 ts, self.s, ctx=self.ctx)
+
+    def getCoeffs(self):
+        return self._coeffs[0] if self._single else self._coeffs
+
+    def getEnergy(self):
+        return float(self._energy[0]) if self._single else self._energy
+
+
+class MINCO_S2NU(MINCO):
+    def __init__(self, ctx=None):
+        super().__init__(2, ctx)
+
+
+class MINCO_S3NU(MINCO):
+    def __init__(self, ctx=None):
+        super().__init__(3, ctx)
+
+
+class MINCO_S4NU(MINCO):
+    def __init__(self, ctx=None):
+        super().__init__(4, ctx)

@@ -1,0 +1,104 @@
+/*
+ * allocnet_amd -- C ABI of the MI355X-native batched MINCO / min-jerk / min-snap trajectory
+ * solver.  Plain C: opaque handle, POD arrays, no C++ or torch types cross this line.
+ *
+ * What each entry point replaces in the reference (KumarRobotics/AllocNet, paths relative to
+ * the reference root) is cited per function.  `minco.hpp` itself is NOT part of the reference
+ * tree; the MINCO entry points follow the upstream GCOPTER method names
+ * the north star asks for (setConditions / setParameters / getEnergy / getCoeffs /
+ * getEnergyPartialGradBy{Coeffs,Times} / propogateGrad).
+ *
+ * Conventions (the reference's own):
+ *   - s      : order, 3 = min-jerk (degree 5), 4 = min-snap (degree 7); 2 = min-acc also works.
+ *   - D      : 2*s coefficients per axis per piece, HIGHEST POWER FIRST
+ *              (src/planner/include/gcopter/trajectory.hpp:75-133).
+ *   - coeffs : piece-major, then axis x,y,z, then the D coefficients
+ *              (src/planner/include/planner/learning_planner.hpp:212,227).
+ *   - head/tail : 3 x c, row = axis, columns p,v,a[,j] (src/planner/src/learning_planning.cpp:150-151);
+ *              c = number of boundary derivatives fixed per end: 3 = reference convention
+ *              (qp_solver.hpp:37,152-158; for snap the end jerk is then free -> natural
+ *              condition p''''=0), c = s = classic MINCO convention.
+ *   - wps    : interior waypoints, (N-1) x 3 (waypoint-major, like GCOPTER's 3 x (N-1)
+ *              column-major inPs).
+ *   - energy : int (p^(s))^2 dt summed over axes (MINCO getEnergy convention, no 1/2);
+ *              the reference's Trajectory::getTrajCost convention (1/2, m_34=1400) is
+ *              available through anet_traj_cost*.
+ *
+ * Two families of entry points:
+ *   *_dev : pointers are DEVICE pointers in the batch-minor layout: value f of trajectory b
+ *           lives at ptr[f*ld + b] (f = the flattened per-trajectory index in the order given
+ *           above, ld >= batch).  Asynchronous on `stream` (a hipStream_t, NULL = default).
+ *   plain : pointers are HOST pointers, trajectory-major (each trajectory's values contiguous,
+ *           exactly the reference's flattening).  Synchronous.
+ *
+ * All functions return ANET_OK (0) or a negative error code; anet_last_error() gives text.
+ * One context per host thread per device; a context is not re-entrant (same as the
+ * reference's QPSolver, qp_solver.hpp:43-45).
+ */
+#ifndef ALLOCNET_AMD_H
+#define ALLOCNET_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANET_ABI_VERSION 1
+
+enum {
+  ANET_OK = 0,
+  ANET_ERR_INVALID = -1,     /* bad argument (order, piece count, batch, NULL pointer ...) */
+  ANET_ERR_HIP = -2,         /* a HIP runtime call failed; text in anet_last_error()       */
+  ANET_ERR_UNSUPPORTED = -3, /* valid request this build has no kernel for                 */
+  ANET_ERR_NOMEM = -4,
+  ANET_ERR_NODEVICE = -5     /* no usable gfx950 device: the product path has NO CPU fallback */
+};
+
+#define ANET_MAX_PIECES 16   /* register-resident kernels are instantiated for N <= 16      */
+#define ANET_MAX_POLY_ROWS 50 /* learning_planner.hpp:40 (eigen_stacked_hpolys 4*50)        */
+
+typedef struct anet_ctx anet_ctx;
+
+int anet_abi_version(void);
+int anet_device_count(void);
+int anet_create(int device, anet_ctx **out);
+void anet_destroy(anet_ctx *ctx);
+const char *anet_last_error(const anet_ctx *ctx);
+/* hipStream_t the plain (host) entry points run on. */
+void *anet_stream(anet_ctx *ctx);
+int anet_synchronize(anet_ctx *ctx);
+
+/* ---- layout helpers: trajectory-major host/device <-> batch-minor device ---------------- */
+/* dst[f*ld + b] = src[b*nfield + f]  (both device pointers). */
+int anet_to_batch_minor_dev(anet_ctx *ctx, int64_t batch, int64_t nfield, int64_t ld,
+                            const double *src, double *dst, void *stream);
+/* dst[b*nfield + f] = src[f*ld + b]. */
+int anet_to_traj_major_dev(anet_ctx *ctx, int64_t batch, int64_t nfield, int64_t ld,
+                           const double *src, double *dst, void *stream);
+
+/* ---- MINCO coefficient solve + energy --------------------------------------------------- */
+/* Replaces (north star; upstream GCOPTER minco.hpp, absent from the reference tree):
+ *   MINCO_S{2,3,4}NU::setConditions(head,tail,N) + setParameters(inPs,ts) + getCoeffs +
+ *   getEnergy, batched.  Fixed waypoints and durations; minimises int (p^(s))^2.
+ * coeffs may be NULL (energy only); energy may be NULL.                                      */
+int anet_minco_solve_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                         const double *head,  /* [3*c][ld]        */
+                         const double *tail,  /* [3*c][ld]        */
+                         const double *wps,   /* [(N-1)*3][ld]    (ignored when N == 1) */
+                         const double *T,     /* [N][ld]          */
+                         double *coeffs,      /* [N*3*2s][ld]     */
+                         double *energy,      /* [batch]          */
+                         void *stream);
+int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch,
+                     const double *head,  /* [batch][3][c]     */
+                     const double *tail,  /* [batch][3][c]     */
+                     const double *wps,   /* [batch][N-1][3]   */
+                     const double *T,     /* [batch][N]        */
+                     double *coeffs,      /* [batch][N][3][2s] */
+                     double *energy);     /* [batch]           */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALLOCNET_AMD_H */

@@ -1,0 +1,107 @@
+"""GPU parity: HIP MINCO solve vs the numpy oracle (classic dense collocation) and vs the golden
+KKT solutions computed from the reference-assembled QP matrices."""
+import numpy as np
+import pytest
+
+from oracle import minco_np as onp
+from tests.util import golden_files, random_problem, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6   # north-star tolerance (relative, coefficients and energy); we assert much tighter
+TIGHT = 1e-9
+
+
+@pytest.mark.parametrize("s,c,N", [(4, 3, 8), (4, 4, 8), (3, 3, 16), (3, 3, 5), (4, 3, 5), (4, 4, 1),
+                                   (4, 3, 1), (3, 3, 1), (3, 2, 3), (2, 2, 6), (4, 1, 4), (4, 2, 11),
+                                   (3, 1, 9), (2, 1, 1), (4, 3, 16), (4, 4, 13)])
+def test_solve_matches_oracle(anet_ctx, s, c, N):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(100 * s + 10 * c + N)
+    B = 67          # ragged: not a multiple of the wave size
+    head, tail, wps, T = random_problem(rng, B, N, c)
+    coeffs, energy = aa.minco_solve(head, tail, wps, T, s, ctx=anet_ctx)
+    for b in range(B):
+        co, e, *_ = onp.minco_dense_solve(s, head[b], tail[b], wps[b].T, T[b]) if s > 2 else (None, None)
+        if co is None:
+            continue
+        assert rel_err(coeffs[b], co) < TIGHT
+        assert abs(energy[b] - e) / e < TIGHT
+
+
+@pytest.mark.parametrize("path", golden_files())
+def test_solve_matches_reference_kkt(anet_ctx, path):
+    """z_wp_* are minimisers of the REFERENCE-ASSEMBLED Q(1440),A,b with waypoint rows appended."""
+    import allocnet_amd as aa
+    d = np.load(path)
+    s, N = int(d["order"]), int(d["N"]); D = 2 * s
+    st = d["state"]
+    head = np.array([st[3 * j:3 * j + 3, 0] for j in range(3)])[None]
+    tail = np.array([st[3 * j:3 * j + 3, 1] for j in range(3)])[None]
+    wps = d["pts"][1:N][None]
+    T = d["T"][None]
+    coeffs, energy = aa.minco_solve(head, tail, wps, T, s, ctx=anet_ctx)
+    assert rel_err(coeffs.reshape(-1), d["z_wp_c3"]) < TOL
+    assert abs(0.5 * energy[0] - d["e_wp_c3"]) / d["e_wp_c3"] < TOL
+    if s == 4:
+        head4 = np.concatenate([head, d["jerk_head"][None, :, None]], axis=2)
+        tail4 = np.concatenate([tail, d["jerk_tail"][None, :, None]], axis=2)
+        coeffs, energy = aa.minco_solve(head4, tail4, wps, T, s, ctx=anet_ctx)
+        assert rel_err(coeffs.reshape(-1), d["z_wp_cs"]) < TOL
+        assert abs(0.5 * energy[0] - d["e_wp_cs"]) / d["e_wp_cs"] < TOL
+
+
+def test_class_mirror(anet_ctx):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(5)
+    head, tail, wps, T = random_problem(rng, 1, 8, 4)
+    m = aa.MINCO_S4NU(ctx=anet_ctx)
+    m.setConditions(head[0], tail[0], 8)
+    m.setParameters(wps[0], T[0])
+    co, e, *_ = onp.minco_dense_solve(4, head[0], tail[0], wps[0].T, T[0])
+    assert rel_err(m.getCoeffs(), co) < TIGHT
+    assert abs(m.getEnergy() - e) / e < TIGHT
+
+
+def test_large_batch_properties(anet_ctx):
+    """Full-size batch (config 2 x 64): size-independent properties instead of the oracle --
+    waypoint interpolation, C^(2s-2) continuity at knots, boundary conditions, energy == cost
+    recomputed from the coefficients."""
+    import allocnet_amd as aa
+    s, c, N, B = 4, 3, 8, 65536
+    rng = np.random.default_rng(0)
+    head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
+    coeffs, energy = aa.minco_solve(head, tail, wps, T, s, ctx=anet_ctx)
+    D = 2 * s
+    pw = np.arange(D - 1, -1, -1)
+
+    def deriv_at(cm, t, d):      # cm (B,3,D), t (B,)
+        k = pw[None, None, :]
+        f = np.ones_like(k, dtype=float)
+        for i in range(d):
+            f = f * np.clip(k - i, 0, None)
+        tt = np.where(k - d >= 0, t[:, None, None] ** np.clip(k - d, 0, None), 0.0)
+        return np.sum(cm * f * tt, axis=2)
+    scale = np.abs(coeffs).max()
+    zero = np.zeros(B)
+    for i in range(N):
+        p0 = deriv_at(coeffs[:, i], zero, 0)
+        target = head[:, :, 0] if i == 0 else wps[:, i - 1]
+        assert np.abs(p0 - target).max() < 1e-9 * scale
+        if i + 1 < N:
+            for d in range(2 * s - 1):
+                a = deriv_at(coeffs[:, i], T[:, i], d); b = deriv_at(coeffs[:, i + 1], zero, d)
+                assert np.abs(a - b).max() < 1e-7 * max(1.0, np.abs(a).max())
+    pe = deriv_at(coeffs[:, N - 1], T[:, N - 1], 0)
+    assert np.abs(pe - tail[:, :, 0]).max() < 1e-9 * scale
+    # energy recomputed from coefficients with the true-integral cost block
+    e2 = np.zeros(B)
+    for i in range(N):
+        t = T[:, i]
+        Q = np.array([[100800 * t**7, 50400 * t**6, 20160 * t**5, 5040 * t**4],
+                      [50400 * t**6, 25920 * t**5, 10800 * t**4, 2880 * t**3],
+                      [20160 * t**5, 10800 * t**4, 4800 * t**3, 1440 * t**2],
+                      [5040 * t**4, 2880 * t**3, 1440 * t**2, 576 * t]])      # (4,4,B)
+        z = coeffs[:, i, :, :4]                                               # (B,3,4)
+        e2 += np.einsum("bak,klb,bal->b", z, Q, z)
+    assert np.abs(e2 - energy).max() / energy.max() < 1e-9
