@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Benchmark of the MINCO hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_PER_GPU] [--pieces 8] [--order 4]
+
+One "step" = one pass of the hot path over one batch of synthetic input: for every trajectory of
+the batch the banded minimum-control-effort coefficient solve + energy (BASELINE.json configs[1]:
+8-segment min-snap, random waypoints, energy-only), inputs already resident in HBM in the library's
+batch-minor layout, followed (N > 1) by the all-gather of the per-trajectory costs over RCCL/xGMI
+that the north star names.  Batches shard across ranks (weak scaling, fixed per-GPU batch).
+
+Prints ONE JSON line (rank 0).  `value` is whole-job trajectories/s.  Extra objects:
+  roofline      dominant kernel (k_minco_solve) against HBM: algorithmic bytes / mean kernel time
+                measured with HIP events on the launch stream
+  cpu_baseline  the C oracle (classic banded-LU MINCO, oracle/minco_oracle.c) on the host cores
+  config1_b1024 the literal configs[1] batch (B=1024), which is launch-latency bound
+  host_api      PCIe-inclusive rate through the host-pointer entry point (never `value`)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s measured copy
+
+
+def algorithmic_bytes(s, c, N):
+    """compulsory FP64 read+write once per trajectory, energy-only solve."""
+    return 8 * (2 * 3 * c + N + 3 * (N - 1) + 3 * 2 * s * N + 1)
+
+
+def synth_batch_minor(torch, B, ld, N, c, seed, device):
+    """SURVEY.md 8(d) config 2 generator, produced directly on the device in batch-minor layout:
+    random walk, step ~U(1,3) m in a random direction, z clamped to [0,5]; T ~U(0.5,2); rest-to-rest."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    f64 = torch.float64
+    d = torch.randn(N, 3, ld, generator=g, device=device, dtype=f64)
+    d = d / d.norm(dim=1, keepdim=True)
+    d = d * (1.0 + 2.0 * torch.rand(N, 1, ld, generator=g, device=device, dtype=f64))
+    pts = torch.cat([torch.zeros(1, 3, ld, device=device, dtype=f64), torch.cumsum(d, dim=0)], dim=0)
+    pts[:, 2] = (pts[:, 2] + 1.0).clamp(0.0, 5.0)
+    head = torch.zeros(3, c, ld, device=device, dtype=f64)
+    tail = torch.zeros(3, c, ld, device=device, dtype=f64)
+    head[:, 0] = pts[0]
+    tail[:, 0] = pts[N]
+    wps = pts[1:N].contiguous().view((N - 1) * 3, ld)
+    T = 0.5 + 1.5 * torch.rand(N, ld, generator=g, device=device, dtype=f64)
+    return head.view(3 * c, ld), tail.view(3 * c, ld), wps, T
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="trajectories per GPU per step")
+    ap.add_argument("--pieces", type=int, default=8)
+    ap.add_argument("--order", type=int, default=4)
+    ap.add_argument("--bc", type=int, default=3, help="boundary derivatives fixed per end (3 = reference PVA)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import allocnet_amd as aa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (allocnet_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    s, c, N, B = args.order, args.bc, args.pieces, args.batch
+    D = 2 * s
+    ld = (B + 63) // 64 * 64
+    ctx = aa.Context(local_rank)
+    head, tail, wps, T = synth_batch_minor(torch, B, ld, N, c, seed=rank, device=device)
+    coeffs = torch.empty(N * 3 * D, ld, device=device, dtype=torch.float64)
+    energy = torch.empty(ld, device=device, dtype=torch.float64)
+    gathered = torch.empty(world * ld, device=device, dtype=torch.float64) if world > 1 else None
+
+    def step():
+        aa.minco_solve_dev(head, tail, wps, T, s, c, N, B, coeffs=coeffs, energy=energy, ctx=ctx)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, energy)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        aa.minco_solve_dev(head, tail, wps, T, s, c, N, B, coeffs=coeffs, energy=energy, ctx=ctx)
+        ev[i][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, energy)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total = world * B * args.steps
+    value = total / elapsed
+    abytes = algorithmic_bytes(s, c, N)
+    achieved = B * abytes / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "MINCO trajectories solved/sec (8-seg min-snap)",
+        "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"configs[1] problem ({N}-segment order-{s} MINCO, random-walk waypoints, "
+                               f"energy-only, PVA boundary c={c}) at saturating batch {B}/GPU",
+                   "batch_per_gpu": B, "pieces": N, "order": s, "global_batch": world * B,
+                   "parallelism": f"dp{world}" + ("+allgather(costs)" if world > 1 else "")},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_minco_solve", "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_trajectory": abytes,
+                     "frac_of_measured_copy_6290": achieved / 6290.0},
+    }
+
+    if world == 1:
+        # literal configs[1]: B = 1024 (launch-latency bound; reported, not the headline)
+        b2 = 1024
+        K2 = 200
+        for _ in range(20):
+            aa.minco_solve_dev(head, tail, wps, T, s, c, N, b2, coeffs=coeffs, energy=energy, ctx=ctx)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(K2):
+            aa.minco_solve_dev(head, tail, wps, T, s, c, N, b2, coeffs=coeffs, energy=energy, ctx=ctx)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["config1_b1024"] = {"batch": b2, "value": b2 * K2 / dt, "ms_per_step": dt / K2 * 1e3,
+                                "stream_ms_per_step": e0.elapsed_time(e1) / K2,
+                                "hbm_frac": b2 * abytes / (e0.elapsed_time(e1) / K2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "launch-latency bound: 2 MB per launch"}
+        # PCIe-inclusive host API
+        import numpy as np
+        from tests.util import random_problem
+        rng = np.random.default_rng(0)
+        bh = 1 << 16
+        h_head, h_tail, h_wps, h_T = random_problem(rng, bh, N, c, rest=True)
+        aa.minco_solve(h_head, h_tail, h_wps, h_T, s, ctx=ctx)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            aa.minco_solve(h_head, h_tail, h_wps, h_T, s, ctx=ctx)
+        out["host_api"] = {"batch": bh, "value": 3 * bh / (time.perf_counter() - t0),
+                           "note": "host pointers in/out, PCIe + layout transposes included"}
+
+        if not args.no_cpu_baseline:
+            from oracle import cbind
+            nthreads = os.cpu_count() or 1
+            probe = 2000
+            hp, tp, wp, Tp = random_problem(rng, probe, N, c, rest=True)
+            t0 = time.perf_counter()
+            cbind.minco_solve_batch(s, hp, tp, wp, Tp, nthreads=nthreads)
+            rate = probe / max(time.perf_counter() - t0, 1e-6)
+            n_cpu = int(min(max(rate * args.cpu_seconds, 4000), 4_000_000))
+            hp, tp, wp, Tp = random_problem(rng, n_cpu, N, c, rest=True)
+            t0 = time.perf_counter()
+            co_cpu, en_cpu = cbind.minco_solve_batch(s, hp, tp, wp, Tp, nthreads=nthreads)
+            dt = time.perf_counter() - t0
+            # the same sample through the GPU path must agree with the CPU oracle
+            co_gpu, en_gpu = aa.minco_solve(hp[:4096], tp[:4096], wp[:4096], Tp[:4096], s, ctx=ctx)
+            err = float(np.abs(co_gpu - co_cpu[:4096]).max() / np.abs(co_cpu[:4096]).max())
+            out["cpu_baseline"] = {"value": n_cpu / dt, "unit": "trajectories/s", "cores": nthreads,
+                                   "kind": "port",
+                                   "sample": f"{n_cpu} trajectories of the same workload, classic banded-LU "
+                                             f"MINCO in C (oracle/minco_oracle.c), {nthreads} threads",
+                                   "gpu_vs_cpu_max_rel_coeff_err": err}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
