@@ -65,9 +65,10 @@ struct Factor {
     for (int j = 0; j < m; ++j)
 #pragma unroll
       for (int l = 0; l < m; ++l) {
-        double v = Tab<S>::M[1 + j][S + 1 + l] * p[2 * S - 3 - j - l];
-        if ((i == 0 && j < np) || (i == N - 1 && l < np)) v = 0.0;
-        Ko[j][l] = v;
+        // pinned rows/columns of an end node are masked on the (wave-uniform) constant
+        const double mc =
+            ((i == 0 && j < np) || (i == N - 1 && l < np)) ? 0.0 : Tab<S>::M[1 + j][S + 1 + l];
+        Ko[j][l] = mc * p[2 * S - 3 - j - l];
       }
   }
   // Y = L_k^-1 Ko (column-wise unit-lower forward substitution)
@@ -211,8 +212,8 @@ __device__ __forceinline__ double solve_axis(const Factor<S, NB> &F, int N, int 
               if (j < np && l >= np)
                 y[l] = __builtin_fma(-Tab<S>::M[1 + l][1 + j] * p[2 * S - 3 - l - j], hv[j], y[l]);
         }
-        if (k == N) {
-          Pw<S> p(rr[N - 1]);
+        if (k == N && k > 0) {
+          Pw<S> p(rr[k > 0 ? k - 1 : 0]);
 #pragma unroll
           for (int l = 0; l < m; ++l)
 #pragma unroll
