@@ -7,4 +7,6 @@ from ._lib import AnetError, load, LIB_PATH  # noqa: F401
 from .context import Context, default_context  # noqa: F401
 from .minco import MINCO, MINCO_S2NU, MINCO_S3NU, MINCO_S4NU, minco_solve, minco_solve_dev  # noqa: F401
 
+from .trajectory import Piece, Trajectory, traj_eval, traj_cost  # noqa: F401
+
 __version__ = "0.1.0"

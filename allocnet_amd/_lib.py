@@ -31,6 +31,13 @@ PROTOTYPES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "anet_minco_solve": (c_int, [c_void_p, c_int, c_int, c_int, c_int64,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anet_traj_eval_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
+                                   c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "anet_traj_eval": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
+                               c_int, c_void_p, c_int, c_void_p]),
+    "anet_traj_cost_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
+                                   c_double, c_void_p, c_void_p]),
+    "anet_traj_cost": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_double, c_void_p]),
 }
 
 _lib = None

@@ -77,6 +77,108 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_solve(SolveArgs a) {
   if (a.energy) a.energy[b] = etot;
 }
 
+// Trajectory<D>::getPos/Vel/Acc/Jer: one lane per trajectory, nq queries each.  The accumulation
+// order is the reference's (ascending powers, tn *= t), trajectory.hpp:75-133.
+struct EvalArgs {
+  const double *coeffs, *T, *tq;
+  double *out;
+  int64_t B, ld;
+  int N, nq, deriv;
+};
+template <int S>
+__global__ void __launch_bounds__(256) k_traj_eval(EvalArgs a) {
+  constexpr int D = 2 * S, DEG = D - 1;
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const int64_t ld = a.ld;
+  const int N = a.N, d = a.deriv;
+  for (int q = 0; q < a.nq; ++q) {
+    double t = a.tq[(int64_t)q * ld + b];
+    // locatePieceIdx (trajectory.hpp:496-514)
+    int idx = 0;
+    double dur = 0.0;
+    for (; idx < N; ++idx) {
+      dur = a.T[(int64_t)idx * ld + b];
+      if (!(t > dur)) break;
+      t -= dur;
+    }
+    if (idx == N) {
+      --idx;
+      t += a.T[(int64_t)idx * ld + b];
+    }
+    const double *cm = a.coeffs + (int64_t)(idx * 3 * D) * ld + b;
+    double acc[3] = {0.0, 0.0, 0.0};
+    double tn = 1.0;
+    for (int i = DEG - d; i >= 0; --i) {
+      const int k = DEG - i;  // power of column i
+      double f = 1.0;
+      for (int e = 0; e < d; ++e) f *= (double)(k - e);
+      const double w = f * tn;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) acc[ax] += w * cm[(int64_t)(ax * D + i) * ld];
+      tn *= t;
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) a.out[(int64_t)(q * 3 + ax) * ld + b] = acc[ax];
+  }
+}
+
+// Trajectory<D>::getTrajCost (trajectory.hpp:354-427).
+struct CostArgs {
+  const double *coeffs, *T;
+  double *cost;
+  int64_t B, ld;
+  int N;
+  double m34;
+};
+template <int S>
+__global__ void __launch_bounds__(256) k_traj_cost(CostArgs a) {
+  constexpr int D = 2 * S;
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const int64_t ld = a.ld;
+  double energy = 0.0;
+  for (int i = 0; i < a.N; ++i) {
+    const double t = a.T[(int64_t)i * ld + b];
+    const double t2 = t * t, t3 = t * t2, t4 = t2 * t2, t5 = t2 * t3;
+    double Q[S][S];
+    if constexpr (S == 4) {
+      const double t6 = t3 * t3, t7 = t4 * t3;
+      Q[0][0] = 100800 * t7; Q[0][1] = 50400 * t6; Q[0][2] = 20160 * t5; Q[0][3] = 5040 * t4;
+      Q[1][1] = 25920 * t5;  Q[1][2] = 10800 * t4; Q[1][3] = 2880 * t3;
+      Q[2][2] = 4800 * t3;   Q[2][3] = a.m34 * t2;
+      Q[3][3] = 576 * t;
+    } else if constexpr (S == 3) {
+      Q[0][0] = 720 * t5; Q[0][1] = 360 * t4; Q[0][2] = 120 * t3;
+      Q[1][1] = 192 * t3; Q[1][2] = 72 * t2;
+      Q[2][2] = 36 * t;
+    } else {
+      Q[0][0] = 12 * t3; Q[0][1] = 6 * t2;
+      Q[1][1] = 4 * t;
+    }
+#pragma unroll
+    for (int j = 1; j < S; ++j)
+#pragma unroll
+      for (int k = 0; k < j; ++k) Q[j][k] = Q[k][j];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      double z[S];
+#pragma unroll
+      for (int j = 0; j < S; ++j) z[j] = a.coeffs[(int64_t)((i * 3 + ax) * D + j) * ld + b];
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) r += Q[j][k] * z[k];
+        acc += z[j] * r;
+      }
+      energy += 0.5 * acc;
+    }
+  }
+  a.cost[b] = energy;
+}
+
 // dst[f*ld + b] = src[b*nf + f] through a padded LDS tile (both sides coalesced).
 constexpr int kTile = 32;
 __global__ void __launch_bounds__(kTile * 8) k_to_batch_minor(const double *__restrict__ src,
@@ -346,6 +448,125 @@ int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
   if (energy)
     ANET_HIP(ctx, hipMemcpyAsync(energy, s_en, sizeof(double) * batch, hipMemcpyDeviceToHost, st));
   ANET_HIP(ctx, hipStreamSynchronize(st));
+  return ANET_OK;
+}
+
+int anet_traj_eval_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
+                       const double *coeffs, const double *T, int nq, const double *tq, int deriv,
+                       double *out, void *stream) {
+  int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
+  if (rc) return rc;
+  if (deriv < 0 || deriv > 3 || nq < 0) return fail(ctx, ANET_ERR_INVALID, "anet_traj_eval: deriv in [0,3], nq >= 0");
+  if (batch == 0 || nq == 0) return ANET_OK;
+  if (!coeffs || !T || !tq || !out || ld < batch) return fail(ctx, ANET_ERR_INVALID, "anet_traj_eval_dev: NULL pointer or ld < batch");
+  anet::EvalArgs a{coeffs, T, tq, out, batch, ld, n_pieces, nq, deriv};
+  const dim3 grid((unsigned)((batch + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (s == 2) hipLaunchKernelGGL(anet::k_traj_eval<2>, grid, block, 0, st, a);
+  else if (s == 3) hipLaunchKernelGGL(anet::k_traj_eval<3>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(anet::k_traj_eval<4>, grid, block, 0, st, a);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+int anet_traj_cost_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
+                       const double *coeffs, const double *T, double m34, double *cost, void *stream) {
+  int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
+  if (rc) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!coeffs || !T || !cost || ld < batch) return fail(ctx, ANET_ERR_INVALID, "anet_traj_cost_dev: NULL pointer or ld < batch");
+  anet::CostArgs a{coeffs, T, cost, batch, ld, n_pieces, m34};
+  const dim3 grid((unsigned)((batch + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (s == 2) hipLaunchKernelGGL(anet::k_traj_cost<2>, grid, block, 0, st, a);
+  else if (s == 3) hipLaunchKernelGGL(anet::k_traj_cost<3>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(anet::k_traj_cost<4>, grid, block, 0, st, a);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+// Host (trajectory-major) wrappers: stage -> batch-minor -> kernel -> back.
+namespace {
+struct Stager {
+  anet_ctx *ctx;
+  int64_t batch, ld;
+  double *stage;   // batch * max_fields doubles
+  double *cursor;  // next free batch-minor region
+  int upload(const double *host, int64_t nf, double **dev) {
+    *dev = cursor;
+    cursor += nf * ld;
+    if (nf == 0) return ANET_OK;
+    hipError_t e = hipMemcpyAsync(stage, host, sizeof(double) * batch * nf, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpyAsync(H2D)");
+    return anet_to_batch_minor_dev(ctx, batch, nf, ld, stage, *dev, ctx->stream);
+  }
+  double *reserve(int64_t nf) {
+    double *p = cursor;
+    cursor += nf * ld;
+    return p;
+  }
+  int download(const double *dev, int64_t nf, double *host) {
+    int rc = anet_to_traj_major_dev(ctx, batch, nf, ld, dev, stage, ctx->stream);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(host, stage, sizeof(double) * batch * nf, hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpyAsync(D2H)");
+    // the staging buffer is reused by the next transfer
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamSynchronize");
+    return ANET_OK;
+  }
+};
+int make_stager(anet_ctx *ctx, int64_t batch, int64_t max_field, int64_t total_fields, Stager *st) {
+  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t ld = round_up(batch, 64);
+  int rc = ensure_scratch(ctx, sizeof(double) * (size_t)(batch * max_field + total_fields * ld));
+  if (rc) return rc;
+  st->ctx = ctx; st->batch = batch; st->ld = ld;
+  st->stage = (double *)ctx->scratch;
+  st->cursor = st->stage + batch * max_field;
+  return ANET_OK;
+}
+}  // namespace
+
+int anet_traj_eval(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
+                   const double *T, int nq, const double *tq, int deriv, double *out) {
+  int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
+  if (rc) return rc;
+  if (batch == 0 || nq <= 0) return nq < 0 ? fail(ctx, ANET_ERR_INVALID, "nq < 0") : ANET_OK;
+  if (!coeffs || !T || !tq || !out) return fail(ctx, ANET_ERR_INVALID, "anet_traj_eval: NULL pointer");
+  const int64_t nco = (int64_t)n_pieces * 3 * 2 * s;
+  const int64_t mx = nco > 3 * (int64_t)nq ? nco : 3 * (int64_t)nq;
+  Stager st;
+  rc = make_stager(ctx, batch, mx, nco + n_pieces + nq + 3 * (int64_t)nq, &st);
+  if (rc) return rc;
+  double *d_co, *d_T, *d_tq;
+  if ((rc = st.upload(coeffs, nco, &d_co))) return rc;
+  if ((rc = st.upload(T, n_pieces, &d_T))) return rc;
+  if ((rc = st.upload(tq, nq, &d_tq))) return rc;
+  double *d_out = st.reserve(3 * (int64_t)nq);
+  rc = anet_traj_eval_dev(ctx, s, n_pieces, batch, st.ld, d_co, d_T, nq, d_tq, deriv, d_out, ctx->stream);
+  if (rc) return rc;
+  return st.download(d_out, 3 * (int64_t)nq, out);
+}
+
+int anet_traj_cost(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
+                   const double *T, double m34, double *cost) {
+  int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
+  if (rc) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!coeffs || !T || !cost) return fail(ctx, ANET_ERR_INVALID, "anet_traj_cost: NULL pointer");
+  const int64_t nco = (int64_t)n_pieces * 3 * 2 * s;
+  Stager st;
+  rc = make_stager(ctx, batch, nco, nco + n_pieces + 1, &st);
+  if (rc) return rc;
+  double *d_co, *d_T;
+  if ((rc = st.upload(coeffs, nco, &d_co))) return rc;
+  if ((rc = st.upload(T, n_pieces, &d_T))) return rc;
+  double *d_cost = st.reserve(1);
+  rc = anet_traj_cost_dev(ctx, s, n_pieces, batch, st.ld, d_co, d_T, m34, d_cost, ctx->stream);
+  if (rc) return rc;
+  ANET_HIP(ctx, hipMemcpyAsync(cost, d_cost, sizeof(double) * batch, hipMemcpyDeviceToHost, ctx->stream));
+  ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ANET_OK;
 }
 

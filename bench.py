@@ -33,6 +33,24 @@ def algorithmic_bytes(s, c, N):
     return 8 * (2 * 3 * c + N + 3 * (N - 1) + 3 * 2 * s * N + 1)
 
 
+def pmc_traffic_bytes(B, N, s):
+    """HBM bytes per launch of k_minco_solve from the committed rocprofv3 PMC passes
+    (profiles/*_pmc.json, written by tools/summarize_prof.py): WRITE_SIZE + 2 x FETCH_SIZE in KiB
+    (gfx950 FETCH_SIZE counts half of a coalesced read stream, MI355X_MICROARCH.md, HBM section).
+    None when no profile of this launch shape is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for e in d.get("k_minco_solve", []):
+            if e.get("grid") == B and e.get("pieces") == N and e.get("order") == s:
+                best = (2.0 * e["fetch_kib"] + e["write_kib"]) * 1024.0
+    return best
+
+
 def synth_batch_minor(torch, B, ld, N, c, seed, device):
     """SURVEY.md 8(d) config 2 generator, produced directly on the device in batch-minor layout:
     random walk, step ~U(1,3) m in a random direction, z clamped to [0,5]; T ~U(0.5,2); rest-to-rest."""
@@ -63,6 +81,8 @@ def main():
     ap.add_argument("--order", type=int, default=4)
     ap.add_argument("--bc", type=int, default=3, help="boundary derivatives fixed per end (3 = reference PVA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--main-only", action="store_true",
+                    help="only the timed main workload (used under rocprofv3 so kernel stats are not mixed)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -149,7 +169,8 @@ def main():
                      "frac_of_measured_copy_6290": achieved / 6290.0},
     }
 
-    if world == 1:
+    out["roofline"]["traffic"] = pmc_traffic_bytes(B, N, s)
+    if world == 1 and not args.main_only:
         # literal configs[1]: B = 1024 (launch-latency bound; reported, not the headline)
         b2 = 1024
         K2 = 200

@@ -98,6 +98,34 @@ int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch,
                      double *coeffs,      /* [batch][N][3][2s] */
                      double *energy);     /* [batch]           */
 
+/* ---- Trajectory<D> evaluation --------------------------------------------------------- */
+/* Replaces Trajectory<D>::getPos/getVel/getAcc/getJer (gcopter/trajectory.hpp:516-538) =
+ * locatePieceIdx (:496-514, including its clamp to the last piece for t beyond the total
+ * duration) + Piece<D>::getPos/getVel/getAcc/getJer (:75-133), and network/utils/trajectory.py
+ * get_pos/get_vel/get_acc (:47-98), batched: nq query times per trajectory.
+ * deriv: 0 position, 1 velocity, 2 acceleration, 3 jerk.                                      */
+int anet_traj_eval_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
+                       const double *coeffs, /* [N*3*2s][ld] */
+                       const double *T,      /* [N][ld]      */
+                       int nq, const double *tq, /* [nq][ld] absolute times from trajectory start */
+                       int deriv, double *out,   /* [nq*3][ld]  (query-major, then axis) */
+                       void *stream);
+int anet_traj_eval(anet_ctx *ctx, int s, int n_pieces, int64_t batch,
+                   const double *coeffs, /* [batch][N][3][2s] */
+                   const double *T,      /* [batch][N]        */
+                   int nq, const double *tq, /* [batch][nq]   */
+                   int deriv, double *out);  /* [batch][nq][3] */
+
+/* Replaces Trajectory<D>::getTrajCost(order) (gcopter/trajectory.hpp:354-427):
+ * sum over pieces and axes of 1/2 z' Q_s(T) z on the s highest coefficients.  m34 is the (3,4)
+ * entry constant of the snap block: 1400.0 reproduces the reference (qp_solver.hpp:212,
+ * trajectory.hpp:385, min_traj_opt.py:493), 1440.0 is the true integral.  Ignored for s != 4. */
+int anet_traj_cost_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
+                       const double *coeffs, const double *T, double m34, double *cost /* [batch] */,
+                       void *stream);
+int anet_traj_cost(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
+                   const double *T, double m34, double *cost);
+
 #ifdef __cplusplus
 }
 #endif

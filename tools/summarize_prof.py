@@ -22,7 +22,7 @@ for f in find("trace/**/*kernel_trace.csv"):
     d = defaultdict(list)
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            key = (row["Kernel_Name"][:70], row.get("Grid_Size", "?"), row.get("VGPR_Count", "?"),
+            key = (row["Kernel_Name"][:70], row.get("Grid_Size_X", row.get("Grid_Size", "?")), row.get("VGPR_Count", "?"),
                    row.get("Accum_VGPR_Count", "?"), row.get("SGPR_Count", "?"))
             d[key].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:8]:
@@ -42,3 +42,24 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
             for cn, v in cs.items():
                 print(f"{k[:80]:80s} {cn:22s} n={len(v):4d} mean={sum(v)/len(v):.6g} max={max(v):.6g}")
     print()
+
+# machine-readable PMC summary for bench.py's roofline.traffic
+if len(sys.argv) > 2:
+    import json, re
+    tag = sys.argv[2]
+    acc = defaultdict(dict)
+    for name, cn in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        for f in find(f"{name}/**/*counter_collection.csv"):
+            tmp = defaultdict(list)
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    m = re.match(r"void anet::k_minco_solve<(\d+), (\d+)", row["Kernel_Name"])
+                    if m and row["Counter_Name"] == cn:
+                        tmp[(int(m.group(1)), int(m.group(2)), int(row["Grid_Size"]))].append(float(row["Counter_Value"]))
+            for k, v in tmp.items():
+                acc[k][cn] = sum(v) / len(v)
+    entries = [{"order": k[0], "pieces": k[1], "grid": k[2], "fetch_kib": v.get("FETCH_SIZE"),
+                "write_kib": v.get("WRITE_SIZE")} for k, v in sorted(acc.items())
+               if "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+    with open(os.path.join(out, f"{tag}_pmc.json"), "w") as fh:
+        json.dump({"k_minco_solve": entries, "note": "mean per launch; KiB as reported by rocprofv3"}, fh, indent=1)
