@@ -38,7 +38,22 @@ PROTOTYPES = {
     "anet_traj_cost_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
                                    c_double, c_void_p, c_void_p]),
     "anet_traj_cost": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_double, c_void_p]),
+    "anet_minco_partial_grads_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anet_minco_propagate_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anet_minco_cost_grad_workspace": (c_int64, [c_int, c_int, c_int64]),
+    "anet_minco_cost_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64] + [c_void_p] * 12),
+    "anet_minco_cost_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_int64] + [c_void_p] * 10),
 }
+
+
+class Penalty(ctypes.Structure):
+    """struct anet_penalty (include/allocnet_amd.h)."""
+    _fields_ = [("rho", c_double), ("w_corridor", c_double), ("w_vel", c_double), ("w_acc", c_double),
+                ("smooth_mu", c_double), ("max_vel", c_double), ("max_acc", c_double),
+                ("res", ctypes.c_int32), ("poly_rows", ctypes.c_int32)]
+
 
 _lib = None
 

@@ -179,6 +179,342 @@ __global__ void __launch_bounds__(256) k_traj_cost(CostArgs a) {
   a.cost[b] = energy;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// cost / gradient path: partial gradients per piece, then adjoint propagation per trajectory
+// ------------------------------------------------------------------------------------------
+struct Penalty {
+  double rho, wc, wv, wa, mu, vmax, amax;
+  int res, M;
+};
+
+// firi::smoothedL1 (gcopter/firi.hpp:60-84), 0 below 0.
+__device__ __forceinline__ void smoothed_l1(double mu, double inv_mu, double x, double &f, double &df) {
+  const double xd = x * inv_mu, sq = xd * xd, mm = __builtin_fma(-0.5, x, mu);
+  double fm = mm * sq * xd, dm = sq * __builtin_fma(-0.5, xd, 3.0 * mm * inv_mu);
+  const bool hi = x > mu, neg = x < 0.0;
+  f = neg ? 0.0 : (hi ? x - 0.5 * mu : fm);
+  df = neg ? 0.0 : (hi ? 1.0 : dm);
+}
+
+struct PieceGradArgs {
+  const double *coeffs, *T, *hpolys;
+  double *gdC, *gdT, *pcost;
+  int64_t B, ld;
+  int N, with_energy, with_penalty;
+  Penalty pp;
+};
+
+// One lane per (trajectory, piece): blockIdx.y = piece.  Writes (not accumulates) the partial
+// gradients of  [with_energy] int (p^(s))^2  +  [with_penalty] J_pen  w.r.t. the piece's
+// coefficients and duration.  J_pen = (T/res) sum_{j<res} [wc sum_rows phi(a.p-b) + wv sum phi(+-v-vmax)
+// + wa sum phi(+-a-amax)] sampled at t = j T/res: the rows of the reference's inequality block
+// (qp_solver.hpp:244-296 / min_traj_opt.py:535-613) turned into a smoothed-L1 penalty.
+template <int S>
+__global__ void __launch_bounds__(256) k_piece_grad(PieceGradArgs a) {
+  constexpr int D = 2 * S;
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const int i = blockIdx.y;
+  const int64_t ld = a.ld;
+  const double Ti = a.T[(int64_t)i * ld + b];
+  double c[3][D], gC[3][D];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+    for (int col = 0; col < D; ++col) {
+      c[ax][col] = a.coeffs[(int64_t)((i * 3 + ax) * D + col) * ld + b];
+      gC[ax][col] = 0.0;
+    }
+  double gT = 0.0, pc = 0.0;
+  if (a.with_energy) {
+    // d/dc of sum_{j,k>=S} c_j c_k f_j f_k T^(j+k-2S+1)/(j+k-2S+1) ;  d/dT = (p^(S)(T))^2
+    double tp[D];
+    tp[0] = 1.0;
+#pragma unroll
+    for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      double ps = 0.0;
+#pragma unroll
+      for (int j = S; j < D; ++j) {
+        double fj = 1.0;
+#pragma unroll
+        for (int e = 0; e < S; ++e) fj *= (double)(j - e);
+        ps = __builtin_fma(fj * tp[j - S], c[ax][D - 1 - j], ps);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = S; k < D; ++k) {
+          double fk = 1.0;
+#pragma unroll
+          for (int e = 0; e < S; ++e) fk *= (double)(k - e);
+          acc = __builtin_fma(2.0 * fj * fk / (double)(j + k - 2 * S + 1) * tp[j + k - 2 * S + 1],
+                              c[ax][D - 1 - k], acc);
+        }
+        gC[ax][D - 1 - j] = acc;
+      }
+      gT = __builtin_fma(ps, ps, gT);
+    }
+  }
+  if (a.with_penalty) {
+    const Penalty pp = a.pp;
+    const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
+    const double step = Ti * inv_res;
+    for (int j = 0; j < pp.res; ++j) {
+      const double t = (double)j * step;
+      double tp[D];
+      tp[0] = 1.0;
+#pragma unroll
+      for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * t;
+      double be[4][D];  // basis rows p,v,a,j at t (highest power first)
+#pragma unroll
+      for (int col = 0; col < D; ++col) {
+        const int k = D - 1 - col;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          double f = 1.0;
+#pragma unroll
+          for (int e = 0; e < d; ++e) f *= (double)(k - e);
+          be[d][col] = (k >= d) ? f * tp[k >= d ? k - d : 0] : 0.0;
+        }
+      }
+      double st[4][3];
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          double acc = 0.0;
+#pragma unroll
+          for (int col = 0; col < D; ++col) acc = __builtin_fma(c[ax][col], be[d][col], acc);
+          st[d][ax] = acc;
+        }
+      double cost = 0.0, g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // d cost / d (p,v,a)
+      if (a.hpolys) {
+        const double *hp = a.hpolys + (int64_t)(i * pp.M * 4) * ld + b;
+        for (int r = 0; r < pp.M; ++r) {
+          const double a0 = hp[(int64_t)(r * 4 + 0) * ld], a1 = hp[(int64_t)(r * 4 + 1) * ld];
+          const double a2 = hp[(int64_t)(r * 4 + 2) * ld], bb = hp[(int64_t)(r * 4 + 3) * ld];
+          const double viol = __builtin_fma(a0, st[0][0], __builtin_fma(a1, st[0][1], a2 * st[0][2])) - bb;
+          double f, df;
+          smoothed_l1(pp.mu, inv_mu, viol, f, df);
+          cost = __builtin_fma(pp.wc, f, cost);
+          df *= pp.wc;
+          g[0][0] = __builtin_fma(df, a0, g[0][0]);
+          g[0][1] = __builtin_fma(df, a1, g[0][1]);
+          g[0][2] = __builtin_fma(df, a2, g[0][2]);
+        }
+      }
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          const double sgn = sg ? -1.0 : 1.0;
+          double f, df;
+          smoothed_l1(pp.mu, inv_mu, sgn * st[1][ax] - pp.vmax, f, df);
+          cost = __builtin_fma(pp.wv, f, cost);
+          g[1][ax] = __builtin_fma(pp.wv * sgn, df, g[1][ax]);
+          smoothed_l1(pp.mu, inv_mu, sgn * st[2][ax] - pp.amax, f, df);
+          cost = __builtin_fma(pp.wa, f, cost);
+          g[2][ax] = __builtin_fma(pp.wa * sgn, df, g[2][ax]);
+        }
+      }
+      pc = __builtin_fma(step, cost, pc);
+      double dt = 0.0;  // d cost / d t = g_p.v + g_v.a + g_a.j
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) dt = __builtin_fma(g[d][ax], st[d + 1][ax], dt);
+      gT += cost * inv_res + step * dt * ((double)j * inv_res);
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+        for (int col = 0; col < D; ++col) {
+          double acc = g[0][ax] * be[0][col];
+          acc = __builtin_fma(g[1][ax], be[1][col], acc);
+          acc = __builtin_fma(g[2][ax], be[2][col], acc);
+          gC[ax][col] = __builtin_fma(step, acc, gC[ax][col]);
+        }
+    }
+  }
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+    for (int col = 0; col < D; ++col) a.gdC[(int64_t)((i * 3 + ax) * D + col) * ld + b] = gC[ax][col];
+  a.gdT[(int64_t)i * ld + b] = gT;
+  if (a.pcost) a.pcost[(int64_t)i * ld + b] = pc;
+}
+
+struct PropArgs {
+  const double *T, *coeffs, *gdC, *gdT;
+  double *gradP, *gradT;
+  // optional total cost: cost = energy_in + rho sum T + sum_i pcost_i ; gradT += rho
+  const double *energy_in, *pcost;
+  double *cost;
+  double rho;
+  int64_t B, ld;
+  int N, c;
+};
+
+// MINCO propogateGrad: given the partial gradients (gdC, gdT) of a scalar J(c, T), return its total
+// gradient w.r.t. the interior waypoints and the durations, c = c(waypoints, T) being the minimum-
+// control-effort coefficients.  Adjoint of the Hermite/block-tridiagonal solve:
+//   g_x = Phi' gdC (node-state adjoint), K lam = g_x|free, gradP_k = g_x[k].p - (W lam^)[p rows],
+//   gradT_i = gdT_i + gdC_i.(dPhi_i/dT) x^ - lam^' (dW_i/dT) x^.
+template <int S, int NB, bool NEXACT = false, int NPC = -1>
+__global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
+  constexpr int m = S - 1, D = 2 * S;
+  const int64_t b = (int64_t)blockIdx.x * kSolveBlock + threadIdx.x;
+  if (b >= a.B) return;
+  const int N = NEXACT ? NB : a.N;
+  const int np = NPC >= 0 ? NPC : a.c - 1;
+  const int64_t ld = a.ld;
+
+  Factor<S, NB> F;
+  double gT[NB];
+  double tsum = 0.0, Tlast = 0.0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < N) {
+      const double t = a.T[i * ld + b];
+      F.r[i] = fast_rcp(t);
+      gT[i] = a.gdT[i * ld + b];
+      tsum += t;
+      if (i == N - 1) Tlast = t;
+    }
+  F.factorize(N, np);
+
+#pragma unroll 1
+  for (int ax = 0; ax < 3; ++ax) {
+    double rr[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
+    // ---- node states from the coefficients: x_k[j] = j! c_j(piece k); last node by evaluation
+    double XS[NB + 1][S], GX[NB + 1][S], XA[NB + 1][m];
+#pragma unroll
+    for (int k = 0; k <= NB; ++k)
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        XS[k][j] = 0.0;
+        GX[k][j] = 0.0;
+      }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (k < N) {
+        double fact = 1.0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          if (j > 0) fact *= (double)j;
+          XS[k][j] = fact * a.coeffs[(int64_t)((k * 3 + ax) * D + (D - 1 - j)) * ld + b];
+        }
+        if (k == N - 1) {
+          double cl[D], tp[D];
+          tp[0] = 1.0;
+#pragma unroll
+          for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Tlast;
+#pragma unroll
+          for (int col = 0; col < D; ++col) cl[col] = a.coeffs[(int64_t)((k * 3 + ax) * D + col) * ld + b];
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int p = j; p < D; ++p) {
+              double f = 1.0;
+#pragma unroll
+              for (int e = 0; e < j; ++e) f *= (double)(p - e);
+              acc = __builtin_fma(f * tp[p - j], cl[D - 1 - p], acc);
+            }
+            XS[k + 1][j] = acc;
+          }
+        }
+      }
+    // ---- g_x = Phi' gdC and the direct dPhi/dT term
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (i < N) {
+        Pw<S> p(rr[i]);
+        double gc[D];
+#pragma unroll
+        for (int col = 0; col < D; ++col) gc[col] = a.gdC[(int64_t)((i * 3 + ax) * D + col) * ld + b];
+        // low powers k < S: c_k = x_i[k]/k!
+        double fact = 1.0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+          if (k > 0) fact *= (double)k;
+          GX[i][k] = __builtin_fma(gc[D - 1 - k], 1.0 / fact, GX[i][k]);
+        }
+        double h[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) h[q] = gc[S - 1 - q] * p[q];  // gc of power S+q times r^q
+        double dsum = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < 2 * S; ++bb) {
+          const int dg = bb % S;
+          double u = 0.0, qd = 0.0;
+#pragma unroll
+          for (int q = 0; q < S; ++q) {
+            u = __builtin_fma(Tab<S>::BHI[q][bb], h[q], u);
+            qd = __builtin_fma((double)(S + q - dg) * Tab<S>::BHI[q][bb], h[q], qd);
+          }
+          const double sc = p[S - dg];
+          const double xb = (bb < S) ? XS[i][dg] : XS[i + 1][dg];
+          if (bb < S)
+            GX[i][dg] = __builtin_fma(u, sc, GX[i][dg]);
+          else
+            GX[i + 1][dg] = __builtin_fma(u, sc, GX[i + 1][dg]);
+          dsum = __builtin_fma(xb * sc, qd, dsum);
+        }
+        gT[i] = __builtin_fma(-p[1], dsum, gT[i]);
+      }
+    // ---- adjoint solve K lam = g_x|free (pinned rows 0)
+    sweep_forward<S, NB>(F, N, np, rr, XA, [&](int k, double (&y)[m]) {
+#pragma unroll
+      for (int l = 0; l < m; ++l) y[l] = ((k == 0 || k == N) && l < np) ? 0.0 : GX[k][1 + l];
+    });
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
+    sweep_backward<S, NB>(F, N, np, rr, XA, [&](int k, const Pw<S> &p) {
+      // (W_k lam^)[position row of node k]; the row of node k+1 is its negative
+      double wl = 0.0;
+#pragma unroll
+      for (int l = 0; l < m; ++l) {
+        wl = __builtin_fma(Tab<S>::M[0][1 + l] * p[2 * S - 2 - l], XA[k][l], wl);
+        wl = __builtin_fma(Tab<S>::M[0][S + 1 + l] * p[2 * S - 2 - l], XA[k + 1][l], wl);
+      }
+      GX[k][0] -= wl;
+      GX[k + 1][0] += wl;
+      // - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b
+      double xs[2 * S];
+#pragma unroll
+      for (int bb = 0; bb < 2 * S; ++bb)
+        xs[bb] = ((bb < S) ? XS[k][bb % S] : XS[k + 1][bb % S]) * p[S - bb % S];
+      double acc = 0.0;
+#pragma unroll
+      for (int aa = 0; aa < 2 * S; ++aa) {
+        const int da = aa % S;
+        if (da == 0) continue;
+        double row = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < 2 * S; ++bb)
+          row = __builtin_fma(Tab<S>::M[aa][bb] * (double)(2 * S - 1 - da - bb % S), xs[bb], row);
+        const double ls = ((aa < S) ? XA[k][da - 1] : XA[k + 1][da - 1]) * p[S - da];
+        acc = __builtin_fma(ls, row, acc);
+      }
+      gT[k] += acc;
+    });
+#pragma unroll
+    for (int k = 1; k < NB; ++k)
+      if (k < N) a.gradP[(int64_t)((k - 1) * 3 + ax) * ld + b] = GX[k][0];
+  }
+  double csum = 0.0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < N) {
+      a.gradT[i * ld + b] = gT[i] + a.rho;
+      if (a.pcost) csum += a.pcost[i * ld + b];
+    }
+  if (a.cost) a.cost[b] = (a.energy_in ? a.energy_in[b] : 0.0) + a.rho * tsum + csum;
+}
+
 // dst[f*ld + b] = src[b*nf + f] through a padded LDS tile (both sides coalesced).
 constexpr int kTile = 32;
 __global__ void __launch_bounds__(kTile * 8) k_to_batch_minor(const double *__restrict__ src,
@@ -297,6 +633,26 @@ int launch_solve(anet_ctx *ctx, const anet::SolveArgs &a, hipStream_t st) {
   return ANET_OK;
 }
 
+template <int S>
+int launch_prop(anet_ctx *ctx, const anet::PropArgs &a, hipStream_t st) {
+  const dim3 grid((unsigned)((a.B + anet::kSolveBlock - 1) / anet::kSolveBlock));
+  const dim3 block(anet::kSolveBlock);
+  if (a.N <= 4)
+    hipLaunchKernelGGL((anet::k_minco_propagate<S, 4>), grid, block, 0, st, a);
+  else if (a.N <= 8)
+    hipLaunchKernelGGL((anet::k_minco_propagate<S, 8>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((anet::k_minco_propagate<S, 16>), grid, block, 0, st, a);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+int do_propagate(anet_ctx *ctx, int s, const anet::PropArgs &a, hipStream_t st) {
+  switch (s) {
+    case 2: return launch_prop<2>(ctx, a, st);
+    case 3: return launch_prop<3>(ctx, a, st);
+    default: return launch_prop<4>(ctx, a, st);
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -566,6 +922,127 @@ int anet_traj_cost(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const doub
   rc = anet_traj_cost_dev(ctx, s, n_pieces, batch, st.ld, d_co, d_T, m34, d_cost, ctx->stream);
   if (rc) return rc;
   ANET_HIP(ctx, hipMemcpyAsync(cost, d_cost, sizeof(double) * batch, hipMemcpyDeviceToHost, ctx->stream));
+  ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ANET_OK;
+}
+
+// ---- cost / gradient entry points ---------------------------------------------------------------
+static int check_penalty(anet_ctx *ctx, const anet_penalty *pen) {
+  if (!pen) return ANET_OK;
+  if (!(pen->smooth_mu > 0.0)) return fail(ctx, ANET_ERR_INVALID, "anet_penalty.smooth_mu must be > 0");
+  if (pen->res < 1) return fail(ctx, ANET_ERR_INVALID, "anet_penalty.res must be >= 1");
+  if (pen->poly_rows < 0 || pen->poly_rows > ANET_MAX_POLY_ROWS)
+    return fail(ctx, ANET_ERR_INVALID, "anet_penalty.poly_rows must be in [0, ANET_MAX_POLY_ROWS]");
+  return ANET_OK;
+}
+
+int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
+                                 const double *coeffs, const double *T, const double *hpolys,
+                                 const anet_penalty *pen, int with_energy, double *gdC, double *gdT,
+                                 double *piece_cost, void *stream) {
+  int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
+  if (rc) return rc;
+  if ((rc = check_penalty(ctx, pen))) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!coeffs || !T || !gdC || !gdT || ld < batch)
+    return fail(ctx, ANET_ERR_INVALID, "anet_minco_partial_grads_dev: NULL pointer or ld < batch");
+  anet::PieceGradArgs a{};
+  a.coeffs = coeffs; a.T = T; a.hpolys = (pen && pen->poly_rows > 0) ? hpolys : nullptr;
+  a.gdC = gdC; a.gdT = gdT; a.pcost = piece_cost;
+  a.B = batch; a.ld = ld; a.N = n_pieces; a.with_energy = with_energy ? 1 : 0; a.with_penalty = pen ? 1 : 0;
+  if (pen) a.pp = anet::Penalty{pen->rho, pen->w_corridor, pen->w_vel, pen->w_acc, pen->smooth_mu,
+                               pen->max_vel, pen->max_acc, pen->res, pen->poly_rows};
+  const dim3 grid((unsigned)((batch + 255) / 256), (unsigned)n_pieces), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (s == 2) hipLaunchKernelGGL(anet::k_piece_grad<2>, grid, block, 0, st, a);
+  else if (s == 3) hipLaunchKernelGGL(anet::k_piece_grad<3>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(anet::k_piece_grad<4>, grid, block, 0, st, a);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+
+int anet_minco_propagate_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                                  const double *T, const double *coeffs, const double *gdC,
+                                  const double *gdT, double *gradP, double *gradT, void *stream) {
+  int rc = check_solve_args(ctx, s, c, n_pieces, batch);
+  if (rc) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!T || !coeffs || !gdC || !gdT || !gradT || (n_pieces > 1 && !gradP) || ld < batch)
+    return fail(ctx, ANET_ERR_INVALID, "anet_minco_propagate_grad_dev: NULL pointer or ld < batch");
+  anet::PropArgs a{T, coeffs, gdC, gdT, gradP, gradT, nullptr, nullptr, nullptr, 0.0, batch, ld, n_pieces, c};
+  return do_propagate(ctx, s, a, (hipStream_t)stream);
+}
+
+int64_t anet_minco_cost_grad_workspace(int s, int n_pieces, int64_t ld) {
+  // coeffs + gdC + gdT + piece cost + energy
+  return ((int64_t)n_pieces * 3 * 2 * s * 2 + 2 * (int64_t)n_pieces + 1) * ld;
+}
+
+int anet_minco_cost_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                             const double *head, const double *tail, const double *wps,
+                             const double *T, const double *hpolys, const anet_penalty *pen,
+                             double *work, double *cost, double *gradP, double *gradT,
+                             double *coeffs_out, void *stream) {
+  int rc = check_solve_args(ctx, s, c, n_pieces, batch);
+  if (rc) return rc;
+  if ((rc = check_penalty(ctx, pen))) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!work || !cost || !gradT || (n_pieces > 1 && !gradP))
+    return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad_dev: NULL output or workspace");
+  const int64_t nco = (int64_t)n_pieces * 3 * 2 * s;
+  double *w_co = coeffs_out ? coeffs_out : work;
+  double *w_gdC = work + nco * ld;
+  double *w_gdT = w_gdC + nco * ld;
+  double *w_pc = w_gdT + (int64_t)n_pieces * ld;
+  double *w_en = w_pc + (int64_t)n_pieces * ld;
+  rc = anet_minco_solve_dev(ctx, s, c, n_pieces, batch, ld, head, tail, wps, T, w_co, w_en, stream);
+  if (rc) return rc;
+  rc = anet_minco_partial_grads_dev(ctx, s, n_pieces, batch, ld, w_co, T, hpolys, pen, 1, w_gdC, w_gdT,
+                                    w_pc, stream);
+  if (rc) return rc;
+  anet::PropArgs a{T, w_co, w_gdC, w_gdT, gradP, gradT, w_en, pen ? w_pc : nullptr, cost,
+                   pen ? pen->rho : 0.0, batch, ld, n_pieces, c};
+  return do_propagate(ctx, s, a, (hipStream_t)stream);
+}
+
+int anet_minco_cost_grad(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
+                         const double *tail, const double *wps, const double *T, const double *hpolys,
+                         const anet_penalty *pen, double *cost, double *gradP, double *gradT,
+                         double *coeffs_out) {
+  int rc = check_solve_args(ctx, s, c, n_pieces, batch);
+  if (rc) return rc;
+  if ((rc = check_penalty(ctx, pen))) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!head || !tail || !T || (n_pieces > 1 && (!wps || !gradP)) || !cost || !gradT)
+    return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad: NULL pointer");
+  const int N = n_pieces;
+  const int64_t nco = (int64_t)N * 3 * 2 * s;
+  const int64_t M = (pen && hpolys) ? pen->poly_rows : 0;
+  const int64_t nhp = (int64_t)N * M * 4;
+  const int64_t n_in = 6 * (int64_t)c + (int64_t)(N - 1) * 3 + N + nhp;
+  const int64_t n_out = 1 + (int64_t)(N - 1) * 3 + N + nco;
+  int64_t mx = nco > nhp ? nco : nhp;
+  if (mx < 3 * (int64_t)c) mx = 3 * c;
+  Stager st;
+  rc = make_stager(ctx, batch, mx, n_in + n_out + anet_minco_cost_grad_workspace(s, N, 1), &st);
+  if (rc) return rc;
+  double *d_head, *d_tail, *d_wps, *d_T, *d_hp = nullptr;
+  if ((rc = st.upload(head, 3 * c, &d_head))) return rc;
+  if ((rc = st.upload(tail, 3 * c, &d_tail))) return rc;
+  if ((rc = st.upload(wps, (int64_t)(N - 1) * 3, &d_wps))) return rc;
+  if ((rc = st.upload(T, N, &d_T))) return rc;
+  if (nhp && (rc = st.upload(hpolys, nhp, &d_hp))) return rc;
+  double *d_cost = st.reserve(1), *d_gP = st.reserve((int64_t)(N - 1) * 3), *d_gT = st.reserve(N);
+  double *d_co = st.reserve(nco);
+  double *d_work = st.reserve(anet_minco_cost_grad_workspace(s, N, 1));
+  rc = anet_minco_cost_grad_dev(ctx, s, c, N, batch, st.ld, d_head, d_tail, d_wps, d_T, d_hp, pen, d_work,
+                                d_cost, d_gP, d_gT, d_co, ctx->stream);
+  if (rc) return rc;
+  ANET_HIP(ctx, hipMemcpyAsync(cost, d_cost, sizeof(double) * batch, hipMemcpyDeviceToHost, ctx->stream));
+  if (N > 1 && (rc = st.download(d_gP, (int64_t)(N - 1) * 3, gradP))) return rc;
+  if ((rc = st.download(d_gT, N, gradT))) return rc;
+  if (coeffs_out && (rc = st.download(d_co, nco, coeffs_out))) return rc;
   ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ANET_OK;
 }

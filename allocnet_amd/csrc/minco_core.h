@@ -153,23 +153,93 @@ struct Factor {
   }
 };
 
-// One axis: forward sweep, backward sweep, emit coefficients (highest power first) and the
-// axis' share of int (p^(s))^2.  `emit(piece, col, value)` receives the D coefficients.
-//   P[k]   : node positions (k = 0..N), hv/tv : pinned head/tail derivatives (orders 1..np)
-template <int S, int NB, class Emit>
-__device__ __forceinline__ double solve_axis(const Factor<S, NB> &F, int N, int np,
-                                             const double (&P)[NB + 1], const double (&hv)[S - 1],
-                                             const double (&tv)[S - 1], double (&X)[NB + 1][S - 1],
-                                             Emit &&emit) {
+// ---- sweeps of the block-tridiagonal system for ONE right-hand side (one axis) -------------------
+// X[k][l] holds the right-hand side on entry (pinned rows: the pinned value / 0 for an adjoint).
+// forward : X <- w,   w_k = L_k^-1 (rhs_k - Ko_{k-1}' D_{k-1}^-1 y_{k-1})
+// backward: X <- x,   x_k = L_k^-T dinv (w_k - Y_k x_{k+1});  after(k, p) runs for every piece k
+//           (k < N) as soon as X[k] and X[k+1] are final, with p = powers of r_k.
+// `rhs(k, y)` fills the right-hand side of node k just before it is eliminated (fused so the powers
+// of r it needs are shared with the elimination step instead of being held for all nodes).
+template <int S, int NB, class Rhs>
+__device__ __forceinline__ void sweep_forward(const Factor<S, NB> &F, int N, int np,
+                                              const double (&rr)[NB], double (&X)[NB + 1][S - 1],
+                                              Rhs &&rhs) {
   constexpr int m = S - 1;
-  double rr[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
-  // ---- forward: w_k = L_k^-1 (rhs_k - Ko_{k-1}' D_{k-1}^-1 y_{k-1}) stored in X
 #pragma unroll
   for (int k = 0; k <= NB; ++k) {
     if (k <= N) {
       double y[m];
+      rhs(k, y);
+      if (k > 0) {
+        Pw<S> p(rr[k - 1]);
+        double Y[m][m];
+        F.build_Ko(k - 1, N, np, p, Y);
+        F.apply_Linv(k - 1, Y);
+#pragma unroll
+        for (int l = 0; l < m; ++l)
+#pragma unroll
+          for (int j = 0; j < m; ++j)
+            y[l] = __builtin_fma(-Y[j][l] * F.dinv[k - 1][j], X[k - 1][j], y[l]);
+      }
+#pragma unroll
+      for (int i = 1; i < m; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j)
+          y[i] = __builtin_fma(-F.L[k][Factor<S, NB>::li(i, j)], y[j], y[i]);
+#pragma unroll
+      for (int l = 0; l < m; ++l) X[k][l] = y[l];
+    }
+  }
+}
+
+template <int S, int NB, class After>
+__device__ __forceinline__ void sweep_backward(const Factor<S, NB> &F, int N, int np,
+                                               const double (&rr)[NB], double (&X)[NB + 1][S - 1],
+                                               After &&after) {
+  constexpr int m = S - 1;
+#pragma unroll
+  for (int k = NB; k >= 0; --k) {
+    if (k <= N) {
+      double x[m];
+#pragma unroll
+      for (int l = 0; l < m; ++l) x[l] = X[k][l];
+      if (k < N) {
+        Pw<S> p(rr[k]);
+        double Y[m][m];
+        F.build_Ko(k, N, np, p, Y);
+        F.apply_Linv(k, Y);
+#pragma unroll
+        for (int l = 0; l < m; ++l)
+#pragma unroll
+          for (int j = 0; j < m; ++j) x[l] = __builtin_fma(-Y[l][j], X[k + 1][j], x[l]);
+      }
+#pragma unroll
+      for (int l = 0; l < m; ++l) x[l] *= F.dinv[k][l];
+#pragma unroll
+      for (int i = m - 2; i >= 0; --i)
+#pragma unroll
+        for (int j = i + 1; j < m; ++j)
+          x[i] = __builtin_fma(-F.L[k][Factor<S, NB>::li(j, i)], x[j], x[i]);
+#pragma unroll
+      for (int l = 0; l < m; ++l) X[k][l] = x[l];
+      if (k < N) {
+        Pw<S> p(rr[k]);
+        after(k, p);
+      }
+    }
+  }
+}
+
+// Right-hand side of the primal problem for one axis: stationarity rows moved to the right,
+//   rhs_free = -sum W[free, known] x_known   (known = node positions and pinned end derivatives).
+//   P[k]: node positions, hv/tv: pinned head/tail derivatives (orders 1..np).
+template <int S, int NB>
+__device__ __forceinline__ void rhs_primal_node(int k, int N, int np, const double (&rr)[NB],
+                                                const double (&P)[NB + 1], const double (&hv)[S - 1],
+                                                const double (&tv)[S - 1], double (&y)[S - 1]) {
+  constexpr int m = S - 1;
+  {
+    {
 #pragma unroll
       for (int l = 0; l < m; ++l) y[l] = 0.0;
       if (k < N) {  // piece k, node k is its start
@@ -203,7 +273,7 @@ __device__ __forceinline__ double solve_axis(const Factor<S, NB> &F, int N, int 
       }
       if (k == 0 || k == N) {
         // unknowns of an end node also see that node's own pinned derivatives
-        if (k == 0 && N > 0) {
+        if (k == 0) {
           Pw<S> p(rr[0]);
 #pragma unroll
           for (int l = 0; l < m; ++l)
@@ -226,103 +296,76 @@ __device__ __forceinline__ double solve_axis(const Factor<S, NB> &F, int N, int 
         for (int l = 0; l < m; ++l)
           if (l < np) y[l] = (k == 0) ? hv[l] : tv[l];
       }
-      if (k > 0) {
-        Pw<S> p(rr[k - 1]);
-        double Y[m][m];
-        F.build_Ko(k - 1, N, np, p, Y);
-        F.apply_Linv(k - 1, Y);
-#pragma unroll
-        for (int l = 0; l < m; ++l)
-#pragma unroll
-          for (int j = 0; j < m; ++j)
-            y[l] = __builtin_fma(-Y[j][l] * F.dinv[k - 1][j], X[k - 1][j], y[l]);
-      }
-      // w_k = L_k^-1 y
-#pragma unroll
-      for (int i = 1; i < m; ++i)
-#pragma unroll
-        for (int j = 0; j < i; ++j)
-          y[i] = __builtin_fma(-F.L[k][Factor<S, NB>::li(i, j)], y[j], y[i]);
-#pragma unroll
-      for (int l = 0; l < m; ++l) X[k][l] = y[l];
     }
   }
-  // ---- backward: x_k = L_k^-T dinv (w_k - Y_k x_{k+1}); emit piece k as soon as x_k is known
-  double energy = 0.0;
+}
+
+// Coefficients of piece k from its end states, highest power first, and the piece's share of
+// int (p^(s))^2:  v_b = x_b r^(S-1-deg b);  g_i = sum_b BHI[i][b] v_b;  c_{S+i} = r^(i+1) g_i;
+// piece energy = r g' QB g.  Only non-negative powers of r (p = powers of r_k).
+template <int S, class Emit>
+__device__ __forceinline__ double emit_piece(int k, const Pw<S> &p, double P0, double P1,
+                                             const double (&x0)[S - 1], const double (&x1)[S - 1],
+                                             Emit &&emit) {
+  double v[2 * S];
+  v[0] = P0 * p[S - 1];
+  v[S] = P1 * p[S - 1];
+#pragma unroll
+  for (int j = 1; j < S; ++j) {
+    v[j] = x0[j - 1] * p[S - 1 - j];
+    v[S + j] = x1[j - 1] * p[S - 1 - j];
+  }
+  double g[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    // BHI[i][0] = -BHI[i][S]: use the position difference
+    double acc = Tab<S>::BHI[i][S] * (v[S] - v[0]);
+#pragma unroll
+    for (int b = 1; b < S; ++b) {
+      acc = __builtin_fma(Tab<S>::BHI[i][b], v[b], acc);
+      acc = __builtin_fma(Tab<S>::BHI[i][S + b], v[S + b], acc);
+    }
+    g[i] = acc;
+  }
+  double e = 0.0;
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    double t = Tab<S>::QB[i][i] * g[i];
+#pragma unroll
+    for (int j = i + 1; j < S; ++j) t = __builtin_fma(2.0 * Tab<S>::QB[i][j], g[j], t);
+    e = __builtin_fma(t, g[i], e);
+  }
+  double fact = 1.0;
+  emit(k, 2 * S - 1, P0);
+#pragma unroll
+  for (int j = 1; j < S; ++j) {
+    fact *= (double)j;
+    emit(k, 2 * S - 1 - j, x0[j - 1] * (1.0 / fact));
+  }
+#pragma unroll
+  for (int i = 0; i < S; ++i) emit(k, S - 1 - i, g[i] * p[i + 1]);
+  return e * p[1];
+}
+
+// One axis of the primal solve: rhs, forward, backward; emits the coefficients piece by piece and
+// returns the axis' share of int (p^(s))^2.
+template <int S, int NB, class Emit>
+__device__ __forceinline__ double solve_axis(const Factor<S, NB> &F, int N, int np,
+                                             const double (&P)[NB + 1], const double (&hv)[S - 1],
+                                             const double (&tv)[S - 1], double (&X)[NB + 1][S - 1],
+                                             Emit &&emit) {
+  double rr[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
+  sweep_forward<S, NB>(F, N, np, rr, X, [&](int k, double (&y)[S - 1]) {
+    rhs_primal_node<S, NB>(k, N, np, rr, P, hv, tv, y);
+  });
 #pragma unroll
   for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
-#pragma unroll
-  for (int k = NB; k >= 0; --k) {
-    if (k <= N) {
-      double x[m];
-#pragma unroll
-      for (int l = 0; l < m; ++l) x[l] = X[k][l];
-      if (k < N) {
-        Pw<S> p(rr[k]);
-        double Y[m][m];
-        F.build_Ko(k, N, np, p, Y);
-        F.apply_Linv(k, Y);
-#pragma unroll
-        for (int l = 0; l < m; ++l)
-#pragma unroll
-          for (int j = 0; j < m; ++j) x[l] = __builtin_fma(-Y[l][j], X[k + 1][j], x[l]);
-      }
-#pragma unroll
-      for (int l = 0; l < m; ++l) x[l] *= F.dinv[k][l];
-#pragma unroll
-      for (int i = m - 2; i >= 0; --i)
-#pragma unroll
-        for (int j = i + 1; j < m; ++j)
-          x[i] = __builtin_fma(-F.L[k][Factor<S, NB>::li(j, i)], x[j], x[i]);
-#pragma unroll
-      for (int l = 0; l < m; ++l) X[k][l] = x[l];
-
-      if (k < N) {  // piece k: states (P[k], X[k]) -> (P[k+1], X[k+1])
-        Pw<S> p(rr[k]);
-        // v_b = x_b r^(S-1-deg b);  g_i = sum_b BHI[i][b] v_b (= T a_{S+i} r^S);
-        // c_{S+i} = r^(i+1) g_i;  piece energy = r g' QB g.   Only non-negative powers of r.
-        double v[2 * S];
-        v[0] = P[k] * p[S - 1];
-        v[S] = P[k + 1] * p[S - 1];
-#pragma unroll
-        for (int j = 1; j < S; ++j) {
-          v[j] = X[k][j - 1] * p[S - 1 - j];
-          v[S + j] = X[k + 1][j - 1] * p[S - 1 - j];
-        }
-        double g[S];
-#pragma unroll
-        for (int i = 0; i < S; ++i) {
-          // BHI[i][0] = -BHI[i][S]: use the position difference
-          double acc = Tab<S>::BHI[i][S] * (v[S] - v[0]);
-#pragma unroll
-          for (int b = 1; b < S; ++b) {
-            acc = __builtin_fma(Tab<S>::BHI[i][b], v[b], acc);
-            acc = __builtin_fma(Tab<S>::BHI[i][S + b], v[S + b], acc);
-          }
-          g[i] = acc;
-        }
-        double e = 0.0;
-#pragma unroll
-        for (int i = 0; i < S; ++i) {
-          double t = Tab<S>::QB[i][i] * g[i];
-#pragma unroll
-          for (int j = i + 1; j < S; ++j) t = __builtin_fma(2.0 * Tab<S>::QB[i][j], g[j], t);
-          e = __builtin_fma(t, g[i], e);
-        }
-        energy = __builtin_fma(e, p[1], energy);
-        // low coefficients: c_j = x^(j)/j!
-        double fact = 1.0;
-        emit(k, 2 * S - 1, P[k]);
-#pragma unroll
-        for (int j = 1; j < S; ++j) {
-          fact *= (double)j;
-          emit(k, 2 * S - 1 - j, X[k][j - 1] * (1.0 / fact));
-        }
-#pragma unroll
-        for (int i = 0; i < S; ++i) emit(k, S - 1 - i, g[i] * p[i + 1]);
-      }
-    }
-  }
+  double energy = 0.0;
+  sweep_backward<S, NB>(F, N, np, rr, X, [&](int k, const Pw<S> &p) {
+    energy += emit_piece<S>(k, p, P[k], P[k + 1], X[k], X[k + 1], emit);
+  });
   return energy;
 }
 

@@ -123,3 +123,40 @@ class MINCO_S3NU(MINCO):
 class MINCO_S4NU(MINCO):
     def __init__(self, ctx=None):
         super().__init__(4, ctx)
+
+
+# ---------------------------------------------------------------------------------------------
+# cost + analytic gradients (penalty functional on the reference's inequality rows)
+# ---------------------------------------------------------------------------------------------
+def make_penalty(rho=0.0, w_corridor=0.0, w_vel=0.0, w_acc=0.0, smooth_mu=1e-2, max_vel=4.0,
+                 max_acc=6.0, res=20, poly_rows=0):
+    """struct anet_penalty.  Defaults: MaxVelBox/MaxAccBox/ConstRes of config/planner.yaml:17-21 and
+    the smoothing FIRI uses for its own smoothedL1 (firi.hpp:218)."""
+    from ._lib import Penalty
+    return Penalty(rho, w_corridor, w_vel, w_acc, smooth_mu, max_vel, max_acc, int(res), int(poly_rows))
+
+
+def minco_cost_grad(head, tail, wps, T, s, hpolys=None, penalty=None, want_coeffs=False, ctx=None):
+    """Host entry point -> anet_minco_cost_grad.
+    head, tail (B,3,c); wps (B,N-1,3); T (B,N); hpolys (B,N,M,4) rows a.x<=b (zero rows = padding).
+    Returns cost (B,), gradP (B,N-1,3), gradT (B,N) [, coeffs (B,N,3,2s)]."""
+    ctx = ctx or default_context()
+    head = _f64c(head)
+    B, _, c = head.shape
+    tail = _f64c(tail, (B, 3, c))
+    T = _f64c(T)
+    N = T.shape[1]
+    wps = _f64c(wps if wps is not None else np.zeros((B, 0, 3)), (B, N - 1, 3))
+    pen = penalty
+    if hpolys is not None:
+        hpolys = _f64c(hpolys)
+        if pen is None or hpolys.shape != (B, N, pen.poly_rows, 4):
+            raise ValueError("hpolys must be (B, N, penalty.poly_rows, 4)")
+    cost = np.empty(B); gradP = np.empty((B, N - 1, 3)); gradT = np.empty((B, N))
+    coeffs = np.empty((B, N, 3, 2 * s)) if want_coeffs else None
+    ctx.check(ctx.lib.anet_minco_cost_grad(
+        ctx.handle, s, c, N, B, _ptr(head), _ptr(tail), _ptr(wps), _ptr(T),
+        _ptr(hpolys) if hpolys is not None else None,
+        ctypes.cast(ctypes.pointer(pen), ctypes.c_void_p) if pen is not None else None,
+        _ptr(cost), _ptr(gradP), _ptr(gradT), _ptr(coeffs)))
+    return (cost, gradP, gradT, coeffs) if want_coeffs else (cost, gradP, gradT)

@@ -126,6 +126,65 @@ int anet_traj_cost_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_
 int anet_traj_cost(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
                    const double *T, double m34, double *cost);
 
+/* ---- cost + analytic gradients ----------------------------------------------------------- */
+/* Penalty functional on the reference's own inequality rows (QPSolver::solve step three,
+ * planner/qp_solver.hpp:244-296; MinTrajOpt.fill_ineq, network/utils/min_traj_opt.py:535-613):
+ * for piece i and sample j in [0,res) at t = j*T_i/res
+ *     corridor rows   a_r . p(t) - b_r            (hPolys[i] rows, a.x <= b form)
+ *     box rows        +-v_axis(t) - max_vel,  +-a_axis(t) - max_acc     (per axis)
+ * the reference imposes them as hard constraints of a QP; here each row g enters the cost as
+ *     J_pen = sum_i (T_i/res) sum_j sum_rows w_row * smoothedL1(smooth_mu, g)
+ * with firi::smoothedL1 (gcopter/firi.hpp:60-84), the MINCO/GCOPTER penalty-functional form the
+ * north star asks for.  Total cost: J = int (p^(s))^2 + rho*sum(T) + J_pen.                    */
+typedef struct anet_penalty {
+  double rho;        /* weight of sum(T)                                               */
+  double w_corridor; /* weight of corridor rows                                        */
+  double w_vel;      /* weight of velocity box rows                                    */
+  double w_acc;      /* weight of acceleration box rows                                */
+  double smooth_mu;  /* smoothedL1 mu, > 0                                             */
+  double max_vel;    /* MaxVelBox (config/planner.yaml:17)                             */
+  double max_acc;    /* MaxAccBox (config/planner.yaml:19)                             */
+  int32_t res;       /* ConstRes, samples per piece (config/planner.yaml:21)           */
+  int32_t poly_rows; /* M: rows per polytope in `hpolys`; all-zero rows are padding    */
+} anet_penalty;
+
+/* Partial gradients of  [with_energy] int (p^(s))^2  +  [pen != NULL] J_pen  with respect to the
+ * coefficients and durations, the coefficients being treated as independent variables
+ * (MINCO getEnergyPartialGradByCoeffs / getEnergyPartialGradByTimes + the penalty functional).
+ * hpolys: [N*M*4][ld], row r of polytope i at fields (i*M + r)*4 + {0,1,2,3} = a_x,a_y,a_z,b;
+ * may be NULL (box rows only).  piece_cost (may be NULL): per-piece J_pen share, [N][ld].      */
+int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
+                                 const double *coeffs, const double *T, const double *hpolys,
+                                 const anet_penalty *pen, int with_energy,
+                                 double *gdC,        /* [N*3*2s][ld] */
+                                 double *gdT,        /* [N][ld]      */
+                                 double *piece_cost, /* [N][ld]      */
+                                 void *stream);
+
+/* MINCO propogateGrad: total gradient of a scalar J(c(wps,T), T) w.r.t. the interior waypoints and
+ * the durations from its partial gradients gdC, gdT; coeffs must be the MINCO coefficients for
+ * (c, wps, T).  gradP: [(N-1)*3][ld] (waypoint-major, like wps), gradT: [N][ld].               */
+int anet_minco_propagate_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                                  const double *T, const double *coeffs, const double *gdC,
+                                  const double *gdT, double *gradP, double *gradT, void *stream);
+
+/* Whole objective in one call: solve -> partial gradients -> propagate.
+ * work: device scratch of anet_minco_cost_grad_workspace(s, N, ld) doubles.
+ * coeffs_out may be NULL.  cost: [batch].                                                     */
+int64_t anet_minco_cost_grad_workspace(int s, int n_pieces, int64_t ld);
+int anet_minco_cost_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                             const double *head, const double *tail, const double *wps,
+                             const double *T, const double *hpolys, const anet_penalty *pen,
+                             double *work, double *cost, double *gradP, double *gradT,
+                             double *coeffs_out, void *stream);
+int anet_minco_cost_grad(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch,
+                         const double *head, const double *tail, const double *wps, const double *T,
+                         const double *hpolys, /* [batch][N][M][4] or NULL */
+                         const anet_penalty *pen, double *cost, /* [batch] */
+                         double *gradP,  /* [batch][N-1][3] */
+                         double *gradT,  /* [batch][N]      */
+                         double *coeffs_out /* [batch][N][3][2s] or NULL */);
+
 #ifdef __cplusplus
 }
 #endif

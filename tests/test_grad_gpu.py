@@ -1,0 +1,80 @@
+"""GPU parity of the cost/gradient path: partial gradients + penalty functional + propogateGrad
+vs the numpy oracle (classic dense adjoint), which itself is pinned by finite differences and by
+the G z - h rows of the reference-pinned QP assembly (tests/test_oracle_cpu.py)."""
+import numpy as np
+import pytest
+
+from oracle import minco_np as onp
+from tests.util import random_problem, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def make_corridors(rng, head, tail, wps, M, tight=1.0):
+    B, Nm1, _ = wps.shape
+    N = Nm1 + 1
+    pts = np.concatenate([head[:, None, :, 0], wps, tail[:, None, :, 0]], axis=1)   # (B,N+1,3)
+    hp = np.zeros((B, N, M, 4))
+    for b in range(B):
+        for i in range(N):
+            k = rng.integers(max(1, M - 3), M + 1)          # some zero-padded rows
+            for r in range(k):
+                a = rng.normal(size=3); a /= np.linalg.norm(a)
+                hp[b, i, r, :3] = a
+                hp[b, i, r, 3] = a @ (0.5 * (pts[b, i] + pts[b, i + 1])) + rng.uniform(0.2, 1.0) * tight
+    return hp
+
+
+@pytest.mark.parametrize("s,c,N,M", [(4, 3, 8, 16), (4, 4, 5, 7), (3, 3, 16, 12), (3, 3, 2, 5), (4, 3, 1, 6),
+                                     (3, 2, 4, 0), (2, 2, 3, 4)])
+def test_cost_grad_matches_oracle(anet_ctx, s, c, N, M):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(1000 + 10 * N + s)
+    B = 37
+    head, tail, wps, T = random_problem(rng, B, N, c)
+    hp = make_corridors(rng, head, tail, wps, M) if M else None
+    kw = dict(res=7, vmax=1.5, amax=2.5, wc=60.0, wv=25.0, wa=9.0, mu=0.05)
+    pen = aa.make_penalty(rho=0.8, w_corridor=kw["wc"], w_vel=kw["wv"], w_acc=kw["wa"], smooth_mu=kw["mu"],
+                          max_vel=kw["vmax"], max_acc=kw["amax"], res=kw["res"], poly_rows=M)
+    cost, gP, gT, co = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, want_coeffs=True,
+                                          ctx=anet_ctx)
+    if s == 2:
+        return      # numpy oracle covers s >= 3 (the reference's orders)
+    nz = 0
+    for b in range(0, B, 3):
+        hpb = np.transpose(hp[b], (1, 2, 0)) if M else np.zeros((1, 4, N))
+        co0, e0, *_ = onp.minco_dense_solve(s, head[b], tail[b], wps[b].T, T[b])
+        jp, gC, gTp, pc = onp.penalty_partials(s, co0, T[b], hpb, **kw)
+        eC, eT = onp.energy_partials(s, co0, T[b])
+        gP0, gT0 = onp.minco_dense_propagate(s, head[b], tail[b], wps[b].T, T[b], gC + eC, gTp + eT + 0.8)
+        c0 = e0 + 0.8 * T[b].sum() + jp
+        nz += jp > 0
+        assert rel_err(co[b], co0) < 1e-9
+        assert abs(cost[b] - c0) <= 1e-9 * abs(c0)
+        if N > 1:
+            assert np.abs(gP[b].T - gP0).max() <= 1e-7 * max(1.0, np.abs(gP0).max())
+        assert np.abs(gT[b] - gT0).max() <= 1e-7 * max(1.0, np.abs(gT0).max())
+    assert nz > 0       # the penalty really was active in the compared samples
+
+
+def test_energy_only_gradient_finite_difference(anet_ctx):
+    """No penalty: cost == energy + rho sum T, gradient vs central differences of the GPU cost itself."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(77)
+    s, c, N, B = 4, 3, 6, 8
+    head, tail, wps, T = random_problem(rng, B, N, c)
+    pen = aa.make_penalty(rho=2.0, res=4)
+    cost, gP, gT = aa.minco_cost_grad(head, tail, wps, T, s, penalty=pen, ctx=anet_ctx)
+    _, energy = aa.minco_solve(head, tail, wps, T, s, ctx=anet_ctx)
+    assert rel_err(cost, energy + 2.0 * T.sum(axis=1)) < 1e-12
+    h = 1e-6
+    for (k, ax) in [(0, 0), (2, 1), (4, 2)]:
+        wp = wps.copy(); wp[:, k, ax] += h; wm = wps.copy(); wm[:, k, ax] -= h
+        fd = (aa.minco_cost_grad(head, tail, wp, T, s, penalty=pen, ctx=anet_ctx)[0]
+              - aa.minco_cost_grad(head, tail, wm, T, s, penalty=pen, ctx=anet_ctx)[0]) / (2 * h)
+        assert np.abs(fd - gP[:, k, ax]).max() <= 2e-5 * max(1.0, np.abs(gP[:, k, ax]).max())
+    for i in (0, 3, 5):
+        tp = T.copy(); tp[:, i] += h; tm = T.copy(); tm[:, i] -= h
+        fd = (aa.minco_cost_grad(head, tail, wps, tp, s, penalty=pen, ctx=anet_ctx)[0]
+              - aa.minco_cost_grad(head, tail, wps, tm, s, penalty=pen, ctx=anet_ctx)[0]) / (2 * h)
+        assert np.abs(fd - gT[:, i]).max() <= 2e-5 * max(1.0, np.abs(gT[:, i]).max())
