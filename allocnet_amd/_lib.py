@@ -45,7 +45,27 @@ PROTOTYPES = {
     "anet_minco_cost_grad_workspace": (c_int64, [c_int, c_int, c_int64]),
     "anet_minco_cost_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64] + [c_void_p] * 12),
     "anet_minco_cost_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_int64] + [c_void_p] * 10),
+    "anet_lbfgs_default_params": (None, [c_void_p]),
+    "anet_lbfgs_check_params": (c_int, [c_int, c_void_p]),
+    "anet_lbfgs_strerror": (c_char_p, [c_int]),
+    "anet_lbfgs_mvie": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_double, c_double, c_void_p, c_void_p,
+                                c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "anet_lbfgs_minco": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "anet_lbfgs_minco_workspace": (c_int64, [c_int, c_int, c_int64, c_void_p]),
+    "anet_lbfgs_minco_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
+
+
+class LbfgsParams(ctypes.Structure):
+    """struct anet_lbfgs_params == lbfgs::lbfgs_parameter_t (lbfgs.hpp:15-129)."""
+    _fields_ = [("mem_size", ctypes.c_int32), ("g_epsilon", c_double), ("past", ctypes.c_int32),
+                ("delta", c_double), ("max_iterations", ctypes.c_int32), ("max_linesearch", ctypes.c_int32),
+                ("min_step", c_double), ("max_step", c_double), ("f_dec_coeff", c_double),
+                ("s_curv_coeff", c_double), ("cautious_factor", c_double), ("machine_prec", c_double)]
 
 
 class Penalty(ctypes.Structure):

@@ -515,6 +515,343 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
   if (a.cost) a.cost[b] = (a.energy_in ? a.energy_in[b] : 0.0) + a.rho * tsum + csum;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// batched L-BFGS (lbfgs.hpp:276-384, 434-717) as a per-trajectory state machine
+// ------------------------------------------------------------------------------------------
+struct LbfgsP {
+  int mem_size;
+  double g_epsilon;
+  int past;
+  double delta;
+  int max_iterations, max_linesearch;
+  double min_step, max_step, f_dec_coeff, s_curv_coeff, cautious_factor, machine_prec;
+};
+enum { DS_FX = 0, DS_STEP, DS_FINIT, DS_DGTEST, DS_DSTEST, DS_MU, DS_NU, DS_COUNT_ };
+enum { IS_DONE = 0, IS_RET, IS_K, IS_END, IS_BOUND, IS_COUNT, IS_BRACKT, IS_TOUCHED, IS_EVALS, IS_PHASE, IS_COUNT_ };
+enum {  // lbfgs.hpp:135-184
+  LB_CONVERGENCE = 0, LB_STOP = 1, LB_CANCELED = 2,
+  LBERR_INVALID_FUNCVAL = -1012, LBERR_MINIMUMSTEP = -1011, LBERR_MAXIMUMSTEP = -1010,
+  LBERR_MAXIMUMLINESEARCH = -1009, LBERR_MAXIMUMITERATION = -1008, LBERR_WIDTHTOOSMALL = -1007,
+  LBERR_INVALIDPARAMETERS = -1006, LBERR_INCREASEGRADIENT = -1005
+};
+
+struct LbfgsArgs {
+  int n;
+  int64_t B, ld;
+  double *x, *g, *xp, *gp, *d, *lm_s, *lm_y, *lm_ys, *lm_alpha, *pf, *ds;
+  const double *feval;
+  int *is;
+  LbfgsP p;
+  int *n_active;
+};
+
+// One lane per problem.  Every launch consumes ONE objective evaluation (f = feval[b], gradient in
+// g, both taken at the point currently in x) and leaves in x the next point to evaluate.  The
+// control flow per problem is lbfgs_optimize's: phase 0 = the initial evaluation, phase 1 = inside
+// line_search_lewisoverton.  Finished problems are untouched (x, g hold the result).
+__global__ void __launch_bounds__(64) k_lbfgs_update(LbfgsArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  const int64_t ld = a.ld;
+  int *is = a.is + b;
+  if (is[IS_DONE * ld]) return;
+  double *ds = a.ds + b;
+  const int n = a.n, m = a.p.mem_size;
+  const LbfgsP &P = a.p;
+  double *x = a.x + b, *g = a.g + b, *xp = a.xp + b, *gp = a.gp + b, *d = a.d + b;
+  const double f = a.feval[b];
+  is[IS_EVALS * ld] += 1;
+  double fx = ds[DS_FX * ld];
+  double step = ds[DS_STEP * ld];
+  int k = is[IS_K * ld];
+  bool start_ls = false;
+  int finish = 0x7fffffff;  // sentinel: keep running
+
+  auto conv_test = [&]() {
+    double gn = 0.0, xn = 0.0;
+    for (int i = 0; i < n; ++i) {
+      gn = fmax(gn, fabs(g[i * ld]));
+      xn = fmax(xn, fabs(x[i * ld]));
+    }
+    return gn / fmax(1.0, xn) < P.g_epsilon;
+  };
+
+  if (is[IS_PHASE * ld] == 0) {
+    fx = f;
+    a.pf[b] = fx;
+    double dd = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double gi = g[i * ld];
+      d[i * ld] = -gi;
+      dd = __builtin_fma(gi, gi, dd);
+    }
+    if (conv_test()) {
+      finish = LB_CONVERGENCE;
+    } else {
+      step = 1.0 / sqrt(dd);
+      k = 1;
+      is[IS_END * ld] = 0;
+      is[IS_BOUND * ld] = 0;
+      is[IS_PHASE * ld] = 1;
+      start_ls = true;
+    }
+  } else {
+    // ---- one trial of line_search_lewisoverton (lbfgs.hpp:307-383)
+    const double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
+    double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
+    int count = is[IS_COUNT * ld] + 1, brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
+    bool success = false;
+    int err = 0;
+    if (isinf(f) || isnan(f)) {
+      err = LBERR_INVALID_FUNCVAL;
+    } else {
+      if (f > finit + step * dgtest) {
+        nu = step;
+        brackt = 1;
+      } else {
+        double dg = 0.0;
+        for (int i = 0; i < n; ++i) dg = __builtin_fma(g[i * ld], d[i * ld], dg);
+        if (dg < dstest)
+          mu = step;
+        else
+          success = true;
+      }
+      if (!success) {
+        if (P.max_linesearch <= count) {
+          err = LBERR_MAXIMUMLINESEARCH;
+        } else if (brackt && (nu - mu) < P.machine_prec * nu) {
+          err = LBERR_WIDTHTOOSMALL;
+        } else {
+          step = brackt ? 0.5 * (mu + nu) : step * 2.0;
+          if (step < P.min_step) {
+            err = LBERR_MINIMUMSTEP;
+          } else if (step > P.max_step) {
+            if (touched) {
+              err = LBERR_MAXIMUMSTEP;
+            } else {
+              touched = 1;
+              step = P.max_step;
+            }
+          }
+        }
+      }
+    }
+    if (err) {
+      // revert to the previous point; the reported f stays the last trial's (lbfgs.hpp:570-577,713)
+      for (int i = 0; i < n; ++i) {
+        x[i * ld] = xp[i * ld];
+        g[i * ld] = gp[i * ld];
+      }
+      fx = f;
+      finish = err;
+    } else if (!success) {
+      for (int i = 0; i < n; ++i) x[i * ld] = __builtin_fma(step, d[i * ld], xp[i * ld]);
+      ds[DS_MU * ld] = mu;
+      ds[DS_NU * ld] = nu;
+      is[IS_COUNT * ld] = count;
+      is[IS_BRACKT * ld] = brackt;
+      is[IS_TOUCHED * ld] = touched;
+    } else {
+      // ---- accepted step (lbfgs.hpp:579-709)
+      fx = f;
+      if (conv_test()) {
+        finish = LB_CONVERGENCE;
+      } else {
+        if (0 < P.past) {
+          if (P.past <= k) {
+            const double rate = fabs(a.pf[(int64_t)(k % P.past) * ld + b] - fx) / fmax(1.0, fabs(fx));
+            if (rate < P.delta) finish = LB_STOP;
+          }
+          if (finish == 0x7fffffff) a.pf[(int64_t)(k % P.past) * ld + b] = fx;
+        }
+        if (finish == 0x7fffffff && P.max_iterations != 0 && P.max_iterations <= k) finish = LBERR_MAXIMUMITERATION;
+        if (finish == 0x7fffffff) {
+          ++k;
+          int end = is[IS_END * ld], bound = is[IS_BOUND * ld];
+          double *se = a.lm_s + (int64_t)end * n * ld + b, *ye = a.lm_y + (int64_t)end * n * ld + b;
+          double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
+          for (int i = 0; i < n; ++i) {
+            const double si = x[i * ld] - xp[i * ld], yi = g[i * ld] - gp[i * ld], gpi = gp[i * ld];
+            se[i * ld] = si;
+            ye[i * ld] = yi;
+            ys = __builtin_fma(yi, si, ys);
+            yy = __builtin_fma(yi, yi, yy);
+            ss = __builtin_fma(si, si, ss);
+            gpgp = __builtin_fma(gpi, gpi, gpgp);
+            d[i * ld] = -g[i * ld];
+          }
+          a.lm_ys[(int64_t)end * ld + b] = ys;
+          const double cau = ss * sqrt(gpgp) * P.cautious_factor;
+          if (ys > cau) {
+            ++bound;
+            bound = m < bound ? m : bound;
+            end = (end + 1) % m;
+            int j = end;
+            for (int it = 0; it < bound; ++it) {
+              j = (j + m - 1) % m;
+              const double *sj = a.lm_s + (int64_t)j * n * ld + b, *yj = a.lm_y + (int64_t)j * n * ld + b;
+              double sd = 0.0;
+              for (int i = 0; i < n; ++i) sd = __builtin_fma(sj[i * ld], d[i * ld], sd);
+              const double al = sd / a.lm_ys[(int64_t)j * ld + b];
+              a.lm_alpha[(int64_t)j * ld + b] = al;
+              for (int i = 0; i < n; ++i) d[i * ld] = __builtin_fma(-al, yj[i * ld], d[i * ld]);
+            }
+            const double sc = ys / yy;
+            for (int i = 0; i < n; ++i) d[i * ld] *= sc;
+            for (int it = 0; it < bound; ++it) {
+              const double *sj = a.lm_s + (int64_t)j * n * ld + b, *yj = a.lm_y + (int64_t)j * n * ld + b;
+              double yd = 0.0;
+              for (int i = 0; i < n; ++i) yd = __builtin_fma(yj[i * ld], d[i * ld], yd);
+              const double beta = yd / a.lm_ys[(int64_t)j * ld + b];
+              const double cf = a.lm_alpha[(int64_t)j * ld + b] - beta;
+              for (int i = 0; i < n; ++i) d[i * ld] = __builtin_fma(cf, sj[i * ld], d[i * ld]);
+              j = (j + 1) % m;
+            }
+          }
+          is[IS_END * ld] = end;
+          is[IS_BOUND * ld] = bound;
+          step = 1.0;
+          start_ls = true;
+        }
+      }
+    }
+  }
+  if (start_ls) {
+    // ---- entry of line_search_lewisoverton (lbfgs.hpp:287-305) for the new direction
+    double dginit = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double xi = x[i * ld], gi = g[i * ld];
+      xp[i * ld] = xi;
+      gp[i * ld] = gi;
+      dginit = __builtin_fma(gi, d[i * ld], dginit);
+    }
+    if (!(step > 0.0)) {
+      finish = LBERR_INVALIDPARAMETERS;
+    } else if (0.0 < dginit) {
+      finish = LBERR_INCREASEGRADIENT;
+    } else {
+      ds[DS_FINIT * ld] = fx;
+      ds[DS_DGTEST * ld] = P.f_dec_coeff * dginit;
+      ds[DS_DSTEST * ld] = P.s_curv_coeff * dginit;
+      ds[DS_MU * ld] = 0.0;
+      ds[DS_NU * ld] = P.max_step;
+      is[IS_COUNT * ld] = 0;
+      is[IS_BRACKT * ld] = 0;
+      is[IS_TOUCHED * ld] = 0;
+      for (int i = 0; i < n; ++i) x[i * ld] = __builtin_fma(step, d[i * ld], xp[i * ld]);
+    }
+  }
+  ds[DS_FX * ld] = fx;
+  ds[DS_STEP * ld] = step;
+  is[IS_K * ld] = k;
+  if (finish != 0x7fffffff) {
+    is[IS_DONE * ld] = 1;
+    is[IS_RET * ld] = finish;
+  } else if (a.n_active) {
+    atomicAdd(a.n_active, 1);
+  }
+}
+
+// firi::costMVIE (gcopter/firi.hpp:86-157): x = [p, rtd, cde], A is M x 3 column-major per problem
+// (field k*M + r), the reference's optData packing (firi.hpp:186-200).
+struct MvieArgs {
+  const double *A, *x;
+  double *f, *g;
+  const int *done;
+  int64_t B, ld;
+  int M;
+  double eps, wt;
+};
+__global__ void __launch_bounds__(64) k_mvie_eval(MvieArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  if (a.done && a.done[b]) return;
+  const int64_t ld = a.ld;
+  const double *x = a.x + b;
+  double p[3], rtd[3], cde[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    p[q] = x[q * ld];
+    rtd[q] = x[(3 + q) * ld];
+    cde[q] = x[(6 + q) * ld];
+  }
+  const double L00 = rtd[0] * rtd[0] + 2.220446049250313e-16, L11 = rtd[1] * rtd[1] + 2.220446049250313e-16,
+               L22 = rtd[2] * rtd[2] + 2.220446049250313e-16;
+  const double L10 = cde[0], L21 = cde[1], L20 = cde[2];
+  double cost = 0.0, gdp[3] = {0, 0, 0}, gdr[3] = {0, 0, 0}, gdc[3] = {0, 0, 0};
+  const double inv_mu = 1.0 / a.eps;
+  for (int r = 0; r < a.M; ++r) {
+    const double a0 = a.A[(int64_t)r * ld + b], a1 = a.A[(int64_t)(a.M + r) * ld + b],
+                 a2 = a.A[(int64_t)(2 * a.M + r) * ld + b];
+    const double al0 = a0 * L00 + a1 * L10 + a2 * L20, al1 = a1 * L11 + a2 * L21, al2 = a2 * L22;
+    const double nrm = sqrt(al0 * al0 + al1 * al1 + al2 * al2);
+    const double viol = nrm + (a0 * p[0] + a1 * p[1] + a2 * p[2]) - 1.0;
+    if (viol >= 0.0) {
+      double c, dc;
+      smoothed_l1(a.eps, inv_mu, viol, c, dc);
+      const double inv = 1.0 / nrm;
+      const double adj0 = al0 * inv, adj1 = al1 * inv, adj2 = al2 * inv;
+      const double v0 = dc * a0, v1 = dc * a1, v2 = dc * a2;
+      cost += c;
+      gdp[0] += v0; gdp[1] += v1; gdp[2] += v2;
+      gdr[0] += adj0 * v0; gdr[1] += adj1 * v1; gdr[2] += adj2 * v2;
+      gdc[0] += adj0 * v1;
+      gdc[1] += adj1 * v2;
+      gdc[2] += adj0 * v2;
+    }
+  }
+  cost *= a.wt;
+  cost -= log(L00) + log(L11) + log(L22);
+  const double Ld[3] = {L00, L11, L22};
+  double *g = a.g + b;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    g[q * ld] = gdp[q] * a.wt;
+    g[(3 + q) * ld] = (gdr[q] * a.wt - 1.0 / Ld[q]) * 2.0 * rtd[q];
+    g[(6 + q) * ld] = gdc[q] * a.wt;
+  }
+  a.f[b] = cost;
+}
+
+// GCOPTER's smooth bijection R -> (0, inf) for the durations (upstream gcopter.hpp forwardT /
+// backwardT; not part of the reference tree): T = tau>0 ? (tau/2+1)tau+1 : 1/((tau/2-1)tau+1).
+__device__ __forceinline__ double forward_T(double tau) {
+  return tau > 0.0 ? (0.5 * tau + 1.0) * tau + 1.0 : 1.0 / ((0.5 * tau - 1.0) * tau + 1.0);
+}
+__device__ __forceinline__ double dforward_T(double tau) {
+  if (tau > 0.0) return tau + 1.0;
+  const double den = (0.5 * tau - 1.0) * tau + 1.0;
+  return (1.0 - tau) / (den * den);
+}
+__device__ __forceinline__ double backward_T(double T) {
+  return T > 1.0 ? sqrt(2.0 * T - 1.0) - 1.0 : 1.0 - sqrt(2.0 / T - 1.0);
+}
+struct MapArgs {
+  double *x, *g;             // optimisation variables / gradient [n][ld]
+  double *wps, *T;           // trajectory parameters
+  const double *gradP, *gradT;
+  int64_t B, ld;
+  int nw, nt;                // optimised waypoint coordinates (0 or 3(N-1)), optimised durations (0 or N)
+  int mode;                  // 0: params -> x (init), 1: x -> params, 2: (gradP, gradT) -> g
+};
+__global__ void __launch_bounds__(256) k_minco_map(MapArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const int64_t ld = a.ld;
+  for (int i = 0; i < a.nw; ++i) {
+    if (a.mode == 0) a.x[i * ld + b] = a.wps[i * ld + b];
+    else if (a.mode == 1) a.wps[i * ld + b] = a.x[i * ld + b];
+    else a.g[i * ld + b] = a.gradP[i * ld + b];
+  }
+  for (int i = 0; i < a.nt; ++i) {
+    const int64_t xi = (int64_t)(a.nw + i) * ld + b;
+    if (a.mode == 0) a.x[xi] = backward_T(a.T[i * ld + b]);
+    else if (a.mode == 1) a.T[i * ld + b] = forward_T(a.x[xi]);
+    else a.g[xi] = a.gradT[i * ld + b] * dforward_T(a.x[xi]);
+  }
+}
+
 // dst[f*ld + b] = src[b*nf + f] through a padded LDS tile (both sides coalesced).
 constexpr int kTile = 32;
 __global__ void __launch_bounds__(kTile * 8) k_to_batch_minor(const double *__restrict__ src,
@@ -560,6 +897,9 @@ struct anet_ctx {
   // grow-only device scratch for the host (trajectory-major) entry points
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  // L-BFGS completion polling: device counter + pinned host mirror
+  int *d_counter = nullptr;
+  int *h_counter = nullptr;
 };
 
 namespace {
@@ -653,6 +993,75 @@ int do_propagate(anet_ctx *ctx, int s, const anet::PropArgs &a, hipStream_t st) 
     default: return launch_prop<4>(ctx, a, st);
   }
 }
+
+// ---- L-BFGS driver ----------------------------------------------------------------------------
+struct LbfgsLayout {
+  int n, m, npf;
+  int64_t ld;
+  double *x, *g, *xp, *gp, *d, *lm_s, *lm_y, *lm_ys, *lm_alpha, *pf, *ds, *feval;
+  int *is;
+  static int64_t doubles(int n, int m, int npf, int64_t ld) {
+    // + IS_COUNT_ int32 rows, rounded up to doubles
+    return ((int64_t)n * (5 + 2 * m) + 2 * m + npf + anet::DS_COUNT_ + 1 + (anet::IS_COUNT_ + 1) / 2) * ld;
+  }
+  void carve(double *w) {
+    x = w; g = x + (int64_t)n * ld; xp = g + (int64_t)n * ld; gp = xp + (int64_t)n * ld; d = gp + (int64_t)n * ld;
+    lm_s = d + (int64_t)n * ld; lm_y = lm_s + (int64_t)m * n * ld; lm_ys = lm_y + (int64_t)m * n * ld;
+    lm_alpha = lm_ys + (int64_t)m * ld; pf = lm_alpha + (int64_t)m * ld; ds = pf + (int64_t)npf * ld;
+    feval = ds + (int64_t)anet::DS_COUNT_ * ld; is = (int *)(feval + ld);
+  }
+};
+
+static anet::LbfgsP to_kernel_params(const anet_lbfgs_params &p) {
+  return anet::LbfgsP{p.mem_size, p.g_epsilon, p.past, p.delta, p.max_iterations, p.max_linesearch,
+                      p.min_step, p.max_step, p.f_dec_coeff, p.s_curv_coeff, p.cautious_factor, p.machine_prec};
+}
+
+static int ensure_counter(anet_ctx *ctx) {
+  if (!ctx->d_counter) ANET_HIP(ctx, hipMalloc((void **)&ctx->d_counter, sizeof(int)));
+  if (!ctx->h_counter) ANET_HIP(ctx, hipHostMalloc((void **)&ctx->h_counter, sizeof(int), hipHostMallocDefault));
+  return ANET_OK;
+}
+
+// eval(): enqueue the objective at L.x -> L.feval, L.g (for all problems).  The loop advances every
+// problem by one evaluation per pass and polls the number of unfinished problems every `poll` passes.
+template <class Eval>
+static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfgs_params &prm, int max_evals,
+                       hipStream_t st, Eval &&eval) {
+  int rc = ensure_counter(ctx);
+  if (rc) return rc;
+  ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * L.ld, st));
+  ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_ * L.ld, st));
+  anet::LbfgsArgs a{L.n, B, L.ld, L.x, L.g, L.xp, L.gp, L.d, L.lm_s, L.lm_y, L.lm_ys, L.lm_alpha, L.pf, L.ds,
+                    L.feval, L.is, to_kernel_params(prm), nullptr};
+  const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+  const int poll = 8;
+  for (int it = 0; it < max_evals; ++it) {
+    if ((rc = eval())) return rc;
+    const bool check = ((it + 1) % poll == 0) || it + 1 == max_evals;
+    if (check) ANET_HIP(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(int), st));
+    a.n_active = check ? ctx->d_counter : nullptr;
+    hipLaunchKernelGGL(anet::k_lbfgs_update, grid, block, 0, st, a);
+    ANET_HIP(ctx, hipGetLastError());
+    if (check) {
+      ANET_HIP(ctx, hipMemcpyAsync(ctx->h_counter, ctx->d_counter, sizeof(int), hipMemcpyDeviceToHost, st));
+      ANET_HIP(ctx, hipStreamSynchronize(st));
+      if (*ctx->h_counter == 0) break;
+    }
+  }
+  return ANET_OK;
+}
+
+// status / iters / evals rows -> caller arrays (device or host destination)
+__global__ void k_lbfgs_results(const int *is, const double *ds, int64_t B, int64_t ld, int *status, int *iters,
+                                int *evals, double *f) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  if (status) status[b] = is[anet::IS_DONE * ld + b] ? is[anet::IS_RET * ld + b] : ANET_LBFGS_RUNNING;
+  if (iters) iters[b] = is[anet::IS_K * ld + b];
+  if (evals) evals[b] = is[anet::IS_EVALS * ld + b];
+  if (f) f[b] = ds[anet::DS_FX * ld + b];
+}
 }  // namespace
 
 extern "C" {
@@ -692,6 +1101,8 @@ void anet_destroy(anet_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->d_counter) (void)hipFree(ctx->d_counter);
+  if (ctx->h_counter) (void)hipHostFree(ctx->h_counter);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1044,6 +1455,218 @@ int anet_minco_cost_grad(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
   if ((rc = st.download(d_gT, N, gradT))) return rc;
   if (coeffs_out && (rc = st.download(d_co, nco, coeffs_out))) return rc;
   ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ANET_OK;
+}
+
+// ---- L-BFGS entry points -------------------------------------------------------------------------
+void anet_lbfgs_default_params(anet_lbfgs_params *p) {
+  if (!p) return;
+  p->mem_size = 8; p->g_epsilon = 1.0e-5; p->past = 3; p->delta = 1.0e-6; p->max_iterations = 0;
+  p->max_linesearch = 64; p->min_step = 1.0e-20; p->max_step = 1.0e+20; p->f_dec_coeff = 1.0e-4;
+  p->s_curv_coeff = 0.9; p->cautious_factor = 1.0e-6; p->machine_prec = 1.0e-16;
+}
+
+int anet_lbfgs_check_params(int n, const anet_lbfgs_params *p) {
+  if (!p) return -1024;
+  if (n <= 0) return -1023;
+  if (p->mem_size <= 0) return -1022;
+  if (p->g_epsilon < 0.0) return -1021;
+  if (p->past < 0) return -1020;
+  if (p->delta < 0.0) return -1019;
+  if (p->min_step < 0.0) return -1018;
+  if (p->max_step < p->min_step) return -1017;
+  if (!(p->f_dec_coeff > 0.0 && p->f_dec_coeff < 1.0)) return -1016;
+  if (!(p->s_curv_coeff < 1.0 && p->s_curv_coeff > p->f_dec_coeff)) return -1015;
+  if (!(p->machine_prec > 0.0)) return -1014;
+  if (p->max_linesearch <= 0) return -1013;
+  return 0;
+}
+
+const char *anet_lbfgs_strerror(int code) {
+  switch (code) {
+    case 0: return "Success: reached convergence (g_epsilon).";
+    case 1: return "Success: met stopping criteria (past f decrease less than delta).";
+    case 2: return "The iteration has been canceled by the monitor callback.";
+    case -1024: return "Unknown error.";
+    case -1023: return "Invalid number of variables specified.";
+    case -1022: return "Invalid parameter lbfgs_parameter_t::mem_size specified.";
+    case -1021: return "Invalid parameter lbfgs_parameter_t::g_epsilon specified.";
+    case -1020: return "Invalid parameter lbfgs_parameter_t::past specified.";
+    case -1019: return "Invalid parameter lbfgs_parameter_t::delta specified.";
+    case -1018: return "Invalid parameter lbfgs_parameter_t::min_step specified.";
+    case -1017: return "Invalid parameter lbfgs_parameter_t::max_step specified.";
+    case -1016: return "Invalid parameter lbfgs_parameter_t::f_dec_coeff specified.";
+    case -1015: return "Invalid parameter lbfgs_parameter_t::s_curv_coeff specified.";
+    case -1014: return "Invalid parameter lbfgs_parameter_t::machine_prec specified.";
+    case -1013: return "Invalid parameter lbfgs_parameter_t::max_linesearch specified.";
+    case -1012: return "The function value became NaN or Inf.";
+    case -1011: return "The line-search step became smaller than lbfgs_parameter_t::min_step.";
+    case -1010: return "The line-search step became larger than lbfgs_parameter_t::max_step.";
+    case -1009: return "Line search reaches the maximum try number, assumptions not satisfied or precision not achievable.";
+    case -1008: return "The algorithm routine reaches the maximum number of iterations.";
+    case -1007: return "Relative search interval width is at least lbfgs_parameter_t::machine_prec.";
+    case -1006: return "A logic error (negative line-search step) occurred.";
+    case -1005: return "The current search direction increases the cost function value.";
+    case ANET_LBFGS_RUNNING: return "Still running: the evaluation budget (max_evals) was exhausted.";
+    default: return "(unknown)";
+  }
+}
+
+static int check_lbfgs(anet_ctx *ctx, int n, const anet_lbfgs_params *params, int max_evals) {
+  const int code = anet_lbfgs_check_params(n, params);
+  if (code) return fail(ctx, ANET_ERR_INVALID, std::string("lbfgs parameters rejected: ") + anet_lbfgs_strerror(code));
+  if (max_evals <= 0) return fail(ctx, ANET_ERR_INVALID, "max_evals must be > 0");
+  return ANET_OK;
+}
+
+int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A, double smooth_eps,
+                    double penalty_wt, double *x, double *f, const anet_lbfgs_params *params,
+                    int max_evals, int32_t *status, int32_t *iters, int32_t *evals) {
+  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  int rc = check_lbfgs(ctx, 9, params, max_evals);
+  if (rc) return rc;
+  if (batch < 0 || M < 1 || !(smooth_eps > 0.0)) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_mvie: bad batch, M or smooth_eps");
+  if (batch == 0) return ANET_OK;
+  if (!A || !x) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_mvie: NULL pointer");
+  const int n = 9, m = params->mem_size, npf = params->past > 1 ? params->past : 1;
+  Stager st;
+  const int64_t wdoubles = LbfgsLayout::doubles(n, m, npf, 1);
+  const int64_t mx = 3 * (int64_t)M > n ? 3 * (int64_t)M : n;
+  rc = make_stager(ctx, batch, mx, 3 * (int64_t)M + n + wdoubles + 3, &st);
+  if (rc) return rc;
+  double *d_A, *d_x0;
+  if ((rc = st.upload(A, 3 * (int64_t)M, &d_A))) return rc;
+  if ((rc = st.upload(x, n, &d_x0))) return rc;
+  LbfgsLayout L{n, m, npf, st.ld};
+  L.carve(st.reserve(wdoubles));
+  int *d_res = (int *)st.reserve(3);  // status, iters, evals rows (int32, ld each; 3*ld doubles is ample)
+  hipStream_t s0 = ctx->stream;
+  ANET_HIP(ctx, hipMemcpyAsync(L.x, d_x0, sizeof(double) * n * st.ld, hipMemcpyDeviceToDevice, s0));
+  anet::MvieArgs ma{d_A, L.x, L.feval, L.g, L.is, batch, st.ld, M, smooth_eps, penalty_wt};
+  const dim3 grid((unsigned)((batch + 63) / 64)), block(64);
+  rc = lbfgs_drive(ctx, L, batch, *params, max_evals, s0, [&]() -> int {
+    hipLaunchKernelGGL(anet::k_mvie_eval, grid, block, 0, s0, ma);
+    ANET_HIP(ctx, hipGetLastError());
+    return ANET_OK;
+  });
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_lbfgs_results, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, s0, L.is, L.ds, batch,
+                     st.ld, d_res, d_res + st.ld, d_res + 2 * st.ld, L.feval);
+  ANET_HIP(ctx, hipGetLastError());
+  if (status) ANET_HIP(ctx, hipMemcpyAsync(status, d_res, sizeof(int) * batch, hipMemcpyDeviceToHost, s0));
+  if (iters) ANET_HIP(ctx, hipMemcpyAsync(iters, d_res + st.ld, sizeof(int) * batch, hipMemcpyDeviceToHost, s0));
+  if (evals) ANET_HIP(ctx, hipMemcpyAsync(evals, d_res + 2 * st.ld, sizeof(int) * batch, hipMemcpyDeviceToHost, s0));
+  if (f) ANET_HIP(ctx, hipMemcpyAsync(f, L.feval, sizeof(double) * batch, hipMemcpyDeviceToHost, s0));
+  return st.download(L.x, n, x);
+}
+
+int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_lbfgs_params *params) {
+  if (!params || params->mem_size <= 0) return -1;
+  const int n = 3 * (n_pieces - 1) + n_pieces;
+  const int npf = params->past > 1 ? params->past : 1;
+  // L-BFGS state + cost/grad workspace + gradP + gradT
+  return LbfgsLayout::doubles(n, params->mem_size, npf, ld) + anet_minco_cost_grad_workspace(s, n_pieces, ld) +
+         (int64_t)n * ld;
+}
+
+int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                         const double *head, const double *tail, double *wps, double *T,
+                         const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
+                         int opt_flags, int max_evals, double *work, double *cost, double *coeffs_out,
+                         int32_t *status, int32_t *iters, int32_t *evals, void *stream) {
+  int rc = check_solve_args(ctx, s, c, n_pieces, batch);
+  if (rc) return rc;
+  if ((rc = check_penalty(ctx, pen))) return rc;
+  const int N = n_pieces;
+  const int nw = (opt_flags & ANET_OPT_WAYPOINTS) ? 3 * (N - 1) : 0;
+  const int nt = (opt_flags & ANET_OPT_TIMES) ? N : 0;
+  const int n = nw + nt;
+  if (n <= 0) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_minco: nothing to optimise (opt_flags / N)");
+  if ((rc = check_lbfgs(ctx, n, params, max_evals))) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!head || !tail || !T || (N > 1 && !wps) || !work || ld < batch)
+    return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_minco_dev: NULL pointer or ld < batch");
+  const int m = params->mem_size, npf = params->past > 1 ? params->past : 1;
+  LbfgsLayout L{n, m, npf, ld};
+  L.carve(work);
+  double *w_cg = work + LbfgsLayout::doubles(n, m, npf, ld);
+  double *w_gP = w_cg + anet_minco_cost_grad_workspace(s, N, ld);
+  double *w_gT = w_gP + (int64_t)3 * (N - 1) * ld;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g256((unsigned)((batch + 255) / 256)), b256(256);
+  anet::MapArgs mp{L.x, L.g, wps, T, w_gP, w_gT, batch, ld, nw, nt, 0};
+  hipLaunchKernelGGL(anet::k_minco_map, g256, b256, 0, st, mp);
+  ANET_HIP(ctx, hipGetLastError());
+  bool first = true;
+  rc = lbfgs_drive(ctx, L, batch, *params, max_evals, st, [&]() -> int {
+    if (!first) {
+      mp.mode = 1;
+      hipLaunchKernelGGL(anet::k_minco_map, g256, b256, 0, st, mp);
+      ANET_HIP(ctx, hipGetLastError());
+    }
+    first = false;
+    int r = anet_minco_cost_grad_dev(ctx, s, c, N, batch, ld, head, tail, wps, T, hpolys, pen, w_cg, L.feval,
+                                     w_gP, w_gT, nullptr, st);
+    if (r) return r;
+    mp.mode = 2;
+    hipLaunchKernelGGL(anet::k_minco_map, g256, b256, 0, st, mp);
+    ANET_HIP(ctx, hipGetLastError());
+    return ANET_OK;
+  });
+  if (rc) return rc;
+  // final parameters (x may have been reverted by a failed line search) and outputs
+  mp.mode = 1;
+  hipLaunchKernelGGL(anet::k_minco_map, g256, b256, 0, st, mp);
+  ANET_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_lbfgs_results, g256, b256, 0, st, L.is, L.ds, batch, ld, status, iters, evals, cost);
+  ANET_HIP(ctx, hipGetLastError());
+  if (coeffs_out) return anet_minco_solve_dev(ctx, s, c, N, batch, ld, head, tail, wps, T, coeffs_out, nullptr, st);
+  return ANET_OK;
+}
+
+int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
+                     const double *tail, double *wps, double *T, const double *hpolys,
+                     const anet_penalty *pen, const anet_lbfgs_params *params, int opt_flags,
+                     int max_evals, double *cost, double *coeffs_out, int32_t *status, int32_t *iters,
+                     int32_t *evals) {
+  int rc = check_solve_args(ctx, s, c, n_pieces, batch);
+  if (rc) return rc;
+  if ((rc = check_penalty(ctx, pen))) return rc;
+  if (!params) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_minco: params is NULL");
+  if (batch == 0) return ANET_OK;
+  if (!head || !tail || !T || (n_pieces > 1 && !wps)) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_minco: NULL pointer");
+  const int N = n_pieces;
+  const int64_t nco = (int64_t)N * 3 * 2 * s;
+  const int64_t M = (pen && hpolys) ? pen->poly_rows : 0;
+  const int64_t nhp = (int64_t)N * M * 4;
+  const int64_t wdoubles = anet_lbfgs_minco_workspace(s, N, 1, params);
+  if (wdoubles < 0) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_minco: bad lbfgs parameters");
+  int64_t mx = nco > nhp ? nco : nhp;
+  if (mx < 3 * (int64_t)c) mx = 3 * c;
+  Stager st;
+  rc = make_stager(ctx, batch, mx, 6 * (int64_t)c + 3 * (int64_t)(N - 1) + N + nhp + nco + wdoubles + 4, &st);
+  if (rc) return rc;
+  double *d_head, *d_tail, *d_wps, *d_T, *d_hp = nullptr;
+  if ((rc = st.upload(head, 3 * c, &d_head))) return rc;
+  if ((rc = st.upload(tail, 3 * c, &d_tail))) return rc;
+  if ((rc = st.upload(wps, (int64_t)(N - 1) * 3, &d_wps))) return rc;
+  if ((rc = st.upload(T, N, &d_T))) return rc;
+  if (nhp && (rc = st.upload(hpolys, nhp, &d_hp))) return rc;
+  double *d_co = st.reserve(nco), *d_work = st.reserve(wdoubles), *d_cost = st.reserve(1);
+  int *d_res = (int *)st.reserve(3);
+  rc = anet_lbfgs_minco_dev(ctx, s, c, N, batch, st.ld, d_head, d_tail, d_wps, d_T, d_hp, pen, params, opt_flags,
+                            max_evals, d_work, d_cost, coeffs_out ? d_co : nullptr, d_res, d_res + st.ld,
+                            d_res + 2 * st.ld, ctx->stream);
+  if (rc) return rc;
+  hipStream_t s0 = ctx->stream;
+  if (status) ANET_HIP(ctx, hipMemcpyAsync(status, d_res, sizeof(int) * batch, hipMemcpyDeviceToHost, s0));
+  if (iters) ANET_HIP(ctx, hipMemcpyAsync(iters, d_res + st.ld, sizeof(int) * batch, hipMemcpyDeviceToHost, s0));
+  if (evals) ANET_HIP(ctx, hipMemcpyAsync(evals, d_res + 2 * st.ld, sizeof(int) * batch, hipMemcpyDeviceToHost, s0));
+  if (cost) ANET_HIP(ctx, hipMemcpyAsync(cost, d_cost, sizeof(double) * batch, hipMemcpyDeviceToHost, s0));
+  if (N > 1 && (rc = st.download(d_wps, (int64_t)(N - 1) * 3, wps))) return rc;
+  if ((rc = st.download(d_T, N, T))) return rc;
+  if (coeffs_out && (rc = st.download(d_co, nco, coeffs_out))) return rc;
+  ANET_HIP(ctx, hipStreamSynchronize(s0));
   return ANET_OK;
 }
 

@@ -1,0 +1,105 @@
+"""Host mirror of the reference's L-BFGS surface (gcopter/lbfgs.hpp): the parameter struct, the
+return codes and lbfgs_strerror keep the reference's names and values; lbfgs_optimize itself is a
+host-callback API and has exactly one caller in the reference (firi::maxVolInsEllipsoid with
+costMVIE, firi.hpp:207-227) -- the batched entry points below run that objective, and the MINCO
+trajectory cost, entirely on the GPU."""
+import ctypes
+import numpy as np
+
+from .context import default_context
+from ._lib import LbfgsParams, load
+
+# lbfgs.hpp:135-184
+LBFGS_CONVERGENCE = 0
+LBFGS_STOP = 1
+LBFGS_CANCELED = 2
+LBFGSERR_UNKNOWNERROR = -1024
+LBFGSERR_INVALID_N = -1023
+LBFGSERR_INVALID_MEMSIZE = -1022
+LBFGSERR_INVALID_GEPSILON = -1021
+LBFGSERR_INVALID_TESTPERIOD = -1020
+LBFGSERR_INVALID_DELTA = -1019
+LBFGSERR_INVALID_MINSTEP = -1018
+LBFGSERR_INVALID_MAXSTEP = -1017
+LBFGSERR_INVALID_FDECCOEFF = -1016
+LBFGSERR_INVALID_SCURVCOEFF = -1015
+LBFGSERR_INVALID_MACHINEPREC = -1014
+LBFGSERR_INVALID_MAXLINESEARCH = -1013
+LBFGSERR_INVALID_FUNCVAL = -1012
+LBFGSERR_MINIMUMSTEP = -1011
+LBFGSERR_MAXIMUMSTEP = -1010
+LBFGSERR_MAXIMUMLINESEARCH = -1009
+LBFGSERR_MAXIMUMITERATION = -1008
+LBFGSERR_WIDTHTOOSMALL = -1007
+LBFGSERR_INVALIDPARAMETERS = -1006
+LBFGSERR_INCREASEGRADIENT = -1005
+LBFGS_RUNNING = 2147483647
+
+OPT_WAYPOINTS = 1
+OPT_TIMES = 2
+
+
+def lbfgs_parameter_t(**over):
+    """lbfgs::lbfgs_parameter_t with the reference's defaults (lbfgs.hpp:15-129)."""
+    p = LbfgsParams()
+    load().anet_lbfgs_default_params(ctypes.byref(p))
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def lbfgs_strerror(code):
+    return load().anet_lbfgs_strerror(int(code)).decode()
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def lbfgs_mvie(A, x0, smooth_eps=1.0e-2, penalty_wt=1.0e3, param=None, max_evals=4000, ctx=None):
+    """Batched firi::maxVolInsEllipsoid inner optimisation (firi.hpp:202-227).
+    A: (B, M, 3) rows of A (a.x <= 1 form, firi.hpp:198-200); x0: (B, 9).
+    Default parameters are the call site's (firi.hpp:212-217) when param is None.
+    Returns x (B,9), f (B,), status (B,), iters (B,), evals (B,)."""
+    ctx = ctx or default_context()
+    if param is None:
+        param = lbfgs_parameter_t(mem_size=18, g_epsilon=0.0, min_step=1.0e-32, past=3, delta=1.0e-7)
+    A = np.asarray(A, dtype=np.float64)
+    B, M, _ = A.shape
+    Acm = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))       # per problem column-major M x 3
+    x = np.array(x0, dtype=np.float64).reshape(B, 9).copy()
+    f = np.empty(B)
+    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); evals = np.empty(B, dtype=np.int32)
+    ctx.check(ctx.lib.anet_lbfgs_mvie(ctx.handle, B, M, _ptr(Acm), float(smooth_eps), float(penalty_wt), _ptr(x),
+                                      _ptr(f), ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(max_evals),
+                                      _ptr(status), _ptr(iters), _ptr(evals)))
+    return x, f, status, iters, evals
+
+
+def lbfgs_minco(head, tail, wps, T, s, hpolys=None, penalty=None, param=None, opt=OPT_WAYPOINTS | OPT_TIMES,
+                max_evals=2000, want_coeffs=True, ctx=None):
+    """Batched spatial-temporal trajectory optimisation: L-BFGS on the MINCO cost
+    (anet_lbfgs_minco).  Returns dict(wps, T, cost, coeffs, status, iters, evals)."""
+    ctx = ctx or default_context()
+    param = param or lbfgs_parameter_t()
+    head = np.ascontiguousarray(head, dtype=np.float64)
+    B, _, c = head.shape
+    tail = np.ascontiguousarray(tail, dtype=np.float64)
+    T = np.array(T, dtype=np.float64).copy()
+    N = T.shape[1]
+    wps = np.array(wps if wps is not None else np.zeros((B, 0, 3)), dtype=np.float64).reshape(B, N - 1, 3).copy()
+    if hpolys is not None:
+        hpolys = np.ascontiguousarray(hpolys, dtype=np.float64)
+        if penalty is None or hpolys.shape != (B, N, penalty.poly_rows, 4):
+            raise ValueError("hpolys must be (B, N, penalty.poly_rows, 4)")
+    cost = np.empty(B)
+    coeffs = np.empty((B, N, 3, 2 * s)) if want_coeffs else None
+    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); evals = np.empty(B, dtype=np.int32)
+    ctx.check(ctx.lib.anet_lbfgs_minco(
+        ctx.handle, s, c, N, B, _ptr(head), _ptr(tail), _ptr(wps), _ptr(T), _ptr(hpolys),
+        ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p) if penalty is not None else None,
+        ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), _ptr(cost), _ptr(coeffs),
+        _ptr(status), _ptr(iters), _ptr(evals)))
+    return dict(wps=wps, T=T, cost=cost, coeffs=coeffs, status=status, iters=iters, evals=evals)

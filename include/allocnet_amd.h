@@ -185,6 +185,66 @@ int anet_minco_cost_grad(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                          double *gradT,  /* [batch][N]      */
                          double *coeffs_out /* [batch][N][3][2s] or NULL */);
 
+/* ---- batched L-BFGS ------------------------------------------------------------------------ */
+/* lbfgs::lbfgs_parameter_t, same fields and defaults (gcopter/lbfgs.hpp:15-129). */
+typedef struct anet_lbfgs_params {
+  int32_t mem_size;       /* 8      */
+  double g_epsilon;       /* 1e-5   */
+  int32_t past;           /* 3      */
+  double delta;           /* 1e-6   */
+  int32_t max_iterations; /* 0 = until convergence */
+  int32_t max_linesearch; /* 64     */
+  double min_step;        /* 1e-20  */
+  double max_step;        /* 1e+20  */
+  double f_dec_coeff;     /* 1e-4   */
+  double s_curv_coeff;    /* 0.9    */
+  double cautious_factor; /* 1e-6   */
+  double machine_prec;    /* 1e-16  */
+} anet_lbfgs_params;
+void anet_lbfgs_default_params(anet_lbfgs_params *p);
+/* lbfgs_optimize's own parameter validation (lbfgs.hpp:449-495): 0 or the LBFGSERR_INVALID_* code. */
+int anet_lbfgs_check_params(int n, const anet_lbfgs_params *p);
+/* lbfgs::lbfgs_strerror (lbfgs.hpp:724-799). */
+const char *anet_lbfgs_strerror(int code);
+
+/* Per problem the control flow, line search (Lewis-Overton weak Wolfe), cautious update, stopping
+ * tests and return codes are those of lbfgs::lbfgs_optimize / line_search_lewisoverton
+ * (gcopter/lbfgs.hpp:276-384, 434-717); the batch advances one objective evaluation per step, each
+ * problem in its own state.  status[b] is lbfgs_optimize's return value (0 convergence, 1 stop,
+ * negative LBFGSERR_*), iters[b] its iteration counter k, evals[b] the number of objective
+ * evaluations.  max_evals (> 0) bounds the evaluations per problem; problems still running then
+ * report status ANET_LBFGS_RUNNING.                                                            */
+#define ANET_LBFGS_RUNNING 2147483647
+
+/* Objective = firi::costMVIE (gcopter/firi.hpp:86-157), the reference's only L-BFGS call site
+ * (firi::maxVolInsEllipsoid, firi.hpp:207-227).  A: per problem the M x 3 matrix COLUMN-major, as the
+ * reference packs optData (firi.hpp:186-200); x: 9 variables [p, sqrt-diag, off-diag], in/out.   */
+int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A /* [batch][3*M] */,
+                    double smooth_eps, double penalty_wt, double *x /* [batch][9] */,
+                    double *f /* [batch] */, const anet_lbfgs_params *params, int max_evals,
+                    int32_t *status, int32_t *iters, int32_t *evals);
+
+/* Objective = the MINCO cost  int (p^(s))^2 + rho*sum(T) + J_pen  (anet_minco_cost_grad) over the
+ * interior waypoints (opt_flags bit 0) and/or the durations (bit 1), the durations through the
+ * smooth bijection T(tau) so the problem is unconstrained.  wps and T are in/out.               */
+#define ANET_OPT_WAYPOINTS 1
+#define ANET_OPT_TIMES 2
+int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
+                     const double *tail, double *wps, double *T, const double *hpolys,
+                     const anet_penalty *pen, const anet_lbfgs_params *params, int opt_flags,
+                     int max_evals, double *cost, double *coeffs_out, int32_t *status, int32_t *iters,
+                     int32_t *evals);
+/* Device variant: batch-minor device arrays, workspace from anet_lbfgs_minco_workspace() doubles.
+ * status/iters/evals are device int32 arrays [batch].  Enqueues work on `stream` and synchronises it
+ * every few evaluations to test for completion.                                                 */
+int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_lbfgs_params *params);
+int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                         const double *head, const double *tail, double *wps, double *T,
+                         const double *hpolys, const anet_penalty *pen,
+                         const anet_lbfgs_params *params, int opt_flags, int max_evals, double *work,
+                         double *cost, double *coeffs_out, int32_t *status, int32_t *iters,
+                         int32_t *evals, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,8 +11,8 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "minco_oracle.c")
-    if force or not os.path.exists(_PATH) or os.path.getmtime(_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("minco_oracle.c", "lbfgs_oracle.c")]
+    if force or not os.path.exists(_PATH) or any(os.path.getmtime(_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
     return _PATH
 
@@ -28,8 +28,76 @@ def lib():
         L.oracle_traj_cost.argtypes = [c_int, c_int, c_void_p, c_void_p, c_double]
         L.oracle_piece_eval.restype = None
         L.oracle_piece_eval.argtypes = [c_int, c_void_p, c_double, c_int, c_void_p]
+        L.oracle_lbfgs_default_param.argtypes = [ctypes.POINTER(LbfgsParam)]
+        L.oracle_lbfgs_optimize.restype = c_int
+        L.oracle_lbfgs_optimize.argtypes = [c_int, c_void_p, c_void_p, EVAL_T, c_void_p,
+                                            ctypes.POINTER(LbfgsParam), c_void_p, c_void_p]
+        L.oracle_lbfgs_mvie.restype = c_int
+        L.oracle_lbfgs_mvie.argtypes = [c_int, c_void_p, c_double, c_double, c_void_p, c_void_p,
+                                        ctypes.POINTER(LbfgsParam), c_void_p, c_void_p]
+        L.oracle_cost_mvie.restype = c_double
+        L.oracle_cost_mvie.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
         _lib = L
     return _lib
+
+
+class LbfgsParam(ctypes.Structure):
+    """lbfgs::lbfgs_parameter_t (lbfgs.hpp:15-129)."""
+    _fields_ = [("mem_size", c_int), ("g_epsilon", c_double), ("past", c_int), ("delta", c_double),
+                ("max_iterations", c_int), ("max_linesearch", c_int), ("min_step", c_double),
+                ("max_step", c_double), ("f_dec_coeff", c_double), ("s_curv_coeff", c_double),
+                ("cautious_factor", c_double), ("machine_prec", c_double)]
+
+
+class MvieData(ctypes.Structure):
+    _fields_ = [("M", c_int), ("eps", c_double), ("wt", c_double), ("A", c_void_p)]
+
+
+EVAL_T = ctypes.CFUNCTYPE(c_double, c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double), c_int)
+
+
+def lbfgs_default_param(**over):
+    p = LbfgsParam()
+    lib().oracle_lbfgs_default_param(ctypes.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def lbfgs_optimize(x0, fun, param=None):
+    """fun(x) -> (f, g).  Returns ret, x, f, iters, evals."""
+    param = param or lbfgs_default_param()
+    x = np.array(x0, dtype=np.float64)
+    n = x.size
+
+    def cb(inst, xp, gp, nn):
+        xv = np.ctypeslib.as_array(xp, shape=(nn,))
+        f, g = fun(xv.copy())
+        np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
+        return float(f)
+    f = c_double(0.0); it = c_int(0); ev = c_int(0)
+    ret = lib().oracle_lbfgs_optimize(n, _p(x), ctypes.byref(f), EVAL_T(cb), None, ctypes.byref(param),
+                                      ctypes.byref(it), ctypes.byref(ev))
+    return ret, x, f.value, it.value, ev.value
+
+
+def cost_mvie(A, eps, wt, x):
+    """A: (M,3) rows of the normalised polytope (firi.hpp:198-200)."""
+    Ac = np.asfortranarray(np.asarray(A, dtype=np.float64))
+    d = MvieData(Ac.shape[0], eps, wt, Ac.ctypes.data)
+    x = np.ascontiguousarray(x, dtype=np.float64); g = np.zeros(9)
+    f = lib().oracle_cost_mvie(ctypes.byref(d), _p(x), _p(g), 9)
+    return f, g
+
+
+def lbfgs_mvie(A, eps, wt, x0, param=None):
+    param = param or lbfgs_default_param()
+    Ac = np.asfortranarray(np.asarray(A, dtype=np.float64))
+    x = np.array(x0, dtype=np.float64)
+    f = c_double(0.0); it = c_int(0); ev = c_int(0)
+    ret = lib().oracle_lbfgs_mvie(Ac.shape[0], Ac.ctypes.data, eps, wt, _p(x), ctypes.byref(f),
+                                  ctypes.byref(param), ctypes.byref(it), ctypes.byref(ev))
+    return ret, x, f.value, it.value, ev.value
 
 
 def _p(a):

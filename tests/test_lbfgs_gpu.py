@@ -1,0 +1,139 @@
+"""GPU parity of the batched L-BFGS against the C restatement of lbfgs.hpp (oracle/lbfgs_oracle.c):
+(1) the reference's own objective and call-site parameters (firi::costMVIE, firi.hpp:207-227),
+(2) the MINCO trajectory cost, objective evaluated by the numpy oracle through a C callback."""
+import numpy as np
+import pytest
+
+from oracle import cbind
+from oracle import minco_np as onp
+from tests.util import random_problem
+from tests.test_grad_gpu import make_corridors
+
+pytestmark = pytest.mark.gpu
+
+
+def _mvie_batch(rng, B, M):
+    A = rng.normal(size=(B, M, 3)); A /= np.linalg.norm(A, axis=2, keepdims=True)
+    A[:, :6] = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=float)
+    A /= rng.uniform(0.8, 2.5, size=(B, M, 1))      # bounded polytopes a.x <= 1 around the origin
+    k = rng.integers(max(6, M // 2), M + 1, size=B)
+    for b in range(B):
+        A[b, k[b]:] = 0.0                       # zero rows: inactive padding (ragged polytopes)
+    x0 = np.tile(np.r_[np.zeros(3), np.sqrt([0.3, 0.3, 0.3]), np.zeros(3)], (B, 1))
+    x0[:, :3] += rng.normal(size=(B, 3)) * 0.02
+    return A, x0, k
+
+
+def test_mvie_matches_oracle(anet_ctx):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(3)
+    B, M = 150, 18
+    A, x0, k = _mvie_batch(rng, B, M)
+    call_site = dict(mem_size=18, g_epsilon=0.0, min_step=1e-32, past=3, delta=1e-7)   # firi.hpp:212-217
+    # (a) fixed iteration budgets: the control flow is lbfgs.hpp's statement for statement, so the
+    #     iterates agree to rounding and the iteration / evaluation counters exactly
+    # (rounding differences grow with the iteration count on this weight-1e3 non-smooth penalty)
+    for mi, tol in ((1, 1e-12), (3, 1e-11), (7, 1e-8), (15, 1e-5)):
+        x, f, status, iters, evals = aa.lbfgs_mvie(A, x0, param=aa.lbfgs_parameter_t(max_iterations=mi, **call_site),
+                                                   ctx=anet_ctx)
+        prm = cbind.lbfgs_default_param(max_iterations=mi, **call_site)
+        for b in range(0, B, 3):
+            ret, xo, fo, it, ev = cbind.lbfgs_mvie(A[b, :k[b]], 1e-2, 1e3, x0[b], prm)
+            assert (status[b], iters[b]) == (ret, it), (mi, b)
+            if mi <= 15:
+                assert evals[b] == ev, (mi, b)
+            assert np.abs(x[b] - xo).max() <= tol * max(1.0, np.abs(xo).max()), (mi, b)
+            assert abs(f[b] - fo) <= tol * max(1.0, abs(fo))
+    # (b) to convergence with the call-site parameters: hundreds of iterations on a weight-1e3
+    #     penalty amplify rounding differences, so only the outcome is compared
+    x, f, status, iters, evals = aa.lbfgs_mvie(A, x0, ctx=anet_ctx)
+    prm = cbind.lbfgs_default_param(**call_site)
+    for b in range(0, B, 2):
+        ret, xo, fo, it, ev = cbind.lbfgs_mvie(A[b, :k[b]], 1e-2, 1e3, x0[b], prm)
+        assert status[b] >= 0 and ret >= 0
+        assert abs(f[b] - fo) <= 2e-3 * max(1.0, abs(fo)), (b, f[b], fo)
+        fchk, _ = cbind.cost_mvie(A[b, :k[b]], 1e-2, 1e3, x[b])
+        assert abs(fchk - f[b]) <= 1e-9 * max(1.0, abs(f[b]))      # reported f is f(x returned)
+        L = np.array([[x[b, 3] ** 2, 0, 0], [x[b, 6], x[b, 4] ** 2, 0], [x[b, 8], x[b, 7], x[b, 5] ** 2]])
+        Ab = A[b, :k[b]]
+        assert (np.linalg.norm(Ab @ L, axis=1) + Ab @ x[b, :3] - 1.0).max() < 2e-2   # ellipsoid inside
+
+
+def test_mvie_error_codes_and_budget(anet_ctx):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(4)
+    A, x0, k = _mvie_batch(rng, 70, 10)
+    with pytest.raises(aa.AnetError):
+        aa.lbfgs_mvie(A, x0, param=aa.lbfgs_parameter_t(mem_size=0), ctx=anet_ctx)
+    # iteration cap -> LBFGSERR_MAXIMUMITERATION for every problem
+    x, f, status, iters, evals = aa.lbfgs_mvie(A, x0, param=aa.lbfgs_parameter_t(max_iterations=2, g_epsilon=0.0,
+                                                                                   delta=0.0), ctx=anet_ctx)
+    assert (status == aa.lbfgs.LBFGSERR_MAXIMUMITERATION).all() and (iters == 2).all()
+    # evaluation budget exhausted -> still running
+    x, f, status, iters, evals = aa.lbfgs_mvie(A, x0, max_evals=3, ctx=anet_ctx)
+    assert (status == aa.lbfgs.LBFGS_RUNNING).all() and (evals == 3).all()
+    assert "max_evals" in aa.lbfgs_strerror(aa.lbfgs.LBFGS_RUNNING)
+    assert aa.lbfgs_strerror(-1009).startswith("Line search reaches the maximum")
+
+
+def _fwd(tau):
+    return np.where(tau > 0, (0.5 * tau + 1) * tau + 1, 1.0 / ((0.5 * tau - 1) * tau + 1))
+
+
+def _dfwd(tau):
+    den = (0.5 * tau - 1) * tau + 1
+    return np.where(tau > 0, tau + 1, (1 - tau) / den ** 2)
+
+
+def _bwd(T):
+    return np.where(T > 1, np.sqrt(2 * T - 1) - 1, 1 - np.sqrt(2 / T - 1))
+
+
+@pytest.mark.parametrize("s,c,N,M", [(4, 3, 4, 8), (3, 3, 5, 6)])
+def test_minco_lbfgs_matches_oracle(anet_ctx, s, c, N, M):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(40 + s)
+    B = 6
+    head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
+    hp = make_corridors(rng, head, tail, wps, M, tight=1.5)
+    kw = dict(res=8, vmax=3.0, amax=4.0, wc=1e3, wv=1e2, wa=1e2, mu=1e-2)
+    rho = 20.0
+    pen = aa.make_penalty(rho=rho, w_corridor=kw["wc"], w_vel=kw["wv"], w_acc=kw["wa"], smooth_mu=kw["mu"],
+                          max_vel=kw["vmax"], max_acc=kw["amax"], res=kw["res"], poly_rows=M)
+    nw = 3 * (N - 1)
+
+    def make_fun(b):
+        hpb = np.transpose(hp[b], (1, 2, 0))
+
+        def fun(x):
+            w = x[:nw].reshape(N - 1, 3).T
+            tau = x[nw:]; Tt = _fwd(tau)
+            co, e, *_ = onp.minco_dense_solve(s, head[b], tail[b], w, Tt)
+            jp, gC, gTp, _ = onp.penalty_partials(s, co, Tt, hpb, **kw)
+            eC, eT = onp.energy_partials(s, co, Tt)
+            gP, gT = onp.minco_dense_propagate(s, head[b], tail[b], w, Tt, gC + eC, gTp + eT + rho)
+            return e + rho * Tt.sum() + jp, np.r_[gP.T.reshape(-1), gT * _dfwd(tau)]
+        return fun
+    # fixed iteration budgets: same control flow -> same counters, iterates equal to rounding;
+    # long runs only agree in outcome (rounding differences are amplified by the penalty weights)
+    for mi, tol in ((2, 1e-9), (6, 1e-7), (200, 5e-3)):
+        prm = aa.lbfgs_parameter_t(g_epsilon=1e-6, delta=1e-8, past=3, max_iterations=mi)
+        out = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=prm, ctx=anet_ctx)
+        for b in range(B):
+            fun = make_fun(b)
+            x0 = np.r_[wps[b].reshape(-1), _bwd(T[b])]
+            f0, _ = fun(x0)
+            ret, xo, fo, it, ev = cbind.lbfgs_optimize(x0, fun, cbind.lbfgs_default_param(
+                g_epsilon=1e-6, delta=1e-8, past=3, max_iterations=mi))
+            assert out["cost"][b] < f0                                   # it optimised something
+            assert abs(out["cost"][b] - fo) <= tol * abs(fo), (mi, b, out["cost"][b], fo, out["status"][b], ret)
+            if mi <= 6:
+                assert (out["status"][b], out["iters"][b], out["evals"][b]) == (ret, it, ev), (mi, b)
+                xg = np.r_[out["wps"][b].reshape(-1), _bwd(out["T"][b])]
+                assert np.abs(xg - xo).max() <= tol * max(1.0, np.abs(xo).max())
+            # returned parameters reproduce the returned cost
+            fchk, _ = fun(np.r_[out["wps"][b].reshape(-1), _bwd(out["T"][b])])
+            assert abs(fchk - out["cost"][b]) <= 1e-8 * abs(fchk)
+            # coefficients returned are the MINCO solution of the returned parameters
+            co, *_ = onp.minco_dense_solve(s, head[b], tail[b], out["wps"][b].T, out["T"][b])
+            assert np.abs(out["coeffs"][b] - co).max() <= 1e-8 * np.abs(co).max()
