@@ -25,6 +25,10 @@ PROTOTYPES = {
     "anet_last_error": (c_char_p, [c_void_p]),
     "anet_stream": (c_void_p, [c_void_p]),
     "anet_synchronize": (c_int, [c_void_p]),
+    "anet_dev_alloc": (c_int, [c_void_p, ctypes.c_size_t, POINTER(c_void_p)]),
+    "anet_dev_free": (None, [c_void_p]),
+    "anet_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),
+    "anet_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),
     "anet_to_batch_minor_dev": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "anet_to_traj_major_dev": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "anet_minco_solve_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64,

@@ -1117,6 +1117,30 @@ int anet_synchronize(anet_ctx *ctx) {
   return ANET_OK;
 }
 
+int anet_dev_alloc(anet_ctx *ctx, size_t n_doubles, double **out) {
+  if (!ctx || !out) return fail(ctx, ANET_ERR_INVALID, "anet_dev_alloc: NULL argument");
+  *out = nullptr;
+  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc((void **)out, sizeof(double) * (n_doubles ? n_doubles : 1));
+  if (e != hipSuccess) return fail(ctx, ANET_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return ANET_OK;
+}
+void anet_dev_free(double *p) {
+  if (p) (void)hipFree(p);
+}
+int anet_dev_upload(anet_ctx *ctx, double *dst_dev, const double *src_host, size_t n_doubles) {
+  if (!ctx || !dst_dev || !src_host) return fail(ctx, ANET_ERR_INVALID, "anet_dev_upload: NULL argument");
+  ANET_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, sizeof(double) * n_doubles, hipMemcpyHostToDevice, ctx->stream));
+  ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ANET_OK;
+}
+int anet_dev_download(anet_ctx *ctx, double *dst_host, const double *src_dev, size_t n_doubles) {
+  if (!ctx || !dst_host || !src_dev) return fail(ctx, ANET_ERR_INVALID, "anet_dev_download: NULL argument");
+  ANET_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, sizeof(double) * n_doubles, hipMemcpyDeviceToHost, ctx->stream));
+  ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ANET_OK;
+}
+
 int anet_to_batch_minor_dev(anet_ctx *ctx, int64_t batch, int64_t nfield, int64_t ld,
                             const double *src, double *dst, void *stream) {
   if (!ctx || !src || !dst || batch < 0 || nfield < 0 || ld < batch)

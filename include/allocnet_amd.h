@@ -38,6 +38,7 @@
 #ifndef ALLOCNET_AMD_H
 #define ALLOCNET_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -68,6 +69,12 @@ const char *anet_last_error(const anet_ctx *ctx);
 /* hipStream_t the plain (host) entry points run on. */
 void *anet_stream(anet_ctx *ctx);
 int anet_synchronize(anet_ctx *ctx);
+
+/* ---- device buffers for callers that do not link the HIP runtime themselves ---------------- */
+int anet_dev_alloc(anet_ctx *ctx, size_t n_doubles, double **out);
+void anet_dev_free(double *p);
+int anet_dev_upload(anet_ctx *ctx, double *dst_dev, const double *src_host, size_t n_doubles);   /* synchronous */
+int anet_dev_download(anet_ctx *ctx, double *dst_host, const double *src_dev, size_t n_doubles); /* synchronous */
 
 /* ---- layout helpers: trajectory-major host/device <-> batch-minor device ---------------- */
 /* dst[f*ld + b] = src[b*nfield + f]  (both device pointers). */

@@ -1,0 +1,99 @@
+// Exercises the C++ facade (include/allocnet_amd/*.hpp) the way the reference's planner uses its
+// headers (learning_planner.hpp:203-233): fill a Trajectory<7> from solver output, evaluate it,
+// query its cost; plus the MINCO_S4NU surface.  Prints one JSON object; tests/test_facade_gpu.py
+// checks it against the oracle.  `Mat` stands in for an Eigen matrix (duck typing only).
+#include <cstdio>
+#include <vector>
+
+#include "allocnet_amd/lbfgs.hpp"
+#include "allocnet_amd/minco.hpp"
+#include "allocnet_amd/trajectory.hpp"
+
+struct Mat {  // Eigen-like: (r,c) access, default constructible
+  int R, C;
+  std::vector<double> a;
+  Mat(int r = 3, int c = 8) : R(r), C(c), a((size_t)r * c, 0.0) {}
+  double &operator()(int r, int c) { return a[(size_t)r * C + c]; }
+  double operator()(int r, int c) const { return a[(size_t)r * C + c]; }
+};
+struct Vec {
+  std::vector<double> a;
+  explicit Vec(int n) : a(n, 0.0) {}
+  double &operator()(int i) { return a[i]; }
+  double operator()(int i) const { return a[i]; }
+};
+struct V3 {  // Eigen::Vector3d-like: constructible from three scalars
+  double x, y, z;
+  V3(double a, double b, double c) : x(a), y(b), z(c) {}
+};
+
+static void print_vec(const char *name, const std::vector<double> &v, bool last = false) {
+  printf("\"%s\": [", name);
+  for (size_t i = 0; i < v.size(); ++i) printf("%s%.17g", i ? ", " : "", v[i]);
+  printf("]%s\n", last ? "" : ",");
+}
+
+int main() {
+  try {
+    // one 8-segment min-snap trajectory, fixed waypoints on the chord, T_i = 1
+    const int N = 8;
+    Mat head(3, 3), tail(3, 3), inPs(3, N - 1);
+    Vec ts(N);
+    const double goal[3] = {8.0, 3.0, 1.0};
+    for (int a = 0; a < 3; ++a) tail(a, 0) = goal[a];
+    for (int k = 0; k < N - 1; ++k)
+      for (int a = 0; a < 3; ++a) inPs(a, k) = goal[a] * (k + 1) / (double)N;
+    for (int i = 0; i < N; ++i) ts(i) = 1.0;
+
+    minco::MINCO_S4NU opt;
+    opt.setConditions(head, tail, N, 3);  // PVA ends: the reference's convention
+    opt.setParameters(inPs, ts);
+    Trajectory<7> traj;
+    opt.getTrajectory(traj);
+
+    std::vector<double> gdC, gdT, gradP, gradT;
+    opt.getEnergyPartialGradByCoeffs(gdC);
+    opt.getEnergyPartialGradByTimes(gdT);
+    opt.propogateGrad(gdC, gdT, gradP, gradT);
+
+    // the way learning_planner.hpp fills a trajectory from a flat solution vector
+    Trajectory<7> copy;
+    copy.reserve(N);
+    const std::vector<double> &flat = opt.getCoeffs();
+    for (int i = 0; i < N; ++i) {
+      Mat cm(3, 8);
+      for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 8; ++k) cm(j, k) = flat[(size_t)i * 3 * 8 + j * 8 + k];
+      copy.emplace_back(ts(i), cm);
+    }
+    V3 mid = copy.getPos(3.5);  // conversion to an Eigen-like vector type
+    anet::Vec3 vel = copy.getVel(3.5), acc = copy.getAcc(3.5), jer = copy.getJer(3.5);
+    anet::Vec3 endp = copy.getPos(copy.getTotalDuration() + 0.25);  // clamp branch
+    double tloc = 2.25;
+    int idx = copy.locatePieceIdx(tloc);
+
+    printf("{\n");
+    print_vec("coeffs", flat);
+    print_vec("gradP", gradP);
+    print_vec("gradT", gradT);
+    print_vec("gdT", gdT);
+    printf("\"energy\": %.17g,\n", opt.getEnergy());
+    printf("\"traj_cost_1400\": %.17g,\n", copy.getTrajCost(4));
+    printf("\"traj_cost_1440\": %.17g,\n", copy.getTrajCost(4, 1440.0));
+    printf("\"pos\": [%.17g, %.17g, %.17g],\n", mid.x, mid.y, mid.z);
+    printf("\"vel\": [%.17g, %.17g, %.17g],\n", vel(0), vel(1), vel(2));
+    printf("\"acc\": [%.17g, %.17g, %.17g],\n", acc(0), acc(1), acc(2));
+    printf("\"jer\": [%.17g, %.17g, %.17g],\n", jer(0), jer(1), jer(2));
+    printf("\"endp\": [%.17g, %.17g, %.17g],\n", endp(0), endp(1), endp(2));
+    printf("\"junc_vel_3\": [%.17g, %.17g, %.17g],\n", copy.getJuncVel(3)(0), copy.getJuncVel(3)(1), copy.getJuncVel(3)(2));
+    printf("\"locate\": [%d, %.17g],\n", idx, tloc);
+    printf("\"pieces\": %d, \"total\": %.17g,\n", copy.getPieceNum(), copy.getTotalDuration());
+    lbfgs::lbfgs_parameter_t prm;
+    printf("\"lbfgs_default_mem\": %d, \"strerror\": \"%s\"\n", prm.mem_size, lbfgs::lbfgs_strerror(lbfgs::LBFGSERR_MAXIMUMLINESEARCH));
+    printf("}\n");
+    return 0;
+  } catch (const anet::Error &e) {
+    fprintf(stderr, "anet error %d: %s\n", e.code, e.what());
+    return 2;
+  }
+}

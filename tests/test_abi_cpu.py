@@ -54,3 +54,13 @@ def test_oracle_is_not_imported_by_the_product():
     for dp, _, files in os.walk(os.path.join(ROOT, "include")):
         for f in files:
             assert "oracle" not in open(os.path.join(dp, f)).read()
+
+
+def test_cpp_facade_compiles_as_cxx14():
+    """The facade headers must build with the reference's language level (-std=c++14,
+    src/planner/CMakeLists.txt:4) and without Eigen or HIP headers on the include path."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "test_facade.cpp")
+    res = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
+                          "-I", os.path.join(ROOT, "include"), src], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr

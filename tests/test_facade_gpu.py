@@ -1,0 +1,44 @@
+"""C++ facade (include/allocnet_amd/*.hpp) end to end on the GPU: the program in tests/cpp mirrors how
+learning_planner.hpp:203-233 consumes solver output; its numbers are checked against the oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import minco_np as onp
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_facade_program():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True, capture_output=True)
+    res = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_facade")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    out = json.loads(res.stdout)
+    N, s = 8, 4
+    goal = np.array([8.0, 3.0, 1.0])
+    head = np.zeros((3, 3)); tail = np.zeros((3, 3)); tail[:, 0] = goal
+    wps = np.array([goal * (k + 1) / N for k in range(N - 1)]).T
+    T = np.ones(N)
+    co, e, *_ = onp.minco_dense_solve(s, head, tail, wps, T)
+    assert rel_err(np.array(out["coeffs"]).reshape(N, 3, 8), co) < 1e-9
+    assert abs(out["energy"] - e) <= 1e-9 * e
+    assert abs(out["traj_cost_1440"] - 0.5 * e) <= 1e-9 * e
+    assert abs(out["traj_cost_1400"] - onp.traj_cost(co, T, s, 1400.0)) <= 1e-9 * e
+    eC, eT = onp.energy_partials(s, co, T)
+    gP, gT = onp.minco_dense_propagate(s, head, tail, wps, T, eC, eT)
+    assert np.abs(np.array(out["gdT"]) - eT).max() <= 1e-8 * np.abs(eT).max()
+    assert np.abs(np.array(out["gradP"]).reshape(N - 1, 3).T - gP).max() <= 1e-7 * max(1.0, np.abs(gP).max())
+    assert np.abs(np.array(out["gradT"]) - gT).max() <= 1e-7 * max(1.0, np.abs(gT).max())
+    for key, d in (("pos", 0), ("vel", 1), ("acc", 2), ("jer", 3)):
+        ref = onp.traj_eval(co, T, 3.5, d)
+        assert np.abs(np.array(out[key]) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
+    assert np.abs(np.array(out["endp"]) - onp.traj_eval(co, T, 8.25, 0)).max() < 1e-9
+    assert np.abs(np.array(out["junc_vel_3"]) - onp.piece_eval(co[3], 0.0, 1)).max() < 1e-12
+    assert out["locate"][0] == 2 and abs(out["locate"][1] - 0.25) < 1e-15
+    assert out["pieces"] == 8 and out["total"] == 8.0
+    assert out["lbfgs_default_mem"] == 8 and out["strerror"].startswith("Line search reaches")
