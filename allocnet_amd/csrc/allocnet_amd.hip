@@ -544,6 +544,7 @@ struct LbfgsArgs {
   int *is;
   LbfgsP p;
   int *n_active;
+  int64_t vs, ps;  // internal vectors (xp, gp, d, lm_s, lm_y): element i of problem b at [i*vs + b*ps]
 };
 
 // One lane per problem.  Every launch consumes ONE objective evaluation (f = feval[b], gradient in
@@ -753,6 +754,251 @@ __global__ void __launch_bounds__(64) k_lbfgs_update(LbfgsArgs a) {
   }
 }
 
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Same state machine, ONE WAVE per problem: the n variables are spread over the 64 lanes, every dot
+// product / norm is a wavefront shuffle reduction, scalars are computed redundantly by all lanes
+// (no divergence: a wave holds one problem).  Used for small batches, where one lane per problem
+// leaves the chip idle and serialises ~16 n-long dependent loops per accepted step.
+__global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
+  const int64_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t ld = a.ld;
+  int *is = a.is + b;
+  if (is[IS_DONE * ld]) return;
+  double *ds = a.ds + b;
+  const int n = a.n, m = a.p.mem_size;
+  const LbfgsP &P = a.p;
+  const int64_t vs = a.vs, ps = a.ps;
+  double *x = a.x + b, *g = a.g + b;                       // batch-minor (shared with the objective)
+  double *xp = a.xp + b * ps, *gp = a.gp + b * ps, *d = a.d + b * ps;
+  const double f = a.feval[b];
+  double fx = ds[DS_FX * ld];
+  double step = ds[DS_STEP * ld];
+  int k = is[IS_K * ld];
+  int evals = is[IS_EVALS * ld] + 1;
+  int end = is[IS_END * ld], bound = is[IS_BOUND * ld], phase = is[IS_PHASE * ld];
+  int count = is[IS_COUNT * ld], brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
+  double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
+  double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
+  bool start_ls = false;
+  int finish = 0x7fffffff;
+
+  auto conv_test = [&]() {
+    double gn = 0.0, xn = 0.0;
+    for (int i = lane; i < n; i += 64) {
+      gn = fmax(gn, fabs(g[i * ld]));
+      xn = fmax(xn, fabs(x[i * ld]));
+    }
+    gn = wave_max(gn);
+    xn = wave_max(xn);
+    return gn / fmax(1.0, xn) < P.g_epsilon;
+  };
+
+  if (phase == 0) {
+    fx = f;
+    if (lane == 0) a.pf[b] = fx;
+    double dd = 0.0;
+    for (int i = lane; i < n; i += 64) {
+      const double gi = g[i * ld];
+      d[i * vs] = -gi;
+      dd = __builtin_fma(gi, gi, dd);
+    }
+    dd = wave_sum(dd);
+    if (conv_test()) {
+      finish = LB_CONVERGENCE;
+    } else {
+      step = 1.0 / sqrt(dd);
+      k = 1;
+      end = 0;
+      bound = 0;
+      phase = 1;
+      start_ls = true;
+    }
+  } else {
+    ++count;
+    bool success = false;
+    int err = 0;
+    if (isinf(f) || isnan(f)) {
+      err = LBERR_INVALID_FUNCVAL;
+    } else {
+      if (f > finit + step * dgtest) {
+        nu = step;
+        brackt = 1;
+      } else {
+        double dg = 0.0;
+        for (int i = lane; i < n; i += 64) dg = __builtin_fma(g[i * ld], d[i * vs], dg);
+        dg = wave_sum(dg);
+        if (dg < dstest)
+          mu = step;
+        else
+          success = true;
+      }
+      if (!success) {
+        if (P.max_linesearch <= count) {
+          err = LBERR_MAXIMUMLINESEARCH;
+        } else if (brackt && (nu - mu) < P.machine_prec * nu) {
+          err = LBERR_WIDTHTOOSMALL;
+        } else {
+          step = brackt ? 0.5 * (mu + nu) : step * 2.0;
+          if (step < P.min_step) {
+            err = LBERR_MINIMUMSTEP;
+          } else if (step > P.max_step) {
+            if (touched) {
+              err = LBERR_MAXIMUMSTEP;
+            } else {
+              touched = 1;
+              step = P.max_step;
+            }
+          }
+        }
+      }
+    }
+    if (err) {
+      for (int i = lane; i < n; i += 64) {
+        x[i * ld] = xp[i * vs];
+        g[i * ld] = gp[i * vs];
+      }
+      fx = f;
+      finish = err;
+    } else if (!success) {
+      for (int i = lane; i < n; i += 64) x[i * ld] = __builtin_fma(step, d[i * vs], xp[i * vs]);
+    } else {
+      fx = f;
+      if (conv_test()) {
+        finish = LB_CONVERGENCE;
+      } else {
+        if (0 < P.past) {
+          if (P.past <= k) {
+            const double rate = fabs(a.pf[(int64_t)(k % P.past) * ld + b] - fx) / fmax(1.0, fabs(fx));
+            if (rate < P.delta) finish = LB_STOP;
+          }
+          if (finish == 0x7fffffff && lane == 0) a.pf[(int64_t)(k % P.past) * ld + b] = fx;
+        }
+        if (finish == 0x7fffffff && P.max_iterations != 0 && P.max_iterations <= k) finish = LBERR_MAXIMUMITERATION;
+        if (finish == 0x7fffffff) {
+          ++k;
+          double *lms = a.lm_s + b * ps * m, *lmy = a.lm_y + b * ps * m;  // [j][i] at (j*n_stride + i*vs)
+          const int64_t js = (vs == 1) ? ps : (int64_t)n * vs;             // stride between history slots
+          double *se = lms + (int64_t)end * js, *ye = lmy + (int64_t)end * js;
+          // this lane's variable(s) live in registers for the whole two-loop recursion (n <= 128)
+          double dv[2] = {0.0, 0.0};
+          double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
+          int q = 0;
+          for (int i = lane; i < n; i += 64, ++q) {
+            const double gi = g[i * ld], gpi = gp[i * vs];
+            const double si = x[i * ld] - xp[i * vs], yi = gi - gpi;
+            se[i * vs] = si;
+            ye[i * vs] = yi;
+            ys = __builtin_fma(yi, si, ys);
+            yy = __builtin_fma(yi, yi, yy);
+            ss = __builtin_fma(si, si, ss);
+            gpgp = __builtin_fma(gpi, gpi, gpgp);
+            dv[q] = -gi;
+          }
+          ys = wave_sum(ys); yy = wave_sum(yy); ss = wave_sum(ss); gpgp = wave_sum(gpgp);
+          if (lane == 0) a.lm_ys[(int64_t)end * ld + b] = ys;
+          const double cau = ss * sqrt(gpgp) * P.cautious_factor;
+          if (ys > cau) {
+            ++bound;
+            bound = m < bound ? m : bound;
+            const int newest = end;
+            end = (end + 1) % m;
+            int j = end;
+            double alpha = 0.0;  // lane `it` keeps alpha of the it-th visited slot (mem_size <= 64, host-checked)
+            for (int it = 0; it < bound; ++it) {
+              j = (j + m - 1) % m;
+              const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
+              double sd = 0.0, yv[2] = {0.0, 0.0};
+              q = 0;
+              for (int i = lane; i < n; i += 64, ++q) {
+                sd = __builtin_fma(sj[i * vs], dv[q], sd);
+                yv[q] = yj[i * vs];
+              }
+              sd = wave_sum(sd);
+              const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
+              const double al = sd / ysj;
+              alpha = (lane == it) ? al : alpha;
+              dv[0] = __builtin_fma(-al, yv[0], dv[0]);
+              dv[1] = __builtin_fma(-al, yv[1], dv[1]);
+            }
+            const double sc = ys / yy;
+            dv[0] *= sc;
+            dv[1] *= sc;
+            for (int it = 0; it < bound; ++it) {
+              const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
+              double yd = 0.0, sv[2] = {0.0, 0.0};
+              q = 0;
+              for (int i = lane; i < n; i += 64, ++q) {
+                yd = __builtin_fma(yj[i * vs], dv[q], yd);
+                sv[q] = sj[i * vs];
+              }
+              yd = wave_sum(yd);
+              const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
+              const double cf = __shfl(alpha, bound - 1 - it) - yd / ysj;
+              dv[0] = __builtin_fma(cf, sv[0], dv[0]);
+              dv[1] = __builtin_fma(cf, sv[1], dv[1]);
+              j = (j + 1) % m;
+            }
+          }
+          q = 0;
+          for (int i = lane; i < n; i += 64, ++q) d[i * vs] = dv[q];
+          step = 1.0;
+          start_ls = true;
+        }
+      }
+    }
+  }
+  if (start_ls) {
+    double dginit = 0.0;
+    for (int i = lane; i < n; i += 64) {
+      const double xi = x[i * ld], gi = g[i * ld];
+      xp[i * vs] = xi;
+      gp[i * vs] = gi;
+      dginit = __builtin_fma(gi, d[i * vs], dginit);
+    }
+    dginit = wave_sum(dginit);
+    if (!(step > 0.0)) {
+      finish = LBERR_INVALIDPARAMETERS;
+    } else if (0.0 < dginit) {
+      finish = LBERR_INCREASEGRADIENT;
+    } else {
+      finit = fx;
+      dgtest = P.f_dec_coeff * dginit;
+      dstest = P.s_curv_coeff * dginit;
+      mu = 0.0;
+      nu = P.max_step;
+      count = 0;
+      brackt = 0;
+      touched = 0;
+      for (int i = lane; i < n; i += 64) x[i * ld] = __builtin_fma(step, d[i * vs], xp[i * vs]);
+    }
+  }
+  if (lane == 0) {
+    ds[DS_FX * ld] = fx; ds[DS_STEP * ld] = step; ds[DS_FINIT * ld] = finit; ds[DS_DGTEST * ld] = dgtest;
+    ds[DS_DSTEST * ld] = dstest; ds[DS_MU * ld] = mu; ds[DS_NU * ld] = nu;
+    is[IS_K * ld] = k; is[IS_END * ld] = end; is[IS_BOUND * ld] = bound; is[IS_PHASE * ld] = phase;
+    is[IS_COUNT * ld] = count; is[IS_BRACKT * ld] = brackt; is[IS_TOUCHED * ld] = touched;
+    is[IS_EVALS * ld] = evals;
+    if (finish != 0x7fffffff) {
+      is[IS_DONE * ld] = 1;
+      is[IS_RET * ld] = finish;
+    } else if (a.n_active) {
+      atomicAdd(a.n_active, 1);
+    }
+  }
+}
+
 // firi::costMVIE (gcopter/firi.hpp:86-157): x = [p, rtd, cde], A is M x 3 column-major per problem
 // (field k*M + r), the reference's optData packing (firi.hpp:186-200).
 struct MvieArgs {
@@ -839,16 +1085,17 @@ __global__ void __launch_bounds__(256) k_minco_map(MapArgs a) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= a.B) return;
   const int64_t ld = a.ld;
-  for (int i = 0; i < a.nw; ++i) {
-    if (a.mode == 0) a.x[i * ld + b] = a.wps[i * ld + b];
-    else if (a.mode == 1) a.wps[i * ld + b] = a.x[i * ld + b];
-    else a.g[i * ld + b] = a.gradP[i * ld + b];
-  }
-  for (int i = 0; i < a.nt; ++i) {
-    const int64_t xi = (int64_t)(a.nw + i) * ld + b;
-    if (a.mode == 0) a.x[xi] = backward_T(a.T[i * ld + b]);
-    else if (a.mode == 1) a.T[i * ld + b] = forward_T(a.x[xi]);
-    else a.g[xi] = a.gradT[i * ld + b] * dforward_T(a.x[xi]);
+  const int v = blockIdx.y;  // variable index: [0, nw) waypoint coordinates, [nw, nw+nt) durations
+  if (v < a.nw) {
+    const int64_t i = (int64_t)v * ld + b;
+    if (a.mode == 0) a.x[i] = a.wps[i];
+    else if (a.mode == 1) a.wps[i] = a.x[i];
+    else a.g[i] = a.gradP[i];
+  } else {
+    const int64_t xi = (int64_t)v * ld + b, ti = (int64_t)(v - a.nw) * ld + b;
+    if (a.mode == 0) a.x[xi] = backward_T(a.T[ti]);
+    else if (a.mode == 1) a.T[ti] = forward_T(a.x[xi]);
+    else a.g[xi] = a.gradT[ti] * dforward_T(a.x[xi]);
   }
 }
 
@@ -977,6 +1224,21 @@ template <int S>
 int launch_prop(anet_ctx *ctx, const anet::PropArgs &a, hipStream_t st) {
   const dim3 grid((unsigned)((a.B + anet::kSolveBlock - 1) / anet::kSolveBlock));
   const dim3 block(anet::kSolveBlock);
+  if constexpr (S == 4) {
+    if (a.N == 8 && (a.c == 3 || a.c == 4)) {
+      if (a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate<4, 8, true, 2>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((anet::k_minco_propagate<4, 8, true, 3>), grid, block, 0, st, a);
+      ANET_HIP(ctx, hipGetLastError());
+      return ANET_OK;
+    }
+  }
+  if constexpr (S == 3) {
+    if (a.N == 16 && a.c == 3) {
+      hipLaunchKernelGGL((anet::k_minco_propagate<3, 16, true, 2>), grid, block, 0, st, a);
+      ANET_HIP(ctx, hipGetLastError());
+      return ANET_OK;
+    }
+  }
   if (a.N <= 4)
     hipLaunchKernelGGL((anet::k_minco_propagate<S, 4>), grid, block, 0, st, a);
   else if (a.N <= 8)
@@ -1032,16 +1294,22 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
   if (rc) return rc;
   ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * L.ld, st));
   ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_ * L.ld, st));
+  // small batches: one wave per problem (shuffle reductions, internal vectors problem-major);
+  // large batches: one lane per problem (internal vectors batch-minor)
+  const bool wave = B <= 32768 && L.n <= 128 && prm.mem_size <= 64;
   anet::LbfgsArgs a{L.n, B, L.ld, L.x, L.g, L.xp, L.gp, L.d, L.lm_s, L.lm_y, L.lm_ys, L.lm_alpha, L.pf, L.ds,
-                    L.feval, L.is, to_kernel_params(prm), nullptr};
-  const dim3 grid((unsigned)((B + 63) / 64)), block(64);
+                    L.feval, L.is, to_kernel_params(prm), nullptr, wave ? 1 : L.ld, wave ? L.n : 1};
+  const dim3 grid(wave ? (unsigned)B : (unsigned)((B + 63) / 64)), block(64);
   const int poll = 8;
   for (int it = 0; it < max_evals; ++it) {
     if ((rc = eval())) return rc;
     const bool check = ((it + 1) % poll == 0) || it + 1 == max_evals;
     if (check) ANET_HIP(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(int), st));
     a.n_active = check ? ctx->d_counter : nullptr;
-    hipLaunchKernelGGL(anet::k_lbfgs_update, grid, block, 0, st, a);
+    if (wave)
+      hipLaunchKernelGGL(anet::k_lbfgs_update_wave, grid, block, 0, st, a);
+    else
+      hipLaunchKernelGGL(anet::k_lbfgs_update, grid, block, 0, st, a);
     ANET_HIP(ctx, hipGetLastError());
     if (check) {
       ANET_HIP(ctx, hipMemcpyAsync(ctx->h_counter, ctx->d_counter, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1619,13 +1887,14 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
   hipStream_t st = (hipStream_t)stream;
   const dim3 g256((unsigned)((batch + 255) / 256)), b256(256);
   anet::MapArgs mp{L.x, L.g, wps, T, w_gP, w_gT, batch, ld, nw, nt, 0};
-  hipLaunchKernelGGL(anet::k_minco_map, g256, b256, 0, st, mp);
+  const dim3 gmap(g256.x, (unsigned)n);
+  hipLaunchKernelGGL(anet::k_minco_map, gmap, b256, 0, st, mp);
   ANET_HIP(ctx, hipGetLastError());
   bool first = true;
   rc = lbfgs_drive(ctx, L, batch, *params, max_evals, st, [&]() -> int {
     if (!first) {
       mp.mode = 1;
-      hipLaunchKernelGGL(anet::k_minco_map, g256, b256, 0, st, mp);
+      hipLaunchKernelGGL(anet::k_minco_map, gmap, b256, 0, st, mp);
       ANET_HIP(ctx, hipGetLastError());
     }
     first = false;
@@ -1633,14 +1902,14 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                                      w_gP, w_gT, nullptr, st);
     if (r) return r;
     mp.mode = 2;
-    hipLaunchKernelGGL(anet::k_minco_map, g256, b256, 0, st, mp);
+    hipLaunchKernelGGL(anet::k_minco_map, gmap, b256, 0, st, mp);
     ANET_HIP(ctx, hipGetLastError());
     return ANET_OK;
   });
   if (rc) return rc;
   // final parameters (x may have been reverted by a failed line search) and outputs
   mp.mode = 1;
-  hipLaunchKernelGGL(anet::k_minco_map, g256, b256, 0, st, mp);
+  hipLaunchKernelGGL(anet::k_minco_map, gmap, b256, 0, st, mp);
   ANET_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_lbfgs_results, g256, b256, 0, st, L.is, L.ds, batch, ld, status, iters, evals, cost);
   ANET_HIP(ctx, hipGetLastError());

@@ -103,3 +103,29 @@ def lbfgs_minco(head, tail, wps, T, s, hpolys=None, penalty=None, param=None, op
         ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), _ptr(cost), _ptr(coeffs),
         _ptr(status), _ptr(iters), _ptr(evals)))
     return dict(wps=wps, T=T, cost=cost, coeffs=coeffs, status=status, iters=iters, evals=evals)
+
+
+def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, param=None,
+                    opt=OPT_WAYPOINTS | OPT_TIMES, max_evals=2000, coeffs=None, stream=None, ctx=None):
+    """Device entry point -> anet_lbfgs_minco_dev.  torch CUDA float64 tensors, batch-minor, common row
+    stride; wps and T are updated in place.  Returns dict(cost, status, iters, evals) of device tensors."""
+    import torch
+    ctx = ctx or default_context(T.device.index or 0)
+    param = param or lbfgs_parameter_t()
+    ld = T.stride(0)
+    dev = T.device
+    nwork = ctx.lib.anet_lbfgs_minco_workspace(s, N, ld, ctypes.cast(ctypes.pointer(param), ctypes.c_void_p))
+    work = torch.empty(nwork, device=dev, dtype=torch.float64)
+    cost = torch.empty(ld, device=dev, dtype=torch.float64)
+    status = torch.empty(ld, device=dev, dtype=torch.int32)
+    iters = torch.empty(ld, device=dev, dtype=torch.int32)
+    evals = torch.empty(ld, device=dev, dtype=torch.int32)
+    if stream is None:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    ctx.check(ctx.lib.anet_lbfgs_minco_dev(
+        ctx.handle, s, c, N, B, ld, p(head), p(tail), p(wps) if N > 1 else None, p(T), p(hpolys),
+        ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p) if penalty is not None else None,
+        ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), p(work), p(cost), p(coeffs),
+        p(status), p(iters), p(evals), ctypes.c_void_p(stream)))
+    return dict(cost=cost[:B], status=status[:B], iters=iters[:B], evals=evals[:B])

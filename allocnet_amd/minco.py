@@ -160,3 +160,28 @@ def minco_cost_grad(head, tail, wps, T, s, hpolys=None, penalty=None, want_coeff
         ctypes.cast(ctypes.pointer(pen), ctypes.c_void_p) if pen is not None else None,
         _ptr(cost), _ptr(gradP), _ptr(gradT), _ptr(coeffs)))
     return (cost, gradP, gradT, coeffs) if want_coeffs else (cost, gradP, gradT)
+
+
+def _tptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def minco_cost_grad_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, work=None, cost=None,
+                        gradP=None, gradT=None, coeffs=None, stream=None, ctx=None):
+    """Device entry point -> anet_minco_cost_grad_dev (torch CUDA float64, batch-minor, common ld)."""
+    import torch
+    ctx = ctx or default_context(T.device.index or 0)
+    ld = T.stride(0)
+    dev = T.device
+    if work is None:
+        work = torch.empty(ctx.lib.anet_minco_cost_grad_workspace(s, N, ld), device=dev, dtype=torch.float64)
+    cost = cost if cost is not None else torch.empty(ld, device=dev, dtype=torch.float64)
+    gradP = gradP if gradP is not None else torch.empty(max(3 * (N - 1), 1), ld, device=dev, dtype=torch.float64)
+    gradT = gradT if gradT is not None else torch.empty(N, ld, device=dev, dtype=torch.float64)
+    if stream is None:
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx.check(ctx.lib.anet_minco_cost_grad_dev(
+        ctx.handle, s, c, N, B, ld, _tptr(head), _tptr(tail), _tptr(wps) if N > 1 else None, _tptr(T),
+        _tptr(hpolys), ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p) if penalty is not None else None,
+        _tptr(work), _tptr(cost), _tptr(gradP), _tptr(gradT), _tptr(coeffs), ctypes.c_void_p(stream)))
+    return cost, gradP, gradT, work

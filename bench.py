@@ -110,31 +110,45 @@ def main():
     ctx = aa.Context(local_rank)
     head, tail, wps, T = synth_batch_minor(torch, B, ld, N, c, seed=rank, device=device)
     coeffs = torch.empty(N * 3 * D, ld, device=device, dtype=torch.float64)
-    energy = torch.empty(ld, device=device, dtype=torch.float64)
-    gathered = torch.empty(world * ld, device=device, dtype=torch.float64) if world > 1 else None
+    # two cost buffers: the all-gather of step k (RCCL stream) overlaps the solve of step k+1
+    energies = [torch.empty(ld, device=device, dtype=torch.float64) for _ in range(2)]
+    gathered = [torch.empty(world * B, device=device, dtype=torch.float64) for _ in range(2)] if world > 1 else None
+    works = [None, None]
+    energy = energies[0]
 
-    def step():
-        aa.minco_solve_dev(head, tail, wps, T, s, c, N, B, coeffs=coeffs, energy=energy, ctx=ctx)
+    def step(i, ev=None):
+        j = i % 2
+        if works[j] is not None:
+            works[j].wait()                       # the collective that read energies[j] two steps ago
+            works[j] = None
+        if ev is not None:
+            ev[0].record()
+        aa.minco_solve_dev(head, tail, wps, T, s, c, N, B, coeffs=coeffs, energy=energies[j], ctx=ctx)
+        if ev is not None:
+            ev[1].record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, energy)
+            works[j] = dist.all_gather_into_tensor(gathered[j], energies[j][:B], async_op=True)
+
+    def drain():
+        for j in range(2):
+            if works[j] is not None:
+                works[j].wait()
+                works[j] = None
 
     def sync():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     sync()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
-        aa.minco_solve_dev(head, tail, wps, T, s, c, N, B, coeffs=coeffs, energy=energy, ctx=ctx)
-        ev[i][1].record()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, energy)
+        step(i, ev[i])
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Secondary timings for BASELINE.json configs 3 and 4 (parity-test configurations, not the bench
+line): cost+gradient evaluation with corridor/limit penalties, and full L-BFGS to convergence.
+    gpurun -- 'python tools/bench_configs.py > gpurun_out/configs.json'
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def to_bm(torch, a, B, ld, device):
+    """(B, ...) host array -> batch-minor (F, ld) device tensor."""
+    f = a.reshape(B, -1)
+    t = torch.zeros(f.shape[1], ld, device=device, dtype=torch.float64)
+    t[:, :B] = torch.from_numpy(np.ascontiguousarray(f.T)).to(device)
+    return t
+
+
+def synth(rng, B, N, c, M):
+    """SURVEY 8(d) config 3 generator: random-walk waypoints, axis-aligned box around each segment
+    inflated by U(0.5,3) plus k~U{0,6} random tangent half-spaces, rows normalised, a.x <= b, padded to M."""
+    from tests.util import random_problem
+    head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
+    pts = np.concatenate([head[:, None, :, 0], wps, tail[:, None, :, 0]], axis=1)
+    hp = np.zeros((B, N, M, 4))
+    lo = np.minimum(pts[:, :-1], pts[:, 1:]) - rng.uniform(0.5, 3.0, size=(B, N, 3))
+    hi = np.maximum(pts[:, :-1], pts[:, 1:]) + rng.uniform(0.5, 3.0, size=(B, N, 3))
+    for ax in range(3):
+        hp[:, :, 2 * ax, ax] = 1.0; hp[:, :, 2 * ax, 3] = hi[:, :, ax]
+        hp[:, :, 2 * ax + 1, ax] = -1.0; hp[:, :, 2 * ax + 1, 3] = -lo[:, :, ax]
+    k = rng.integers(0, min(6, M - 6) + 1, size=(B, N))
+    mid = 0.5 * (pts[:, :-1] + pts[:, 1:])
+    for r in range(min(6, M - 6)):
+        a = rng.normal(size=(B, N, 3)); a /= np.linalg.norm(a, axis=2, keepdims=True)
+        b = np.einsum("bnk,bnk->bn", a, mid) + rng.uniform(1.0, 3.0, size=(B, N))
+        use = (k > r)[..., None]
+        hp[:, :, 6 + r, :3] = np.where(use, a, 0.0)
+        hp[:, :, 6 + r, 3] = np.where(use[..., 0], b, 0.0)
+    return head, tail, wps, T, hp
+
+
+def main():
+    import torch
+    import allocnet_amd as aa
+    dev = torch.device("cuda", 0)
+    ctx = aa.Context(0)
+    out = {}
+    # ---- config 3: B=4096 x 8-seg min-snap, corridor penalties + time gradients -------------------
+    for B in (4096, 1 << 17):
+        s, c, N, M = 4, 3, 8, 16
+        ld = (B + 63) // 64 * 64
+        rng = np.random.default_rng(1)
+        head, tail, wps, T, hp = synth(rng, B, N, c, M)
+        pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0,
+                              max_acc=6.0, res=20, poly_rows=M)
+        th, tt, tw, tT, thp = (to_bm(torch, x, B, ld, dev) for x in (head, tail, wps, T, hp))
+        cost, gP, gT, work = aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, ctx=ctx)
+        torch.cuda.synchronize()
+        K = 50 if B <= 4096 else 10
+        t0 = time.perf_counter()
+        for _ in range(K):
+            aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, work=work, cost=cost,
+                                   gradP=gP, gradT=gT, ctx=ctx)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        out[f"config3_cost_grad_B{B}"] = {"ms_per_eval": dt * 1e3, "evals_per_s": B / dt,
+                                           "active_penalty_frac": float((cost[:B].cpu().numpy() > 0).mean())}
+    # ---- config 4: B=4096 x 16-seg min-jerk, full L-BFGS to convergence ---------------------------
+    B, s, c, N, M = 4096, 3, 3, 16, 16
+    ld = B
+    rng = np.random.default_rng(2)
+    head, tail, wps, T, hp = synth(rng, B, N, c, M)
+    pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0,
+                          res=20, poly_rows=M)
+    prm = aa.lbfgs_parameter_t()            # lbfgs.hpp defaults
+    th, tt, tw, tT, thp = (to_bm(torch, x, B, ld, dev) for x in (head, tail, wps, T, hp))
+    c0 = aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, ctx=ctx)[0][:B].cpu().numpy()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, param=prm, max_evals=3000, ctx=ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = res["status"].cpu().numpy(); it = res["iters"].cpu().numpy(); ev = res["evals"].cpu().numpy()
+    cf = res["cost"].cpu().numpy()
+    hist = {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))}
+    out["config4_lbfgs_B4096_N16_jerk"] = {
+        "seconds": dt, "trajectories_per_s": B / dt, "iters_mean": float(it.mean()), "iters_max": int(it.max()),
+        "evals_mean": float(ev.mean()), "evals_max": int(ev.max()), "status_hist": hist,
+        "cost_initial_mean": float(c0.mean()), "cost_final_mean": float(cf.mean()),
+        "lbfgs_params": "lbfgs_parameter_t defaults (mem 8, g_eps 1e-5, past 3, delta 1e-6)"}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
