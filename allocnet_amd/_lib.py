@@ -25,6 +25,7 @@ PROTOTYPES = {
     "anet_last_error": (c_char_p, [c_void_p]),
     "anet_stream": (c_void_p, [c_void_p]),
     "anet_synchronize": (c_int, [c_void_p]),
+    "anet_recommended_ld": (c_int64, [c_int64]),
     "anet_dev_alloc": (c_int, [c_void_p, ctypes.c_size_t, POINTER(c_void_p)]),
     "anet_dev_free": (None, [c_void_p]),
     "anet_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),

@@ -1385,6 +1385,12 @@ int anet_synchronize(anet_ctx *ctx) {
   return ANET_OK;
 }
 
+int64_t anet_recommended_ld(int64_t batch) {
+  int64_t ld = round_up(batch < 1 ? 1 : batch, 64);
+  if (ld % 512 == 0) ld += 576;  // 512 doubles = 4 KiB: break (near-)power-of-two row strides
+  return ld;
+}
+
 int anet_dev_alloc(anet_ctx *ctx, size_t n_doubles, double **out) {
   if (!ctx || !out) return fail(ctx, ANET_ERR_INVALID, "anet_dev_alloc: NULL argument");
   *out = nullptr;
@@ -1472,7 +1478,7 @@ int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
     return fail(ctx, ANET_ERR_INVALID, "anet_minco_solve: NULL input");
   ANET_HIP(ctx, hipSetDevice(ctx->device));
   const int N = n_pieces, D = 2 * s;
-  const int64_t ld = round_up(batch, 64);
+  const int64_t ld = anet_recommended_ld(batch);
   const int64_t n_in = 3 * c * 2 + (int64_t)(N - 1) * 3 + N;  // fields in per trajectory
   const int64_t n_co = (int64_t)N * 3 * D;
   const int64_t n_stage = (n_in > n_co ? n_in : n_co);
@@ -1577,7 +1583,7 @@ struct Stager {
 };
 int make_stager(anet_ctx *ctx, int64_t batch, int64_t max_field, int64_t total_fields, Stager *st) {
   ANET_HIP(ctx, hipSetDevice(ctx->device));
-  const int64_t ld = round_up(batch, 64);
+  const int64_t ld = anet_recommended_ld(batch);
   int rc = ensure_scratch(ctx, sizeof(double) * (size_t)(batch * max_field + total_fields * ld));
   if (rc) return rc;
   st->ctx = ctx; st->batch = batch; st->ld = ld;

@@ -48,6 +48,10 @@ struct Pw {  // r^1 .. r^(2S-1)
 
 // Block-tridiagonal SPD factor, one trajectory.  Node k in [0, N]; unknown j in [0, m) is the
 // derivative of order j+1 at that node.  `np` = c-1 derivatives are pinned at nodes 0 and N.
+//
+// Coupling block of piece i (unknowns of node i x unknowns of node i+1):
+//   Ko(j,l) = M[1+j][S+1+l] r^(2S-3-j-l) = a_j * M[1+j][S+1+l] * b_l,  a_j = r^(S-2-j), b_l = r^(S-1-l)
+// so products with Ko are a scale, an m x m product with CONSTANTS, and a scale.
 template <int S, int NB>
 struct Factor {
   static constexpr int m = S - 1;
@@ -58,30 +62,55 @@ struct Factor {
 
   __device__ __forceinline__ static int li(int i, int j) { return i * (i - 1) / 2 + j; }  // i>j
 
-  // Off-diagonal block of piece i: Ko(j,l) couples unknown j of node i with unknown l of node i+1.
-  __device__ __forceinline__ void build_Ko(int i, int N, int np, const Pw<S> &p,
-                                           double Ko[m][m]) const {
-#pragma unroll
-    for (int j = 0; j < m; ++j)
-#pragma unroll
-      for (int l = 0; l < m; ++l) {
-        // pinned rows/columns of an end node are masked on the (wave-uniform) constant
-        const double mc =
-            ((i == 0 && j < np) || (i == N - 1 && l < np)) ? 0.0 : Tab<S>::M[1 + j][S + 1 + l];
-        Ko[j][l] = mc * p[2 * S - 3 - j - l];
-      }
+  // masked constant of Ko: pinned rows (node i = 0) / columns (node i+1 = N) are zero
+  __device__ __forceinline__ static double ko_const(int i, int N, int np, int j, int l) {
+    return ((i == 0 && j < np) || (i == N - 1 && l < np)) ? 0.0 : Tab<S>::M[1 + j][S + 1 + l];
   }
-  // Y = L_k^-1 Ko (column-wise unit-lower forward substitution)
-  __device__ __forceinline__ void apply_Linv(int k, double Y[m][m]) const {
+  // out[l] -= sum_j Ko_i(j,l) v[j]      (Ko' v)
+  __device__ __forceinline__ static void sub_KoT(int i, int N, int np, const Pw<S> &p, const double (&v)[m],
+                                                 double (&out)[m]) {
+    double sv[m];
 #pragma unroll
-    for (int col = 0; col < m; ++col)
+    for (int j = 0; j < m; ++j) sv[j] = v[j] * p[S - 2 - j];
 #pragma unroll
-      for (int i = 1; i < m; ++i)
+    for (int l = 0; l < m; ++l) {
+      double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < i; ++j) Y[i][col] = __builtin_fma(-L[k][li(i, j)], Y[j][col], Y[i][col]);
+      for (int j = 0; j < m; ++j) acc = __builtin_fma(ko_const(i, N, np, j, l), sv[j], acc);
+      out[l] = __builtin_fma(-acc, p[S - 1 - l], out[l]);
+    }
+  }
+  // out[j] = sum_l Ko_i(j,l) v[l]       (Ko v)
+  __device__ __forceinline__ static void mul_Ko(int i, int N, int np, const Pw<S> &p, const double (&v)[m],
+                                                double (&out)[m]) {
+    double sv[m];
+#pragma unroll
+    for (int l = 0; l < m; ++l) sv[l] = v[l] * p[S - 1 - l];
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < m; ++l) acc = __builtin_fma(ko_const(i, N, np, j, l), sv[l], acc);
+      out[j] = acc * p[S - 2 - j];
+    }
+  }
+  // v <- L_k^-1 v   (unit lower)
+  __device__ __forceinline__ void solve_L(int k, double (&v)[m]) const {
+#pragma unroll
+    for (int i = 1; i < m; ++i)
+#pragma unroll
+      for (int j = 0; j < i; ++j) v[i] = __builtin_fma(-L[k][li(i, j)], v[j], v[i]);
+  }
+  // v <- L_k^-T v
+  __device__ __forceinline__ void solve_LT(int k, double (&v)[m]) const {
+#pragma unroll
+    for (int i = m - 2; i >= 0; --i)
+#pragma unroll
+      for (int j = i + 1; j < m; ++j) v[i] = __builtin_fma(-L[k][li(j, i)], v[j], v[i]);
   }
 
   __device__ __forceinline__ void factorize(int N, int np) {
+    // lower triangle of the current diagonal block (symmetric): Dk[j][l], l <= j
     double Dk[m][m];
 #pragma unroll
     for (int j = 0; j < m; ++j)
@@ -96,7 +125,7 @@ struct Factor {
 #pragma unroll
           for (int j = 0; j < m; ++j)
 #pragma unroll
-            for (int l = 0; l < m; ++l)
+            for (int l = 0; l <= j; ++l)
               Dk[j][l] = __builtin_fma(Tab<S>::M[1 + j][1 + l], p[2 * S - 3 - j - l], Dk[j][l]);
         }
         if (k > 0) {
@@ -104,7 +133,7 @@ struct Factor {
 #pragma unroll
           for (int j = 0; j < m; ++j)
 #pragma unroll
-            for (int l = 0; l < m; ++l)
+            for (int l = 0; l <= j; ++l)
               Dk[j][l] =
                   __builtin_fma(Tab<S>::M[S + 1 + j][S + 1 + l], p[2 * S - 3 - j - l], Dk[j][l]);
         }
@@ -112,7 +141,7 @@ struct Factor {
 #pragma unroll
           for (int j = 0; j < m; ++j)
 #pragma unroll
-            for (int l = 0; l < m; ++l)
+            for (int l = 0; l <= j; ++l)
               if (j < np || l < np) Dk[j][l] = (j == l) ? 1.0 : 0.0;
         }
         // --- LDL^T of the m x m block
@@ -120,31 +149,45 @@ struct Factor {
 #pragma unroll
         for (int j = 0; j < m; ++j) {
           double dj = Dk[j][j];
+          double ld_[m];  // L[j][q] * d[q]
 #pragma unroll
-          for (int q = 0; q < j; ++q) dj = __builtin_fma(-L[k][li(j, q)] * d[q], L[k][li(j, q)], dj);
+          for (int q = 0; q < j; ++q) {
+            ld_[q] = L[k][li(j, q)] * d[q];
+            dj = __builtin_fma(-ld_[q], L[k][li(j, q)], dj);
+          }
           d[j] = dj;
           dinv[k][j] = fast_rcp(dj);
 #pragma unroll
           for (int i = j + 1; i < m; ++i) {
             double v = Dk[i][j];
 #pragma unroll
-            for (int q = 0; q < j; ++q) v = __builtin_fma(-L[k][li(i, q)] * d[q], L[k][li(j, q)], v);
+            for (int q = 0; q < j; ++q) v = __builtin_fma(-L[k][li(i, q)], ld_[q], v);
             L[k][li(i, j)] = v * dinv[k][j];
           }
         }
-        // --- Schur complement seed for node k+1:  -Ko' D_k^-1 Ko
+        // --- Schur complement seed for node k+1:  -Ko' D_k^-1 Ko = -Y' diag(dinv) Y,  Y = L^-1 Ko
         if (k < N) {
           Pw<S> p(r[k]);
-          double Y[m][m];
-          build_Ko(k, N, np, p, Y);
-          apply_Linv(k, Y);
+          double Y[m][m], Z[m][m];
+#pragma unroll
+          for (int l = 0; l < m; ++l) {
+            double col[m];
+#pragma unroll
+            for (int j = 0; j < m; ++j) col[j] = ko_const(k, N, np, j, l) * p[2 * S - 3 - j - l];
+            solve_L(k, col);
+#pragma unroll
+            for (int j = 0; j < m; ++j) {
+              Y[j][l] = col[j];
+              Z[j][l] = col[j] * dinv[k][j];
+            }
+          }
 #pragma unroll
           for (int a = 0; a < m; ++a)
 #pragma unroll
-            for (int b = 0; b < m; ++b) {
+            for (int b = 0; b <= a; ++b) {
               double acc = 0.0;
 #pragma unroll
-              for (int j = 0; j < m; ++j) acc = __builtin_fma(-Y[j][a] * dinv[k][j], Y[j][b], acc);
+              for (int j = 0; j < m; ++j) acc = __builtin_fma(-Y[j][a], Z[j][b], acc);
               Dk[a][b] = acc;
             }
         }
@@ -154,12 +197,11 @@ struct Factor {
 };
 
 // ---- sweeps of the block-tridiagonal system for ONE right-hand side (one axis) -------------------
-// X[k][l] holds the right-hand side on entry (pinned rows: the pinned value / 0 for an adjoint).
-// forward : X <- w,   w_k = L_k^-1 (rhs_k - Ko_{k-1}' D_{k-1}^-1 y_{k-1})
-// backward: X <- x,   x_k = L_k^-T dinv (w_k - Y_k x_{k+1});  after(k, p) runs for every piece k
-//           (k < N) as soon as X[k] and X[k+1] are final, with p = powers of r_k.
-// `rhs(k, y)` fills the right-hand side of node k just before it is eliminated (fused so the powers
-// of r it needs are shared with the elimination step instead of being held for all nodes).
+// forward : X <- w,   y_k = rhs_k - Ko_{k-1}' D_{k-1}^-1 y_{k-1},  w_k = L_k^-1 y_k
+//           `rhs(k, y)` fills the right-hand side of node k just before it is eliminated (fused so
+//           the powers of r it needs are shared with the elimination step).
+// backward: X <- x,   x_k = L_k^-T dinv (w_k - L_k^-1 Ko_k x_{k+1});  after(k, p) runs for every piece
+//           k (k < N) as soon as X[k] and X[k+1] are final, with p = powers of r_k.
 template <int S, int NB, class Rhs>
 __device__ __forceinline__ void sweep_forward(const Factor<S, NB> &F, int N, int np,
                                               const double (&rr)[NB], double (&X)[NB + 1][S - 1],
@@ -172,20 +214,13 @@ __device__ __forceinline__ void sweep_forward(const Factor<S, NB> &F, int N, int
       rhs(k, y);
       if (k > 0) {
         Pw<S> p(rr[k - 1]);
-        double Y[m][m];
-        F.build_Ko(k - 1, N, np, p, Y);
-        F.apply_Linv(k - 1, Y);
+        double v[m];  // D_{k-1}^-1 y_{k-1} = L^-T (dinv . w_{k-1})
 #pragma unroll
-        for (int l = 0; l < m; ++l)
-#pragma unroll
-          for (int j = 0; j < m; ++j)
-            y[l] = __builtin_fma(-Y[j][l] * F.dinv[k - 1][j], X[k - 1][j], y[l]);
+        for (int j = 0; j < m; ++j) v[j] = X[k - 1][j] * F.dinv[k - 1][j];
+        F.solve_LT(k - 1, v);
+        Factor<S, NB>::sub_KoT(k - 1, N, np, p, v, y);
       }
-#pragma unroll
-      for (int i = 1; i < m; ++i)
-#pragma unroll
-        for (int j = 0; j < i; ++j)
-          y[i] = __builtin_fma(-F.L[k][Factor<S, NB>::li(i, j)], y[j], y[i]);
+      F.solve_L(k, y);
 #pragma unroll
       for (int l = 0; l < m; ++l) X[k][l] = y[l];
     }
@@ -205,21 +240,15 @@ __device__ __forceinline__ void sweep_backward(const Factor<S, NB> &F, int N, in
       for (int l = 0; l < m; ++l) x[l] = X[k][l];
       if (k < N) {
         Pw<S> p(rr[k]);
-        double Y[m][m];
-        F.build_Ko(k, N, np, p, Y);
-        F.apply_Linv(k, Y);
+        double t[m];
+        Factor<S, NB>::mul_Ko(k, N, np, p, X[k + 1], t);
+        F.solve_L(k, t);
 #pragma unroll
-        for (int l = 0; l < m; ++l)
-#pragma unroll
-          for (int j = 0; j < m; ++j) x[l] = __builtin_fma(-Y[l][j], X[k + 1][j], x[l]);
+        for (int l = 0; l < m; ++l) x[l] -= t[l];
       }
 #pragma unroll
       for (int l = 0; l < m; ++l) x[l] *= F.dinv[k][l];
-#pragma unroll
-      for (int i = m - 2; i >= 0; --i)
-#pragma unroll
-        for (int j = i + 1; j < m; ++j)
-          x[i] = __builtin_fma(-F.L[k][Factor<S, NB>::li(j, i)], x[j], x[i]);
+      F.solve_LT(k, x);
 #pragma unroll
       for (int l = 0; l < m; ++l) X[k][l] = x[l];
       if (k < N) {

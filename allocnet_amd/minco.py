@@ -23,6 +23,12 @@ def _f64c(a, shape=None):
     return a
 
 
+def recommended_ld(batch):
+    """Row stride for the batch-minor layout that avoids power-of-two strides (anet_recommended_ld)."""
+    from ._lib import load
+    return int(load().anet_recommended_ld(int(batch)))
+
+
 def minco_solve(head, tail, wps, T, s, want_coeffs=True, ctx=None):
     """Host (numpy, trajectory-major) entry point -> anet_minco_solve.
 

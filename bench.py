@@ -106,7 +106,7 @@ def main():
 
     s, c, N, B = args.order, args.bc, args.pieces, args.batch
     D = 2 * s
-    ld = (B + 63) // 64 * 64
+    ld = aa.recommended_ld(B)      # non-power-of-two row stride (HBM channel/bank spread)
     ctx = aa.Context(local_rank)
     head, tail, wps, T = synth_batch_minor(torch, B, ld, N, c, seed=rank, device=device)
     coeffs = torch.empty(N * 3 * D, ld, device=device, dtype=torch.float64)
@@ -174,7 +174,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"configs[1] problem ({N}-segment order-{s} MINCO, random-walk waypoints, "
                                f"energy-only, PVA boundary c={c}) at saturating batch {B}/GPU",
-                   "batch_per_gpu": B, "pieces": N, "order": s, "global_batch": world * B,
+                   "batch_per_gpu": B, "row_stride_ld": ld, "pieces": N, "order": s, "global_batch": world * B,
                    "parallelism": f"dp{world}" + ("+allgather(costs)" if world > 1 else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,

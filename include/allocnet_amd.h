@@ -76,6 +76,12 @@ void anet_dev_free(double *p);
 int anet_dev_upload(anet_ctx *ctx, double *dst_dev, const double *src_host, size_t n_doubles);   /* synchronous */
 int anet_dev_download(anet_ctx *ctx, double *dst_host, const double *src_dev, size_t n_doubles); /* synchronous */
 
+/* Recommended row stride for `batch` trajectories in the batch-minor layout: a multiple of 64 that
+ * is >= batch and NOT a multiple of 4 KiB worth of doubles.  A power-of-two row stride puts the same
+ * column of every field on the same HBM channel/bank; measured on MI355X the 8-segment solve runs
+ * 59 % of the HBM roofline at ld = 2^20 and 63-65 % at ld = 2^20 + 576.      */
+int64_t anet_recommended_ld(int64_t batch);
+
 /* ---- layout helpers: trajectory-major host/device <-> batch-minor device ---------------- */
 /* dst[f*ld + b] = src[b*nfield + f]  (both device pointers). */
 int anet_to_batch_minor_dev(anet_ctx *ctx, int64_t batch, int64_t nfield, int64_t ld,

@@ -1,0 +1,68 @@
+// Microbenchmark: the batch-minor store pattern at LIMITED occupancy (LDS-capped waves per CU) and
+// with stores spread out between arithmetic, to see what bounds k_minco_solve.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int F, int FIN, int LDSB, int WORK>
+__global__ void __launch_bounds__(64) k(const double* __restrict__ in, double* __restrict__ out, long B, long ld) {
+  __shared__ double pad[LDSB / 8];
+  long b = (long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  if (LDSB > 8 && threadIdx.x == 1000) pad[0] = 1.0;   // keep the allocation
+  double acc = 0;
+#pragma unroll
+  for (int f = 0; f < FIN; ++f) acc += in[f * ld + b];
+#pragma unroll 1
+  for (int g = 0; g < F / 8; ++g) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = acc + q;
+#pragma unroll 1
+    for (int w = 0; w < WORK; ++w) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = __builtin_fma(v[q], 1.0000001, 0.5);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) out[(g * 8 + q) * ld + b] = v[q];
+    acc += v[0];
+  }
+  if (LDSB > 8 && threadIdx.x == 1001) out[0] = pad[0];
+}
+
+template <int LDSB, int WORK>
+int run(const double* in, double* out, long B, long ld, const char* name) {
+  constexpr int F = 192, FIN = 48;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e9;
+  for (int it = 0; it < 10; ++it) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k<F, FIN, LDSB, WORK>), dim3(B / 64), dim3(64), 0, 0, in, out, B, ld);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 2 && ms < best) best = ms;
+  }
+  const double bytes = (double)(F + FIN) * 8 * B;
+  printf("%-44s %.3f ms  %.0f GB/s (%.1f%% of 8 TB/s)\n", name, best, bytes / best / 1e6, bytes / best / 1e6 / 80.0);
+  return 0;
+}
+
+int main() {
+  const long B = 1 << 20, ld = B;
+  double *in, *out;
+  CK(hipMalloc(&in, sizeof(double) * 48 * ld));
+  CK(hipMalloc(&out, sizeof(double) * 192 * ld));
+  CK(hipMemset(in, 0, sizeof(double) * 48 * ld));
+  run<8, 0>(in, out, B, ld, "occ max (8/SIMD), no work");
+  run<20000, 0>(in, out, B, ld, "occ 2/SIMD (LDS 20KB/wave), no work");
+  run<40000, 0>(in, out, B, ld, "occ 1/SIMD (LDS 40KB/wave), no work");
+  run<20000, 5>(in, out, B, ld, "occ 2/SIMD, 40 FMA per 8 stores");
+  run<20000, 15>(in, out, B, ld, "occ 2/SIMD, 120 FMA per 8 stores");
+  run<20000, 25>(in, out, B, ld, "occ 2/SIMD, 200 FMA per 8 stores");
+  run<8, 25>(in, out, B, ld, "occ max, 200 FMA per 8 stores");
+  run<13000, 25>(in, out, B, ld, "occ 3/SIMD, 200 FMA per 8 stores");
+  run<10000, 25>(in, out, B, ld, "occ 4/SIMD, 200 FMA per 8 stores");
+  return 0;
+}
