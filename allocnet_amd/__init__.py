@@ -10,5 +10,7 @@ from .minco import MINCO, MINCO_S2NU, MINCO_S3NU, MINCO_S4NU, minco_solve, minco
 from .trajectory import Piece, Trajectory, traj_eval, traj_cost  # noqa: F401
 from . import lbfgs  # noqa: F401
 from .lbfgs import lbfgs_parameter_t, lbfgs_strerror, lbfgs_mvie, lbfgs_minco, lbfgs_minco_dev  # noqa: F401
+from . import qp  # noqa: F401
+from .qp import qp_assemble, qp_dims  # noqa: F401
 
 __version__ = "0.1.0"

@@ -50,6 +50,11 @@ PROTOTYPES = {
     "anet_minco_cost_grad_workspace": (c_int64, [c_int, c_int, c_int64]),
     "anet_minco_cost_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64] + [c_void_p] * 12),
     "anet_minco_cost_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_int64] + [c_void_p] * 10),
+    "anet_qp_dims_of": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),
+    "anet_qp_assemble_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double,
+                                     c_int, c_int] + [c_void_p] * 10),
+    "anet_qp_assemble": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double,
+                                 c_int, c_int] + [c_void_p] * 9),
     "anet_lbfgs_default_params": (None, [c_void_p]),
     "anet_lbfgs_check_params": (c_int, [c_int, c_void_p]),
     "anet_lbfgs_strerror": (c_char_p, [c_int]),
@@ -63,6 +68,10 @@ PROTOTYPES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
+
+
+class QpDims(ctypes.Structure):
+    _fields_ = [("n", c_int64), ("m_e", c_int64), ("m_g", c_int64)]
 
 
 class LbfgsParams(ctypes.Structure):

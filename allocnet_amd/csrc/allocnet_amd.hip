@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <vector>
 #include <new>
 
 #include "../../include/allocnet_amd.h"
@@ -1099,6 +1100,179 @@ __global__ void __launch_bounds__(256) k_minco_map(MapArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// QP assembly, dense, in the reference's own shapes (qp_solver.hpp:119-296, min_traj_opt.py:377-613)
+// ------------------------------------------------------------------------------------------
+struct QpArgs {
+  const double *state, *T, *hpolys;
+  const int *rows;
+  double *Q, *A, *b, *G, *h;
+  int64_t B, n, me, mg;
+  int N, res, M, float_time, row_order;
+  double vmax, amax, m34;
+};
+
+// Row d (0 = p, 1 = v, 2 = a, 3 = j) of the monomial basis at t, column `col` (highest power first),
+// with the reference's multiplication order for the powers (get_t_state, qp_solver.hpp:90-116 /
+// min_traj_opt.py:300-336): t_2 = t*t, t_3 = t*t_2, t_4 = t_2*t_2, t_5 = t_2*t_3, t_6 = t_3*t_3,
+// t_7 = t_4*t_3, each entry = integer coefficient * power.  F = float reproduces the C++ planner.
+template <int S, class F>
+__device__ __forceinline__ double basis_entry(F t, int d, int col) {
+  constexpr int D = 2 * S;
+  const int k = D - 1 - col;  // power of this column
+  if (k < d) return 0.0;
+  const F t2 = t * t, t3 = t * t2, t4 = t2 * t2, t5 = t2 * t3, t6 = t3 * t3, t7 = t4 * t3;
+  const F pw[8] = {(F)1, t, t2, t3, t4, t5, t6, t7};
+  int coef = 1;
+  for (int e = 0; e < d; ++e) coef *= (k - e);
+  const int e = k - d;
+  if (e == 0) return (double)coef;       // constant entries are written as literals in the reference
+  if (coef == 1) return (double)pw[e];
+  return (double)((F)coef * pw[e]);
+}
+
+// cost block entry (j,k) of piece time t (qp_solver.hpp:186-236 / min_traj_opt.py:466-508)
+template <int S, class F>
+__device__ __forceinline__ double cost_entry(F t, int j, int k, double m34) {
+  if (j > k) { const int q = j; j = k; k = q; }
+  const F t2 = t * t, t3 = t * t2, t4 = t2 * t2, t5 = t2 * t3;
+  if (S == 4) {
+    const F t6 = t3 * t3, t7 = t4 * t3;
+    const F m[4][4] = {{(F)100800 * t7, (F)50400 * t6, (F)20160 * t5, (F)5040 * t4},
+                       {0, (F)25920 * t5, (F)10800 * t4, (F)2880 * t3},
+                       {0, 0, (F)4800 * t3, (F)m34 * t2},
+                       {0, 0, 0, (F)576 * t}};
+    return (double)m[j][k];
+  } else {
+    const F m[3][3] = {{(F)720 * t5, (F)360 * t4, (F)120 * t3}, {0, (F)192 * t3, (F)72 * t2}, {0, 0, (F)36 * t}};
+    return (double)m[j][k];
+  }
+}
+
+template <int S, class F>
+__device__ __forceinline__ F seg_time(const QpArgs &a, int64_t b, int i) {
+  return (F)a.T[b * a.N + i];
+}
+
+// Q and [A | b]: one thread per element.
+template <int S, class F>
+__global__ void __launch_bounds__(256) k_qp_eq_obj(QpArgs a) {
+  constexpr int D = 2 * S;
+  const int64_t b = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = a.n, me = a.me, nQ = n * n, nA = me * n;
+  const int N = a.N;
+  if (e < nQ) {
+    const int64_t r = e / n, c = e % n;
+    double v = 0.0;
+    if (r / D == c / D) {  // same (piece, axis) block
+      const int jr = (int)(r % D), jc = (int)(c % D);
+      if (jr < S && jc < S) v = cost_entry<S, F>(seg_time<S, F>(a, b, (int)(r / (3 * D))), jr, jc, a.m34);
+    }
+    a.Q[b * nQ + e] = v;
+  } else if (e < nQ + nA) {
+    const int64_t ea = e - nQ, r = ea / n, c = ea % n;
+    double v = 0.0;
+    const int64_t s_num = (int64_t)(N - 1) * 3 * D;
+    if (r < 18) {  // boundary rows: per axis 3 start rows then 3 end rows (qp_solver.hpp:152-162)
+      const int ax = (int)(r / 6), q = (int)(r % 6);
+      if (q < 3) {
+        if (c >= ax * D && c < (ax + 1) * D) v = basis_entry<S, F>((F)0, q, (int)(c - ax * D));
+      } else {
+        const int64_t c0 = s_num + ax * D;
+        if (c >= c0 && c < c0 + D) v = basis_entry<S, F>(seg_time<S, F>(a, b, N - 1), q - 3, (int)(c - c0));
+      }
+    } else {  // continuity rows (qp_solver.hpp:165-177): [basis(T_i) | -zero_A] per knot, per axis
+      const int64_t rr = r - 18;
+      const int i = (int)(rr / (3 * S)), ax = (int)((rr / S) % 3), d = (int)(rr % S);
+      const int64_t c0 = (int64_t)i * 3 * D + ax * D, c1 = c0 + 3 * D;
+      if (c >= c0 && c < c0 + D) v = basis_entry<S, F>(seg_time<S, F>(a, b, i), d, (int)(c - c0));
+      else if (c >= c1 && c < c1 + D) v = -basis_entry<S, F>((F)0, d, (int)(c - c1));
+    }
+    a.A[b * nA + ea] = v;
+  } else if (e < nQ + nA + me) {
+    const int64_t r = e - nQ - nA;
+    double v = 0.0;
+    if (r < 18) {
+      const int ax = (int)(r / 6), q = (int)(r % 6);
+      v = a.state[b * 18 + (q < 3 ? 0 : 9) + ax * 3 + (q % 3)];
+    }
+    a.b[b * me + r] = v;
+  }
+}
+
+// [G | h]: one thread per element of G, the thread of column 0 also writes h.
+template <int S, class F>
+__global__ void __launch_bounds__(256) k_qp_ineq(QpArgs a) {
+  constexpr int D = 2 * S;
+  const int64_t b = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = a.n, mg = a.mg;
+  if (e >= mg * n) return;
+  const int64_t r = e / n, c = e % n;
+  const int N = a.N, res = a.res;
+  const int *rows = a.rows + b * N;
+  // locate (piece i, sample j, local row q; box?) for this row in the requested ordering
+  int i = 0, j = 0, q = 0;
+  bool box = false;
+  if (a.row_order == 0) {
+    int64_t rr = r;
+    for (i = 0; i < N; ++i) {
+      const int64_t blk = (int64_t)res * (rows[i] + 12);
+      if (rr < blk) break;
+      rr -= blk;
+    }
+    j = (int)(rr / (rows[i] + 12));
+    q = (int)(rr % (rows[i] + 12));
+    box = q >= rows[i];
+    if (box) q -= rows[i];
+  } else {
+    int64_t tot = 0;
+    for (int p = 0; p < N; ++p) tot += rows[p];
+    if (r < tot * res) {
+      int64_t rr = r;
+      for (i = 0; i < N; ++i) {
+        const int64_t blk = (int64_t)res * rows[i];
+        if (rr < blk) break;
+        rr -= blk;
+      }
+      j = (int)(rr / rows[i]);
+      q = (int)(rr % rows[i]);
+    } else {
+      const int64_t rr = r - tot * res;
+      box = true;
+      i = (int)(rr / (12 * res));
+      j = (int)((rr / 12) % res);
+      q = (int)(rr % 12);
+    }
+  }
+  // sample time (qp_solver.hpp:252-263): step = T_i / res, t = step * j, j == 0 uses zero_A
+  const F step = seg_time<S, F>(a, b, i) / (F)res;
+  const F t = (j == 0) ? (F)0 : step * (F)j;
+  const int64_t c0 = (int64_t)i * 3 * D;
+  double v = 0.0, hv = 0.0;
+  if (!box) {
+    const double *hp = a.hpolys + ((b * N + i) * a.M + q) * 4;
+    if (c >= c0 && c < c0 + 3 * D) {
+      const int ax = (int)((c - c0) / D);
+      v = hp[ax] * basis_entry<S, F>(t, 0, (int)((c - c0) % D));
+    }
+    hv = hp[3];
+  } else {
+    // per axis: +v, +a, -v, -a  (qp_solver.hpp:280-291, min_traj_opt.py:598-611)
+    const int ax = q / 4, w = q % 4;
+    const int64_t ca = c0 + ax * D;
+    if (c >= ca && c < ca + D) {
+      const double be = basis_entry<S, F>(t, 1 + (w & 1), (int)(c - ca));
+      v = (w < 2) ? be : -be;
+    }
+    hv = (w & 1) ? a.amax : a.vmax;
+  }
+  a.G[b * mg * n + e] = v;
+  if (c == 0) a.h[b * mg + r] = hv;
+}
+
 // dst[f*ld + b] = src[b*nf + f] through a padded LDS tile (both sides coalesced).
 constexpr int kTile = 32;
 __global__ void __launch_bounds__(kTile * 8) k_to_batch_minor(const double *__restrict__ src,
@@ -1966,6 +2140,100 @@ int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
   if ((rc = st.download(d_T, N, T))) return rc;
   if (coeffs_out && (rc = st.download(d_co, nco, coeffs_out))) return rc;
   ANET_HIP(ctx, hipStreamSynchronize(s0));
+  return ANET_OK;
+}
+
+// ---- QP assembly entry points --------------------------------------------------------------------
+int anet_qp_dims_of(int s, int n_pieces, int res, const int32_t *rows, anet_qp_dims *out) {
+  if (!out || !rows || (s != 3 && s != 4) || n_pieces < 1 || res < 1) return ANET_ERR_INVALID;
+  int64_t tot = 0;
+  for (int i = 0; i < n_pieces; ++i) {
+    if (rows[i] < 0) return ANET_ERR_INVALID;
+    tot += rows[i];
+  }
+  out->n = (int64_t)3 * 2 * s * n_pieces;
+  out->m_e = 3 * (6 + (int64_t)s * (n_pieces - 1));
+  out->m_g = (int64_t)res * (tot + 12 * (int64_t)n_pieces);
+  return ANET_OK;
+}
+
+int anet_qp_assemble_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M,
+                         double max_vel, double max_acc, double m34, int float_time, int row_order,
+                         const double *state, const double *T, const double *hpolys, const int32_t *rows,
+                         double *Q, double *A, double *b, double *G, double *h, void *stream) {
+  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  if (s != 3 && s != 4) return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: order must be 3 (jerk) or 4 (snap), qp_solver.hpp:61-83");
+  if (n_pieces < 1 || batch < 0 || res < 1 || M < 0 || (row_order != 0 && row_order != 1))
+    return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: bad argument");
+  if (batch == 0) return ANET_OK;
+  if (!state || !T || !rows || (M > 0 && !hpolys) || !Q || !A || !b || !G || !h)
+    return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: NULL pointer");
+  // one shape for the whole batch: read the first trajectory's row counts (device -> host, tiny)
+  std::vector<int32_t> r0((size_t)n_pieces * batch);
+  ANET_HIP(ctx, hipMemcpy(r0.data(), rows, sizeof(int32_t) * n_pieces * batch, hipMemcpyDeviceToHost));
+  anet_qp_dims dm;
+  if (anet_qp_dims_of(s, n_pieces, res, r0.data(), &dm)) return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: bad row counts");
+  for (int64_t bb = 0; bb < batch; ++bb) {
+    int64_t tot = 0;
+    for (int i = 0; i < n_pieces; ++i) {
+      const int32_t v = r0[(size_t)bb * n_pieces + i];
+      if (v < 0 || v > M) return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: rows[b][i] must be in [0, M]");
+      tot += v;
+    }
+    if ((int64_t)res * (tot + 12 * (int64_t)n_pieces) != dm.m_g)
+      return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: every trajectory of a batch needs the same total polytope row count");
+  }
+  anet::QpArgs a{state, T, hpolys, rows, Q, A, b, G, h, batch, dm.n, dm.m_e, dm.m_g, n_pieces, res, M,
+                 float_time ? 1 : 0, row_order, max_vel, max_acc, m34};
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t ne = dm.n * dm.n + dm.m_e * dm.n + dm.m_e, ng = dm.m_g * dm.n;
+  const dim3 blk(256), g1((unsigned)((ne + 255) / 256), (unsigned)batch), g2((unsigned)((ng + 255) / 256), (unsigned)batch);
+  if (s == 4) {
+    if (float_time) { hipLaunchKernelGGL((anet::k_qp_eq_obj<4, float>), g1, blk, 0, st, a); if (ng) hipLaunchKernelGGL((anet::k_qp_ineq<4, float>), g2, blk, 0, st, a); }
+    else { hipLaunchKernelGGL((anet::k_qp_eq_obj<4, double>), g1, blk, 0, st, a); if (ng) hipLaunchKernelGGL((anet::k_qp_ineq<4, double>), g2, blk, 0, st, a); }
+  } else {
+    if (float_time) { hipLaunchKernelGGL((anet::k_qp_eq_obj<3, float>), g1, blk, 0, st, a); if (ng) hipLaunchKernelGGL((anet::k_qp_ineq<3, float>), g2, blk, 0, st, a); }
+    else { hipLaunchKernelGGL((anet::k_qp_eq_obj<3, double>), g1, blk, 0, st, a); if (ng) hipLaunchKernelGGL((anet::k_qp_ineq<3, double>), g2, blk, 0, st, a); }
+  }
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+int anet_qp_assemble(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                     double max_acc, double m34, int float_time, int row_order, const double *state,
+                     const double *T, const double *hpolys, const int32_t *rows, double *Q, double *A,
+                     double *b, double *G, double *h) {
+  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  if ((s != 3 && s != 4) || n_pieces < 1 || batch < 0 || res < 1 || M < 0 || !rows)
+    return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: bad argument");
+  if (batch == 0) return ANET_OK;
+  anet_qp_dims dm;
+  if (anet_qp_dims_of(s, n_pieces, res, rows, &dm)) return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: bad row counts");
+  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n_state = 18 * (size_t)batch, n_T = (size_t)n_pieces * batch, n_hp = (size_t)batch * n_pieces * M * 4;
+  const size_t n_rows = ((size_t)n_pieces * batch + 1) / 2;  // int32 pairs in doubles
+  const size_t nQ = (size_t)(dm.n * dm.n) * batch, nA = (size_t)(dm.m_e * dm.n) * batch, nb = (size_t)dm.m_e * batch;
+  const size_t nG = (size_t)(dm.m_g * dm.n) * batch, nh = (size_t)dm.m_g * batch;
+  int rc = ensure_scratch(ctx, sizeof(double) * (n_state + n_T + n_hp + n_rows + nQ + nA + nb + nG + nh + 8));
+  if (rc) return rc;
+  double *d_state = (double *)ctx->scratch, *d_T = d_state + n_state, *d_hp = d_T + n_T;
+  int32_t *d_rows = (int32_t *)(d_hp + n_hp);
+  double *d_Q = d_hp + n_hp + n_rows, *d_A = d_Q + nQ, *d_b = d_A + nA, *d_G = d_b + nb, *d_h = d_G + nG;
+  hipStream_t st = ctx->stream;
+  ANET_HIP(ctx, hipMemcpyAsync(d_state, state, sizeof(double) * n_state, hipMemcpyHostToDevice, st));
+  ANET_HIP(ctx, hipMemcpyAsync(d_T, T, sizeof(double) * n_T, hipMemcpyHostToDevice, st));
+  if (n_hp) ANET_HIP(ctx, hipMemcpyAsync(d_hp, hpolys, sizeof(double) * n_hp, hipMemcpyHostToDevice, st));
+  ANET_HIP(ctx, hipMemcpyAsync(d_rows, rows, sizeof(int32_t) * n_pieces * batch, hipMemcpyHostToDevice, st));
+  ANET_HIP(ctx, hipStreamSynchronize(st));
+  rc = anet_qp_assemble_dev(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, float_time, row_order, d_state,
+                            d_T, d_hp, d_rows, d_Q, d_A, d_b, d_G, d_h, st);
+  if (rc) return rc;
+  if (Q) ANET_HIP(ctx, hipMemcpyAsync(Q, d_Q, sizeof(double) * nQ, hipMemcpyDeviceToHost, st));
+  if (A) ANET_HIP(ctx, hipMemcpyAsync(A, d_A, sizeof(double) * nA, hipMemcpyDeviceToHost, st));
+  if (b) ANET_HIP(ctx, hipMemcpyAsync(b, d_b, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+  if (G && nG) ANET_HIP(ctx, hipMemcpyAsync(G, d_G, sizeof(double) * nG, hipMemcpyDeviceToHost, st));
+  if (h && nh) ANET_HIP(ctx, hipMemcpyAsync(h, d_h, sizeof(double) * nh, hipMemcpyDeviceToHost, st));
+  ANET_HIP(ctx, hipStreamSynchronize(st));
   return ANET_OK;
 }
 

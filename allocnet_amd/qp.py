@@ -1,0 +1,70 @@
+"""Host mirror of the reference's QP assembly: QPSolver::solve steps one to three
+(src/planner/include/planner/qp_solver.hpp:119-296) and MinTrajOpt.update / fill_eq_obj / fill_ineq
+(network/utils/min_traj_opt.py:68-178, 377-613), batched on the GPU (anet_qp_assemble)."""
+import ctypes
+import numpy as np
+
+from .context import default_context
+from ._lib import QpDims
+
+ORDER_CPP = 0      # per sample: polytope rows then 12 box rows (qp_solver.hpp:258-294)
+ORDER_PYTHON = 1   # all corridor rows (G1,h1), then all box rows (G2,h2) (min_traj_opt.py:535-613)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def qp_dims(order, rows, res, ctx=None):
+    ctx = ctx or default_context()
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    d = QpDims()
+    rc = ctx.lib.anet_qp_dims_of(int(order), len(rows), int(res), _p(rows), ctypes.byref(d))
+    if rc:
+        raise ValueError("bad QP dimensions")
+    return d.n, d.m_e, d.m_g
+
+
+def qp_assemble(order, iniPVA, finPVA, hPolys, times, res=20, max_vel=4.0, max_acc=6.0, m34=1400.0,
+                float_time=False, row_order=ORDER_CPP, ctx=None):
+    """Batched QP assembly.
+    iniPVA, finPVA : (B,3,3) row = axis, cols p,v,a          (learning_planning.cpp:150-151)
+    hPolys         : (B,N,M,4) rows (a,b), a.x <= b, zero rows = padding; or a list (one trajectory)
+                     of N arrays (m_i,4) like the reference's std::vector<Eigen::MatrixX4d>
+    times          : (B,N)
+    Returns Q (B,n,n), A (B,me,n), b (B,me), G (B,mg,n), h (B,mg).
+    Defaults: MaxVelBox/MaxAccBox/ConstRes of config/planner.yaml:17-21."""
+    ctx = ctx or default_context()
+    single = isinstance(hPolys, (list, tuple))
+    if single:
+        N = len(hPolys)
+        M = max(1, max(p.shape[0] for p in hPolys))
+        hp = np.zeros((1, N, M, 4))
+        rows = np.zeros((1, N), dtype=np.int32)
+        for i, p in enumerate(hPolys):
+            hp[0, i, :p.shape[0]] = p
+            rows[0, i] = p.shape[0]
+        iniPVA = np.asarray(iniPVA, dtype=np.float64)[None]
+        finPVA = np.asarray(finPVA, dtype=np.float64)[None]
+        times = np.asarray(times, dtype=np.float64)[None]
+    else:
+        hp = np.ascontiguousarray(hPolys, dtype=np.float64)
+        rows = (np.abs(hp).sum(axis=3) > 0).sum(axis=2).astype(np.int32)   # valid rows are leading
+        N, M = hp.shape[1], hp.shape[2]
+        # zero rows are kept as inert rows so that every trajectory has the same shape
+        rows[:] = M
+    B = hp.shape[0]
+    state = np.ascontiguousarray(np.stack([np.asarray(iniPVA, dtype=np.float64),
+                                           np.asarray(finPVA, dtype=np.float64)], axis=1))      # (B,2,3,3)
+    T = np.ascontiguousarray(times, dtype=np.float64)
+    if T.shape != (B, N) or state.shape != (B, 2, 3, 3):
+        raise ValueError("shape mismatch")
+    n, me, mg = qp_dims(order, rows[0], res, ctx)
+    Q = np.empty((B, n, n)); A = np.empty((B, me, n)); b = np.empty((B, me)); G = np.empty((B, mg, n)); h = np.empty((B, mg))
+    hp = np.ascontiguousarray(hp); rows = np.ascontiguousarray(rows)
+    ctx.check(ctx.lib.anet_qp_assemble(ctx.handle, int(order), N, B, int(res), M, float(max_vel), float(max_acc),
+                                       float(m34), int(bool(float_time)), int(row_order), _p(state), _p(T), _p(hp),
+                                       _p(rows), _p(Q), _p(A), _p(b), _p(G), _p(h)))
+    if single:
+        return Q[0], A[0], b[0], G[0], h[0]
+    return Q, A, b, G, h

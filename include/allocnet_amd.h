@@ -198,6 +198,41 @@ int anet_minco_cost_grad(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                          double *gradT,  /* [batch][N]      */
                          double *coeffs_out /* [batch][N][3][2s] or NULL */);
 
+/* ---- QP assembly (the reference's own formulation) ----------------------------------------- */
+/* Replaces the assembly part of QPSolver::solve (planner/qp_solver.hpp:61-296: setOrder/zero_A_,
+ * get_t_state, equality rows :139-177, objective :180-242, inequality rows :244-296) and its Python
+ * twin MinTrajOpt.fill_eq_obj / fill_ineq (network/utils/min_traj_opt.py:300-697), batched.
+ * Dense, trajectory-major outputs with the reference's shapes:
+ *   n = 3*2s*N variables, m_e = 3*(6 + s*(N-1)) equalities, m_g = res*(sum_i rows_i + 12*N) inequalities
+ *   Q [n][n], A [m_e][n], b [m_e], G [m_g][n], h [m_g]      (row-major, one set per trajectory)
+ * row_order:  ANET_QP_ORDER_CPP    per piece, per sample: the polytope rows, then 12 box rows
+ *                                  (qp_solver.hpp:258-294)
+ *             ANET_QP_ORDER_PYTHON all corridor rows (G1,h1) first, then all box rows (G2,h2)
+ *                                  (min_traj_opt.py:535-613; OsqpLayer stacks them, layers.py:66-70)
+ * float_time != 0 reproduces the C++ planner's arithmetic: segment times arrive as float32 and the
+ * time powers of the basis rows and of the cost block are formed in float (qp_solver.hpp:90-116 with
+ * T = float, :183-236, :252-263); 0 = float64 throughout (the Python twin).
+ * m34: (3,4) entry constant of the snap cost block, 1400.0 = reference, 1440.0 = true integral.
+ * state: ini/fin PVA, [batch][2][3][3] = {ini,fin} x axis x (p,v,a) (learning_planning.cpp:150-151).
+ * hpolys [batch][N][M][4] rows (a_x,a_y,a_z,b) meaning a.x <= b; rows[batch][N] = valid rows per
+ * polytope (<= M).  All pointers are DEVICE pointers in the _dev variant.                        */
+#define ANET_QP_ORDER_CPP 0
+#define ANET_QP_ORDER_PYTHON 1
+typedef struct anet_qp_dims { int64_t n, m_e, m_g; } anet_qp_dims;
+/* Sizes for ONE trajectory given its polytope row counts (host array rows[N]). */
+int anet_qp_dims_of(int s, int n_pieces, int res, const int32_t *rows, anet_qp_dims *out);
+/* Every trajectory of a batch must have the same sum of polytope rows (so the dense outputs have one
+ * shape); pad polytopes with all-zero rows (0.x <= 0, inert) to equalise, as the reference's own
+ * tensor packing does (learning_planner.hpp:157-166, 50 x 4 x 5 zero-padded).                     */
+int anet_qp_assemble_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M,
+                         double max_vel, double max_acc, double m34, int float_time, int row_order,
+                         const double *state, const double *T, const double *hpolys, const int32_t *rows,
+                         double *Q, double *A, double *b, double *G, double *h, void *stream);
+int anet_qp_assemble(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                     double max_acc, double m34, int float_time, int row_order, const double *state,
+                     const double *T, const double *hpolys, const int32_t *rows, double *Q, double *A,
+                     double *b, double *G, double *h);
+
 /* ---- batched L-BFGS ------------------------------------------------------------------------ */
 /* lbfgs::lbfgs_parameter_t, same fields and defaults (gcopter/lbfgs.hpp:15-129). */
 typedef struct anet_lbfgs_params {
