@@ -98,10 +98,16 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (allocnet_amd has no CPU fallback)")
+    if rank != 0:
+        # only rank 0 reports; keep other ranks' library banners (RCCL prints one) off the job's stdout
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # ANET_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (1-GPU boxes)
+    use_dist = world > 1 or os.environ.get("ANET_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     s, c, N, B = args.order, args.bc, args.pieces, args.batch
@@ -112,7 +118,7 @@ def main():
     coeffs = torch.empty(N * 3 * D, ld, device=device, dtype=torch.float64)
     # two cost buffers: the all-gather of step k (RCCL stream) overlaps the solve of step k+1
     energies = [torch.empty(ld, device=device, dtype=torch.float64) for _ in range(2)]
-    gathered = [torch.empty(world * B, device=device, dtype=torch.float64) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty(world * B, device=device, dtype=torch.float64) for _ in range(2)] if use_dist else None
     works = [None, None]
     energy = energies[0]
 
@@ -126,7 +132,7 @@ def main():
         aa.minco_solve_dev(head, tail, wps, T, s, c, N, B, coeffs=coeffs, energy=energies[j], ctx=ctx)
         if ev is not None:
             ev[1].record()
-        if world > 1:
+        if use_dist:
             works[j] = dist.all_gather_into_tensor(gathered[j], energies[j][:B], async_op=True)
 
     def drain():
@@ -137,7 +143,7 @@ def main():
 
     def sync():
         drain()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -151,14 +157,18 @@ def main():
         step(i, ev[i])
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the gathered costs of the last step must be every rank's costs in rank order
+        chk = gathered[(args.steps - 1) % 2][rank * B:(rank + 1) * B]
+        if not torch.equal(chk, energies[(args.steps - 1) % 2][:B]):
+            raise SystemExit("all-gather of costs returned wrong data")
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -175,7 +185,7 @@ def main():
         "config": {"workload": f"configs[1] problem ({N}-segment order-{s} MINCO, random-walk waypoints, "
                                f"energy-only, PVA boundary c={c}) at saturating batch {B}/GPU",
                    "batch_per_gpu": B, "row_stride_ld": ld, "pieces": N, "order": s, "global_batch": world * B,
-                   "parallelism": f"dp{world}" + ("+allgather(costs)" if world > 1 else "")},
+                   "parallelism": f"dp{world}" + ("+allgather(costs)" if use_dist else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_minco_solve", "kernel_ms": kernel_ms,
@@ -237,9 +247,17 @@ def main():
                                    "sample": f"{n_cpu} trajectories of the same workload, classic banded-LU "
                                              f"MINCO in C (oracle/minco_oracle.c), {nthreads} threads",
                                    "gpu_vs_cpu_max_rel_coeff_err": err}
-    print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio, which is only flushed at exit: push it out now so
+    # that the JSON line is the LAST line on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stderr.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
