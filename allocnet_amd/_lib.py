@@ -55,6 +55,12 @@ PROTOTYPES = {
                                      c_int, c_int] + [c_void_p] * 10),
     "anet_qp_assemble": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double,
                                  c_int, c_int] + [c_void_p] * 9),
+    "anet_qp_default_settings": (None, [c_void_p]),
+    "anet_qp_solve": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double]
+                      + [c_void_p] * 9),
+    "anet_qp_solve_workspace": (c_int64, [c_int, c_int, c_int64, c_int, c_int]),
+    "anet_qp_solve_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double]
+                          + [c_void_p] * 11),
     "anet_lbfgs_default_params": (None, [c_void_p]),
     "anet_lbfgs_check_params": (c_int, [c_int, c_void_p]),
     "anet_lbfgs_strerror": (c_char_p, [c_int]),
@@ -68,6 +74,13 @@ PROTOTYPES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
+
+
+class QpSettings(ctypes.Structure):
+    """struct anet_qp_settings (OSQP defaults)."""
+    _fields_ = [("rho", c_double), ("sigma", c_double), ("alpha", c_double), ("eps_abs", c_double),
+                ("eps_rel", c_double), ("max_iter", ctypes.c_int32), ("check_termination", ctypes.c_int32),
+                ("adaptive_rho_interval", ctypes.c_int32)]
 
 
 class QpDims(ctypes.Structure):

@@ -12,6 +12,7 @@
 
 #include "../../include/allocnet_amd.h"
 #include "minco_core.h"
+#include "qp_admm.h"
 
 namespace anet {
 
@@ -2233,6 +2234,91 @@ int anet_qp_assemble(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res,
   if (b) ANET_HIP(ctx, hipMemcpyAsync(b, d_b, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
   if (G && nG) ANET_HIP(ctx, hipMemcpyAsync(G, d_G, sizeof(double) * nG, hipMemcpyDeviceToHost, st));
   if (h && nh) ANET_HIP(ctx, hipMemcpyAsync(h, d_h, sizeof(double) * nh, hipMemcpyDeviceToHost, st));
+  ANET_HIP(ctx, hipStreamSynchronize(st));
+  return ANET_OK;
+}
+
+// ---- QP solve (ADMM) entry points ------------------------------------------------------------------
+void anet_qp_default_settings(anet_qp_settings *s) {
+  if (!s) return;
+  s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
+  s->max_iter = 4000; s->check_termination = 25; s->adaptive_rho_interval = 100;
+}
+
+int64_t anet_qp_solve_workspace(int s, int n_pieces, int64_t batch, int res, int M) {
+  const int64_t m = 3 * (6 + (int64_t)s * (n_pieces - 1)) + (int64_t)n_pieces * res * (M + 12);
+  return 2 * m * batch + 2 * batch;  // z, y, residuals
+}
+
+int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                      double max_acc, double m34, const double *state, const double *T,
+                      const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
+                      double *obj, int32_t *status, int32_t *iters, double *residuals, void *stream) {
+  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  if (s != 3 && s != 4) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: order must be 3 (jerk) or 4 (snap)");
+  if (n_pieces < 1 || batch < 0 || res < 1 || M < 0) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad argument");
+  if (batch == 0) return ANET_OK;
+  if (!state || !T || (M > 0 && !hpolys) || !work || !coeffs || !obj || !status || !iters)
+    return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: NULL pointer");
+  anet_qp_settings st_;
+  anet_qp_default_settings(&st_);
+  if (settings) st_ = *settings;
+  if (!(st_.rho > 0) || !(st_.sigma > 0) || !(st_.alpha > 0 && st_.alpha < 2) || st_.max_iter < 1 ||
+      st_.check_termination < 1 || st_.eps_abs < 0 || st_.eps_rel < 0 || st_.adaptive_rho_interval < 0)
+    return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad settings");
+  const size_t lds = (s == 4) ? anet::qp_admm_lds_bytes<4>(n_pieces, res) : anet::qp_admm_lds_bytes<3>(n_pieces, res);
+  if (lds > 160 * 1024)
+    return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_qp_solve: the block factor of this many pieces does not fit the 160 KB LDS");
+  const int64_t m = 3 * (6 + (int64_t)s * (n_pieces - 1)) + (int64_t)n_pieces * res * (M + 12);
+  int adapt = st_.adaptive_rho_interval;
+  if (adapt > 0) adapt = (adapt + st_.check_termination - 1) / st_.check_termination * st_.check_termination;
+  anet::AdmmArgs a{state, T, hpolys, work, work + m * batch, coeffs, obj, status, iters,
+                   residuals ? residuals : work + 2 * m * batch, batch, n_pieces, res, M, max_vel, max_acc, m34,
+                   anet::AdmmParams{st_.rho, st_.sigma, st_.alpha, st_.eps_abs, st_.eps_rel, st_.max_iter,
+                                    st_.check_termination, adapt}};
+  hipStream_t st = (hipStream_t)stream;
+  if (s == 4) {
+    ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_admm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((anet::k_qp_admm<4>), dim3((unsigned)batch), dim3(256), lds, st, a);
+  } else {
+    ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_admm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((anet::k_qp_admm<3>), dim3((unsigned)batch), dim3(256), lds, st, a);
+  }
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+int anet_qp_solve(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                  double max_acc, double m34, const double *state, const double *T, const double *hpolys,
+                  const anet_qp_settings *settings, double *coeffs, double *obj, int32_t *status,
+                  int32_t *iters, double *residuals) {
+  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  if ((s != 3 && s != 4) || n_pieces < 1 || batch < 0 || res < 1 || M < 0)
+    return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad argument");
+  if (batch == 0) return ANET_OK;
+  if (!state || !T || (M > 0 && !hpolys) || !coeffs) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: NULL pointer");
+  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)3 * 2 * s * n_pieces;
+  const size_t n_state = 18 * (size_t)batch, n_T = (size_t)n_pieces * batch, n_hp = (size_t)batch * n_pieces * M * 4;
+  const size_t n_work = (size_t)anet_qp_solve_workspace(s, n_pieces, batch, res, M);
+  const size_t n_int = (size_t)batch;  // 2 int32 arrays fit in `batch` doubles
+  int rc = ensure_scratch(ctx, sizeof(double) * (n_state + n_T + n_hp + n_work + n * batch + 3 * batch + n_int + 8));
+  if (rc) return rc;
+  double *d_state = (double *)ctx->scratch, *d_T = d_state + n_state, *d_hp = d_T + n_T, *d_work = d_hp + n_hp;
+  double *d_co = d_work + n_work, *d_obj = d_co + n * batch, *d_res = d_obj + batch;
+  int32_t *d_status = (int32_t *)(d_res + 2 * batch), *d_iters = d_status + batch;
+  hipStream_t st = ctx->stream;
+  ANET_HIP(ctx, hipMemcpyAsync(d_state, state, sizeof(double) * n_state, hipMemcpyHostToDevice, st));
+  ANET_HIP(ctx, hipMemcpyAsync(d_T, T, sizeof(double) * n_T, hipMemcpyHostToDevice, st));
+  if (n_hp) ANET_HIP(ctx, hipMemcpyAsync(d_hp, hpolys, sizeof(double) * n_hp, hipMemcpyHostToDevice, st));
+  rc = anet_qp_solve_dev(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, d_state, d_T, d_hp, settings, d_work,
+                         d_co, d_obj, d_status, d_iters, d_res, st);
+  if (rc) return rc;
+  ANET_HIP(ctx, hipMemcpyAsync(coeffs, d_co, sizeof(double) * n * batch, hipMemcpyDeviceToHost, st));
+  if (obj) ANET_HIP(ctx, hipMemcpyAsync(obj, d_obj, sizeof(double) * batch, hipMemcpyDeviceToHost, st));
+  if (status) ANET_HIP(ctx, hipMemcpyAsync(status, d_status, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, st));
+  if (iters) ANET_HIP(ctx, hipMemcpyAsync(iters, d_iters, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, st));
+  if (residuals) ANET_HIP(ctx, hipMemcpyAsync(residuals, d_res, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, st));
   ANET_HIP(ctx, hipStreamSynchronize(st));
   return ANET_OK;
 }

@@ -1,0 +1,538 @@
+// Batched inequality-constrained QP solve replacing OSQP in QPSolver::solve
+// (planner/qp_solver.hpp:299-358; OSQP release-0.6.3 is a third-party dependency that is not part of
+// the reference tree).  Same problem, same algorithm family: OSQP's ADMM (Stellato et al., "OSQP: an
+// operator splitting solver for quadratic programs", Math. Prog. Comp. 2020, Algorithm 1) with its
+// defaults -- rho 0.1, 1e3*rho on equality rows, sigma 1e-6, alpha 1.6, eps_abs = eps_rel = 1e-3,
+// max_iter 4000, termination check every 25 iterations, rho adaptation by the residual-ratio rule.
+//
+// MI355X-specific restatement (one 256-thread workgroup per trajectory, everything except z, y in LDS):
+//  * the QP is posed in NORMALISED time (variables a~_k = c_k T^k, derivative rows scaled by T^d), which
+//    is an analytic equilibration: every basis row depends only on tau_j = j/res, identical for all
+//    pieces and trajectories (tables + their Gram matrices built once per workgroup), and the cost
+//    block is T^(1-2s) times a constant matrix.  It replaces OSQP's iterative Ruiz scaling.
+//  * the KKT system is reduced to  (Q + sigma I + A' R A) x~ = rhs, block tridiagonal with one dense
+//    3D x 3D block per piece; block Cholesky with explicitly inverted diagonal factors lives in LDS,
+//    each ADMM iteration is 4N small mat-vecs, refactorised only when rho changes.
+//  * A x and A' w never form A: per sample the 3 state rows (p, v, a) are evaluated from the piece's
+//    coefficients, the polytope rows reduce to 3-vectors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace anet {
+
+struct AdmmParams {
+  double rho, sigma, alpha, eps_abs, eps_rel;
+  int max_iter, check_every, adapt_every;
+};
+
+struct AdmmArgs {
+  const double *state;   // [B][2][3][3]
+  const double *T;       // [B][N]
+  const double *hpolys;  // [B][N][M][4]
+  double *z, *y;         // [B][m] workspace / duals (scaled problem), m = me + N*R*(M+12)
+  double *coeffs;        // [B][n]  (piece, axis, highest power first) -- the reference's flatten order
+  double *obj;           // [B]  1/2 z'Qz in original units (QPSolver::getObjCost)
+  int *status, *iters;   // [B]  1 = solved, 0 = max_iter reached
+  double *res;           // [B][2] primal / dual residual at exit (scaled problem)
+  int64_t B;
+  int N, R, M;
+  double vmax, amax, m34;
+  AdmmParams p;
+};
+
+__device__ __forceinline__ double atomic_max_pos(double *addr, double v) {  // v >= 0
+  unsigned long long *a = (unsigned long long *)addr;
+  unsigned long long old = atomicMax(a, (unsigned long long)__double_as_longlong(v));
+  return __longlong_as_double((long long)old);
+}
+
+template <int S>
+__device__ __forceinline__ double qblk1(int j, int k, double m34) {  // cost block at t = 1
+  if (j > k) { const int q = j; j = k; k = q; }
+  if (S == 4) {
+    const double m[4][4] = {{100800, 50400, 20160, 5040}, {0, 25920, 10800, 2880}, {0, 0, 4800, m34}, {0, 0, 0, 576}};
+    return m[j][k];
+  }
+  const double m[3][3] = {{720, 360, 120}, {0, 192, 72}, {0, 0, 36}};
+  return m[j][k];
+}
+
+__device__ __forceinline__ double fallf(int k, int d) {
+  double r = 1.0;
+  for (int e = 0; e < d; ++e) r *= (double)(k - e);
+  return r;
+}
+
+template <int S>
+__global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
+  constexpr int D = 2 * S, NB = 3 * D;
+  const int N = a.N, R = a.R, M = a.M;
+  const int n = NB * N;
+  const int me = 3 * (6 + S * (N - 1));
+  const int rows_per_sample = M + 12;
+  const int64_t mtot = me + (int64_t)N * R * rows_per_sample;
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+
+  extern __shared__ double lds[];
+  double *Linv = lds;                       // [N][NB*NB]  inverse of the Cholesky factor of diagonal block i
+  double *Lo = Linv + (size_t)N * NB * NB;  // [N][NB*NB]  L_{i+1,i} (row = block i+1, col = block i)
+  double *Hd = Lo + (size_t)N * NB * NB;    // [NB*NB] scratch
+  double *x = Hd + NB * NB;                 // [n]
+  double *xt = x + n;                       // [n]
+  double *rhs = xt + n;                     // [n]
+  double *aty = rhs + n;                    // [n]  A'y (dual residual) / temp
+  double *be = aty + n;                     // [R][3][D] basis rows at tau_j
+  double *G0 = be + (size_t)R * 3 * D;      // [D*D]  sum_j b0 b0'
+  double *G12 = G0 + D * D;                 // [D*D]  sum_j (b1 b1' + b2 b2')
+  double *Sp = G12 + D * D;                 // [N][9]  sum_q a_q a_q'
+  double *Tn = Sp + (size_t)N * 9;          // [N]
+  double *red = Tn + N;                     // [8] reductions / broadcast
+
+  const double *Tg = a.T + b * N;
+  const double *hp = a.hpolys + b * (int64_t)N * M * 4;
+  const double *st = a.state + b * 18;
+  double *zg = a.z + b * mtot, *yg = a.y + b * mtot;
+
+  // ---- tables -------------------------------------------------------------------------------
+  for (int e = tid; e < R * 3 * D; e += nt) {
+    const int j = e / (3 * D), d = (e / D) % 3, col = e % D, k = D - 1 - col;
+    const double tau = (double)j / (double)R;
+    double v = 0.0;
+    if (k >= d) {
+      v = fallf(k, d);
+      for (int q = 0; q < k - d; ++q) v *= tau;
+    }
+    be[e] = v;
+  }
+  for (int i = tid; i < N; i += nt) Tn[i] = Tg[i];
+  __syncthreads();
+  for (int e = tid; e < D * D; e += nt) {
+    const int c1 = e / D, c2 = e % D;
+    double g0 = 0.0, g12 = 0.0;
+    for (int j = 0; j < R; ++j) {
+      const double *bj = be + (size_t)j * 3 * D;
+      g0 += bj[c1] * bj[c2];
+      g12 += bj[D + c1] * bj[D + c2] + bj[2 * D + c1] * bj[2 * D + c2];
+    }
+    G0[e] = g0;
+    G12[e] = g12;
+  }
+  for (int e = tid; e < N * 9; e += nt) {
+    const int i = e / 9, r = (e / 3) % 3, c = e % 3;
+    double s2 = 0.0;
+    for (int q = 0; q < M; ++q) s2 += hp[((int64_t)i * M + q) * 4 + r] * hp[((int64_t)i * M + q) * 4 + c];
+    Sp[e] = s2;
+  }
+  __syncthreads();
+  // objective scaling: 1 / mean_i( T_i^(1-2s) * mean diag of the cost block )
+  double cobj;
+  {
+    double tr = 0.0;
+    for (int j = 0; j < S; ++j) tr += qblk1<S>(j, j, a.m34);
+    double acc = 0.0;
+    for (int i = 0; i < N; ++i) acc += pow(Tn[i], (double)(1 - 2 * S));
+    cobj = 1.0 / (acc / N * tr / S);
+  }
+
+  double rho = a.p.rho;
+  const double sigma = a.p.sigma, alpha = a.p.alpha;
+
+  // ---- assemble + factorise the block tridiagonal H (again whenever rho changes) ----------------
+  auto factorize = [&]() {
+    const double rho_e = 1.0e3 * rho;
+    for (int i = 0; i < N; ++i) {
+      const double qs = cobj * pow(Tn[i], (double)(1 - 2 * S));
+      const double ratio = (i > 0) ? Tn[i - 1] / Tn[i] : 0.0;
+      // off-diagonal block (i, i-1) -> Lo[i-1] = Ho * Linv_{i-1}'
+      if (i > 0) {
+        for (int e = tid; e < NB * NB; e += nt) {
+          const int r = e / NB, c = e % NB;
+          // Ho[r][k] = rho_e * sum_d (-d! ratio^d [k_r == d]) * e1_d[k] for the same axis
+          const int axr = r / D, kr = D - 1 - r % D;
+          double acc = 0.0;
+          if (kr < S) {
+            const double coef = -rho_e * fallf(kr, kr) * pow(ratio, (double)kr);
+            const double *Li = Linv + (size_t)(i - 1) * NB * NB + (size_t)c * NB;  // row c of Linv_{i-1}
+            for (int col = 0; col < D; ++col) {
+              const int k = D - 1 - col;
+              if (k >= kr) acc += fallf(k, kr) * Li[axr * D + col];
+            }
+            acc *= coef;
+          }
+          Lo[(size_t)(i - 1) * NB * NB + e] = acc;
+        }
+        __syncthreads();
+      }
+      for (int e = tid; e < NB * NB; e += nt) {
+        const int r = e / NB, c = e % NB;
+        const int axr = r / D, axc = c / D, cr = r % D, cc = c % D, kr = D - 1 - cr, kc = D - 1 - cc;
+        double v = rho * Sp[i * 9 + axr * 3 + axc] * G0[cr * D + cc];
+        if (axr == axc) {
+          v += rho * 2.0 * G12[cr * D + cc];
+          if (cr < S && cc < S) v += qs * qblk1<S>(cr, cc, a.m34);
+          if (r == c) v += sigma;
+          double eq = 0.0;
+          if (i < N - 1) {  // continuity rows of knot i: e1_d e1_d'
+            for (int d = 0; d < S; ++d)
+              if (kr >= d && kc >= d) eq += fallf(kr, d) * fallf(kc, d);
+          } else {  // end rows d < 3
+            for (int d = 0; d < 3; ++d)
+              if (kr >= d && kc >= d) eq += fallf(kr, d) * fallf(kc, d);
+          }
+          if (i > 0 && r == c && kr < S) {  // knot i-1 rows seen from the right piece
+            const double cf = fallf(kr, kr) * pow(ratio, (double)kr);
+            eq += cf * cf;
+          }
+          if (i == 0 && r == c && kr < 3) eq += fallf(kr, kr) * fallf(kr, kr);  // start rows
+          v += rho_e * eq;
+        }
+        if (i > 0) {  // Schur complement
+          const double *lr = Lo + (size_t)(i - 1) * NB * NB + (size_t)r * NB;
+          const double *lc = Lo + (size_t)(i - 1) * NB * NB + (size_t)c * NB;
+          double acc = 0.0;
+          for (int k = 0; k < NB; ++k) acc += lr[k] * lc[k];
+          v -= acc;
+        }
+        Hd[e] = v;
+      }
+      __syncthreads();
+      // Cholesky of Hd (lower), in place
+      for (int k = 0; k < NB; ++k) {
+        if (tid == 0) Hd[k * NB + k] = sqrt(Hd[k * NB + k]);
+        __syncthreads();
+        const double piv = Hd[k * NB + k];
+        for (int r = k + 1 + tid; r < NB; r += nt) Hd[r * NB + k] /= piv;
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += nt) {
+          const int r = e / NB, c = e % NB;
+          if (c > k && r >= c) Hd[e] -= Hd[r * NB + k] * Hd[c * NB + k];
+        }
+        __syncthreads();
+      }
+      // Linv_i = L^-1 (lower): column c by forward substitution, one thread per column
+      double *Li = Linv + (size_t)i * NB * NB;
+      for (int c = tid; c < NB; c += nt) {
+        for (int r = 0; r < NB; ++r) {
+          double v = (r == c) ? 1.0 : 0.0;
+          for (int k = c; k < r; ++k) v -= Hd[r * NB + k] * Li[k * NB + c];
+          Li[r * NB + c] = (r >= c) ? v / Hd[r * NB + r] : 0.0;
+        }
+      }
+      __syncthreads();
+    }
+  };
+
+  // x~ = H^-1 rhs  (in place: rhs -> xt)
+  auto solve = [&]() {
+    // forward: y_i = Linv_i (rhs_i - Lo_{i-1} y_{i-1})
+    for (int i = 0; i < N; ++i) {
+      if (tid < NB) {
+        double v = rhs[i * NB + tid];
+        if (i > 0) {
+          const double *lo = Lo + (size_t)(i - 1) * NB * NB + (size_t)tid * NB;
+          for (int k = 0; k < NB; ++k) v -= lo[k] * xt[(i - 1) * NB + k];
+        }
+        aty[tid] = v;
+      }
+      __syncthreads();
+      if (tid < NB) {
+        const double *li = Linv + (size_t)i * NB * NB + (size_t)tid * NB;
+        double v = 0.0;
+        for (int k = 0; k <= tid; ++k) v += li[k] * aty[k];
+        xt[i * NB + tid] = v;
+      }
+      __syncthreads();
+    }
+    // backward: x_i = Linv_i' (y_i - Lo_i' x_{i+1})
+    for (int i = N - 1; i >= 0; --i) {
+      if (tid < NB) {
+        double v = xt[i * NB + tid];
+        if (i < N - 1) {
+          const double *lo = Lo + (size_t)i * NB * NB;
+          for (int k = 0; k < NB; ++k) v -= lo[k * NB + tid] * xt[(i + 1) * NB + k];
+        }
+        aty[tid] = v;
+      }
+      __syncthreads();
+      if (tid < NB) {
+        const double *li = Linv + (size_t)i * NB * NB;
+        double v = 0.0;
+        for (int k = tid; k < NB; ++k) v += li[k * NB + tid] * aty[k];
+        xt[i * NB + tid] = v;
+      }
+      __syncthreads();
+    }
+  };
+
+  // ---- init -----------------------------------------------------------------------------------
+  for (int e = tid; e < n; e += nt) { x[e] = 0.0; rhs[e] = 0.0; }
+  for (int64_t e = tid; e < mtot; e += nt) { zg[e] = 0.0; yg[e] = 0.0; }
+  factorize();
+  __syncthreads();
+
+  int it = 0, status = 0;
+  double rp = 0.0, rd = 0.0;
+  for (it = 1; it <= a.p.max_iter; ++it) {
+    const bool check = (it % a.p.check_every) == 0;
+    const double rho_e = 1.0e3 * rho;
+    solve();
+    // x+ = alpha x~ + (1-alpha) x ; next rhs starts as sigma x+
+    for (int e = tid; e < n; e += nt) {
+      const double xn = alpha * xt[e] + (1.0 - alpha) * x[e];
+      x[e] = xn;
+      rhs[e] = sigma * xn;
+      aty[e] = 0.0;
+    }
+    if (tid < 8) red[tid] = 0.0;
+    __syncthreads();
+    double l_rp = 0.0, l_ax = 0.0, l_z = 0.0;
+    // ---- equality rows ------------------------------------------------------------------------
+    for (int r = tid; r < me; r += nt) {
+      // row = sum over (block, axis, col) of coefficient * variable ; rhs value bval
+      double zt = 0.0, ax_new = 0.0, bval = 0.0;
+      int i0, ax, d, kind;  // kind 0 start, 1 end, 2 continuity
+      if (r < 18) {
+        ax = r / 6;
+        const int q = r % 6;
+        kind = q < 3 ? 0 : 1;
+        d = q % 3;
+        i0 = kind == 0 ? 0 : N - 1;
+        bval = st[(kind == 0 ? 0 : 9) + ax * 3 + d] * pow(Tn[i0], (double)d);
+      } else {
+        const int rr = r - 18;
+        i0 = rr / (3 * S);
+        ax = (rr / S) % 3;
+        d = rr % S;
+        kind = 2;
+      }
+      const double cf2 = (kind == 2) ? -fallf(d, d) * pow(Tn[i0] / Tn[i0 + 1], (double)d) : 0.0;
+      if (kind == 0) {
+        zt = fallf(d, d) * xt[ax * D + (D - 1 - d)];
+        ax_new = fallf(d, d) * x[ax * D + (D - 1 - d)];
+      } else {
+        const double *xb = xt + i0 * NB + ax * D, *xn = x + i0 * NB + ax * D;
+        for (int col = 0; col < D; ++col) {
+          const int k = D - 1 - col;
+          if (k >= d) { const double f = fallf(k, d); zt += f * xb[col]; ax_new += f * xn[col]; }
+        }
+        if (kind == 2) {
+          zt += cf2 * xt[(i0 + 1) * NB + ax * D + (D - 1 - d)];
+          ax_new += cf2 * x[(i0 + 1) * NB + ax * D + (D - 1 - d)];
+        }
+      }
+      const double zo = zg[r], yo = yg[r];
+      const double zr = alpha * zt + (1.0 - alpha) * zo;
+      const double zn = bval;  // l = u = b
+      const double yn = yo + rho_e * (zr - zn);
+      zg[r] = zn;
+      yg[r] = yn;
+      const double w = rho_e * zn - yn;
+      // scatter A' w (and A' y at check iterations)
+      auto scatter = [&](double *dst, double wv) {
+        if (kind == 0) {
+          atomicAdd(&dst[ax * D + (D - 1 - d)], fallf(d, d) * wv);
+        } else {
+          for (int col = 0; col < D; ++col) {
+            const int k = D - 1 - col;
+            if (k >= d) atomicAdd(&dst[i0 * NB + ax * D + col], fallf(k, d) * wv);
+          }
+          if (kind == 2) atomicAdd(&dst[(i0 + 1) * NB + ax * D + (D - 1 - d)], cf2 * wv);
+        }
+      };
+      scatter(rhs, w);
+      if (check) {
+        scatter(aty, yn);
+        l_rp = fmax(l_rp, fabs(ax_new - zn));
+        l_ax = fmax(l_ax, fabs(ax_new));
+        l_z = fmax(l_z, fabs(zn));
+      }
+    }
+    // ---- inequality rows, one sample (piece i, j) per thread ---------------------------------------
+    for (int smp = tid; smp < N * R; smp += nt) {
+      const int i = smp / R, j = smp % R;
+      const double *bj = be + (size_t)j * 3 * D;
+      const double *xb = xt + i * NB, *xn = x + i * NB;
+      double s3[3][3], s3n[3][3];  // [d][axis] state rows of x~ and of x+
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int axx = 0; axx < 3; ++axx) {
+          double acc = 0.0, accn = 0.0;
+          for (int col = 0; col < D; ++col) {
+            acc += bj[d * D + col] * xb[axx * D + col];
+            accn += bj[d * D + col] * xn[axx * D + col];
+          }
+          s3[d][axx] = acc;
+          s3n[d][axx] = accn;
+        }
+      const int64_t r0 = me + (int64_t)smp * rows_per_sample;
+      double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gy[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      const double Ti = Tn[i];
+      for (int q = 0; q < rows_per_sample; ++q) {
+        double zt, axn, hv, c0 = 0, c1 = 0, c2 = 0;
+        int dsel = 0, axsel = 0;
+        double sgn = 1.0;
+        if (q < M) {
+          const double *hq = hp + ((int64_t)i * M + q) * 4;
+          c0 = hq[0]; c1 = hq[1]; c2 = hq[2];
+          hv = hq[3];
+          zt = c0 * s3[0][0] + c1 * s3[0][1] + c2 * s3[0][2];
+          axn = c0 * s3n[0][0] + c1 * s3n[0][1] + c2 * s3n[0][2];
+        } else {
+          const int qq = q - M;
+          axsel = qq / 4;
+          const int w4 = qq % 4;
+          dsel = 1 + (w4 & 1);
+          sgn = (w4 < 2) ? 1.0 : -1.0;
+          hv = (dsel == 1) ? a.vmax * Ti : a.amax * Ti * Ti;
+          zt = sgn * s3[dsel][axsel];
+          axn = sgn * s3n[dsel][axsel];
+        }
+        const double zo = zg[r0 + q], yo = yg[r0 + q];
+        const double zr = alpha * zt + (1.0 - alpha) * zo;
+        const double zn = fmin(zr + yo / rho, hv);  // l = -inf
+        const double yn = yo + rho * (zr - zn);
+        zg[r0 + q] = zn;
+        yg[r0 + q] = yn;
+        const double w = rho * zn - yn;
+        if (q < M) {
+          g[0][0] += w * c0; g[0][1] += w * c1; g[0][2] += w * c2;
+          if (check) { gy[0][0] += yn * c0; gy[0][1] += yn * c1; gy[0][2] += yn * c2; }
+        } else {
+          g[dsel][axsel] += sgn * w;
+          if (check) gy[dsel][axsel] += sgn * yn;
+        }
+        if (check) {
+          l_rp = fmax(l_rp, fabs(axn - zn));
+          l_ax = fmax(l_ax, fabs(axn));
+          l_z = fmax(l_z, fabs(zn));
+        }
+      }
+      for (int axx = 0; axx < 3; ++axx)
+        for (int col = 0; col < D; ++col) {
+          const double v = g[0][axx] * bj[col] + g[1][axx] * bj[D + col] + g[2][axx] * bj[2 * D + col];
+          if (v != 0.0) atomicAdd(&rhs[i * NB + axx * D + col], v);
+          if (check) {
+            const double vy = gy[0][axx] * bj[col] + gy[1][axx] * bj[D + col] + gy[2][axx] * bj[2 * D + col];
+            if (vy != 0.0) atomicAdd(&aty[i * NB + axx * D + col], vy);
+          }
+        }
+    }
+    if (check) {
+      atomic_max_pos(&red[0], l_rp);
+      atomic_max_pos(&red[1], l_ax);
+      atomic_max_pos(&red[2], l_z);
+    }
+    __syncthreads();
+    if (check) {
+      // dual residual: P x + A'y ; norms of P x and A'y
+      double l_rd = 0.0, l_px = 0.0, l_aty = 0.0;
+      for (int e = tid; e < n; e += nt) {
+        const int i = e / NB, cr = e % D;
+        double px = 0.0;
+        if (cr < S) {
+          const double qs = cobj * pow(Tn[i], (double)(1 - 2 * S));
+          const double *xb = x + (e - cr);
+          for (int k = 0; k < S; ++k) px += qs * qblk1<S>(cr, k, a.m34) * xb[k];
+        }
+        l_rd = fmax(l_rd, fabs(px + aty[e]));
+        l_px = fmax(l_px, fabs(px));
+        l_aty = fmax(l_aty, fabs(aty[e]));
+      }
+      atomic_max_pos(&red[3], l_rd);
+      atomic_max_pos(&red[4], l_px);
+      atomic_max_pos(&red[5], l_aty);
+      __syncthreads();
+      rp = red[0];
+      rd = red[3];
+      const double eps_p = a.p.eps_abs + a.p.eps_rel * fmax(red[1], red[2]);
+      const double eps_d = a.p.eps_abs + a.p.eps_rel * fmax(red[4], red[5]);
+      if (rp <= eps_p && rd <= eps_d) {
+        status = 1;
+        break;
+      }
+      if (a.p.adapt_every > 0 && (it % a.p.adapt_every) == 0) {
+        const double np_ = rp / fmax(fmax(red[1], red[2]), 1e-300), nd_ = rd / fmax(fmax(red[4], red[5]), 1e-300);
+        double rho_new = rho * sqrt(np_ / fmax(nd_, 1e-300));
+        rho_new = fmin(fmax(rho_new, 1e-6), 1e6);
+        if (rho_new > 5.0 * rho || rho_new < 0.2 * rho) {
+          // rhs was accumulated with the old rho: rebuild it for the new one from z, y
+          rho = rho_new;
+          __syncthreads();
+          factorize();
+          const double rho_e2 = 1.0e3 * rho;
+          for (int e = tid; e < n; e += nt) rhs[e] = sigma * x[e];
+          __syncthreads();
+          for (int r = tid; r < me; r += nt) {
+            int i0, ax, d, kind;
+            if (r < 18) { ax = r / 6; const int q = r % 6; kind = q < 3 ? 0 : 1; d = q % 3; i0 = kind == 0 ? 0 : N - 1; }
+            else { const int rr = r - 18; i0 = rr / (3 * S); ax = (rr / S) % 3; d = rr % S; kind = 2; }
+            const double w = rho_e2 * zg[r] - yg[r];
+            if (kind == 0) atomicAdd(&rhs[ax * D + (D - 1 - d)], fallf(d, d) * w);
+            else {
+              for (int col = 0; col < D; ++col) { const int k = D - 1 - col; if (k >= d) atomicAdd(&rhs[i0 * NB + ax * D + col], fallf(k, d) * w); }
+              if (kind == 2) atomicAdd(&rhs[(i0 + 1) * NB + ax * D + (D - 1 - d)], -fallf(d, d) * pow(Tn[i0] / Tn[i0 + 1], (double)d) * w);
+            }
+          }
+          for (int smp = tid; smp < N * R; smp += nt) {
+            const int i = smp / R, j = smp % R;
+            const double *bj = be + (size_t)j * 3 * D;
+            const int64_t r0 = me + (int64_t)smp * rows_per_sample;
+            double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            for (int q = 0; q < rows_per_sample; ++q) {
+              const double w = rho * zg[r0 + q] - yg[r0 + q];
+              if (q < M) {
+                const double *hq = hp + ((int64_t)i * M + q) * 4;
+                g[0][0] += w * hq[0]; g[0][1] += w * hq[1]; g[0][2] += w * hq[2];
+              } else {
+                const int qq = q - M, w4 = qq % 4;
+                g[1 + (w4 & 1)][qq / 4] += ((w4 < 2) ? 1.0 : -1.0) * w;
+              }
+            }
+            for (int axx = 0; axx < 3; ++axx)
+              for (int col = 0; col < D; ++col) {
+                const double v = g[0][axx] * bj[col] + g[1][axx] * bj[D + col] + g[2][axx] * bj[2 * D + col];
+                if (v != 0.0) atomicAdd(&rhs[i * NB + axx * D + col], v);
+              }
+          }
+          __syncthreads();
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (it > a.p.max_iter) it = a.p.max_iter;
+  // ---- unscale and report ---------------------------------------------------------------------
+  __syncthreads();
+  for (int e = tid; e < n; e += nt) {
+    const int i = e / NB, k = D - 1 - e % D;
+    a.coeffs[b * n + e] = x[e] * pow(Tn[i], (double)(-k));
+  }
+  if (tid == 0) {
+    double obj = 0.0;
+    for (int i = 0; i < N; ++i) {
+      const double qs = pow(Tn[i], (double)(1 - 2 * S));
+      for (int axx = 0; axx < 3; ++axx) {
+        const double *xb = x + i * NB + axx * D;
+        for (int j = 0; j < S; ++j)
+          for (int k = 0; k < S; ++k) obj += 0.5 * qs * qblk1<S>(j, k, a.m34) * xb[j] * xb[k];
+      }
+    }
+    a.obj[b] = obj;
+    a.status[b] = status;
+    a.iters[b] = it;
+    a.res[b * 2] = rp;
+    a.res[b * 2 + 1] = rd;
+  }
+}
+
+template <int S>
+inline size_t qp_admm_lds_bytes(int N, int R) {
+  constexpr int D = 2 * S, NB = 3 * D;
+  const size_t n = (size_t)NB * N;
+  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 4 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 8);
+}
+
+}  // namespace anet

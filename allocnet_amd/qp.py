@@ -68,3 +68,85 @@ def qp_assemble(order, iniPVA, finPVA, hPolys, times, res=20, max_vel=4.0, max_a
     if single:
         return Q[0], A[0], b[0], G[0], h[0]
     return Q, A, b, G, h
+
+
+# -------------------------------------------------------------------------------------------------
+# the solve: QPSolver (planner/qp_solver.hpp:28-366)
+# -------------------------------------------------------------------------------------------------
+def qp_settings(**over):
+    """OSQP's default settings as the reference uses them (it never overrides any:
+    qp_solver.hpp:299-302, layers.py:79)."""
+    from ._lib import QpSettings, load
+    s = QpSettings()
+    load().anet_qp_default_settings(ctypes.byref(s))
+    for k, v in over.items():
+        if not hasattr(s, k):
+            raise AttributeError(k)
+        setattr(s, k, v)
+    return s
+
+
+def qp_solve(order, iniPVA, finPVA, hPolys, times, res=20, max_vel=4.0, max_acc=6.0, m34=1400.0,
+             settings=None, ctx=None):
+    """Batched QPSolver::solve.  iniPVA/finPVA (B,3,3); hPolys (B,N,M,4) rows a.x <= b (zero rows =
+    padding); times (B,N).  Returns dict(coeffs (B,N,3,2s), obj (B,), status, iters, residuals (B,2))."""
+    ctx = ctx or default_context()
+    hp = np.ascontiguousarray(hPolys, dtype=np.float64)
+    B, N, M, _ = hp.shape
+    state = np.ascontiguousarray(np.stack([np.asarray(iniPVA, dtype=np.float64),
+                                           np.asarray(finPVA, dtype=np.float64)], axis=1))
+    T = np.ascontiguousarray(times, dtype=np.float64)
+    if state.shape != (B, 2, 3, 3) or T.shape != (B, N):
+        raise ValueError("shape mismatch")
+    D = 2 * order
+    coeffs = np.empty((B, N, 3, D)); obj = np.empty(B)
+    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); resid = np.empty((B, 2))
+    ctx.check(ctx.lib.anet_qp_solve(ctx.handle, int(order), N, B, int(res), M, float(max_vel), float(max_acc),
+                                    float(m34), _p(state), _p(T), _p(hp),
+                                    ctypes.cast(ctypes.pointer(settings), ctypes.c_void_p) if settings is not None else None,
+                                    _p(coeffs), _p(obj), _p(status), _p(iters), _p(resid)))
+    return dict(coeffs=coeffs, obj=obj, status=status, iters=iters, residuals=resid)
+
+
+class QPConfig:
+    """struct QPConfig (qp_solver.hpp:14-26) without the ros::NodeHandle: the three parameters it reads."""
+
+    def __init__(self, MaxVelBox=4.0, MaxAccBox=6.0, ConstRes=20):
+        self.MaxVelBox, self.MaxAccBox, self.ConstRes = float(MaxVelBox), float(MaxAccBox), int(ConstRes)
+
+
+class QPSolver:
+    """class QPSolver (qp_solver.hpp:28-366): setOrder, solve, getObjCost -- one trajectory per call,
+    same acceptance rule (status Solved and -0.01 <= objective <= 5000, qp_solver.hpp:334-352)."""
+
+    def __init__(self, conf, ctx=None):
+        self.config = conf
+        self.order_ = None
+        self.obj_cost_ = -1.0
+        self._ctx = ctx
+
+    def setOrder(self, order):
+        if order not in (3, 4):
+            raise ValueError("order must be 3 (jerk) or 4 (snap)")
+        self.order_ = int(order)
+
+    def getObjCost(self):
+        return self.obj_cost_
+
+    def solve(self, iniPVA, finPVA, hPolys, times):
+        """hPolys: list of (m_i,4) arrays (rows a,b: a.x <= b).  Returns (ok, qp_solution) with
+        qp_solution flattened piece -> axis -> coefficient like the reference's Eigen::VectorXd."""
+        seg = len(hPolys)
+        M = max(1, max(p.shape[0] for p in hPolys))
+        hp = np.zeros((1, seg, M, 4))
+        for i, p in enumerate(hPolys):
+            hp[0, i, :p.shape[0]] = p
+        t = np.asarray(times, dtype=np.float64)[:seg]
+        out = qp_solve(self.order_, np.asarray(iniPVA)[None], np.asarray(finPVA)[None], hp, t[None],
+                       res=self.config.ConstRes, max_vel=self.config.MaxVelBox, max_acc=self.config.MaxAccBox,
+                       ctx=self._ctx)
+        result = float(np.float32(out["obj"][0]))          # the reference reads the objective into a float
+        if result > 5000 or result < -0.01 or out["status"][0] != 1:
+            return False, None
+        self.obj_cost_ = float(out["obj"][0])
+        return True, out["coeffs"][0].reshape(-1)

@@ -233,6 +233,43 @@ int anet_qp_assemble(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res,
                      const double *T, const double *hpolys, const int32_t *rows, double *Q, double *A,
                      double *b, double *G, double *h);
 
+/* ---- inequality-constrained QP solve (replaces OSQP) ------------------------------------- */
+/* Replaces the solver part of QPSolver::solve (planner/qp_solver.hpp:299-358: OsqpEigen data/settings,
+ * initSolver, solveProblem, getObjValue, getStatus, getSolution) and OsqpLayer's forward solve
+ * (network/utils/learning/layers.py:66-81,167-181), batched: the SAME QP the reference assembles
+ *      min 1/2 z'Qz   s.t.  A z = b,   G z <= h                      (anet_qp_assemble gives it densely)
+ * solved with OSQP's ADMM iteration and OSQP's default settings (below).  OSQP itself is a third-party
+ * dependency absent from the reference tree: iterates are not comparable, the solution is (same convex
+ * problem, same stopping rule and tolerances) -- parity is checked through the KKT conditions.
+ * The solve never forms Q, A, G: see allocnet_amd/csrc/qp_admm.h.                                    */
+typedef struct anet_qp_settings {
+  double rho;        /* 0.1   OSQP default; equality rows use 1e3*rho like OSQP                 */
+  double sigma;      /* 1e-6                                                                    */
+  double alpha;      /* 1.6                                                                     */
+  double eps_abs;    /* 1e-3  (the reference never changes it: qp_solver.hpp:301-302, layers.py:79) */
+  double eps_rel;    /* 1e-3                                                                    */
+  int32_t max_iter;  /* 4000                                                                    */
+  int32_t check_termination; /* 25                                                              */
+  int32_t adaptive_rho_interval; /* 100; 0 disables (OSQP picks its interval from wall-clock time) */
+} anet_qp_settings;
+void anet_qp_default_settings(anet_qp_settings *s);
+#define ANET_QP_SOLVED 1          /* OSQP_SOLVED                 */
+#define ANET_QP_MAX_ITER_REACHED 0 /* OSQP_MAX_ITER_REACHED (the reference treats anything but Solved as failure) */
+/* hpolys [batch][N][M][4] rows a.x <= b with all-zero rows as inert padding.
+ * coeffs [batch][N][3][2s] (the flatten order callModel unpacks, learning_planner.hpp:212,227),
+ * obj [batch] = 1/2 z'Qz (QPSolver::getObjCost), status/iters [batch], residuals [batch][2] (primal, dual;
+ * may be NULL).  All HOST pointers; the _dev variant takes DEVICE pointers (same trajectory-major
+ * layout) plus a device workspace of anet_qp_solve_workspace() doubles.                            */
+int anet_qp_solve(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                  double max_acc, double m34, const double *state, const double *T, const double *hpolys,
+                  const anet_qp_settings *settings, double *coeffs, double *obj, int32_t *status,
+                  int32_t *iters, double *residuals);
+int64_t anet_qp_solve_workspace(int s, int n_pieces, int64_t batch, int res, int M);
+int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                      double max_acc, double m34, const double *state, const double *T,
+                      const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
+                      double *obj, int32_t *status, int32_t *iters, double *residuals, void *stream);
+
 /* ---- batched L-BFGS ------------------------------------------------------------------------ */
 /* lbfgs::lbfgs_parameter_t, same fields and defaults (gcopter/lbfgs.hpp:15-129). */
 typedef struct anet_lbfgs_params {

@@ -1,0 +1,60 @@
+"""TEST INFRASTRUCTURE ONLY -- dense primal-dual interior-point solver for the reference's QP
+    min 1/2 z'Qz  s.t.  A z = b,  G z <= h
+used as the high-accuracy oracle for the GPU ADMM solve.  It is a textbook Mehrotra predictor-
+corrector method (Nocedal & Wright, Numerical Optimization, Alg. 16.4), deliberately a different
+algorithm from both OSQP and the GPU kernel.  OSQP itself (the reference's solver, third-party,
+release-0.6.3) is not available in this image: parity with OSQP iterates is UNPINNED; what is checked
+is that the GPU solution satisfies the same problem's KKT conditions to OSQP's own tolerances and
+agrees with this oracle's optimum."""
+import numpy as np
+
+
+def qp_ipm(Q, A, b, G, h, tol=1e-10, max_iter=200):
+    """Returns z, lam, nu, objective, iterations (iterations == max_iter means no convergence: the
+    problem is probably infeasible)."""
+    n = Q.shape[0]; me = A.shape[0]; mg = G.shape[0]
+    z = np.linalg.lstsq(A, b, rcond=None)[0]
+    s = np.maximum(h - G @ z, 1.0); lam = np.ones(mg); nu = np.zeros(me)
+    reg = 1e-10 * max(1.0, np.abs(Q).max())
+    hs = max(1.0, np.abs(h).max())
+    it = 0
+    for it in range(max_iter):
+        rd = Q @ z + A.T @ nu + G.T @ lam
+        rp = A @ z - b
+        rg = G @ z + s - h
+        mu = s @ lam / mg
+        if (np.abs(rd).max() <= tol * max(1.0, np.abs(Q @ z).max(), np.abs(G.T @ lam).max()) and
+                np.abs(rp).max() <= tol * hs and np.abs(rg).max() <= tol * hs and mu <= tol * max(1.0, abs(z @ Q @ z))):
+            break
+        W = lam / s
+        H = Q + G.T @ (W[:, None] * G) + reg * np.eye(n)
+        K = np.block([[H, A.T], [A, -1e-13 * np.eye(me)]])
+        lu = np.linalg.inv(K)
+
+        def step(rc):
+            rhs1 = -rd - G.T @ ((lam * rg - rc) / s)
+            sol = lu @ np.r_[rhs1, -rp]
+            dz = sol[:n]; dnu = sol[n:]
+            ds = -rg - G @ dz
+            dlam = (-rc - lam * ds) / s
+            return dz, dnu, ds, dlam
+
+        def maxstep(v, dv, frac):
+            neg = dv < 0
+            return min(1.0, frac * (-v[neg] / dv[neg]).min()) if neg.any() else 1.0
+        dz, dnu, ds, dlam = step(s * lam)
+        al = min(maxstep(s, ds, 1.0), maxstep(lam, dlam, 1.0))
+        mu_aff = (s + al * ds) @ (lam + al * dlam) / mg
+        sig = (mu_aff / mu) ** 3
+        dz, dnu, ds, dlam = step(s * lam + ds * dlam - sig * mu)
+        al = min(maxstep(s, ds, 0.995), maxstep(lam, dlam, 0.995))
+        z = z + al * dz; s = s + al * ds; lam = lam + al * dlam; nu = nu + al * dnu
+        if not np.isfinite(z).all():
+            it = max_iter
+            break
+    return z, lam, nu, 0.5 * z @ Q @ z, it
+
+
+def kkt_violation(Q, A, b, G, h, z):
+    """Primal feasibility of z (max violation) -- duals are not needed for this check."""
+    return max(np.abs(A @ z - b).max(), np.maximum(G @ z - h, 0.0).max())

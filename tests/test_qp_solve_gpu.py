@@ -1,0 +1,111 @@
+"""GPU QP solve (OSQP replacement) vs an independent interior-point oracle on the matrices produced
+by the reference-pinned assembly."""
+import numpy as np
+import pytest
+
+from oracle import minco_np as onp
+from oracle import qp_np
+from tests.util import golden_files
+
+pytestmark = pytest.mark.gpu
+
+
+def _corridor_problem(rng, N, M, margin=1.0):
+    pts = np.cumsum(np.vstack([np.zeros(3), rng.normal(size=(N, 3)) * 1.5]), axis=0)
+    hp = np.zeros((N, M, 4))
+    for i in range(N):
+        lo = np.minimum(pts[i], pts[i + 1]) - margin
+        hi = np.maximum(pts[i], pts[i + 1]) + margin
+        for ax in range(3):
+            hp[i, 2 * ax, ax] = 1.0; hp[i, 2 * ax, 3] = hi[ax]
+            hp[i, 2 * ax + 1, ax] = -1.0; hp[i, 2 * ax + 1, 3] = -lo[ax]
+        mid = 0.5 * (pts[i] + pts[i + 1])
+        for r in range(6, M - 1):
+            a = rng.normal(size=3); a /= np.linalg.norm(a)
+            hp[i, r, :3] = a; hp[i, r, 3] = max(a @ pts[i], a @ pts[i + 1]) + rng.uniform(0.3, 1.5)
+    ini = np.zeros((3, 3)); fin = np.zeros((3, 3))
+    ini[:, 0] = pts[0]; fin[:, 0] = pts[-1]
+    T = rng.uniform(1.5, 2.5, size=N)
+    return ini, fin, hp, T
+
+
+def _dense(s, ini, fin, hp, T, res, vmax, amax):
+    N, M = hp.shape[0], hp.shape[1]
+    state = np.zeros((9, 2))
+    for ax in range(3):
+        state[3 * ax:3 * ax + 3, 0] = ini[ax]; state[3 * ax:3 * ax + 3, 1] = fin[ax]
+    Q, A, b, G1, h1, G2, h2 = onp.qp_assemble(s, state, np.transpose(hp, (1, 2, 0)), np.full(N, M), T, res, vmax, amax)
+    D = 2 * s; n = 3 * D * N
+    G = np.zeros((G1.shape[0] + G2.shape[0], n))
+    r = 0
+    for i in range(N):
+        for _ in range(res):
+            G[r:r + M, i * 3 * D:(i + 1) * 3 * D] = G1[r:r + M]; r += M
+    r2 = 0
+    for i in range(N):
+        for _ in range(res):
+            for j in range(3):
+                G[r + r2:r + r2 + 4, i * 3 * D + j * D:i * 3 * D + (j + 1) * D] = G2[r2:r2 + 4]; r2 += 4
+    hh = np.r_[h1, h2]
+    keep = (np.abs(G).sum(axis=1) > 0) | (hh != 0)      # drop the inert 0.x <= 0 padding rows for the oracle
+    return Q, A, b, G[keep], hh[keep]
+
+
+@pytest.mark.parametrize("s,N,M,res", [(4, 3, 9, 6), (3, 4, 8, 5), (4, 1, 7, 8), (3, 2, 7, 10)])
+def test_qp_solution_matches_interior_point(anet_ctx, s, N, M, res):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(10 * s + N)
+    B = 6
+    probs = [_corridor_problem(rng, N, M) for _ in range(B)]
+    ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
+    hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs])
+    vmax, amax = 3.0, 4.0
+    # (1) OSQP default tolerances (what the reference runs): solved, objective within a few 1e-3
+    out = aa.qp_solve(s, ini, fin, hp, T, res=res, max_vel=vmax, max_acc=amax, ctx=anet_ctx)
+    # (2) tight tolerances: coefficients agree with the interior-point optimum
+    tight = aa.qp_solve(s, ini, fin, hp, T, res=res, max_vel=vmax, max_acc=amax,
+                        settings=aa.qp_settings(eps_abs=1e-9, eps_rel=1e-9, max_iter=60000), ctx=anet_ctx)
+    feasible = 0
+    for bb in range(B):
+        Q, A, b, G, h = _dense(s, ini[bb], fin[bb], hp[bb], T[bb], res, vmax, amax)
+        z, lam, nu, fo, it = qp_np.qp_ipm(Q, A, b, G, h)
+        if it >= 199 or qp_np.kkt_violation(Q, A, b, G, h, z) > 1e-7:
+            continue                  # the limits make this random instance infeasible: nothing to compare
+        feasible += 1
+        assert out["status"][bb] == 1, (bb, out["iters"][bb], out["residuals"][bb])
+        zg = out["coeffs"][bb].reshape(-1)
+        assert abs(out["obj"][bb] - 0.5 * zg @ Q @ zg) <= 1e-9 * max(1.0, fo)      # reported objective is 1/2 z'Qz
+        assert abs(out["obj"][bb] - fo) <= 2e-2 * max(1.0, fo), (bb, out["obj"][bb], fo)
+        scale = max(1.0, np.abs(h).max())
+        assert qp_np.kkt_violation(Q, A, b, G, h, zg) <= 2e-2 * scale
+        assert tight["status"][bb] == 1, (bb, tight["iters"][bb], tight["residuals"][bb])
+        zt = tight["coeffs"][bb].reshape(-1)
+        assert abs(tight["obj"][bb] - fo) <= 1e-5 * max(1.0, fo), (bb, tight["obj"][bb], fo)
+        assert qp_np.kkt_violation(Q, A, b, G, h, zt) <= 1e-6 * scale
+        # minimiser is unique in the position polynomial: compare sampled positions, not raw coefficients
+        for i in range(N):
+            for tt in np.linspace(0, T[bb, i], 5):
+                pz = onp.piece_eval(z.reshape(N, 3, 2 * s)[i], tt, 0)
+                pg = onp.piece_eval(tight["coeffs"][bb][i], tt, 0)
+                assert np.abs(pz - pg).max() <= 1e-4 * max(1.0, np.abs(pz).max())
+    assert feasible >= 3
+
+
+def test_qpsolver_class_mirror(anet_ctx):
+    """QPSolver(QPConfig).setOrder/solve/getObjCost, the calls of learning_planner.hpp:30,36,196."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(5)
+    ini, fin, hp, T = _corridor_problem(rng, 3, 8)
+    solver = aa.QPSolver(aa.QPConfig(MaxVelBox=3.0, MaxAccBox=4.0, ConstRes=10), ctx=anet_ctx)
+    solver.setOrder(3)
+    polys = [hp[i][np.abs(hp[i]).sum(axis=1) > 0] for i in range(3)]
+    ok, sol = solver.solve(ini, fin, polys, T.astype(np.float32))
+    assert ok and sol.shape == (3 * 3 * 6,)
+    assert solver.getObjCost() > 0
+    traj = aa.Trajectory(list(T), list(sol.reshape(3, 3, 6)), ctx=anet_ctx)       # learning_planner.hpp:205-216
+    assert np.abs(traj.getPos(0.0) - ini[:, 0]).max() < 5e-3
+    assert np.abs(traj.getPos(T.sum()) - fin[:, 0]).max() < 5e-2
+    # infeasible corridor (end point far outside the last polytope) -> the reference's failure path
+    fin_bad = fin.copy(); fin_bad[:, 0] += 50.0
+    ok, sol = solver.solve(ini, fin_bad, polys, T)
+    assert not ok and sol is None
