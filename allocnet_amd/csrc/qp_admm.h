@@ -224,44 +224,52 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
     }
   };
 
-  // x~ = H^-1 rhs  (in place: rhs -> xt)
+  // x~ = H^-1 rhs  (rhs -> xt).  Every NB-long dot product is split over 8 adjacent lanes and reduced
+  // with shuffles (NB*8 <= 192 of the 256 threads work; `aty` holds the intermediate block vector).
   auto solve = [&]() {
+    const int row = tid >> 3, sub = tid & 7;
+    auto reduce8 = [&](double v) {
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      return v;
+    };
     // forward: y_i = Linv_i (rhs_i - Lo_{i-1} y_{i-1})
     for (int i = 0; i < N; ++i) {
-      if (tid < NB) {
-        double v = rhs[i * NB + tid];
-        if (i > 0) {
-          const double *lo = Lo + (size_t)(i - 1) * NB * NB + (size_t)tid * NB;
-          for (int k = 0; k < NB; ++k) v -= lo[k] * xt[(i - 1) * NB + k];
-        }
-        aty[tid] = v;
+      double v = 0.0;
+      if (row < NB && i > 0) {
+        const double *lo = Lo + (size_t)(i - 1) * NB * NB + (size_t)row * NB;
+        for (int k = sub; k < NB; k += 8) v += lo[k] * xt[(i - 1) * NB + k];
       }
+      v = reduce8(v);
+      if (row < NB && sub == 0) aty[row] = rhs[i * NB + row] - v;
       __syncthreads();
-      if (tid < NB) {
-        const double *li = Linv + (size_t)i * NB * NB + (size_t)tid * NB;
-        double v = 0.0;
-        for (int k = 0; k <= tid; ++k) v += li[k] * aty[k];
-        xt[i * NB + tid] = v;
+      v = 0.0;
+      if (row < NB) {
+        const double *li = Linv + (size_t)i * NB * NB + (size_t)row * NB;
+        for (int k = sub; k <= row; k += 8) v += li[k] * aty[k];
       }
+      v = reduce8(v);
+      if (row < NB && sub == 0) xt[i * NB + row] = v;
       __syncthreads();
     }
     // backward: x_i = Linv_i' (y_i - Lo_i' x_{i+1})
     for (int i = N - 1; i >= 0; --i) {
-      if (tid < NB) {
-        double v = xt[i * NB + tid];
-        if (i < N - 1) {
-          const double *lo = Lo + (size_t)i * NB * NB;
-          for (int k = 0; k < NB; ++k) v -= lo[k * NB + tid] * xt[(i + 1) * NB + k];
-        }
-        aty[tid] = v;
+      double v = 0.0;
+      if (row < NB && i < N - 1) {
+        const double *lo = Lo + (size_t)i * NB * NB;
+        for (int k = sub; k < NB; k += 8) v += lo[k * NB + row] * xt[(i + 1) * NB + k];
       }
+      v = reduce8(v);
+      if (row < NB && sub == 0) aty[row] = xt[i * NB + row] - v;
       __syncthreads();
-      if (tid < NB) {
+      v = 0.0;
+      if (row < NB) {
         const double *li = Linv + (size_t)i * NB * NB;
-        double v = 0.0;
-        for (int k = tid; k < NB; ++k) v += li[k * NB + tid] * aty[k];
-        xt[i * NB + tid] = v;
+        for (int k = row + sub; k < NB; k += 8) v += li[k * NB + row] * aty[k];
       }
+      v = reduce8(v);
+      if (row < NB && sub == 0) xt[i * NB + row] = v;
       __syncthreads();
     }
   };
@@ -367,7 +375,8 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
           s3[d][axx] = acc;
           s3n[d][axx] = accn;
         }
-      const int64_t r0 = me + (int64_t)smp * rows_per_sample;
+      const int64_t r0 = me + smp;            // row q of this sample lives at r0 + q*NS (coalesced across samples)
+      const int64_t NS = (int64_t)N * R;
       double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gy[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
       const double Ti = Tn[i];
       for (int q = 0; q < rows_per_sample; ++q) {
@@ -390,12 +399,12 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
           zt = sgn * s3[dsel][axsel];
           axn = sgn * s3n[dsel][axsel];
         }
-        const double zo = zg[r0 + q], yo = yg[r0 + q];
+        const double zo = zg[r0 + q * NS], yo = yg[r0 + q * NS];
         const double zr = alpha * zt + (1.0 - alpha) * zo;
         const double zn = fmin(zr + yo / rho, hv);  // l = -inf
         const double yn = yo + rho * (zr - zn);
-        zg[r0 + q] = zn;
-        yg[r0 + q] = yn;
+        zg[r0 + q * NS] = zn;
+        yg[r0 + q * NS] = yn;
         const double w = rho * zn - yn;
         if (q < M) {
           g[0][0] += w * c0; g[0][1] += w * c1; g[0][2] += w * c2;
@@ -479,10 +488,10 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
           for (int smp = tid; smp < N * R; smp += nt) {
             const int i = smp / R, j = smp % R;
             const double *bj = be + (size_t)j * 3 * D;
-            const int64_t r0 = me + (int64_t)smp * rows_per_sample;
+            const int64_t r0 = me + smp, NS = (int64_t)N * R;
             double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
             for (int q = 0; q < rows_per_sample; ++q) {
-              const double w = rho * zg[r0 + q] - yg[r0 + q];
+              const double w = rho * zg[r0 + q * NS] - yg[r0 + q * NS];
               if (q < M) {
                 const double *hq = hp + ((int64_t)i * M + q) * 4;
                 g[0][0] += w * hq[0]; g[0][1] += w * hq[1]; g[0][2] += w * hq[2];

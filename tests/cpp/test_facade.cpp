@@ -7,6 +7,7 @@
 
 #include "allocnet_amd/lbfgs.hpp"
 #include "allocnet_amd/minco.hpp"
+#include "allocnet_amd/qp_solver.hpp"
 #include "allocnet_amd/trajectory.hpp"
 
 struct Mat {  // Eigen-like: (r,c) access, default constructible
@@ -21,6 +22,20 @@ struct Vec {
   explicit Vec(int n) : a(n, 0.0) {}
   double &operator()(int i) { return a[i]; }
   double operator()(int i) const { return a[i]; }
+};
+struct VecX {  // Eigen::VectorXd-like: resize(n), (i)
+  std::vector<double> a;
+  void resize(long n) { a.assign((size_t)n, 0.0); }
+  double &operator()(long i) { return a[(size_t)i]; }
+  double operator()(long i) const { return a[(size_t)i]; }
+};
+struct Poly {  // Eigen::MatrixX4d-like
+  int R;
+  std::vector<double> a;
+  explicit Poly(int r) : R(r), a((size_t)r * 4, 0.0) {}
+  long rows() const { return R; }
+  double &operator()(int r, int c) { return a[(size_t)r * 4 + c]; }
+  double operator()(int r, int c) const { return a[(size_t)r * 4 + c]; }
 };
 struct V3 {  // Eigen::Vector3d-like: constructible from three scalars
   double x, y, z;
@@ -88,6 +103,46 @@ int main() {
     printf("\"junc_vel_3\": [%.17g, %.17g, %.17g],\n", copy.getJuncVel(3)(0), copy.getJuncVel(3)(1), copy.getJuncVel(3)(2));
     printf("\"locate\": [%d, %.17g],\n", idx, tloc);
     printf("\"pieces\": %d, \"total\": %.17g,\n", copy.getPieceNum(), copy.getTotalDuration());
+    // QPSolver exactly as LearningPlanner drives it (learning_planner.hpp:30,36,196-233): 3 pieces, jerk
+    {
+      QPSolver qp(QPConfig(3.0, 4.0, 10));
+      int optOrder = 3;
+      qp.setOrder(optOrder);
+      Mat ini(3, 3), fin(3, 3);
+      const double wp[4][3] = {{0, 0, 0}, {2, 1, 0.5}, {4, 1.5, 1}, {6, 3, 1}};
+      for (int a = 0; a < 3; ++a) fin(a, 0) = wp[3][a];
+      std::vector<Poly> hPolys;
+      for (int i = 0; i < 3; ++i) {
+        Poly P(6);
+        for (int ax = 0; ax < 3; ++ax) {
+          const double lo = (wp[i][ax] < wp[i + 1][ax] ? wp[i][ax] : wp[i + 1][ax]) - 1.0;
+          const double hi = (wp[i][ax] > wp[i + 1][ax] ? wp[i][ax] : wp[i + 1][ax]) + 1.0;
+          P(2 * ax, ax) = 1.0; P(2 * ax, 3) = hi;
+          P(2 * ax + 1, ax) = -1.0; P(2 * ax + 1, 3) = -lo;
+        }
+        hPolys.push_back(P);
+      }
+      struct TimesF { float v[5]; float operator()(int i) const { return v[i]; } } times = {{2.0f, 1.5f, 2.0f, 0.f, 0.f}};
+      VecX flatten_coffmats;
+      const bool ok = qp.solve(ini, fin, hPolys, times, flatten_coffmats);
+      Trajectory<5> jerk_traj;
+      if (ok) {
+        jerk_traj.clear();
+        jerk_traj.reserve(3);
+        for (int i = 0; i < 3; ++i) {
+          Mat coffMat(3, 6);
+          for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 6; ++k) coffMat(j, k) = flatten_coffmats(i * 3 * 6 + j * 6 + k);
+          jerk_traj.emplace_back(times(i), coffMat);
+        }
+      }
+      anet::Vec3 qe = ok ? jerk_traj.getPos(5.5) : anet::Vec3();
+      anet::Vec3 qv = ok ? jerk_traj.getVel(2.7) : anet::Vec3();
+      printf("\"qp_ok\": %d, \"qp_obj\": %.17g, \"qp_iters\": %d,\n", ok ? 1 : 0, qp.getObjCost(), qp.getIterations());
+      printf("\"qp_end\": [%.17g, %.17g, %.17g],\n", qe(0), qe(1), qe(2));
+      printf("\"qp_vel\": [%.17g, %.17g, %.17g],\n", qv(0), qv(1), qv(2));
+      print_vec("qp_coeffs", flatten_coffmats.a);
+    }
     lbfgs::lbfgs_parameter_t prm;
     printf("\"lbfgs_default_mem\": %d, \"strerror\": \"%s\"\n", prm.mem_size, lbfgs::lbfgs_strerror(lbfgs::LBFGSERR_MAXIMUMLINESEARCH));
     printf("}\n");

@@ -42,3 +42,10 @@ def test_cpp_facade_program():
     assert out["locate"][0] == 2 and abs(out["locate"][1] - 0.25) < 1e-15
     assert out["pieces"] == 8 and out["total"] == 8.0
     assert out["lbfgs_default_mem"] == 8 and out["strerror"].startswith("Line search reaches")
+
+    # QPSolver facade: solved, ends where asked, inside the velocity box, objective == 1/2 z'Qz of its coefficients
+    assert out["qp_ok"] == 1 and out["qp_iters"] > 0
+    assert np.abs(np.array(out["qp_end"]) - np.array([6.0, 3.0, 1.0])).max() < 5e-2
+    assert np.abs(np.array(out["qp_vel"])).max() <= 3.0 + 5e-2
+    zc = np.array(out["qp_coeffs"]).reshape(3, 3, 6)
+    assert abs(onp.traj_cost(zc, np.array([2.0, 1.5, 2.0]), 3) - out["qp_obj"]) <= 1e-9 * max(1.0, out["qp_obj"])
