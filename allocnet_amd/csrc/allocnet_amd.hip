@@ -128,7 +128,8 @@ __global__ void __launch_bounds__(256) k_traj_eval(EvalArgs a) {
 // Trajectory<D>::getTrajCost (trajectory.hpp:354-427).
 struct CostArgs {
   const double *coeffs, *T;
-  double *cost;
+  double *cost;   // [B] or nullptr
+  double *gradT;  // [N][ld] or nullptr: d cost / d T_i at fixed coefficients
   int64_t B, ld;
   int N;
   double m34;
@@ -143,42 +144,61 @@ __global__ void __launch_bounds__(256) k_traj_cost(CostArgs a) {
   for (int i = 0; i < a.N; ++i) {
     const double t = a.T[(int64_t)i * ld + b];
     const double t2 = t * t, t3 = t * t2, t4 = t2 * t2, t5 = t2 * t3;
-    double Q[S][S];
+    double Q[S][S], dQ[S][S];  // cost block and its derivative w.r.t. t
     if constexpr (S == 4) {
       const double t6 = t3 * t3, t7 = t4 * t3;
       Q[0][0] = 100800 * t7; Q[0][1] = 50400 * t6; Q[0][2] = 20160 * t5; Q[0][3] = 5040 * t4;
       Q[1][1] = 25920 * t5;  Q[1][2] = 10800 * t4; Q[1][3] = 2880 * t3;
       Q[2][2] = 4800 * t3;   Q[2][3] = a.m34 * t2;
       Q[3][3] = 576 * t;
+      dQ[0][0] = 7 * 100800 * t6; dQ[0][1] = 6 * 50400 * t5; dQ[0][2] = 5 * 20160 * t4; dQ[0][3] = 4 * 5040 * t3;
+      dQ[1][1] = 5 * 25920 * t4;  dQ[1][2] = 4 * 10800 * t3; dQ[1][3] = 3 * 2880 * t2;
+      dQ[2][2] = 3 * 4800 * t2;   dQ[2][3] = 2 * a.m34 * t;
+      dQ[3][3] = 576;
     } else if constexpr (S == 3) {
       Q[0][0] = 720 * t5; Q[0][1] = 360 * t4; Q[0][2] = 120 * t3;
       Q[1][1] = 192 * t3; Q[1][2] = 72 * t2;
       Q[2][2] = 36 * t;
+      dQ[0][0] = 5 * 720 * t4; dQ[0][1] = 4 * 360 * t3; dQ[0][2] = 3 * 120 * t2;
+      dQ[1][1] = 3 * 192 * t2; dQ[1][2] = 2 * 72 * t;
+      dQ[2][2] = 36;
     } else {
       Q[0][0] = 12 * t3; Q[0][1] = 6 * t2;
       Q[1][1] = 4 * t;
+      dQ[0][0] = 36 * t2; dQ[0][1] = 12 * t;
+      dQ[1][1] = 4;
     }
 #pragma unroll
     for (int j = 1; j < S; ++j)
 #pragma unroll
-      for (int k = 0; k < j; ++k) Q[j][k] = Q[k][j];
+      for (int k = 0; k < j; ++k) {
+        Q[j][k] = Q[k][j];
+        dQ[j][k] = dQ[k][j];
+      }
+    double gti = 0.0;
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
       double z[S];
 #pragma unroll
       for (int j = 0; j < S; ++j) z[j] = a.coeffs[(int64_t)((i * 3 + ax) * D + j) * ld + b];
-      double acc = 0.0;
+      double acc = 0.0, dacc = 0.0;
 #pragma unroll
       for (int j = 0; j < S; ++j) {
-        double r = 0.0;
+        double r = 0.0, dr = 0.0;
 #pragma unroll
-        for (int k = 0; k < S; ++k) r += Q[j][k] * z[k];
+        for (int k = 0; k < S; ++k) {
+          r += Q[j][k] * z[k];
+          dr += dQ[j][k] * z[k];
+        }
         acc += z[j] * r;
+        dacc += z[j] * dr;
       }
       energy += 0.5 * acc;
+      gti += 0.5 * dacc;
     }
+    if (a.gradT) a.gradT[(int64_t)i * ld + b] = gti;
   }
-  a.cost[b] = energy;
+  if (a.cost) a.cost[b] = energy;
 }
 
 
@@ -1715,7 +1735,7 @@ int anet_traj_cost_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_
   if (rc) return rc;
   if (batch == 0) return ANET_OK;
   if (!coeffs || !T || !cost || ld < batch) return fail(ctx, ANET_ERR_INVALID, "anet_traj_cost_dev: NULL pointer or ld < batch");
-  anet::CostArgs a{coeffs, T, cost, batch, ld, n_pieces, m34};
+  anet::CostArgs a{coeffs, T, cost, nullptr, batch, ld, n_pieces, m34};
   const dim3 grid((unsigned)((batch + 255) / 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (s == 2) hipLaunchKernelGGL(anet::k_traj_cost<2>, grid, block, 0, st, a);
@@ -2321,6 +2341,41 @@ int anet_qp_solve(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, in
   if (residuals) ANET_HIP(ctx, hipMemcpyAsync(residuals, d_res, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, st));
   ANET_HIP(ctx, hipStreamSynchronize(st));
   return ANET_OK;
+}
+
+int anet_traj_cost_grad_T_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
+                              const double *coeffs, const double *T, double m34, double *gradT, void *stream) {
+  int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
+  if (rc) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!coeffs || !T || !gradT || ld < batch) return fail(ctx, ANET_ERR_INVALID, "anet_traj_cost_grad_T_dev: NULL pointer or ld < batch");
+  anet::CostArgs a{coeffs, T, nullptr, gradT, batch, ld, n_pieces, m34};
+  const dim3 grid((unsigned)((batch + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (s == 2) hipLaunchKernelGGL(anet::k_traj_cost<2>, grid, block, 0, st, a);
+  else if (s == 3) hipLaunchKernelGGL(anet::k_traj_cost<3>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(anet::k_traj_cost<4>, grid, block, 0, st, a);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+int anet_traj_cost_grad_T(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
+                          const double *T, double m34, double *gradT) {
+  int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
+  if (rc) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!coeffs || !T || !gradT) return fail(ctx, ANET_ERR_INVALID, "anet_traj_cost_grad_T: NULL pointer");
+  const int64_t nco = (int64_t)n_pieces * 3 * 2 * s;
+  Stager st;
+  rc = make_stager(ctx, batch, nco, nco + 2 * (int64_t)n_pieces, &st);
+  if (rc) return rc;
+  double *d_co, *d_T;
+  if ((rc = st.upload(coeffs, nco, &d_co))) return rc;
+  if ((rc = st.upload(T, n_pieces, &d_T))) return rc;
+  double *d_g = st.reserve(n_pieces);
+  rc = anet_traj_cost_grad_T_dev(ctx, s, n_pieces, batch, st.ld, d_co, d_T, m34, d_g, ctx->stream);
+  if (rc) return rc;
+  return st.download(d_g, n_pieces, gradT);
 }
 
 }  // extern "C"

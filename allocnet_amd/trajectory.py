@@ -46,6 +46,18 @@ def traj_cost(coeffs, T, order=None, m34=1400.0, ctx=None):
     return out
 
 
+def traj_cost_grad_T(coeffs, T, m34=1400.0, ctx=None):
+    """d getTrajCost / dT at fixed coefficients, (B,N): the time gradient the reference's training
+    propagates (layers.py:143-147 with the QP solution detached, :121)."""
+    ctx = ctx or default_context()
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    B, N, _, D = coeffs.shape
+    out = np.empty((B, N))
+    ctx.check(ctx.lib.anet_traj_cost_grad_T(ctx.handle, D // 2, N, B, _ptr(coeffs), _ptr(T), float(m34), _ptr(out)))
+    return out
+
+
 class Piece:
     """Piece<D> (trajectory.hpp:37-316): duration + 3 x (D+1) coefficient matrix, highest power first."""
 

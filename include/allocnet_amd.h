@@ -138,6 +138,16 @@ int anet_traj_cost_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_
                        void *stream);
 int anet_traj_cost(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
                    const double *T, double m34, double *cost);
+/* d(getTrajCost)/dT_i with the coefficients held fixed: 1/2 z_i' (dQ_s/dT)(T_i) z_i summed over axes.
+ * This is the time-allocation gradient the reference's training actually back-propagates: in
+ * OsqpLayer the QP solution is a detached leaf (network/utils/learning/layers.py:121,222), so the loss
+ * 1/2 z'Q(T)z / path_length (:143-147, :245) reaches the segment times only through Q(T); the KKT hook
+ * (:136-141, :238-243) rewrites the gradient of that leaf and never reaches the network.
+ * gradT: [N][ld] (dev) / [batch][N] (host).                                                        */
+int anet_traj_cost_grad_T_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
+                              const double *coeffs, const double *T, double m34, double *gradT, void *stream);
+int anet_traj_cost_grad_T(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
+                          const double *T, double m34, double *gradT);
 
 /* ---- cost + analytic gradients ----------------------------------------------------------- */
 /* Penalty functional on the reference's own inequality rows (QPSolver::solve step three,

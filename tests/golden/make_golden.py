@@ -203,6 +203,17 @@ def main():
             acc = np.array([traj.get_acc(t) for t in ts])
         out.update(eval_t=ts, eval_pos=pos, eval_vel=vel, eval_acc=acc)
 
+        # (4) the time gradient the reference's training back-propagates: d(1/2 z'Q(T)z)/dT with the
+        #     solution z detached (layers.py:121,143-147), taken by autograd THROUGH THE REFERENCE'S OWN Q(T)
+        Tt = torch.tensor(T, dtype=torch.float64, requires_grad=True)
+        opt2 = MinTrajOpt(make_params(order, res))
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt2.update(torch.tensor(state), torch.tensor(hpolys), Tt, phase=phase, seq_len=N)
+        zt = torch.tensor(z)
+        loss = 0.5 * zt @ opt2.params[0] @ zt
+        (gT,) = torch.autograd.grad(loss, opt2.Times)
+        out.update(dcost_dT=gT.detach().numpy())
+
         path = os.path.join(OUT, f"qp_{name}.npz")
         np.savez_compressed(path, **out)
         print(f"{name}: n={n} me={A.shape[0]} mg={G1.shape[0]}+{G2.shape[0]} "

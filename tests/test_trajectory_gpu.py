@@ -74,3 +74,17 @@ def test_solve_then_cost_consistency(anet_ctx):
     assert np.abs(traj.getJuncAcc(8) - tail[0, :, 2]).max() < 1e-7
     idx, tl = traj.locatePieceIdx(T[0, 0] + 0.25 * T[0, 1])
     assert idx == 1 and abs(tl - 0.25 * T[0, 1]) < 1e-12
+
+
+@pytest.mark.parametrize("path", golden_files())
+def test_time_gradient_matches_reference_autograd(anet_ctx, path):
+    """d(1/2 z'Q(T)z)/dT with z detached: the fixture value comes from torch.autograd through the
+    REFERENCE's own Q(T) assembly (tests/golden/make_golden.py step 4), i.e. the gradient its training
+    sends to the segment times (layers.py:121,143-147)."""
+    import allocnet_amd as aa
+    d = np.load(path)
+    s, N = int(d["order"]), int(d["N"]); D = 2 * s
+    z = d["z_eq"].reshape(1, N, 3, D)
+    g = aa.traj_cost_grad_T(z, d["T"][None], m34=1400.0, ctx=anet_ctx)[0]
+    ref = d["dcost_dT"]
+    assert np.abs(g - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
