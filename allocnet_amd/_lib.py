@@ -114,6 +114,29 @@ class AnetError(RuntimeError):
         self.code = code
 
 
+def _preload_shared_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64; if this library
+    pulled in /opt/rocm's copy first, a later `import torch` in the same process would find "No HIP
+    GPUs".  When a torch installation is present (it is NOT imported here) its runtime is loaded first,
+    so the import order of torch and allocnet_amd does not matter."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the shared library (building is a separate, explicit step: allocnet_amd.build)."""
     global _lib
@@ -123,6 +146,7 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: run `python -m allocnet_amd.build` (hipcc, gfx950). "
             "allocnet_amd has no CPU fallback.")
+    _preload_shared_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -1,0 +1,95 @@
+"""Edge cases of the C ABI on the GPU: empty and ragged batches, maximum sizes (16 pieces, 50-row
+polytopes = learning_planner.hpp:40), strides larger than the batch, argument validation."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import cbind
+from tests.util import random_problem, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_batch_is_a_noop(anet_ctx):
+    import allocnet_amd as aa
+    co, en = aa.minco_solve(np.zeros((0, 3, 3)), np.zeros((0, 3, 3)), np.zeros((0, 7, 3)), np.zeros((0, 8)), 4, ctx=anet_ctx)
+    assert co.shape == (0, 8, 3, 8) and en.shape == (0,)
+    cost, gP, gT = aa.minco_cost_grad(np.zeros((0, 3, 3)), np.zeros((0, 3, 3)), np.zeros((0, 4, 3)), np.zeros((0, 5)), 3,
+                                      penalty=aa.make_penalty(), ctx=anet_ctx)
+    assert cost.shape == (0,) and gP.shape == (0, 4, 3)
+    assert aa.traj_cost(np.zeros((0, 2, 3, 6)), np.zeros((0, 2)), 3, ctx=anet_ctx).shape == (0,)
+
+
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 129])
+def test_ragged_batches(anet_ctx, B):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(B)
+    head, tail, wps, T = random_problem(rng, B, 8, 3)
+    co, en = aa.minco_solve(head, tail, wps, T, 4, ctx=anet_ctx)
+    cc, ec = cbind.minco_solve_batch(4, head, tail, wps, T)
+    assert rel_err(co, cc) < 1e-9 and rel_err(en, ec) < 1e-9
+
+
+def test_maximum_sizes(anet_ctx):
+    """16 pieces (ANET_MAX_PIECES) for both orders and all boundary conventions; 50-row polytopes."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(16)
+    for s in (3, 4):
+        for c in range(1, s + 1):
+            head, tail, wps, T = random_problem(rng, 70, 16, c)
+            co, en = aa.minco_solve(head, tail, wps, T, s, ctx=anet_ctx)
+            cc, ec = cbind.minco_solve_batch(s, head, tail, wps, T)
+            assert rel_err(co, cc) < 1e-8 and rel_err(en, ec) < 1e-8, (s, c)
+    head, tail, wps, T = random_problem(rng, 9, 5, 3)
+    hp = rng.normal(size=(9, 5, 50, 4)); hp[..., 3] += 8.0
+    pen = aa.make_penalty(rho=1.0, w_corridor=10.0, w_vel=1.0, w_acc=1.0, res=20, poly_rows=50)
+    cost, gP, gT = aa.minco_cost_grad(head, tail, wps, T, 4, hpolys=hp, penalty=pen, ctx=anet_ctx)
+    assert np.isfinite(cost).all() and np.isfinite(gP).all() and np.isfinite(gT).all()
+    with pytest.raises(aa.AnetError):
+        aa.minco_cost_grad(head, tail, wps, T, 4, hpolys=np.zeros((9, 5, 51, 4)),
+                           penalty=aa.make_penalty(poly_rows=51), ctx=anet_ctx)
+
+
+def test_argument_validation(anet_ctx):
+    import allocnet_amd as aa
+    from allocnet_amd import _lib
+    h = np.zeros((2, 3, 3)); T = np.ones((2, 17))
+    with pytest.raises(aa.AnetError) as ei:                       # > ANET_MAX_PIECES
+        aa.minco_solve(h, h, np.zeros((2, 16, 3)), T, 4, ctx=anet_ctx)
+    assert ei.value.code == _lib.ANET_ERR_INVALID
+    with pytest.raises(aa.AnetError):                             # order 5 does not exist
+        aa.minco_solve(h, h, np.zeros((2, 1, 3)), np.ones((2, 2)), 5, ctx=anet_ctx)
+    with pytest.raises(aa.AnetError):                             # c > s
+        aa.minco_solve(np.zeros((2, 3, 4)), np.zeros((2, 3, 4)), np.zeros((2, 1, 3)), np.ones((2, 2)), 3, ctx=anet_ctx)
+    with pytest.raises(aa.AnetError):                             # smoothing must be positive
+        aa.minco_cost_grad(h, h, np.zeros((2, 1, 3)), np.ones((2, 2)), 3, penalty=aa.make_penalty(smooth_mu=0.0),
+                           ctx=anet_ctx)
+    lib = _lib.load()
+    rc = lib.anet_minco_solve(anet_ctx.handle, 4, 3, 2, 2, None, None, None, None, None, None)     # NULL inputs
+    assert rc == _lib.ANET_ERR_INVALID and b"NULL" in lib.anet_last_error(anet_ctx.handle)
+
+
+def test_stride_larger_than_batch(anet_ctx):
+    """Device entry point with ld > batch (the recommended padded stride) leaves the padding untouched."""
+    import torch
+    import allocnet_amd as aa
+    B, N, s, c = 300, 8, 4, 3
+    ld = aa.recommended_ld(B) + 128
+    assert ld % 64 == 0 and ld >= B
+    rng = np.random.default_rng(1)
+    head, tail, wps, T = random_problem(rng, B, N, c)
+    dev = torch.device("cuda", 0)
+
+    def bm(a):
+        t = torch.full((a.reshape(B, -1).shape[1], ld), -7.0, device=dev, dtype=torch.float64)
+        t[:, :B] = torch.from_numpy(np.ascontiguousarray(a.reshape(B, -1).T)).to(dev)
+        return t
+    co = torch.full((N * 3 * 8, ld), -7.0, device=dev, dtype=torch.float64)
+    en = torch.full((ld,), -7.0, device=dev, dtype=torch.float64)
+    aa.minco_solve_dev(bm(head), bm(tail), bm(wps), bm(T), s, c, N, B, coeffs=co, energy=en, ctx=anet_ctx)
+    torch.cuda.synchronize()
+    cc, ec = cbind.minco_solve_batch(s, head, tail, wps, T)
+    got = co[:, :B].T.cpu().numpy().reshape(B, N, 3, 8)
+    assert rel_err(got, cc) < 1e-9 and rel_err(en[:B].cpu().numpy(), ec) < 1e-9
+    assert (co[:, B:] == -7.0).all() and (en[B:] == -7.0).all()
