@@ -33,7 +33,7 @@ struct AdmmArgs {
   double *z, *y;         // [B][m] workspace / duals (scaled problem), m = me + N*R*(M+12)
   double *coeffs;        // [B][n]  (piece, axis, highest power first) -- the reference's flatten order
   double *obj;           // [B]  1/2 z'Qz in original units (QPSolver::getObjCost)
-  int *status, *iters;   // [B]  1 = solved, 0 = max_iter reached
+  int *status, *iters;   // [B]  1 = solved, 0 = max_iter reached, -3 = primal infeasible (OSQP codes)
   double *res;           // [B][2] primal / dual residual at exit (scaled problem)
   int64_t B;
   int N, R, M;
@@ -83,12 +83,13 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   double *xt = x + n;                       // [n]
   double *rhs = xt + n;                     // [n]
   double *aty = rhs + n;                    // [n]  A'y (dual residual) / temp
-  double *be = aty + n;                     // [R][3][D] basis rows at tau_j
+  double *ady = aty + n;                    // [n]  A'(y+ - y) (primal infeasibility certificate)
+  double *be = ady + n;                     // [R][3][D] basis rows at tau_j
   double *G0 = be + (size_t)R * 3 * D;      // [D*D]  sum_j b0 b0'
   double *G12 = G0 + D * D;                 // [D*D]  sum_j (b1 b1' + b2 b2')
   double *Sp = G12 + D * D;                 // [N][9]  sum_q a_q a_q'
   double *Tn = Sp + (size_t)N * 9;          // [N]
-  double *red = Tn + N;                     // [8] reductions / broadcast
+  double *red = Tn + N;                     // [12] reductions / broadcast
 
   const double *Tg = a.T + b * N;
   const double *hp = a.hpolys + b * (int64_t)N * M * 4;
@@ -292,10 +293,11 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       x[e] = xn;
       rhs[e] = sigma * xn;
       aty[e] = 0.0;
+      ady[e] = 0.0;
     }
-    if (tid < 8) red[tid] = 0.0;
+    if (tid < 12) red[tid] = 0.0;
     __syncthreads();
-    double l_rp = 0.0, l_ax = 0.0, l_z = 0.0;
+    double l_rp = 0.0, l_ax = 0.0, l_z = 0.0, l_dy = 0.0, l_sup = 0.0;
     // ---- equality rows ------------------------------------------------------------------------
     for (int r = tid; r < me; r += nt) {
       // row = sum over (block, axis, col) of coefficient * variable ; rhs value bval
@@ -355,6 +357,10 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
         l_rp = fmax(l_rp, fabs(ax_new - zn));
         l_ax = fmax(l_ax, fabs(ax_new));
         l_z = fmax(l_z, fabs(zn));
+        const double dy = yn - yo;  // certificate terms: l = u = b for equality rows
+        scatter(ady, dy);
+        l_dy = fmax(l_dy, fabs(dy));
+        l_sup += bval * dy;
       }
     }
     // ---- inequality rows, one sample (piece i, j) per thread ---------------------------------------
@@ -378,6 +384,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       const int64_t r0 = me + smp;            // row q of this sample lives at r0 + q*NS (coalesced across samples)
       const int64_t NS = (int64_t)N * R;
       double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gy[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      double gd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
       const double Ti = Tn[i];
       for (int q = 0; q < rows_per_sample; ++q) {
         double zt, axn, hv, c0 = 0, c1 = 0, c2 = 0;
@@ -406,17 +413,24 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
         zg[r0 + q * NS] = zn;
         yg[r0 + q * NS] = yn;
         const double w = rho * zn - yn;
+        const double dy = yn - yo;
         if (q < M) {
           g[0][0] += w * c0; g[0][1] += w * c1; g[0][2] += w * c2;
-          if (check) { gy[0][0] += yn * c0; gy[0][1] += yn * c1; gy[0][2] += yn * c2; }
+          if (check) {
+            gy[0][0] += yn * c0; gy[0][1] += yn * c1; gy[0][2] += yn * c2;
+            gd[0][0] += dy * c0; gd[0][1] += dy * c1; gd[0][2] += dy * c2;
+          }
         } else {
           g[dsel][axsel] += sgn * w;
-          if (check) gy[dsel][axsel] += sgn * yn;
+          if (check) { gy[dsel][axsel] += sgn * yn; gd[dsel][axsel] += sgn * dy; }
         }
         if (check) {
           l_rp = fmax(l_rp, fabs(axn - zn));
           l_ax = fmax(l_ax, fabs(axn));
           l_z = fmax(l_z, fabs(zn));
+          // l = -inf: only the positive part of dy can certify (a negative part makes the support +inf)
+          l_dy = fmax(l_dy, fabs(dy));
+          l_sup += (dy > 0.0) ? hv * dy : (dy < 0.0 ? 1e300 : 0.0);
         }
       }
       for (int axx = 0; axx < 3; ++axx)
@@ -426,6 +440,8 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
           if (check) {
             const double vy = gy[0][axx] * bj[col] + gy[1][axx] * bj[D + col] + gy[2][axx] * bj[2 * D + col];
             if (vy != 0.0) atomicAdd(&aty[i * NB + axx * D + col], vy);
+            const double vd = gd[0][axx] * bj[col] + gd[1][axx] * bj[D + col] + gd[2][axx] * bj[2 * D + col];
+            if (vd != 0.0) atomicAdd(&ady[i * NB + axx * D + col], vd);
           }
         }
     }
@@ -433,11 +449,13 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       atomic_max_pos(&red[0], l_rp);
       atomic_max_pos(&red[1], l_ax);
       atomic_max_pos(&red[2], l_z);
+      atomic_max_pos(&red[6], l_dy);
+      if (l_sup != 0.0) atomicAdd(&red[7], fmin(l_sup, 1e300));
     }
     __syncthreads();
     if (check) {
       // dual residual: P x + A'y ; norms of P x and A'y
-      double l_rd = 0.0, l_px = 0.0, l_aty = 0.0;
+      double l_rd = 0.0, l_px = 0.0, l_aty = 0.0, l_ady = 0.0;
       for (int e = tid; e < n; e += nt) {
         const int i = e / NB, cr = e % D;
         double px = 0.0;
@@ -449,10 +467,12 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
         l_rd = fmax(l_rd, fabs(px + aty[e]));
         l_px = fmax(l_px, fabs(px));
         l_aty = fmax(l_aty, fabs(aty[e]));
+        l_ady = fmax(l_ady, fabs(ady[e]));
       }
       atomic_max_pos(&red[3], l_rd);
       atomic_max_pos(&red[4], l_px);
       atomic_max_pos(&red[5], l_aty);
+      atomic_max_pos(&red[8], l_ady);
       __syncthreads();
       rp = red[0];
       rd = red[3];
@@ -461,6 +481,15 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       if (rp <= eps_p && rd <= eps_d) {
         status = 1;
         break;
+      }
+      // OSQP's primal infeasibility test (osqp/src/auxil.c is_primal_infeasible, eps_prim_inf = 1e-4):
+      //   ||A' dy||_inf <= eps ||dy||_inf   and   u'(dy)+ + l'(dy)- <= -eps ||dy||_inf
+      {
+        const double ndy = red[6];
+        if (ndy > 1e-4 && red[8] <= 1e-4 * ndy && red[7] <= -1e-4 * ndy) {
+          status = -3;
+          break;
+        }
       }
       if (a.p.adapt_every > 0 && (it % a.p.adapt_every) == 0) {
         const double np_ = rp / fmax(fmax(red[1], red[2]), 1e-300), nd_ = rd / fmax(fmax(red[4], red[5]), 1e-300);
@@ -541,7 +570,7 @@ template <int S>
 inline size_t qp_admm_lds_bytes(int N, int R) {
   constexpr int D = 2 * S, NB = 3 * D;
   const size_t n = (size_t)NB * N;
-  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 4 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 8);
+  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 5 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 12);
 }
 
 }  // namespace anet

@@ -264,7 +264,8 @@ typedef struct anet_qp_settings {
 } anet_qp_settings;
 void anet_qp_default_settings(anet_qp_settings *s);
 #define ANET_QP_SOLVED 1          /* OSQP_SOLVED                 */
-#define ANET_QP_MAX_ITER_REACHED 0 /* OSQP_MAX_ITER_REACHED (the reference treats anything but Solved as failure) */
+#define ANET_QP_MAX_ITER_REACHED 0 /* the reference treats anything but Solved as failure (qp_solver.hpp:346-350) */
+#define ANET_QP_PRIMAL_INFEASIBLE (-3) /* OSQP_PRIMAL_INFEASIBLE: OSQP's certificate test on y(k+1)-y(k), eps_prim_inf 1e-4 */
 /* hpolys [batch][N][M][4] rows a.x <= b with all-zero rows as inert padding.
  * coeffs [batch][N][3][2s] (the flatten order callModel unpacks, learning_planner.hpp:212,227),
  * obj [batch] = 1/2 z'Qz (QPSolver::getObjCost), status/iters [batch], residuals [batch][2] (primal, dual;

@@ -109,3 +109,8 @@ def test_qpsolver_class_mirror(anet_ctx):
     fin_bad = fin.copy(); fin_bad[:, 0] += 50.0
     ok, sol = solver.solve(ini, fin_bad, polys, T)
     assert not ok and sol is None
+    hp3 = np.zeros((1, 3, max(p.shape[0] for p in polys), 4))
+    for i, p in enumerate(polys):
+        hp3[0, i, :p.shape[0]] = p
+    r = aa.qp_solve(3, ini[None], fin_bad[None], hp3, T[None], res=10, max_vel=3.0, max_acc=4.0, ctx=anet_ctx)
+    assert r["status"][0] == -3 and r["iters"][0] < 4000          # OSQP_PRIMAL_INFEASIBLE, detected early
