@@ -235,6 +235,21 @@ struct PieceGradArgs {
 template <int S>
 __global__ void __launch_bounds__(256) k_piece_grad(PieceGradArgs a) {
   constexpr int D = 2 * S;
+  extern __shared__ double tab[];  // [res][4][D] basis rows in normalised time
+  if (a.with_penalty) {
+    for (int e = threadIdx.x; e < a.pp.res * 4 * D; e += 256) {
+      const int j = e / (4 * D), d = (e / D) % 4, col = e % D, k = D - 1 - col;
+      const double tau = (double)j / (double)a.pp.res;
+      double v = 0.0;
+      if (k >= d) {
+        v = 1.0;
+        for (int q = 0; q < d; ++q) v *= (double)(k - q);
+        for (int q = 0; q < k - d; ++q) v *= tau;
+      }
+      tab[e] = v;
+    }
+    __syncthreads();
+  }
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= a.B) return;
   const int i = blockIdx.y;
@@ -279,83 +294,122 @@ __global__ void __launch_bounds__(256) k_piece_grad(PieceGradArgs a) {
     }
   }
   if (a.with_penalty) {
+    // Normalised time: with c~_k = c_k T^k the state rows at sample j depend on tau_j = j/res only,
+    //   d^d p/dt^d (t_j) = T^-d sum_col c~[col] tab[j][d][col],  tab[j][d][col] = k!/(k-d)! tau_j^(k-d)
+    // the table is built once per block in LDS and read with a wave-uniform index (broadcast).
     const Penalty pp = a.pp;
     const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
     const double step = Ti * inv_res;
-    for (int j = 0; j < pp.res; ++j) {
-      const double t = (double)j * step;
-      double tp[D];
-      tp[0] = 1.0;
+    const double rT = 1.0 / Ti, rT2 = rT * rT, rT3 = rT2 * rT;
+    double ct[3][D];  // c~
+    {
+      double tk = 1.0;
 #pragma unroll
-      for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * t;
-      double be[4][D];  // basis rows p,v,a,j at t (highest power first)
+      for (int col = D - 1; col >= 0; --col) {
 #pragma unroll
-      for (int col = 0; col < D; ++col) {
-        const int k = D - 1 - col;
+        for (int ax = 0; ax < 3; ++ax) ct[ax][col] = c[ax][col] * tk;
+        tk *= Ti;
+      }
+    }
+    double gN[3][D];  // gradient w.r.t. c~
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          double f = 1.0;
+    for (int ax = 0; ax < 3; ++ax)
 #pragma unroll
-          for (int e = 0; e < d; ++e) f *= (double)(k - e);
-          be[d][col] = (k >= d) ? f * tp[k >= d ? k - d : 0] : 0.0;
+      for (int col = 0; col < D; ++col) gN[ax][col] = 0.0;
+    // Polytope rows are held in registers, RC at a time, and the sample loop runs inside: re-reading
+    // them from L2 for every sample (res x M x 32 B per lane) was the bottleneck of this kernel.
+    constexpr int RC = 8;
+    const int nchunk = a.hpolys ? (pp.M + RC - 1) / RC : 0;
+    for (int ch = 0; ch < (nchunk > 0 ? nchunk : 1); ++ch) {
+      double hr[RC][4];
+#pragma unroll
+      for (int r = 0; r < RC; ++r) {
+        const int rr = ch * RC + r;
+        const bool ok = a.hpolys && rr < pp.M;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          hr[r][q] = ok ? a.hpolys[(int64_t)((i * pp.M + rr) * 4 + q) * ld + b] : 0.0;
+      }
+      const bool first = (ch == 0);  // box rows are evaluated with the first chunk
+      for (int j = 0; j < pp.res; ++j) {
+        const double *tb = tab + (size_t)j * 4 * D;
+        double st[4][3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            double acc = 0.0;
+#pragma unroll
+            for (int col = 0; col < D; ++col) acc = __builtin_fma(ct[ax][col], tb[d * D + col], acc);
+            st[d][ax] = acc * (d == 0 ? 1.0 : d == 1 ? rT : d == 2 ? rT2 : rT3);
+          }
+        double cost = 0.0, g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // d cost / d (p,v,a)
+        bool active = false;
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+          const double viol =
+              __builtin_fma(hr[r][0], st[0][0], __builtin_fma(hr[r][1], st[0][1], hr[r][2] * st[0][2])) - hr[r][3];
+          if (__any(viol > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
+            double f, df;
+            smoothed_l1(pp.mu, inv_mu, viol, f, df);
+            cost = __builtin_fma(pp.wc, f, cost);
+            df *= pp.wc;
+            g[0][0] = __builtin_fma(df, hr[r][0], g[0][0]);
+            g[0][1] = __builtin_fma(df, hr[r][1], g[0][1]);
+            g[0][2] = __builtin_fma(df, hr[r][2], g[0][2]);
+            active = true;
+          }
+        }
+        if (first) {
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            const double av = fabs(st[1][ax]) - pp.vmax, aa_ = fabs(st[2][ax]) - pp.amax;
+            if (__any(av > 0.0)) {  // only one of +v, -v can be violated
+              double f, df;
+              smoothed_l1(pp.mu, inv_mu, av, f, df);
+              cost = __builtin_fma(pp.wv, f, cost);
+              g[1][ax] = __builtin_fma(pp.wv * (st[1][ax] < 0.0 ? -1.0 : 1.0), df, g[1][ax]);
+              active = true;
+            }
+            if (__any(aa_ > 0.0)) {
+              double f, df;
+              smoothed_l1(pp.mu, inv_mu, aa_, f, df);
+              cost = __builtin_fma(pp.wa, f, cost);
+              g[2][ax] = __builtin_fma(pp.wa * (st[2][ax] < 0.0 ? -1.0 : 1.0), df, g[2][ax]);
+              active = true;
+            }
+          }
+        }
+        if (__any(active)) {
+          pc = __builtin_fma(step, cost, pc);
+          double dt = 0.0;  // d cost / d t = g_p.v + g_v.a + g_a.j
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) dt = __builtin_fma(g[d][ax], st[d + 1][ax], dt);
+          gT += cost * inv_res + step * dt * ((double)j * inv_res);
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            const double g0 = step * g[0][ax], g1 = step * g[1][ax] * rT, g2 = step * g[2][ax] * rT2;
+#pragma unroll
+            for (int col = 0; col < D; ++col) {
+              double acc = g0 * tb[col];
+              acc = __builtin_fma(g1, tb[D + col], acc);
+              acc = __builtin_fma(g2, tb[2 * D + col], acc);
+              gN[ax][col] += acc;
+            }
+          }
         }
       }
-      double st[4][3];
+    }
+    {  // d/dc = T^k d/dc~
+      double tk = 1.0;
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int col = D - 1; col >= 0; --col) {
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-          double acc = 0.0;
-#pragma unroll
-          for (int col = 0; col < D; ++col) acc = __builtin_fma(c[ax][col], be[d][col], acc);
-          st[d][ax] = acc;
-        }
-      double cost = 0.0, g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // d cost / d (p,v,a)
-      if (a.hpolys) {
-        const double *hp = a.hpolys + (int64_t)(i * pp.M * 4) * ld + b;
-        for (int r = 0; r < pp.M; ++r) {
-          const double a0 = hp[(int64_t)(r * 4 + 0) * ld], a1 = hp[(int64_t)(r * 4 + 1) * ld];
-          const double a2 = hp[(int64_t)(r * 4 + 2) * ld], bb = hp[(int64_t)(r * 4 + 3) * ld];
-          const double viol = __builtin_fma(a0, st[0][0], __builtin_fma(a1, st[0][1], a2 * st[0][2])) - bb;
-          double f, df;
-          smoothed_l1(pp.mu, inv_mu, viol, f, df);
-          cost = __builtin_fma(pp.wc, f, cost);
-          df *= pp.wc;
-          g[0][0] = __builtin_fma(df, a0, g[0][0]);
-          g[0][1] = __builtin_fma(df, a1, g[0][1]);
-          g[0][2] = __builtin_fma(df, a2, g[0][2]);
-        }
+        for (int ax = 0; ax < 3; ++ax) gC[ax][col] = __builtin_fma(gN[ax][col], tk, gC[ax][col]);
+        tk *= Ti;
       }
-#pragma unroll
-      for (int ax = 0; ax < 3; ++ax) {
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg) {
-          const double sgn = sg ? -1.0 : 1.0;
-          double f, df;
-          smoothed_l1(pp.mu, inv_mu, sgn * st[1][ax] - pp.vmax, f, df);
-          cost = __builtin_fma(pp.wv, f, cost);
-          g[1][ax] = __builtin_fma(pp.wv * sgn, df, g[1][ax]);
-          smoothed_l1(pp.mu, inv_mu, sgn * st[2][ax] - pp.amax, f, df);
-          cost = __builtin_fma(pp.wa, f, cost);
-          g[2][ax] = __builtin_fma(pp.wa * sgn, df, g[2][ax]);
-        }
-      }
-      pc = __builtin_fma(step, cost, pc);
-      double dt = 0.0;  // d cost / d t = g_p.v + g_v.a + g_a.j
-#pragma unroll
-      for (int d = 0; d < 3; ++d)
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) dt = __builtin_fma(g[d][ax], st[d + 1][ax], dt);
-      gT += cost * inv_res + step * dt * ((double)j * inv_res);
-#pragma unroll
-      for (int ax = 0; ax < 3; ++ax)
-#pragma unroll
-        for (int col = 0; col < D; ++col) {
-          double acc = g[0][ax] * be[0][col];
-          acc = __builtin_fma(g[1][ax], be[1][col], acc);
-          acc = __builtin_fma(g[2][ax], be[2][col], acc);
-          gC[ax][col] = __builtin_fma(step, acc, gC[ax][col]);
-        }
     }
   }
 #pragma unroll
@@ -1858,9 +1912,11 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
                                pen->max_vel, pen->max_acc, pen->res, pen->poly_rows};
   const dim3 grid((unsigned)((batch + 255) / 256), (unsigned)n_pieces), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (s == 2) hipLaunchKernelGGL(anet::k_piece_grad<2>, grid, block, 0, st, a);
-  else if (s == 3) hipLaunchKernelGGL(anet::k_piece_grad<3>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(anet::k_piece_grad<4>, grid, block, 0, st, a);
+  const size_t lds = pen ? sizeof(double) * (size_t)pen->res * 4 * 2 * s : 0;
+  if (lds > 60 * 1024) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_penalty.res too large for the basis table");
+  if (s == 2) hipLaunchKernelGGL(anet::k_piece_grad<2>, grid, block, lds, st, a);
+  else if (s == 3) hipLaunchKernelGGL(anet::k_piece_grad<3>, grid, block, lds, st, a);
+  else hipLaunchKernelGGL(anet::k_piece_grad<4>, grid, block, lds, st, a);
   ANET_HIP(ctx, hipGetLastError());
   return ANET_OK;
 }
