@@ -12,1376 +12,12 @@
 
 #include "../../include/allocnet_amd.h"
 #include "minco_core.h"
+#include "minco_kernels.h"
+#include "traj_kernels.h"
+#include "lbfgs_kernels.h"
+#include "qp_assemble.h"
 #include "qp_admm.h"
-
-namespace anet {
-
-// ------------------------------------------------------------------------------------------
-// kernels
-// ------------------------------------------------------------------------------------------
-struct SolveArgs {
-  const double *head, *tail, *wps, *T;
-  double *coeffs, *energy;
-  int64_t B, ld;
-  int N, c;
-};
-
-constexpr int kSolveBlock = 64;
-
-// One lane = one trajectory.  The block-tridiagonal factor is shared by the three axes and stays
-// in registers; the axes are swept one after the other so only one axis' right-hand side is live.
-// NEXACT: the piece count is exactly NB (compile time); NPC >= 0: c-1 is NPC (compile time).
-// Both let every end-node / pinned-derivative mask fold away; the generic instantiation
-// (NEXACT = false, NPC = -1) keeps them as wave-uniform selects.
-template <int S, int NB, bool NEXACT = false, int NPC = -1>
-__global__ void __launch_bounds__(kSolveBlock) k_minco_solve(SolveArgs a) {
-  constexpr int m = S - 1, D = 2 * S;
-  const int64_t b = (int64_t)blockIdx.x * kSolveBlock + threadIdx.x;
-  if (b >= a.B) return;
-  const int N = NEXACT ? NB : a.N;
-  const int np = NPC >= 0 ? NPC : a.c - 1;
-  const int c = np + 1;
-  const int64_t ld = a.ld;
-
-  Factor<S, NB> F;
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-    if (i < N) F.r[i] = fast_rcp(a.T[i * ld + b]);
-  F.factorize(N, np);
-
-  double etot = 0.0;
-#pragma unroll 1
-  for (int ax = 0; ax < 3; ++ax) {
-    double P[NB + 1], hv[m], tv[m], X[NB + 1][m];
-    const double *hp = a.head + (int64_t)(ax * c) * ld + b;
-    const double *tp = a.tail + (int64_t)(ax * c) * ld + b;
-#pragma unroll
-    for (int k = 0; k <= NB; ++k) {
-      if (k == 0)
-        P[k] = hp[0];
-      else if (k < N)
-        P[k] = a.wps[(int64_t)((k - 1) * 3 + ax) * ld + b];
-      else if (k == N)
-        P[k] = tp[0];
-      else
-        P[k] = 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < m; ++j) {
-      hv[j] = (j < np) ? hp[(int64_t)(1 + j) * ld] : 0.0;
-      tv[j] = (j < np) ? tp[(int64_t)(1 + j) * ld] : 0.0;
-    }
-    double *cp = a.coeffs ? a.coeffs + (int64_t)(ax * D) * ld + b : nullptr;
-    etot += solve_axis<S, NB>(F, N, np, P, hv, tv, X, [&](int piece, int col, double v) {
-      if (cp) cp[(int64_t)(piece * 3 * D + col) * ld] = v;
-    });
-  }
-  if (a.energy) a.energy[b] = etot;
-}
-
-// Trajectory<D>::getPos/Vel/Acc/Jer: one lane per trajectory, nq queries each.  The accumulation
-// order is the reference's (ascending powers, tn *= t), trajectory.hpp:75-133.
-struct EvalArgs {
-  const double *coeffs, *T, *tq;
-  double *out;
-  int64_t B, ld;
-  int N, nq, deriv;
-};
-template <int S>
-__global__ void __launch_bounds__(256) k_traj_eval(EvalArgs a) {
-  constexpr int D = 2 * S, DEG = D - 1;
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B) return;
-  const int64_t ld = a.ld;
-  const int N = a.N, d = a.deriv;
-  for (int q = 0; q < a.nq; ++q) {
-    double t = a.tq[(int64_t)q * ld + b];
-    // locatePieceIdx (trajectory.hpp:496-514)
-    int idx = 0;
-    double dur = 0.0;
-    for (; idx < N; ++idx) {
-      dur = a.T[(int64_t)idx * ld + b];
-      if (!(t > dur)) break;
-      t -= dur;
-    }
-    if (idx == N) {
-      --idx;
-      t += a.T[(int64_t)idx * ld + b];
-    }
-    const double *cm = a.coeffs + (int64_t)(idx * 3 * D) * ld + b;
-    double acc[3] = {0.0, 0.0, 0.0};
-    double tn = 1.0;
-    for (int i = DEG - d; i >= 0; --i) {
-      const int k = DEG - i;  // power of column i
-      double f = 1.0;
-      for (int e = 0; e < d; ++e) f *= (double)(k - e);
-      const double w = f * tn;
-#pragma unroll
-      for (int ax = 0; ax < 3; ++ax) acc[ax] += w * cm[(int64_t)(ax * D + i) * ld];
-      tn *= t;
-    }
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) a.out[(int64_t)(q * 3 + ax) * ld + b] = acc[ax];
-  }
-}
-
-// Trajectory<D>::getTrajCost (trajectory.hpp:354-427).
-struct CostArgs {
-  const double *coeffs, *T;
-  double *cost;   // [B] or nullptr
-  double *gradT;  // [N][ld] or nullptr: d cost / d T_i at fixed coefficients
-  int64_t B, ld;
-  int N;
-  double m34;
-};
-template <int S>
-__global__ void __launch_bounds__(256) k_traj_cost(CostArgs a) {
-  constexpr int D = 2 * S;
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B) return;
-  const int64_t ld = a.ld;
-  double energy = 0.0;
-  for (int i = 0; i < a.N; ++i) {
-    const double t = a.T[(int64_t)i * ld + b];
-    const double t2 = t * t, t3 = t * t2, t4 = t2 * t2, t5 = t2 * t3;
-    double Q[S][S], dQ[S][S];  // cost block and its derivative w.r.t. t
-    if constexpr (S == 4) {
-      const double t6 = t3 * t3, t7 = t4 * t3;
-      Q[0][0] = 100800 * t7; Q[0][1] = 50400 * t6; Q[0][2] = 20160 * t5; Q[0][3] = 5040 * t4;
-      Q[1][1] = 25920 * t5;  Q[1][2] = 10800 * t4; Q[1][3] = 2880 * t3;
-      Q[2][2] = 4800 * t3;   Q[2][3] = a.m34 * t2;
-      Q[3][3] = 576 * t;
-      dQ[0][0] = 7 * 100800 * t6; dQ[0][1] = 6 * 50400 * t5; dQ[0][2] = 5 * 20160 * t4; dQ[0][3] = 4 * 5040 * t3;
-      dQ[1][1] = 5 * 25920 * t4;  dQ[1][2] = 4 * 10800 * t3; dQ[1][3] = 3 * 2880 * t2;
-      dQ[2][2] = 3 * 4800 * t2;   dQ[2][3] = 2 * a.m34 * t;
-      dQ[3][3] = 576;
-    } else if constexpr (S == 3) {
-      Q[0][0] = 720 * t5; Q[0][1] = 360 * t4; Q[0][2] = 120 * t3;
-      Q[1][1] = 192 * t3; Q[1][2] = 72 * t2;
-      Q[2][2] = 36 * t;
-      dQ[0][0] = 5 * 720 * t4; dQ[0][1] = 4 * 360 * t3; dQ[0][2] = 3 * 120 * t2;
-      dQ[1][1] = 3 * 192 * t2; dQ[1][2] = 2 * 72 * t;
-      dQ[2][2] = 36;
-    } else {
-      Q[0][0] = 12 * t3; Q[0][1] = 6 * t2;
-      Q[1][1] = 4 * t;
-      dQ[0][0] = 36 * t2; dQ[0][1] = 12 * t;
-      dQ[1][1] = 4;
-    }
-#pragma unroll
-    for (int j = 1; j < S; ++j)
-#pragma unroll
-      for (int k = 0; k < j; ++k) {
-        Q[j][k] = Q[k][j];
-        dQ[j][k] = dQ[k][j];
-      }
-    double gti = 0.0;
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-      double z[S];
-#pragma unroll
-      for (int j = 0; j < S; ++j) z[j] = a.coeffs[(int64_t)((i * 3 + ax) * D + j) * ld + b];
-      double acc = 0.0, dacc = 0.0;
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        double r = 0.0, dr = 0.0;
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-          r += Q[j][k] * z[k];
-          dr += dQ[j][k] * z[k];
-        }
-        acc += z[j] * r;
-        dacc += z[j] * dr;
-      }
-      energy += 0.5 * acc;
-      gti += 0.5 * dacc;
-    }
-    if (a.gradT) a.gradT[(int64_t)i * ld + b] = gti;
-  }
-  if (a.cost) a.cost[b] = energy;
-}
-
-
-// ------------------------------------------------------------------------------------------
-// cost / gradient path: partial gradients per piece, then adjoint propagation per trajectory
-// ------------------------------------------------------------------------------------------
-struct Penalty {
-  double rho, wc, wv, wa, mu, vmax, amax;
-  int res, M;
-};
-
-// firi::smoothedL1 (gcopter/firi.hpp:60-84), 0 below 0.
-__device__ __forceinline__ void smoothed_l1(double mu, double inv_mu, double x, double &f, double &df) {
-  const double xd = x * inv_mu, sq = xd * xd, mm = __builtin_fma(-0.5, x, mu);
-  double fm = mm * sq * xd, dm = sq * __builtin_fma(-0.5, xd, 3.0 * mm * inv_mu);
-  const bool hi = x > mu, neg = x < 0.0;
-  f = neg ? 0.0 : (hi ? x - 0.5 * mu : fm);
-  df = neg ? 0.0 : (hi ? 1.0 : dm);
-}
-
-struct PieceGradArgs {
-  const double *coeffs, *T, *hpolys;
-  double *gdC, *gdT, *pcost;
-  int64_t B, ld;
-  int N, with_energy, with_penalty;
-  Penalty pp;
-};
-
-// One lane per (trajectory, piece): blockIdx.y = piece.  Writes (not accumulates) the partial
-// gradients of  [with_energy] int (p^(s))^2  +  [with_penalty] J_pen  w.r.t. the piece's
-// coefficients and duration.  J_pen = (T/res) sum_{j<res} [wc sum_rows phi(a.p-b) + wv sum phi(+-v-vmax)
-// + wa sum phi(+-a-amax)] sampled at t = j T/res: the rows of the reference's inequality block
-// (qp_solver.hpp:244-296 / min_traj_opt.py:535-613) turned into a smoothed-L1 penalty.
-template <int S>
-__global__ void __launch_bounds__(256) k_piece_grad(PieceGradArgs a) {
-  constexpr int D = 2 * S;
-  extern __shared__ double tab[];  // [res][4][D] basis rows in normalised time
-  if (a.with_penalty) {
-    for (int e = threadIdx.x; e < a.pp.res * 4 * D; e += 256) {
-      const int j = e / (4 * D), d = (e / D) % 4, col = e % D, k = D - 1 - col;
-      const double tau = (double)j / (double)a.pp.res;
-      double v = 0.0;
-      if (k >= d) {
-        v = 1.0;
-        for (int q = 0; q < d; ++q) v *= (double)(k - q);
-        for (int q = 0; q < k - d; ++q) v *= tau;
-      }
-      tab[e] = v;
-    }
-    __syncthreads();
-  }
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B) return;
-  const int i = blockIdx.y;
-  const int64_t ld = a.ld;
-  const double Ti = a.T[(int64_t)i * ld + b];
-  double c[3][D], gC[3][D];
-#pragma unroll
-  for (int ax = 0; ax < 3; ++ax)
-#pragma unroll
-    for (int col = 0; col < D; ++col) {
-      c[ax][col] = a.coeffs[(int64_t)((i * 3 + ax) * D + col) * ld + b];
-      gC[ax][col] = 0.0;
-    }
-  double gT = 0.0, pc = 0.0;
-  if (a.with_energy) {
-    // d/dc of sum_{j,k>=S} c_j c_k f_j f_k T^(j+k-2S+1)/(j+k-2S+1) ;  d/dT = (p^(S)(T))^2
-    double tp[D];
-    tp[0] = 1.0;
-#pragma unroll
-    for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-      double ps = 0.0;
-#pragma unroll
-      for (int j = S; j < D; ++j) {
-        double fj = 1.0;
-#pragma unroll
-        for (int e = 0; e < S; ++e) fj *= (double)(j - e);
-        ps = __builtin_fma(fj * tp[j - S], c[ax][D - 1 - j], ps);
-        double acc = 0.0;
-#pragma unroll
-        for (int k = S; k < D; ++k) {
-          double fk = 1.0;
-#pragma unroll
-          for (int e = 0; e < S; ++e) fk *= (double)(k - e);
-          acc = __builtin_fma(2.0 * fj * fk / (double)(j + k - 2 * S + 1) * tp[j + k - 2 * S + 1],
-                              c[ax][D - 1 - k], acc);
-        }
-        gC[ax][D - 1 - j] = acc;
-      }
-      gT = __builtin_fma(ps, ps, gT);
-    }
-  }
-  if (a.with_penalty) {
-    // Normalised time: with c~_k = c_k T^k the state rows at sample j depend on tau_j = j/res only,
-    //   d^d p/dt^d (t_j) = T^-d sum_col c~[col] tab[j][d][col],  tab[j][d][col] = k!/(k-d)! tau_j^(k-d)
-    // the table is built once per block in LDS and read with a wave-uniform index (broadcast).
-    const Penalty pp = a.pp;
-    const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
-    const double step = Ti * inv_res;
-    const double rT = 1.0 / Ti, rT2 = rT * rT, rT3 = rT2 * rT;
-    double ct[3][D];  // c~
-    {
-      double tk = 1.0;
-#pragma unroll
-      for (int col = D - 1; col >= 0; --col) {
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) ct[ax][col] = c[ax][col] * tk;
-        tk *= Ti;
-      }
-    }
-    double gN[3][D];  // gradient w.r.t. c~
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax)
-#pragma unroll
-      for (int col = 0; col < D; ++col) gN[ax][col] = 0.0;
-    // Polytope rows are held in registers, RC at a time, and the sample loop runs inside: re-reading
-    // them from L2 for every sample (res x M x 32 B per lane) was the bottleneck of this kernel.
-    constexpr int RC = 8;
-    const int nchunk = a.hpolys ? (pp.M + RC - 1) / RC : 0;
-    for (int ch = 0; ch < (nchunk > 0 ? nchunk : 1); ++ch) {
-      double hr[RC][4];
-#pragma unroll
-      for (int r = 0; r < RC; ++r) {
-        const int rr = ch * RC + r;
-        const bool ok = a.hpolys && rr < pp.M;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          hr[r][q] = ok ? a.hpolys[(int64_t)((i * pp.M + rr) * 4 + q) * ld + b] : 0.0;
-      }
-      const bool first = (ch == 0);  // box rows are evaluated with the first chunk
-      for (int j = 0; j < pp.res; ++j) {
-        const double *tb = tab + (size_t)j * 4 * D;
-        double st[4][3];
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            double acc = 0.0;
-#pragma unroll
-            for (int col = 0; col < D; ++col) acc = __builtin_fma(ct[ax][col], tb[d * D + col], acc);
-            st[d][ax] = acc * (d == 0 ? 1.0 : d == 1 ? rT : d == 2 ? rT2 : rT3);
-          }
-        double cost = 0.0, g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // d cost / d (p,v,a)
-        bool active = false;
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-          const double viol =
-              __builtin_fma(hr[r][0], st[0][0], __builtin_fma(hr[r][1], st[0][1], hr[r][2] * st[0][2])) - hr[r][3];
-          if (__any(viol > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
-            double f, df;
-            smoothed_l1(pp.mu, inv_mu, viol, f, df);
-            cost = __builtin_fma(pp.wc, f, cost);
-            df *= pp.wc;
-            g[0][0] = __builtin_fma(df, hr[r][0], g[0][0]);
-            g[0][1] = __builtin_fma(df, hr[r][1], g[0][1]);
-            g[0][2] = __builtin_fma(df, hr[r][2], g[0][2]);
-            active = true;
-          }
-        }
-        if (first) {
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            const double av = fabs(st[1][ax]) - pp.vmax, aa_ = fabs(st[2][ax]) - pp.amax;
-            if (__any(av > 0.0)) {  // only one of +v, -v can be violated
-              double f, df;
-              smoothed_l1(pp.mu, inv_mu, av, f, df);
-              cost = __builtin_fma(pp.wv, f, cost);
-              g[1][ax] = __builtin_fma(pp.wv * (st[1][ax] < 0.0 ? -1.0 : 1.0), df, g[1][ax]);
-              active = true;
-            }
-            if (__any(aa_ > 0.0)) {
-              double f, df;
-              smoothed_l1(pp.mu, inv_mu, aa_, f, df);
-              cost = __builtin_fma(pp.wa, f, cost);
-              g[2][ax] = __builtin_fma(pp.wa * (st[2][ax] < 0.0 ? -1.0 : 1.0), df, g[2][ax]);
-              active = true;
-            }
-          }
-        }
-        if (__any(active)) {
-          pc = __builtin_fma(step, cost, pc);
-          double dt = 0.0;  // d cost / d t = g_p.v + g_v.a + g_a.j
-#pragma unroll
-          for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) dt = __builtin_fma(g[d][ax], st[d + 1][ax], dt);
-          gT += cost * inv_res + step * dt * ((double)j * inv_res);
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            const double g0 = step * g[0][ax], g1 = step * g[1][ax] * rT, g2 = step * g[2][ax] * rT2;
-#pragma unroll
-            for (int col = 0; col < D; ++col) {
-              double acc = g0 * tb[col];
-              acc = __builtin_fma(g1, tb[D + col], acc);
-              acc = __builtin_fma(g2, tb[2 * D + col], acc);
-              gN[ax][col] += acc;
-            }
-          }
-        }
-      }
-    }
-    {  // d/dc = T^k d/dc~
-      double tk = 1.0;
-#pragma unroll
-      for (int col = D - 1; col >= 0; --col) {
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) gC[ax][col] = __builtin_fma(gN[ax][col], tk, gC[ax][col]);
-        tk *= Ti;
-      }
-    }
-  }
-#pragma unroll
-  for (int ax = 0; ax < 3; ++ax)
-#pragma unroll
-    for (int col = 0; col < D; ++col) a.gdC[(int64_t)((i * 3 + ax) * D + col) * ld + b] = gC[ax][col];
-  a.gdT[(int64_t)i * ld + b] = gT;
-  if (a.pcost) a.pcost[(int64_t)i * ld + b] = pc;
-}
-
-struct PropArgs {
-  const double *T, *coeffs, *gdC, *gdT;
-  double *gradP, *gradT;
-  // optional total cost: cost = energy_in + rho sum T + sum_i pcost_i ; gradT += rho
-  const double *energy_in, *pcost;
-  double *cost;
-  double rho;
-  int64_t B, ld;
-  int N, c;
-};
-
-// MINCO propogateGrad: given the partial gradients (gdC, gdT) of a scalar J(c, T), return its total
-// gradient w.r.t. the interior waypoints and the durations, c = c(waypoints, T) being the minimum-
-// control-effort coefficients.  Adjoint of the Hermite/block-tridiagonal solve:
-//   g_x = Phi' gdC (node-state adjoint), K lam = g_x|free, gradP_k = g_x[k].p - (W lam^)[p rows],
-//   gradT_i = gdT_i + gdC_i.(dPhi_i/dT) x^ - lam^' (dW_i/dT) x^.
-template <int S, int NB, bool NEXACT = false, int NPC = -1>
-__global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
-  constexpr int m = S - 1, D = 2 * S;
-  const int64_t b = (int64_t)blockIdx.x * kSolveBlock + threadIdx.x;
-  if (b >= a.B) return;
-  const int N = NEXACT ? NB : a.N;
-  const int np = NPC >= 0 ? NPC : a.c - 1;
-  const int64_t ld = a.ld;
-
-  Factor<S, NB> F;
-  double gT[NB];
-  double tsum = 0.0, Tlast = 0.0;
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-    if (i < N) {
-      const double t = a.T[i * ld + b];
-      F.r[i] = fast_rcp(t);
-      gT[i] = a.gdT[i * ld + b];
-      tsum += t;
-      if (i == N - 1) Tlast = t;
-    }
-  F.factorize(N, np);
-
-#pragma unroll 1
-  for (int ax = 0; ax < 3; ++ax) {
-    double rr[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
-    // ---- node states from the coefficients: x_k[j] = j! c_j(piece k); last node by evaluation
-    double XS[NB + 1][S], GX[NB + 1][S], XA[NB + 1][m];
-#pragma unroll
-    for (int k = 0; k <= NB; ++k)
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        XS[k][j] = 0.0;
-        GX[k][j] = 0.0;
-      }
-#pragma unroll
-    for (int k = 0; k < NB; ++k)
-      if (k < N) {
-        double fact = 1.0;
-#pragma unroll
-        for (int j = 0; j < S; ++j) {
-          if (j > 0) fact *= (double)j;
-          XS[k][j] = fact * a.coeffs[(int64_t)((k * 3 + ax) * D + (D - 1 - j)) * ld + b];
-        }
-        if (k == N - 1) {
-          double cl[D], tp[D];
-          tp[0] = 1.0;
-#pragma unroll
-          for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Tlast;
-#pragma unroll
-          for (int col = 0; col < D; ++col) cl[col] = a.coeffs[(int64_t)((k * 3 + ax) * D + col) * ld + b];
-#pragma unroll
-          for (int j = 0; j < S; ++j) {
-            double acc = 0.0;
-#pragma unroll
-            for (int p = j; p < D; ++p) {
-              double f = 1.0;
-#pragma unroll
-              for (int e = 0; e < j; ++e) f *= (double)(p - e);
-              acc = __builtin_fma(f * tp[p - j], cl[D - 1 - p], acc);
-            }
-            XS[k + 1][j] = acc;
-          }
-        }
-      }
-    // ---- g_x = Phi' gdC and the direct dPhi/dT term
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (i < N) {
-        Pw<S> p(rr[i]);
-        double gc[D];
-#pragma unroll
-        for (int col = 0; col < D; ++col) gc[col] = a.gdC[(int64_t)((i * 3 + ax) * D + col) * ld + b];
-        // low powers k < S: c_k = x_i[k]/k!
-        double fact = 1.0;
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-          if (k > 0) fact *= (double)k;
-          GX[i][k] = __builtin_fma(gc[D - 1 - k], 1.0 / fact, GX[i][k]);
-        }
-        double h[S];
-#pragma unroll
-        for (int q = 0; q < S; ++q) h[q] = gc[S - 1 - q] * p[q];  // gc of power S+q times r^q
-        double dsum = 0.0;
-#pragma unroll
-        for (int bb = 0; bb < 2 * S; ++bb) {
-          const int dg = bb % S;
-          double u = 0.0, qd = 0.0;
-#pragma unroll
-          for (int q = 0; q < S; ++q) {
-            u = __builtin_fma(Tab<S>::BHI[q][bb], h[q], u);
-            qd = __builtin_fma((double)(S + q - dg) * Tab<S>::BHI[q][bb], h[q], qd);
-          }
-          const double sc = p[S - dg];
-          const double xb = (bb < S) ? XS[i][dg] : XS[i + 1][dg];
-          if (bb < S)
-            GX[i][dg] = __builtin_fma(u, sc, GX[i][dg]);
-          else
-            GX[i + 1][dg] = __builtin_fma(u, sc, GX[i + 1][dg]);
-          dsum = __builtin_fma(xb * sc, qd, dsum);
-        }
-        gT[i] = __builtin_fma(-p[1], dsum, gT[i]);
-      }
-    // ---- adjoint solve K lam = g_x|free (pinned rows 0)
-    sweep_forward<S, NB>(F, N, np, rr, XA, [&](int k, double (&y)[m]) {
-#pragma unroll
-      for (int l = 0; l < m; ++l) y[l] = ((k == 0 || k == N) && l < np) ? 0.0 : GX[k][1 + l];
-    });
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
-    sweep_backward<S, NB>(F, N, np, rr, XA, [&](int k, const Pw<S> &p) {
-      // (W_k lam^)[position row of node k]; the row of node k+1 is its negative
-      double wl = 0.0;
-#pragma unroll
-      for (int l = 0; l < m; ++l) {
-        wl = __builtin_fma(Tab<S>::M[0][1 + l] * p[2 * S - 2 - l], XA[k][l], wl);
-        wl = __builtin_fma(Tab<S>::M[0][S + 1 + l] * p[2 * S - 2 - l], XA[k + 1][l], wl);
-      }
-      GX[k][0] -= wl;
-      GX[k + 1][0] += wl;
-      // - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b
-      double xs[2 * S];
-#pragma unroll
-      for (int bb = 0; bb < 2 * S; ++bb)
-        xs[bb] = ((bb < S) ? XS[k][bb % S] : XS[k + 1][bb % S]) * p[S - bb % S];
-      double acc = 0.0;
-#pragma unroll
-      for (int aa = 0; aa < 2 * S; ++aa) {
-        const int da = aa % S;
-        if (da == 0) continue;
-        double row = 0.0;
-#pragma unroll
-        for (int bb = 0; bb < 2 * S; ++bb)
-          row = __builtin_fma(Tab<S>::M[aa][bb] * (double)(2 * S - 1 - da - bb % S), xs[bb], row);
-        const double ls = ((aa < S) ? XA[k][da - 1] : XA[k + 1][da - 1]) * p[S - da];
-        acc = __builtin_fma(ls, row, acc);
-      }
-      gT[k] += acc;
-    });
-#pragma unroll
-    for (int k = 1; k < NB; ++k)
-      if (k < N) a.gradP[(int64_t)((k - 1) * 3 + ax) * ld + b] = GX[k][0];
-  }
-  double csum = 0.0;
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-    if (i < N) {
-      a.gradT[i * ld + b] = gT[i] + a.rho;
-      if (a.pcost) csum += a.pcost[i * ld + b];
-    }
-  if (a.cost) a.cost[b] = (a.energy_in ? a.energy_in[b] : 0.0) + a.rho * tsum + csum;
-}
-
-
-// ------------------------------------------------------------------------------------------
-// batched L-BFGS (lbfgs.hpp:276-384, 434-717) as a per-trajectory state machine
-// ------------------------------------------------------------------------------------------
-struct LbfgsP {
-  int mem_size;
-  double g_epsilon;
-  int past;
-  double delta;
-  int max_iterations, max_linesearch;
-  double min_step, max_step, f_dec_coeff, s_curv_coeff, cautious_factor, machine_prec;
-};
-enum { DS_FX = 0, DS_STEP, DS_FINIT, DS_DGTEST, DS_DSTEST, DS_MU, DS_NU, DS_COUNT_ };
-enum { IS_DONE = 0, IS_RET, IS_K, IS_END, IS_BOUND, IS_COUNT, IS_BRACKT, IS_TOUCHED, IS_EVALS, IS_PHASE, IS_COUNT_ };
-enum {  // lbfgs.hpp:135-184
-  LB_CONVERGENCE = 0, LB_STOP = 1, LB_CANCELED = 2,
-  LBERR_INVALID_FUNCVAL = -1012, LBERR_MINIMUMSTEP = -1011, LBERR_MAXIMUMSTEP = -1010,
-  LBERR_MAXIMUMLINESEARCH = -1009, LBERR_MAXIMUMITERATION = -1008, LBERR_WIDTHTOOSMALL = -1007,
-  LBERR_INVALIDPARAMETERS = -1006, LBERR_INCREASEGRADIENT = -1005
-};
-
-struct LbfgsArgs {
-  int n;
-  int64_t B, ld;
-  double *x, *g, *xp, *gp, *d, *lm_s, *lm_y, *lm_ys, *lm_alpha, *pf, *ds;
-  const double *feval;
-  int *is;
-  LbfgsP p;
-  int *n_active;
-  int64_t vs, ps;  // internal vectors (xp, gp, d, lm_s, lm_y): element i of problem b at [i*vs + b*ps]
-};
-
-// One lane per problem.  Every launch consumes ONE objective evaluation (f = feval[b], gradient in
-// g, both taken at the point currently in x) and leaves in x the next point to evaluate.  The
-// control flow per problem is lbfgs_optimize's: phase 0 = the initial evaluation, phase 1 = inside
-// line_search_lewisoverton.  Finished problems are untouched (x, g hold the result).
-__global__ void __launch_bounds__(64) k_lbfgs_update(LbfgsArgs a) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.B) return;
-  const int64_t ld = a.ld;
-  int *is = a.is + b;
-  if (is[IS_DONE * ld]) return;
-  double *ds = a.ds + b;
-  const int n = a.n, m = a.p.mem_size;
-  const LbfgsP &P = a.p;
-  double *x = a.x + b, *g = a.g + b, *xp = a.xp + b, *gp = a.gp + b, *d = a.d + b;
-  const double f = a.feval[b];
-  is[IS_EVALS * ld] += 1;
-  double fx = ds[DS_FX * ld];
-  double step = ds[DS_STEP * ld];
-  int k = is[IS_K * ld];
-  bool start_ls = false;
-  int finish = 0x7fffffff;  // sentinel: keep running
-
-  auto conv_test = [&]() {
-    double gn = 0.0, xn = 0.0;
-    for (int i = 0; i < n; ++i) {
-      gn = fmax(gn, fabs(g[i * ld]));
-      xn = fmax(xn, fabs(x[i * ld]));
-    }
-    return gn / fmax(1.0, xn) < P.g_epsilon;
-  };
-
-  if (is[IS_PHASE * ld] == 0) {
-    fx = f;
-    a.pf[b] = fx;
-    double dd = 0.0;
-    for (int i = 0; i < n; ++i) {
-      const double gi = g[i * ld];
-      d[i * ld] = -gi;
-      dd = __builtin_fma(gi, gi, dd);
-    }
-    if (conv_test()) {
-      finish = LB_CONVERGENCE;
-    } else {
-      step = 1.0 / sqrt(dd);
-      k = 1;
-      is[IS_END * ld] = 0;
-      is[IS_BOUND * ld] = 0;
-      is[IS_PHASE * ld] = 1;
-      start_ls = true;
-    }
-  } else {
-    // ---- one trial of line_search_lewisoverton (lbfgs.hpp:307-383)
-    const double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
-    double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
-    int count = is[IS_COUNT * ld] + 1, brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
-    bool success = false;
-    int err = 0;
-    if (isinf(f) || isnan(f)) {
-      err = LBERR_INVALID_FUNCVAL;
-    } else {
-      if (f > finit + step * dgtest) {
-        nu = step;
-        brackt = 1;
-      } else {
-        double dg = 0.0;
-        for (int i = 0; i < n; ++i) dg = __builtin_fma(g[i * ld], d[i * ld], dg);
-        if (dg < dstest)
-          mu = step;
-        else
-          success = true;
-      }
-      if (!success) {
-        if (P.max_linesearch <= count) {
-          err = LBERR_MAXIMUMLINESEARCH;
-        } else if (brackt && (nu - mu) < P.machine_prec * nu) {
-          err = LBERR_WIDTHTOOSMALL;
-        } else {
-          step = brackt ? 0.5 * (mu + nu) : step * 2.0;
-          if (step < P.min_step) {
-            err = LBERR_MINIMUMSTEP;
-          } else if (step > P.max_step) {
-            if (touched) {
-              err = LBERR_MAXIMUMSTEP;
-            } else {
-              touched = 1;
-              step = P.max_step;
-            }
-          }
-        }
-      }
-    }
-    if (err) {
-      // revert to the previous point; the reported f stays the last trial's (lbfgs.hpp:570-577,713)
-      for (int i = 0; i < n; ++i) {
-        x[i * ld] = xp[i * ld];
-        g[i * ld] = gp[i * ld];
-      }
-      fx = f;
-      finish = err;
-    } else if (!success) {
-      for (int i = 0; i < n; ++i) x[i * ld] = __builtin_fma(step, d[i * ld], xp[i * ld]);
-      ds[DS_MU * ld] = mu;
-      ds[DS_NU * ld] = nu;
-      is[IS_COUNT * ld] = count;
-      is[IS_BRACKT * ld] = brackt;
-      is[IS_TOUCHED * ld] = touched;
-    } else {
-      // ---- accepted step (lbfgs.hpp:579-709)
-      fx = f;
-      if (conv_test()) {
-        finish = LB_CONVERGENCE;
-      } else {
-        if (0 < P.past) {
-          if (P.past <= k) {
-            const double rate = fabs(a.pf[(int64_t)(k % P.past) * ld + b] - fx) / fmax(1.0, fabs(fx));
-            if (rate < P.delta) finish = LB_STOP;
-          }
-          if (finish == 0x7fffffff) a.pf[(int64_t)(k % P.past) * ld + b] = fx;
-        }
-        if (finish == 0x7fffffff && P.max_iterations != 0 && P.max_iterations <= k) finish = LBERR_MAXIMUMITERATION;
-        if (finish == 0x7fffffff) {
-          ++k;
-          int end = is[IS_END * ld], bound = is[IS_BOUND * ld];
-          double *se = a.lm_s + (int64_t)end * n * ld + b, *ye = a.lm_y + (int64_t)end * n * ld + b;
-          double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
-          for (int i = 0; i < n; ++i) {
-            const double si = x[i * ld] - xp[i * ld], yi = g[i * ld] - gp[i * ld], gpi = gp[i * ld];
-            se[i * ld] = si;
-            ye[i * ld] = yi;
-            ys = __builtin_fma(yi, si, ys);
-            yy = __builtin_fma(yi, yi, yy);
-            ss = __builtin_fma(si, si, ss);
-            gpgp = __builtin_fma(gpi, gpi, gpgp);
-            d[i * ld] = -g[i * ld];
-          }
-          a.lm_ys[(int64_t)end * ld + b] = ys;
-          const double cau = ss * sqrt(gpgp) * P.cautious_factor;
-          if (ys > cau) {
-            ++bound;
-            bound = m < bound ? m : bound;
-            end = (end + 1) % m;
-            int j = end;
-            for (int it = 0; it < bound; ++it) {
-              j = (j + m - 1) % m;
-              const double *sj = a.lm_s + (int64_t)j * n * ld + b, *yj = a.lm_y + (int64_t)j * n * ld + b;
-              double sd = 0.0;
-              for (int i = 0; i < n; ++i) sd = __builtin_fma(sj[i * ld], d[i * ld], sd);
-              const double al = sd / a.lm_ys[(int64_t)j * ld + b];
-              a.lm_alpha[(int64_t)j * ld + b] = al;
-              for (int i = 0; i < n; ++i) d[i * ld] = __builtin_fma(-al, yj[i * ld], d[i * ld]);
-            }
-            const double sc = ys / yy;
-            for (int i = 0; i < n; ++i) d[i * ld] *= sc;
-            for (int it = 0; it < bound; ++it) {
-              const double *sj = a.lm_s + (int64_t)j * n * ld + b, *yj = a.lm_y + (int64_t)j * n * ld + b;
-              double yd = 0.0;
-              for (int i = 0; i < n; ++i) yd = __builtin_fma(yj[i * ld], d[i * ld], yd);
-              const double beta = yd / a.lm_ys[(int64_t)j * ld + b];
-              const double cf = a.lm_alpha[(int64_t)j * ld + b] - beta;
-              for (int i = 0; i < n; ++i) d[i * ld] = __builtin_fma(cf, sj[i * ld], d[i * ld]);
-              j = (j + 1) % m;
-            }
-          }
-          is[IS_END * ld] = end;
-          is[IS_BOUND * ld] = bound;
-          step = 1.0;
-          start_ls = true;
-        }
-      }
-    }
-  }
-  if (start_ls) {
-    // ---- entry of line_search_lewisoverton (lbfgs.hpp:287-305) for the new direction
-    double dginit = 0.0;
-    for (int i = 0; i < n; ++i) {
-      const double xi = x[i * ld], gi = g[i * ld];
-      xp[i * ld] = xi;
-      gp[i * ld] = gi;
-      dginit = __builtin_fma(gi, d[i * ld], dginit);
-    }
-    if (!(step > 0.0)) {
-      finish = LBERR_INVALIDPARAMETERS;
-    } else if (0.0 < dginit) {
-      finish = LBERR_INCREASEGRADIENT;
-    } else {
-      ds[DS_FINIT * ld] = fx;
-      ds[DS_DGTEST * ld] = P.f_dec_coeff * dginit;
-      ds[DS_DSTEST * ld] = P.s_curv_coeff * dginit;
-      ds[DS_MU * ld] = 0.0;
-      ds[DS_NU * ld] = P.max_step;
-      is[IS_COUNT * ld] = 0;
-      is[IS_BRACKT * ld] = 0;
-      is[IS_TOUCHED * ld] = 0;
-      for (int i = 0; i < n; ++i) x[i * ld] = __builtin_fma(step, d[i * ld], xp[i * ld]);
-    }
-  }
-  ds[DS_FX * ld] = fx;
-  ds[DS_STEP * ld] = step;
-  is[IS_K * ld] = k;
-  if (finish != 0x7fffffff) {
-    is[IS_DONE * ld] = 1;
-    is[IS_RET * ld] = finish;
-  } else if (a.n_active) {
-    atomicAdd(a.n_active, 1);
-  }
-}
-
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
-}
-
-// Same state machine, ONE WAVE per problem: the n variables are spread over the 64 lanes, every dot
-// product / norm is a wavefront shuffle reduction, scalars are computed redundantly by all lanes
-// (no divergence: a wave holds one problem).  Used for small batches, where one lane per problem
-// leaves the chip idle and serialises ~16 n-long dependent loops per accepted step.
-__global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
-  const int64_t b = blockIdx.x;
-  const int lane = threadIdx.x;
-  const int64_t ld = a.ld;
-  int *is = a.is + b;
-  if (is[IS_DONE * ld]) return;
-  double *ds = a.ds + b;
-  const int n = a.n, m = a.p.mem_size;
-  const LbfgsP &P = a.p;
-  const int64_t vs = a.vs, ps = a.ps;
-  double *x = a.x + b, *g = a.g + b;                       // batch-minor (shared with the objective)
-  double *xp = a.xp + b * ps, *gp = a.gp + b * ps, *d = a.d + b * ps;
-  const double f = a.feval[b];
-  double fx = ds[DS_FX * ld];
-  double step = ds[DS_STEP * ld];
-  int k = is[IS_K * ld];
-  int evals = is[IS_EVALS * ld] + 1;
-  int end = is[IS_END * ld], bound = is[IS_BOUND * ld], phase = is[IS_PHASE * ld];
-  int count = is[IS_COUNT * ld], brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
-  double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
-  double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
-  bool start_ls = false;
-  int finish = 0x7fffffff;
-
-  auto conv_test = [&]() {
-    double gn = 0.0, xn = 0.0;
-    for (int i = lane; i < n; i += 64) {
-      gn = fmax(gn, fabs(g[i * ld]));
-      xn = fmax(xn, fabs(x[i * ld]));
-    }
-    gn = wave_max(gn);
-    xn = wave_max(xn);
-    return gn / fmax(1.0, xn) < P.g_epsilon;
-  };
-
-  if (phase == 0) {
-    fx = f;
-    if (lane == 0) a.pf[b] = fx;
-    double dd = 0.0;
-    for (int i = lane; i < n; i += 64) {
-      const double gi = g[i * ld];
-      d[i * vs] = -gi;
-      dd = __builtin_fma(gi, gi, dd);
-    }
-    dd = wave_sum(dd);
-    if (conv_test()) {
-      finish = LB_CONVERGENCE;
-    } else {
-      step = 1.0 / sqrt(dd);
-      k = 1;
-      end = 0;
-      bound = 0;
-      phase = 1;
-      start_ls = true;
-    }
-  } else {
-    ++count;
-    bool success = false;
-    int err = 0;
-    if (isinf(f) || isnan(f)) {
-      err = LBERR_INVALID_FUNCVAL;
-    } else {
-      if (f > finit + step * dgtest) {
-        nu = step;
-        brackt = 1;
-      } else {
-        double dg = 0.0;
-        for (int i = lane; i < n; i += 64) dg = __builtin_fma(g[i * ld], d[i * vs], dg);
-        dg = wave_sum(dg);
-        if (dg < dstest)
-          mu = step;
-        else
-          success = true;
-      }
-      if (!success) {
-        if (P.max_linesearch <= count) {
-          err = LBERR_MAXIMUMLINESEARCH;
-        } else if (brackt && (nu - mu) < P.machine_prec * nu) {
-          err = LBERR_WIDTHTOOSMALL;
-        } else {
-          step = brackt ? 0.5 * (mu + nu) : step * 2.0;
-          if (step < P.min_step) {
-            err = LBERR_MINIMUMSTEP;
-          } else if (step > P.max_step) {
-            if (touched) {
-              err = LBERR_MAXIMUMSTEP;
-            } else {
-              touched = 1;
-              step = P.max_step;
-            }
-          }
-        }
-      }
-    }
-    if (err) {
-      for (int i = lane; i < n; i += 64) {
-        x[i * ld] = xp[i * vs];
-        g[i * ld] = gp[i * vs];
-      }
-      fx = f;
-      finish = err;
-    } else if (!success) {
-      for (int i = lane; i < n; i += 64) x[i * ld] = __builtin_fma(step, d[i * vs], xp[i * vs]);
-    } else {
-      fx = f;
-      if (conv_test()) {
-        finish = LB_CONVERGENCE;
-      } else {
-        if (0 < P.past) {
-          if (P.past <= k) {
-            const double rate = fabs(a.pf[(int64_t)(k % P.past) * ld + b] - fx) / fmax(1.0, fabs(fx));
-            if (rate < P.delta) finish = LB_STOP;
-          }
-          if (finish == 0x7fffffff && lane == 0) a.pf[(int64_t)(k % P.past) * ld + b] = fx;
-        }
-        if (finish == 0x7fffffff && P.max_iterations != 0 && P.max_iterations <= k) finish = LBERR_MAXIMUMITERATION;
-        if (finish == 0x7fffffff) {
-          ++k;
-          double *lms = a.lm_s + b * ps * m, *lmy = a.lm_y + b * ps * m;  // [j][i] at (j*n_stride + i*vs)
-          const int64_t js = (vs == 1) ? ps : (int64_t)n * vs;             // stride between history slots
-          double *se = lms + (int64_t)end * js, *ye = lmy + (int64_t)end * js;
-          // this lane's variable(s) live in registers for the whole two-loop recursion (n <= 128)
-          double dv[2] = {0.0, 0.0};
-          double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
-          int q = 0;
-          for (int i = lane; i < n; i += 64, ++q) {
-            const double gi = g[i * ld], gpi = gp[i * vs];
-            const double si = x[i * ld] - xp[i * vs], yi = gi - gpi;
-            se[i * vs] = si;
-            ye[i * vs] = yi;
-            ys = __builtin_fma(yi, si, ys);
-            yy = __builtin_fma(yi, yi, yy);
-            ss = __builtin_fma(si, si, ss);
-            gpgp = __builtin_fma(gpi, gpi, gpgp);
-            dv[q] = -gi;
-          }
-          ys = wave_sum(ys); yy = wave_sum(yy); ss = wave_sum(ss); gpgp = wave_sum(gpgp);
-          if (lane == 0) a.lm_ys[(int64_t)end * ld + b] = ys;
-          const double cau = ss * sqrt(gpgp) * P.cautious_factor;
-          if (ys > cau) {
-            ++bound;
-            bound = m < bound ? m : bound;
-            const int newest = end;
-            end = (end + 1) % m;
-            int j = end;
-            double alpha = 0.0;  // lane `it` keeps alpha of the it-th visited slot (mem_size <= 64, host-checked)
-            for (int it = 0; it < bound; ++it) {
-              j = (j + m - 1) % m;
-              const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
-              double sd = 0.0, yv[2] = {0.0, 0.0};
-              q = 0;
-              for (int i = lane; i < n; i += 64, ++q) {
-                sd = __builtin_fma(sj[i * vs], dv[q], sd);
-                yv[q] = yj[i * vs];
-              }
-              sd = wave_sum(sd);
-              const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
-              const double al = sd / ysj;
-              alpha = (lane == it) ? al : alpha;
-              dv[0] = __builtin_fma(-al, yv[0], dv[0]);
-              dv[1] = __builtin_fma(-al, yv[1], dv[1]);
-            }
-            const double sc = ys / yy;
-            dv[0] *= sc;
-            dv[1] *= sc;
-            for (int it = 0; it < bound; ++it) {
-              const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
-              double yd = 0.0, sv[2] = {0.0, 0.0};
-              q = 0;
-              for (int i = lane; i < n; i += 64, ++q) {
-                yd = __builtin_fma(yj[i * vs], dv[q], yd);
-                sv[q] = sj[i * vs];
-              }
-              yd = wave_sum(yd);
-              const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
-              const double cf = __shfl(alpha, bound - 1 - it) - yd / ysj;
-              dv[0] = __builtin_fma(cf, sv[0], dv[0]);
-              dv[1] = __builtin_fma(cf, sv[1], dv[1]);
-              j = (j + 1) % m;
-            }
-          }
-          q = 0;
-          for (int i = lane; i < n; i += 64, ++q) d[i * vs] = dv[q];
-          step = 1.0;
-          start_ls = true;
-        }
-      }
-    }
-  }
-  if (start_ls) {
-    double dginit = 0.0;
-    for (int i = lane; i < n; i += 64) {
-      const double xi = x[i * ld], gi = g[i * ld];
-      xp[i * vs] = xi;
-      gp[i * vs] = gi;
-      dginit = __builtin_fma(gi, d[i * vs], dginit);
-    }
-    dginit = wave_sum(dginit);
-    if (!(step > 0.0)) {
-      finish = LBERR_INVALIDPARAMETERS;
-    } else if (0.0 < dginit) {
-      finish = LBERR_INCREASEGRADIENT;
-    } else {
-      finit = fx;
-      dgtest = P.f_dec_coeff * dginit;
-      dstest = P.s_curv_coeff * dginit;
-      mu = 0.0;
-      nu = P.max_step;
-      count = 0;
-      brackt = 0;
-      touched = 0;
-      for (int i = lane; i < n; i += 64) x[i * ld] = __builtin_fma(step, d[i * vs], xp[i * vs]);
-    }
-  }
-  if (lane == 0) {
-    ds[DS_FX * ld] = fx; ds[DS_STEP * ld] = step; ds[DS_FINIT * ld] = finit; ds[DS_DGTEST * ld] = dgtest;
-    ds[DS_DSTEST * ld] = dstest; ds[DS_MU * ld] = mu; ds[DS_NU * ld] = nu;
-    is[IS_K * ld] = k; is[IS_END * ld] = end; is[IS_BOUND * ld] = bound; is[IS_PHASE * ld] = phase;
-    is[IS_COUNT * ld] = count; is[IS_BRACKT * ld] = brackt; is[IS_TOUCHED * ld] = touched;
-    is[IS_EVALS * ld] = evals;
-    if (finish != 0x7fffffff) {
-      is[IS_DONE * ld] = 1;
-      is[IS_RET * ld] = finish;
-    } else if (a.n_active) {
-      atomicAdd(a.n_active, 1);
-    }
-  }
-}
-
-// firi::costMVIE (gcopter/firi.hpp:86-157): x = [p, rtd, cde], A is M x 3 column-major per problem
-// (field k*M + r), the reference's optData packing (firi.hpp:186-200).
-struct MvieArgs {
-  const double *A, *x;
-  double *f, *g;
-  const int *done;
-  int64_t B, ld;
-  int M;
-  double eps, wt;
-};
-__global__ void __launch_bounds__(64) k_mvie_eval(MvieArgs a) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.B) return;
-  if (a.done && a.done[b]) return;
-  const int64_t ld = a.ld;
-  const double *x = a.x + b;
-  double p[3], rtd[3], cde[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    p[q] = x[q * ld];
-    rtd[q] = x[(3 + q) * ld];
-    cde[q] = x[(6 + q) * ld];
-  }
-  const double L00 = rtd[0] * rtd[0] + 2.220446049250313e-16, L11 = rtd[1] * rtd[1] + 2.220446049250313e-16,
-               L22 = rtd[2] * rtd[2] + 2.220446049250313e-16;
-  const double L10 = cde[0], L21 = cde[1], L20 = cde[2];
-  double cost = 0.0, gdp[3] = {0, 0, 0}, gdr[3] = {0, 0, 0}, gdc[3] = {0, 0, 0};
-  const double inv_mu = 1.0 / a.eps;
-  for (int r = 0; r < a.M; ++r) {
-    const double a0 = a.A[(int64_t)r * ld + b], a1 = a.A[(int64_t)(a.M + r) * ld + b],
-                 a2 = a.A[(int64_t)(2 * a.M + r) * ld + b];
-    const double al0 = a0 * L00 + a1 * L10 + a2 * L20, al1 = a1 * L11 + a2 * L21, al2 = a2 * L22;
-    const double nrm = sqrt(al0 * al0 + al1 * al1 + al2 * al2);
-    const double viol = nrm + (a0 * p[0] + a1 * p[1] + a2 * p[2]) - 1.0;
-    if (viol >= 0.0) {
-      double c, dc;
-      smoothed_l1(a.eps, inv_mu, viol, c, dc);
-      const double inv = 1.0 / nrm;
-      const double adj0 = al0 * inv, adj1 = al1 * inv, adj2 = al2 * inv;
-      const double v0 = dc * a0, v1 = dc * a1, v2 = dc * a2;
-      cost += c;
-      gdp[0] += v0; gdp[1] += v1; gdp[2] += v2;
-      gdr[0] += adj0 * v0; gdr[1] += adj1 * v1; gdr[2] += adj2 * v2;
-      gdc[0] += adj0 * v1;
-      gdc[1] += adj1 * v2;
-      gdc[2] += adj0 * v2;
-    }
-  }
-  cost *= a.wt;
-  cost -= log(L00) + log(L11) + log(L22);
-  const double Ld[3] = {L00, L11, L22};
-  double *g = a.g + b;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    g[q * ld] = gdp[q] * a.wt;
-    g[(3 + q) * ld] = (gdr[q] * a.wt - 1.0 / Ld[q]) * 2.0 * rtd[q];
-    g[(6 + q) * ld] = gdc[q] * a.wt;
-  }
-  a.f[b] = cost;
-}
-
-// GCOPTER's smooth bijection R -> (0, inf) for the durations (upstream gcopter.hpp forwardT /
-// backwardT; not part of the reference tree): T = tau>0 ? (tau/2+1)tau+1 : 1/((tau/2-1)tau+1).
-__device__ __forceinline__ double forward_T(double tau) {
-  return tau > 0.0 ? (0.5 * tau + 1.0) * tau + 1.0 : 1.0 / ((0.5 * tau - 1.0) * tau + 1.0);
-}
-__device__ __forceinline__ double dforward_T(double tau) {
-  if (tau > 0.0) return tau + 1.0;
-  const double den = (0.5 * tau - 1.0) * tau + 1.0;
-  return (1.0 - tau) / (den * den);
-}
-__device__ __forceinline__ double backward_T(double T) {
-  return T > 1.0 ? sqrt(2.0 * T - 1.0) - 1.0 : 1.0 - sqrt(2.0 / T - 1.0);
-}
-struct MapArgs {
-  double *x, *g;             // optimisation variables / gradient [n][ld]
-  double *wps, *T;           // trajectory parameters
-  const double *gradP, *gradT;
-  int64_t B, ld;
-  int nw, nt;                // optimised waypoint coordinates (0 or 3(N-1)), optimised durations (0 or N)
-  int mode;                  // 0: params -> x (init), 1: x -> params, 2: (gradP, gradT) -> g
-};
-__global__ void __launch_bounds__(256) k_minco_map(MapArgs a) {
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B) return;
-  const int64_t ld = a.ld;
-  const int v = blockIdx.y;  // variable index: [0, nw) waypoint coordinates, [nw, nw+nt) durations
-  if (v < a.nw) {
-    const int64_t i = (int64_t)v * ld + b;
-    if (a.mode == 0) a.x[i] = a.wps[i];
-    else if (a.mode == 1) a.wps[i] = a.x[i];
-    else a.g[i] = a.gradP[i];
-  } else {
-    const int64_t xi = (int64_t)v * ld + b, ti = (int64_t)(v - a.nw) * ld + b;
-    if (a.mode == 0) a.x[xi] = backward_T(a.T[ti]);
-    else if (a.mode == 1) a.T[ti] = forward_T(a.x[xi]);
-    else a.g[xi] = a.gradT[ti] * dforward_T(a.x[xi]);
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// QP assembly, dense, in the reference's own shapes (qp_solver.hpp:119-296, min_traj_opt.py:377-613)
-// ------------------------------------------------------------------------------------------
-struct QpArgs {
-  const double *state, *T, *hpolys;
-  const int *rows;
-  double *Q, *A, *b, *G, *h;
-  int64_t B, n, me, mg;
-  int N, res, M, float_time, row_order;
-  double vmax, amax, m34;
-};
-
-// Row d (0 = p, 1 = v, 2 = a, 3 = j) of the monomial basis at t, column `col` (highest power first),
-// with the reference's multiplication order for the powers (get_t_state, qp_solver.hpp:90-116 /
-// min_traj_opt.py:300-336): t_2 = t*t, t_3 = t*t_2, t_4 = t_2*t_2, t_5 = t_2*t_3, t_6 = t_3*t_3,
-// t_7 = t_4*t_3, each entry = integer coefficient * power.  F = float reproduces the C++ planner.
-template <int S, class F>
-__device__ __forceinline__ double basis_entry(F t, int d, int col) {
-  constexpr int D = 2 * S;
-  const int k = D - 1 - col;  // power of this column
-  if (k < d) return 0.0;
-  const F t2 = t * t, t3 = t * t2, t4 = t2 * t2, t5 = t2 * t3, t6 = t3 * t3, t7 = t4 * t3;
-  const F pw[8] = {(F)1, t, t2, t3, t4, t5, t6, t7};
-  int coef = 1;
-  for (int e = 0; e < d; ++e) coef *= (k - e);
-  const int e = k - d;
-  if (e == 0) return (double)coef;       // constant entries are written as literals in the reference
-  if (coef == 1) return (double)pw[e];
-  return (double)((F)coef * pw[e]);
-}
-
-// cost block entry (j,k) of piece time t (qp_solver.hpp:186-236 / min_traj_opt.py:466-508)
-template <int S, class F>
-__device__ __forceinline__ double cost_entry(F t, int j, int k, double m34) {
-  if (j > k) { const int q = j; j = k; k = q; }
-  const F t2 = t * t, t3 = t * t2, t4 = t2 * t2, t5 = t2 * t3;
-  if (S == 4) {
-    const F t6 = t3 * t3, t7 = t4 * t3;
-    const F m[4][4] = {{(F)100800 * t7, (F)50400 * t6, (F)20160 * t5, (F)5040 * t4},
-                       {0, (F)25920 * t5, (F)10800 * t4, (F)2880 * t3},
-                       {0, 0, (F)4800 * t3, (F)m34 * t2},
-                       {0, 0, 0, (F)576 * t}};
-    return (double)m[j][k];
-  } else {
-    const F m[3][3] = {{(F)720 * t5, (F)360 * t4, (F)120 * t3}, {0, (F)192 * t3, (F)72 * t2}, {0, 0, (F)36 * t}};
-    return (double)m[j][k];
-  }
-}
-
-template <int S, class F>
-__device__ __forceinline__ F seg_time(const QpArgs &a, int64_t b, int i) {
-  return (F)a.T[b * a.N + i];
-}
-
-// Q and [A | b]: one thread per element.
-template <int S, class F>
-__global__ void __launch_bounds__(256) k_qp_eq_obj(QpArgs a) {
-  constexpr int D = 2 * S;
-  const int64_t b = blockIdx.y;
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t n = a.n, me = a.me, nQ = n * n, nA = me * n;
-  const int N = a.N;
-  if (e < nQ) {
-    const int64_t r = e / n, c = e % n;
-    double v = 0.0;
-    if (r / D == c / D) {  // same (piece, axis) block
-      const int jr = (int)(r % D), jc = (int)(c % D);
-      if (jr < S && jc < S) v = cost_entry<S, F>(seg_time<S, F>(a, b, (int)(r / (3 * D))), jr, jc, a.m34);
-    }
-    a.Q[b * nQ + e] = v;
-  } else if (e < nQ + nA) {
-    const int64_t ea = e - nQ, r = ea / n, c = ea % n;
-    double v = 0.0;
-    const int64_t s_num = (int64_t)(N - 1) * 3 * D;
-    if (r < 18) {  // boundary rows: per axis 3 start rows then 3 end rows (qp_solver.hpp:152-162)
-      const int ax = (int)(r / 6), q = (int)(r % 6);
-      if (q < 3) {
-        if (c >= ax * D && c < (ax + 1) * D) v = basis_entry<S, F>((F)0, q, (int)(c - ax * D));
-      } else {
-        const int64_t c0 = s_num + ax * D;
-        if (c >= c0 && c < c0 + D) v = basis_entry<S, F>(seg_time<S, F>(a, b, N - 1), q - 3, (int)(c - c0));
-      }
-    } else {  // continuity rows (qp_solver.hpp:165-177): [basis(T_i) | -zero_A] per knot, per axis
-      const int64_t rr = r - 18;
-      const int i = (int)(rr / (3 * S)), ax = (int)((rr / S) % 3), d = (int)(rr % S);
-      const int64_t c0 = (int64_t)i * 3 * D + ax * D, c1 = c0 + 3 * D;
-      if (c >= c0 && c < c0 + D) v = basis_entry<S, F>(seg_time<S, F>(a, b, i), d, (int)(c - c0));
-      else if (c >= c1 && c < c1 + D) v = -basis_entry<S, F>((F)0, d, (int)(c - c1));
-    }
-    a.A[b * nA + ea] = v;
-  } else if (e < nQ + nA + me) {
-    const int64_t r = e - nQ - nA;
-    double v = 0.0;
-    if (r < 18) {
-      const int ax = (int)(r / 6), q = (int)(r % 6);
-      v = a.state[b * 18 + (q < 3 ? 0 : 9) + ax * 3 + (q % 3)];
-    }
-    a.b[b * me + r] = v;
-  }
-}
-
-// [G | h]: one thread per element of G, the thread of column 0 also writes h.
-template <int S, class F>
-__global__ void __launch_bounds__(256) k_qp_ineq(QpArgs a) {
-  constexpr int D = 2 * S;
-  const int64_t b = blockIdx.y;
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t n = a.n, mg = a.mg;
-  if (e >= mg * n) return;
-  const int64_t r = e / n, c = e % n;
-  const int N = a.N, res = a.res;
-  const int *rows = a.rows + b * N;
-  // locate (piece i, sample j, local row q; box?) for this row in the requested ordering
-  int i = 0, j = 0, q = 0;
-  bool box = false;
-  if (a.row_order == 0) {
-    int64_t rr = r;
-    for (i = 0; i < N; ++i) {
-      const int64_t blk = (int64_t)res * (rows[i] + 12);
-      if (rr < blk) break;
-      rr -= blk;
-    }
-    j = (int)(rr / (rows[i] + 12));
-    q = (int)(rr % (rows[i] + 12));
-    box = q >= rows[i];
-    if (box) q -= rows[i];
-  } else {
-    int64_t tot = 0;
-    for (int p = 0; p < N; ++p) tot += rows[p];
-    if (r < tot * res) {
-      int64_t rr = r;
-      for (i = 0; i < N; ++i) {
-        const int64_t blk = (int64_t)res * rows[i];
-        if (rr < blk) break;
-        rr -= blk;
-      }
-      j = (int)(rr / rows[i]);
-      q = (int)(rr % rows[i]);
-    } else {
-      const int64_t rr = r - tot * res;
-      box = true;
-      i = (int)(rr / (12 * res));
-      j = (int)((rr / 12) % res);
-      q = (int)(rr % 12);
-    }
-  }
-  // sample time (qp_solver.hpp:252-263): step = T_i / res, t = step * j, j == 0 uses zero_A
-  const F step = seg_time<S, F>(a, b, i) / (F)res;
-  const F t = (j == 0) ? (F)0 : step * (F)j;
-  const int64_t c0 = (int64_t)i * 3 * D;
-  double v = 0.0, hv = 0.0;
-  if (!box) {
-    const double *hp = a.hpolys + ((b * N + i) * a.M + q) * 4;
-    if (c >= c0 && c < c0 + 3 * D) {
-      const int ax = (int)((c - c0) / D);
-      v = hp[ax] * basis_entry<S, F>(t, 0, (int)((c - c0) % D));
-    }
-    hv = hp[3];
-  } else {
-    // per axis: +v, +a, -v, -a  (qp_solver.hpp:280-291, min_traj_opt.py:598-611)
-    const int ax = q / 4, w = q % 4;
-    const int64_t ca = c0 + ax * D;
-    if (c >= ca && c < ca + D) {
-      const double be = basis_entry<S, F>(t, 1 + (w & 1), (int)(c - ca));
-      v = (w < 2) ? be : -be;
-    }
-    hv = (w & 1) ? a.amax : a.vmax;
-  }
-  a.G[b * mg * n + e] = v;
-  if (c == 0) a.h[b * mg + r] = hv;
-}
-
-// dst[f*ld + b] = src[b*nf + f] through a padded LDS tile (both sides coalesced).
-constexpr int kTile = 32;
-__global__ void __launch_bounds__(kTile * 8) k_to_batch_minor(const double *__restrict__ src,
-                                                              double *__restrict__ dst, int64_t B,
-                                                              int64_t nf, int64_t ld) {
-  __shared__ double tile[kTile][kTile + 1];
-  const int64_t b0 = (int64_t)blockIdx.x * kTile, f0 = (int64_t)blockIdx.y * kTile;
-  for (int i = threadIdx.y; i < kTile; i += 8) {
-    const int64_t bb = b0 + i, ff = f0 + threadIdx.x;
-    if (bb < B && ff < nf) tile[i][threadIdx.x] = src[bb * nf + ff];
-  }
-  __syncthreads();
-  for (int i = threadIdx.y; i < kTile; i += 8) {
-    const int64_t ff = f0 + i, bb = b0 + threadIdx.x;
-    if (bb < B && ff < nf) dst[ff * ld + bb] = tile[threadIdx.x][i];
-  }
-}
-__global__ void __launch_bounds__(kTile * 8) k_to_traj_major(const double *__restrict__ src,
-                                                             double *__restrict__ dst, int64_t B,
-                                                             int64_t nf, int64_t ld) {
-  __shared__ double tile[kTile][kTile + 1];
-  const int64_t b0 = (int64_t)blockIdx.x * kTile, f0 = (int64_t)blockIdx.y * kTile;
-  for (int i = threadIdx.y; i < kTile; i += 8) {
-    const int64_t ff = f0 + i, bb = b0 + threadIdx.x;
-    if (bb < B && ff < nf) tile[i][threadIdx.x] = src[ff * ld + bb];
-  }
-  __syncthreads();
-  for (int i = threadIdx.y; i < kTile; i += 8) {
-    const int64_t bb = b0 + i, ff = f0 + threadIdx.x;
-    if (bb < B && ff < nf) dst[bb * nf + ff] = tile[threadIdx.x][i];
-  }
-}
-
-}  // namespace anet
+#include "layout_kernels.h"
 
 // ------------------------------------------------------------------------------------------
 // context + error plumbing

@@ -1,0 +1,593 @@
+// Batched L-BFGS state machine (lane-per-problem and wave-per-problem), the costMVIE objective and the
+// MINCO variable maps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "minco_kernels.h"
+
+namespace anet {
+
+// ------------------------------------------------------------------------------------------
+// batched L-BFGS (lbfgs.hpp:276-384, 434-717) as a per-trajectory state machine
+// ------------------------------------------------------------------------------------------
+struct LbfgsP {
+  int mem_size;
+  double g_epsilon;
+  int past;
+  double delta;
+  int max_iterations, max_linesearch;
+  double min_step, max_step, f_dec_coeff, s_curv_coeff, cautious_factor, machine_prec;
+};
+enum { DS_FX = 0, DS_STEP, DS_FINIT, DS_DGTEST, DS_DSTEST, DS_MU, DS_NU, DS_COUNT_ };
+enum { IS_DONE = 0, IS_RET, IS_K, IS_END, IS_BOUND, IS_COUNT, IS_BRACKT, IS_TOUCHED, IS_EVALS, IS_PHASE, IS_COUNT_ };
+enum {  // lbfgs.hpp:135-184
+  LB_CONVERGENCE = 0, LB_STOP = 1, LB_CANCELED = 2,
+  LBERR_INVALID_FUNCVAL = -1012, LBERR_MINIMUMSTEP = -1011, LBERR_MAXIMUMSTEP = -1010,
+  LBERR_MAXIMUMLINESEARCH = -1009, LBERR_MAXIMUMITERATION = -1008, LBERR_WIDTHTOOSMALL = -1007,
+  LBERR_INVALIDPARAMETERS = -1006, LBERR_INCREASEGRADIENT = -1005
+};
+
+struct LbfgsArgs {
+  int n;
+  int64_t B, ld;
+  double *x, *g, *xp, *gp, *d, *lm_s, *lm_y, *lm_ys, *lm_alpha, *pf, *ds;
+  const double *feval;
+  int *is;
+  LbfgsP p;
+  int *n_active;
+  int64_t vs, ps;  // internal vectors (xp, gp, d, lm_s, lm_y): element i of problem b at [i*vs + b*ps]
+};
+
+// One lane per problem.  Every launch consumes ONE objective evaluation (f = feval[b], gradient in
+// g, both taken at the point currently in x) and leaves in x the next point to evaluate.  The
+// control flow per problem is lbfgs_optimize's: phase 0 = the initial evaluation, phase 1 = inside
+// line_search_lewisoverton.  Finished problems are untouched (x, g hold the result).
+__global__ void __launch_bounds__(64) k_lbfgs_update(LbfgsArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  const int64_t ld = a.ld;
+  int *is = a.is + b;
+  if (is[IS_DONE * ld]) return;
+  double *ds = a.ds + b;
+  const int n = a.n, m = a.p.mem_size;
+  const LbfgsP &P = a.p;
+  double *x = a.x + b, *g = a.g + b, *xp = a.xp + b, *gp = a.gp + b, *d = a.d + b;
+  const double f = a.feval[b];
+  is[IS_EVALS * ld] += 1;
+  double fx = ds[DS_FX * ld];
+  double step = ds[DS_STEP * ld];
+  int k = is[IS_K * ld];
+  bool start_ls = false;
+  int finish = 0x7fffffff;  // sentinel: keep running
+
+  auto conv_test = [&]() {
+    double gn = 0.0, xn = 0.0;
+    for (int i = 0; i < n; ++i) {
+      gn = fmax(gn, fabs(g[i * ld]));
+      xn = fmax(xn, fabs(x[i * ld]));
+    }
+    return gn / fmax(1.0, xn) < P.g_epsilon;
+  };
+
+  if (is[IS_PHASE * ld] == 0) {
+    fx = f;
+    a.pf[b] = fx;
+    double dd = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double gi = g[i * ld];
+      d[i * ld] = -gi;
+      dd = __builtin_fma(gi, gi, dd);
+    }
+    if (conv_test()) {
+      finish = LB_CONVERGENCE;
+    } else {
+      step = 1.0 / sqrt(dd);
+      k = 1;
+      is[IS_END * ld] = 0;
+      is[IS_BOUND * ld] = 0;
+      is[IS_PHASE * ld] = 1;
+      start_ls = true;
+    }
+  } else {
+    // ---- one trial of line_search_lewisoverton (lbfgs.hpp:307-383)
+    const double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
+    double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
+    int count = is[IS_COUNT * ld] + 1, brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
+    bool success = false;
+    int err = 0;
+    if (isinf(f) || isnan(f)) {
+      err = LBERR_INVALID_FUNCVAL;
+    } else {
+      if (f > finit + step * dgtest) {
+        nu = step;
+        brackt = 1;
+      } else {
+        double dg = 0.0;
+        for (int i = 0; i < n; ++i) dg = __builtin_fma(g[i * ld], d[i * ld], dg);
+        if (dg < dstest)
+          mu = step;
+        else
+          success = true;
+      }
+      if (!success) {
+        if (P.max_linesearch <= count) {
+          err = LBERR_MAXIMUMLINESEARCH;
+        } else if (brackt && (nu - mu) < P.machine_prec * nu) {
+          err = LBERR_WIDTHTOOSMALL;
+        } else {
+          step = brackt ? 0.5 * (mu + nu) : step * 2.0;
+          if (step < P.min_step) {
+            err = LBERR_MINIMUMSTEP;
+          } else if (step > P.max_step) {
+            if (touched) {
+              err = LBERR_MAXIMUMSTEP;
+            } else {
+              touched = 1;
+              step = P.max_step;
+            }
+          }
+        }
+      }
+    }
+    if (err) {
+      // revert to the previous point; the reported f stays the last trial's (lbfgs.hpp:570-577,713)
+      for (int i = 0; i < n; ++i) {
+        x[i * ld] = xp[i * ld];
+        g[i * ld] = gp[i * ld];
+      }
+      fx = f;
+      finish = err;
+    } else if (!success) {
+      for (int i = 0; i < n; ++i) x[i * ld] = __builtin_fma(step, d[i * ld], xp[i * ld]);
+      ds[DS_MU * ld] = mu;
+      ds[DS_NU * ld] = nu;
+      is[IS_COUNT * ld] = count;
+      is[IS_BRACKT * ld] = brackt;
+      is[IS_TOUCHED * ld] = touched;
+    } else {
+      // ---- accepted step (lbfgs.hpp:579-709)
+      fx = f;
+      if (conv_test()) {
+        finish = LB_CONVERGENCE;
+      } else {
+        if (0 < P.past) {
+          if (P.past <= k) {
+            const double rate = fabs(a.pf[(int64_t)(k % P.past) * ld + b] - fx) / fmax(1.0, fabs(fx));
+            if (rate < P.delta) finish = LB_STOP;
+          }
+          if (finish == 0x7fffffff) a.pf[(int64_t)(k % P.past) * ld + b] = fx;
+        }
+        if (finish == 0x7fffffff && P.max_iterations != 0 && P.max_iterations <= k) finish = LBERR_MAXIMUMITERATION;
+        if (finish == 0x7fffffff) {
+          ++k;
+          int end = is[IS_END * ld], bound = is[IS_BOUND * ld];
+          double *se = a.lm_s + (int64_t)end * n * ld + b, *ye = a.lm_y + (int64_t)end * n * ld + b;
+          double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
+          for (int i = 0; i < n; ++i) {
+            const double si = x[i * ld] - xp[i * ld], yi = g[i * ld] - gp[i * ld], gpi = gp[i * ld];
+            se[i * ld] = si;
+            ye[i * ld] = yi;
+            ys = __builtin_fma(yi, si, ys);
+            yy = __builtin_fma(yi, yi, yy);
+            ss = __builtin_fma(si, si, ss);
+            gpgp = __builtin_fma(gpi, gpi, gpgp);
+            d[i * ld] = -g[i * ld];
+          }
+          a.lm_ys[(int64_t)end * ld + b] = ys;
+          const double cau = ss * sqrt(gpgp) * P.cautious_factor;
+          if (ys > cau) {
+            ++bound;
+            bound = m < bound ? m : bound;
+            end = (end + 1) % m;
+            int j = end;
+            for (int it = 0; it < bound; ++it) {
+              j = (j + m - 1) % m;
+              const double *sj = a.lm_s + (int64_t)j * n * ld + b, *yj = a.lm_y + (int64_t)j * n * ld + b;
+              double sd = 0.0;
+              for (int i = 0; i < n; ++i) sd = __builtin_fma(sj[i * ld], d[i * ld], sd);
+              const double al = sd / a.lm_ys[(int64_t)j * ld + b];
+              a.lm_alpha[(int64_t)j * ld + b] = al;
+              for (int i = 0; i < n; ++i) d[i * ld] = __builtin_fma(-al, yj[i * ld], d[i * ld]);
+            }
+            const double sc = ys / yy;
+            for (int i = 0; i < n; ++i) d[i * ld] *= sc;
+            for (int it = 0; it < bound; ++it) {
+              const double *sj = a.lm_s + (int64_t)j * n * ld + b, *yj = a.lm_y + (int64_t)j * n * ld + b;
+              double yd = 0.0;
+              for (int i = 0; i < n; ++i) yd = __builtin_fma(yj[i * ld], d[i * ld], yd);
+              const double beta = yd / a.lm_ys[(int64_t)j * ld + b];
+              const double cf = a.lm_alpha[(int64_t)j * ld + b] - beta;
+              for (int i = 0; i < n; ++i) d[i * ld] = __builtin_fma(cf, sj[i * ld], d[i * ld]);
+              j = (j + 1) % m;
+            }
+          }
+          is[IS_END * ld] = end;
+          is[IS_BOUND * ld] = bound;
+          step = 1.0;
+          start_ls = true;
+        }
+      }
+    }
+  }
+  if (start_ls) {
+    // ---- entry of line_search_lewisoverton (lbfgs.hpp:287-305) for the new direction
+    double dginit = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double xi = x[i * ld], gi = g[i * ld];
+      xp[i * ld] = xi;
+      gp[i * ld] = gi;
+      dginit = __builtin_fma(gi, d[i * ld], dginit);
+    }
+    if (!(step > 0.0)) {
+      finish = LBERR_INVALIDPARAMETERS;
+    } else if (0.0 < dginit) {
+      finish = LBERR_INCREASEGRADIENT;
+    } else {
+      ds[DS_FINIT * ld] = fx;
+      ds[DS_DGTEST * ld] = P.f_dec_coeff * dginit;
+      ds[DS_DSTEST * ld] = P.s_curv_coeff * dginit;
+      ds[DS_MU * ld] = 0.0;
+      ds[DS_NU * ld] = P.max_step;
+      is[IS_COUNT * ld] = 0;
+      is[IS_BRACKT * ld] = 0;
+      is[IS_TOUCHED * ld] = 0;
+      for (int i = 0; i < n; ++i) x[i * ld] = __builtin_fma(step, d[i * ld], xp[i * ld]);
+    }
+  }
+  ds[DS_FX * ld] = fx;
+  ds[DS_STEP * ld] = step;
+  is[IS_K * ld] = k;
+  if (finish != 0x7fffffff) {
+    is[IS_DONE * ld] = 1;
+    is[IS_RET * ld] = finish;
+  } else if (a.n_active) {
+    atomicAdd(a.n_active, 1);
+  }
+}
+
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Same state machine, ONE WAVE per problem: the n variables are spread over the 64 lanes, every dot
+// product / norm is a wavefront shuffle reduction, scalars are computed redundantly by all lanes
+// (no divergence: a wave holds one problem).  Used for small batches, where one lane per problem
+// leaves the chip idle and serialises ~16 n-long dependent loops per accepted step.
+__global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
+  const int64_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t ld = a.ld;
+  int *is = a.is + b;
+  if (is[IS_DONE * ld]) return;
+  double *ds = a.ds + b;
+  const int n = a.n, m = a.p.mem_size;
+  const LbfgsP &P = a.p;
+  const int64_t vs = a.vs, ps = a.ps;
+  double *x = a.x + b, *g = a.g + b;                       // batch-minor (shared with the objective)
+  double *xp = a.xp + b * ps, *gp = a.gp + b * ps, *d = a.d + b * ps;
+  const double f = a.feval[b];
+  double fx = ds[DS_FX * ld];
+  double step = ds[DS_STEP * ld];
+  int k = is[IS_K * ld];
+  int evals = is[IS_EVALS * ld] + 1;
+  int end = is[IS_END * ld], bound = is[IS_BOUND * ld], phase = is[IS_PHASE * ld];
+  int count = is[IS_COUNT * ld], brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
+  double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
+  double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
+  bool start_ls = false;
+  int finish = 0x7fffffff;
+
+  auto conv_test = [&]() {
+    double gn = 0.0, xn = 0.0;
+    for (int i = lane; i < n; i += 64) {
+      gn = fmax(gn, fabs(g[i * ld]));
+      xn = fmax(xn, fabs(x[i * ld]));
+    }
+    gn = wave_max(gn);
+    xn = wave_max(xn);
+    return gn / fmax(1.0, xn) < P.g_epsilon;
+  };
+
+  if (phase == 0) {
+    fx = f;
+    if (lane == 0) a.pf[b] = fx;
+    double dd = 0.0;
+    for (int i = lane; i < n; i += 64) {
+      const double gi = g[i * ld];
+      d[i * vs] = -gi;
+      dd = __builtin_fma(gi, gi, dd);
+    }
+    dd = wave_sum(dd);
+    if (conv_test()) {
+      finish = LB_CONVERGENCE;
+    } else {
+      step = 1.0 / sqrt(dd);
+      k = 1;
+      end = 0;
+      bound = 0;
+      phase = 1;
+      start_ls = true;
+    }
+  } else {
+    ++count;
+    bool success = false;
+    int err = 0;
+    if (isinf(f) || isnan(f)) {
+      err = LBERR_INVALID_FUNCVAL;
+    } else {
+      if (f > finit + step * dgtest) {
+        nu = step;
+        brackt = 1;
+      } else {
+        double dg = 0.0;
+        for (int i = lane; i < n; i += 64) dg = __builtin_fma(g[i * ld], d[i * vs], dg);
+        dg = wave_sum(dg);
+        if (dg < dstest)
+          mu = step;
+        else
+          success = true;
+      }
+      if (!success) {
+        if (P.max_linesearch <= count) {
+          err = LBERR_MAXIMUMLINESEARCH;
+        } else if (brackt && (nu - mu) < P.machine_prec * nu) {
+          err = LBERR_WIDTHTOOSMALL;
+        } else {
+          step = brackt ? 0.5 * (mu + nu) : step * 2.0;
+          if (step < P.min_step) {
+            err = LBERR_MINIMUMSTEP;
+          } else if (step > P.max_step) {
+            if (touched) {
+              err = LBERR_MAXIMUMSTEP;
+            } else {
+              touched = 1;
+              step = P.max_step;
+            }
+          }
+        }
+      }
+    }
+    if (err) {
+      for (int i = lane; i < n; i += 64) {
+        x[i * ld] = xp[i * vs];
+        g[i * ld] = gp[i * vs];
+      }
+      fx = f;
+      finish = err;
+    } else if (!success) {
+      for (int i = lane; i < n; i += 64) x[i * ld] = __builtin_fma(step, d[i * vs], xp[i * vs]);
+    } else {
+      fx = f;
+      if (conv_test()) {
+        finish = LB_CONVERGENCE;
+      } else {
+        if (0 < P.past) {
+          if (P.past <= k) {
+            const double rate = fabs(a.pf[(int64_t)(k % P.past) * ld + b] - fx) / fmax(1.0, fabs(fx));
+            if (rate < P.delta) finish = LB_STOP;
+          }
+          if (finish == 0x7fffffff && lane == 0) a.pf[(int64_t)(k % P.past) * ld + b] = fx;
+        }
+        if (finish == 0x7fffffff && P.max_iterations != 0 && P.max_iterations <= k) finish = LBERR_MAXIMUMITERATION;
+        if (finish == 0x7fffffff) {
+          ++k;
+          double *lms = a.lm_s + b * ps * m, *lmy = a.lm_y + b * ps * m;  // [j][i] at (j*n_stride + i*vs)
+          const int64_t js = (vs == 1) ? ps : (int64_t)n * vs;             // stride between history slots
+          double *se = lms + (int64_t)end * js, *ye = lmy + (int64_t)end * js;
+          // this lane's variable(s) live in registers for the whole two-loop recursion (n <= 128)
+          double dv[2] = {0.0, 0.0};
+          double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
+          int q = 0;
+          for (int i = lane; i < n; i += 64, ++q) {
+            const double gi = g[i * ld], gpi = gp[i * vs];
+            const double si = x[i * ld] - xp[i * vs], yi = gi - gpi;
+            se[i * vs] = si;
+            ye[i * vs] = yi;
+            ys = __builtin_fma(yi, si, ys);
+            yy = __builtin_fma(yi, yi, yy);
+            ss = __builtin_fma(si, si, ss);
+            gpgp = __builtin_fma(gpi, gpi, gpgp);
+            dv[q] = -gi;
+          }
+          ys = wave_sum(ys); yy = wave_sum(yy); ss = wave_sum(ss); gpgp = wave_sum(gpgp);
+          if (lane == 0) a.lm_ys[(int64_t)end * ld + b] = ys;
+          const double cau = ss * sqrt(gpgp) * P.cautious_factor;
+          if (ys > cau) {
+            ++bound;
+            bound = m < bound ? m : bound;
+            const int newest = end;
+            end = (end + 1) % m;
+            int j = end;
+            double alpha = 0.0;  // lane `it` keeps alpha of the it-th visited slot (mem_size <= 64, host-checked)
+            for (int it = 0; it < bound; ++it) {
+              j = (j + m - 1) % m;
+              const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
+              double sd = 0.0, yv[2] = {0.0, 0.0};
+              q = 0;
+              for (int i = lane; i < n; i += 64, ++q) {
+                sd = __builtin_fma(sj[i * vs], dv[q], sd);
+                yv[q] = yj[i * vs];
+              }
+              sd = wave_sum(sd);
+              const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
+              const double al = sd / ysj;
+              alpha = (lane == it) ? al : alpha;
+              dv[0] = __builtin_fma(-al, yv[0], dv[0]);
+              dv[1] = __builtin_fma(-al, yv[1], dv[1]);
+            }
+            const double sc = ys / yy;
+            dv[0] *= sc;
+            dv[1] *= sc;
+            for (int it = 0; it < bound; ++it) {
+              const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
+              double yd = 0.0, sv[2] = {0.0, 0.0};
+              q = 0;
+              for (int i = lane; i < n; i += 64, ++q) {
+                yd = __builtin_fma(yj[i * vs], dv[q], yd);
+                sv[q] = sj[i * vs];
+              }
+              yd = wave_sum(yd);
+              const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
+              const double cf = __shfl(alpha, bound - 1 - it) - yd / ysj;
+              dv[0] = __builtin_fma(cf, sv[0], dv[0]);
+              dv[1] = __builtin_fma(cf, sv[1], dv[1]);
+              j = (j + 1) % m;
+            }
+          }
+          q = 0;
+          for (int i = lane; i < n; i += 64, ++q) d[i * vs] = dv[q];
+          step = 1.0;
+          start_ls = true;
+        }
+      }
+    }
+  }
+  if (start_ls) {
+    double dginit = 0.0;
+    for (int i = lane; i < n; i += 64) {
+      const double xi = x[i * ld], gi = g[i * ld];
+      xp[i * vs] = xi;
+      gp[i * vs] = gi;
+      dginit = __builtin_fma(gi, d[i * vs], dginit);
+    }
+    dginit = wave_sum(dginit);
+    if (!(step > 0.0)) {
+      finish = LBERR_INVALIDPARAMETERS;
+    } else if (0.0 < dginit) {
+      finish = LBERR_INCREASEGRADIENT;
+    } else {
+      finit = fx;
+      dgtest = P.f_dec_coeff * dginit;
+      dstest = P.s_curv_coeff * dginit;
+      mu = 0.0;
+      nu = P.max_step;
+      count = 0;
+      brackt = 0;
+      touched = 0;
+      for (int i = lane; i < n; i += 64) x[i * ld] = __builtin_fma(step, d[i * vs], xp[i * vs]);
+    }
+  }
+  if (lane == 0) {
+    ds[DS_FX * ld] = fx; ds[DS_STEP * ld] = step; ds[DS_FINIT * ld] = finit; ds[DS_DGTEST * ld] = dgtest;
+    ds[DS_DSTEST * ld] = dstest; ds[DS_MU * ld] = mu; ds[DS_NU * ld] = nu;
+    is[IS_K * ld] = k; is[IS_END * ld] = end; is[IS_BOUND * ld] = bound; is[IS_PHASE * ld] = phase;
+    is[IS_COUNT * ld] = count; is[IS_BRACKT * ld] = brackt; is[IS_TOUCHED * ld] = touched;
+    is[IS_EVALS * ld] = evals;
+    if (finish != 0x7fffffff) {
+      is[IS_DONE * ld] = 1;
+      is[IS_RET * ld] = finish;
+    } else if (a.n_active) {
+      atomicAdd(a.n_active, 1);
+    }
+  }
+}
+
+// firi::costMVIE (gcopter/firi.hpp:86-157): x = [p, rtd, cde], A is M x 3 column-major per problem
+// (field k*M + r), the reference's optData packing (firi.hpp:186-200).
+struct MvieArgs {
+  const double *A, *x;
+  double *f, *g;
+  const int *done;
+  int64_t B, ld;
+  int M;
+  double eps, wt;
+};
+__global__ void __launch_bounds__(64) k_mvie_eval(MvieArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  if (a.done && a.done[b]) return;
+  const int64_t ld = a.ld;
+  const double *x = a.x + b;
+  double p[3], rtd[3], cde[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    p[q] = x[q * ld];
+    rtd[q] = x[(3 + q) * ld];
+    cde[q] = x[(6 + q) * ld];
+  }
+  const double L00 = rtd[0] * rtd[0] + 2.220446049250313e-16, L11 = rtd[1] * rtd[1] + 2.220446049250313e-16,
+               L22 = rtd[2] * rtd[2] + 2.220446049250313e-16;
+  const double L10 = cde[0], L21 = cde[1], L20 = cde[2];
+  double cost = 0.0, gdp[3] = {0, 0, 0}, gdr[3] = {0, 0, 0}, gdc[3] = {0, 0, 0};
+  const double inv_mu = 1.0 / a.eps;
+  for (int r = 0; r < a.M; ++r) {
+    const double a0 = a.A[(int64_t)r * ld + b], a1 = a.A[(int64_t)(a.M + r) * ld + b],
+                 a2 = a.A[(int64_t)(2 * a.M + r) * ld + b];
+    const double al0 = a0 * L00 + a1 * L10 + a2 * L20, al1 = a1 * L11 + a2 * L21, al2 = a2 * L22;
+    const double nrm = sqrt(al0 * al0 + al1 * al1 + al2 * al2);
+    const double viol = nrm + (a0 * p[0] + a1 * p[1] + a2 * p[2]) - 1.0;
+    if (viol >= 0.0) {
+      double c, dc;
+      smoothed_l1(a.eps, inv_mu, viol, c, dc);
+      const double inv = 1.0 / nrm;
+      const double adj0 = al0 * inv, adj1 = al1 * inv, adj2 = al2 * inv;
+      const double v0 = dc * a0, v1 = dc * a1, v2 = dc * a2;
+      cost += c;
+      gdp[0] += v0; gdp[1] += v1; gdp[2] += v2;
+      gdr[0] += adj0 * v0; gdr[1] += adj1 * v1; gdr[2] += adj2 * v2;
+      gdc[0] += adj0 * v1;
+      gdc[1] += adj1 * v2;
+      gdc[2] += adj0 * v2;
+    }
+  }
+  cost *= a.wt;
+  cost -= log(L00) + log(L11) + log(L22);
+  const double Ld[3] = {L00, L11, L22};
+  double *g = a.g + b;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    g[q * ld] = gdp[q] * a.wt;
+    g[(3 + q) * ld] = (gdr[q] * a.wt - 1.0 / Ld[q]) * 2.0 * rtd[q];
+    g[(6 + q) * ld] = gdc[q] * a.wt;
+  }
+  a.f[b] = cost;
+}
+
+// GCOPTER's smooth bijection R -> (0, inf) for the durations (upstream gcopter.hpp forwardT /
+// backwardT; not part of the reference tree): T = tau>0 ? (tau/2+1)tau+1 : 1/((tau/2-1)tau+1).
+__device__ __forceinline__ double forward_T(double tau) {
+  return tau > 0.0 ? (0.5 * tau + 1.0) * tau + 1.0 : 1.0 / ((0.5 * tau - 1.0) * tau + 1.0);
+}
+__device__ __forceinline__ double dforward_T(double tau) {
+  if (tau > 0.0) return tau + 1.0;
+  const double den = (0.5 * tau - 1.0) * tau + 1.0;
+  return (1.0 - tau) / (den * den);
+}
+__device__ __forceinline__ double backward_T(double T) {
+  return T > 1.0 ? sqrt(2.0 * T - 1.0) - 1.0 : 1.0 - sqrt(2.0 / T - 1.0);
+}
+struct MapArgs {
+  double *x, *g;             // optimisation variables / gradient [n][ld]
+  double *wps, *T;           // trajectory parameters
+  const double *gradP, *gradT;
+  int64_t B, ld;
+  int nw, nt;                // optimised waypoint coordinates (0 or 3(N-1)), optimised durations (0 or N)
+  int mode;                  // 0: params -> x (init), 1: x -> params, 2: (gradP, gradT) -> g
+};
+__global__ void __launch_bounds__(256) k_minco_map(MapArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const int64_t ld = a.ld;
+  const int v = blockIdx.y;  // variable index: [0, nw) waypoint coordinates, [nw, nw+nt) durations
+  if (v < a.nw) {
+    const int64_t i = (int64_t)v * ld + b;
+    if (a.mode == 0) a.x[i] = a.wps[i];
+    else if (a.mode == 1) a.wps[i] = a.x[i];
+    else a.g[i] = a.gradP[i];
+  } else {
+    const int64_t xi = (int64_t)v * ld + b, ti = (int64_t)(v - a.nw) * ld + b;
+    if (a.mode == 0) a.x[xi] = backward_T(a.T[ti]);
+    else if (a.mode == 1) a.T[ti] = forward_T(a.x[xi]);
+    else a.g[xi] = a.gradT[ti] * dforward_T(a.x[xi]);
+  }
+}
+
+}  // namespace anet

@@ -1,0 +1,463 @@
+// MINCO kernels: coefficient solve + energy (k_minco_solve), per-piece partial gradients with the
+// penalty functional (k_piece_grad), adjoint propagation (k_minco_propagate).  One lane per trajectory
+// (or per (trajectory, piece)); batch-minor global layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "minco_core.h"
+
+namespace anet {
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+struct SolveArgs {
+  const double *head, *tail, *wps, *T;
+  double *coeffs, *energy;
+  int64_t B, ld;
+  int N, c;
+};
+
+constexpr int kSolveBlock = 64;
+
+// One lane = one trajectory.  The block-tridiagonal factor is shared by the three axes and stays
+// in registers; the axes are swept one after the other so only one axis' right-hand side is live.
+// NEXACT: the piece count is exactly NB (compile time); NPC >= 0: c-1 is NPC (compile time).
+// Both let every end-node / pinned-derivative mask fold away; the generic instantiation
+// (NEXACT = false, NPC = -1) keeps them as wave-uniform selects.
+template <int S, int NB, bool NEXACT = false, int NPC = -1>
+__global__ void __launch_bounds__(kSolveBlock) k_minco_solve(SolveArgs a) {
+  constexpr int m = S - 1, D = 2 * S;
+  const int64_t b = (int64_t)blockIdx.x * kSolveBlock + threadIdx.x;
+  if (b >= a.B) return;
+  const int N = NEXACT ? NB : a.N;
+  const int np = NPC >= 0 ? NPC : a.c - 1;
+  const int c = np + 1;
+  const int64_t ld = a.ld;
+
+  Factor<S, NB> F;
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < N) F.r[i] = fast_rcp(a.T[i * ld + b]);
+  F.factorize(N, np);
+
+  double etot = 0.0;
+#pragma unroll 1
+  for (int ax = 0; ax < 3; ++ax) {
+    double P[NB + 1], hv[m], tv[m], X[NB + 1][m];
+    const double *hp = a.head + (int64_t)(ax * c) * ld + b;
+    const double *tp = a.tail + (int64_t)(ax * c) * ld + b;
+#pragma unroll
+    for (int k = 0; k <= NB; ++k) {
+      if (k == 0)
+        P[k] = hp[0];
+      else if (k < N)
+        P[k] = a.wps[(int64_t)((k - 1) * 3 + ax) * ld + b];
+      else if (k == N)
+        P[k] = tp[0];
+      else
+        P[k] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      hv[j] = (j < np) ? hp[(int64_t)(1 + j) * ld] : 0.0;
+      tv[j] = (j < np) ? tp[(int64_t)(1 + j) * ld] : 0.0;
+    }
+    double *cp = a.coeffs ? a.coeffs + (int64_t)(ax * D) * ld + b : nullptr;
+    etot += solve_axis<S, NB>(F, N, np, P, hv, tv, X, [&](int piece, int col, double v) {
+      if (cp) cp[(int64_t)(piece * 3 * D + col) * ld] = v;
+    });
+  }
+  if (a.energy) a.energy[b] = etot;
+}
+
+// ------------------------------------------------------------------------------------------
+// cost / gradient path: partial gradients per piece, then adjoint propagation per trajectory
+// ------------------------------------------------------------------------------------------
+struct Penalty {
+  double rho, wc, wv, wa, mu, vmax, amax;
+  int res, M;
+};
+
+// firi::smoothedL1 (gcopter/firi.hpp:60-84), 0 below 0.
+__device__ __forceinline__ void smoothed_l1(double mu, double inv_mu, double x, double &f, double &df) {
+  const double xd = x * inv_mu, sq = xd * xd, mm = __builtin_fma(-0.5, x, mu);
+  double fm = mm * sq * xd, dm = sq * __builtin_fma(-0.5, xd, 3.0 * mm * inv_mu);
+  const bool hi = x > mu, neg = x < 0.0;
+  f = neg ? 0.0 : (hi ? x - 0.5 * mu : fm);
+  df = neg ? 0.0 : (hi ? 1.0 : dm);
+}
+
+struct PieceGradArgs {
+  const double *coeffs, *T, *hpolys;
+  double *gdC, *gdT, *pcost;
+  int64_t B, ld;
+  int N, with_energy, with_penalty;
+  Penalty pp;
+};
+
+// One lane per (trajectory, piece): blockIdx.y = piece.  Writes (not accumulates) the partial
+// gradients of  [with_energy] int (p^(s))^2  +  [with_penalty] J_pen  w.r.t. the piece's
+// coefficients and duration.  J_pen = (T/res) sum_{j<res} [wc sum_rows phi(a.p-b) + wv sum phi(+-v-vmax)
+// + wa sum phi(+-a-amax)] sampled at t = j T/res: the rows of the reference's inequality block
+// (qp_solver.hpp:244-296 / min_traj_opt.py:535-613) turned into a smoothed-L1 penalty.
+template <int S>
+__global__ void __launch_bounds__(256) k_piece_grad(PieceGradArgs a) {
+  constexpr int D = 2 * S;
+  extern __shared__ double tab[];  // [res][4][D] basis rows in normalised time
+  if (a.with_penalty) {
+    for (int e = threadIdx.x; e < a.pp.res * 4 * D; e += 256) {
+      const int j = e / (4 * D), d = (e / D) % 4, col = e % D, k = D - 1 - col;
+      const double tau = (double)j / (double)a.pp.res;
+      double v = 0.0;
+      if (k >= d) {
+        v = 1.0;
+        for (int q = 0; q < d; ++q) v *= (double)(k - q);
+        for (int q = 0; q < k - d; ++q) v *= tau;
+      }
+      tab[e] = v;
+    }
+    __syncthreads();
+  }
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const int i = blockIdx.y;
+  const int64_t ld = a.ld;
+  const double Ti = a.T[(int64_t)i * ld + b];
+  double c[3][D], gC[3][D];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+    for (int col = 0; col < D; ++col) {
+      c[ax][col] = a.coeffs[(int64_t)((i * 3 + ax) * D + col) * ld + b];
+      gC[ax][col] = 0.0;
+    }
+  double gT = 0.0, pc = 0.0;
+  if (a.with_energy) {
+    // d/dc of sum_{j,k>=S} c_j c_k f_j f_k T^(j+k-2S+1)/(j+k-2S+1) ;  d/dT = (p^(S)(T))^2
+    double tp[D];
+    tp[0] = 1.0;
+#pragma unroll
+    for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      double ps = 0.0;
+#pragma unroll
+      for (int j = S; j < D; ++j) {
+        double fj = 1.0;
+#pragma unroll
+        for (int e = 0; e < S; ++e) fj *= (double)(j - e);
+        ps = __builtin_fma(fj * tp[j - S], c[ax][D - 1 - j], ps);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = S; k < D; ++k) {
+          double fk = 1.0;
+#pragma unroll
+          for (int e = 0; e < S; ++e) fk *= (double)(k - e);
+          acc = __builtin_fma(2.0 * fj * fk / (double)(j + k - 2 * S + 1) * tp[j + k - 2 * S + 1],
+                              c[ax][D - 1 - k], acc);
+        }
+        gC[ax][D - 1 - j] = acc;
+      }
+      gT = __builtin_fma(ps, ps, gT);
+    }
+  }
+  if (a.with_penalty) {
+    // Normalised time: with c~_k = c_k T^k the state rows at sample j depend on tau_j = j/res only,
+    //   d^d p/dt^d (t_j) = T^-d sum_col c~[col] tab[j][d][col],  tab[j][d][col] = k!/(k-d)! tau_j^(k-d)
+    // the table is built once per block in LDS and read with a wave-uniform index (broadcast).
+    const Penalty pp = a.pp;
+    const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
+    const double step = Ti * inv_res;
+    const double rT = 1.0 / Ti, rT2 = rT * rT, rT3 = rT2 * rT;
+    double ct[3][D];  // c~
+    {
+      double tk = 1.0;
+#pragma unroll
+      for (int col = D - 1; col >= 0; --col) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) ct[ax][col] = c[ax][col] * tk;
+        tk *= Ti;
+      }
+    }
+    double gN[3][D];  // gradient w.r.t. c~
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+      for (int col = 0; col < D; ++col) gN[ax][col] = 0.0;
+    // Polytope rows are held in registers, RC at a time, and the sample loop runs inside: re-reading
+    // them from L2 for every sample (res x M x 32 B per lane) was the bottleneck of this kernel.
+    constexpr int RC = 8;
+    const int nchunk = a.hpolys ? (pp.M + RC - 1) / RC : 0;
+    for (int ch = 0; ch < (nchunk > 0 ? nchunk : 1); ++ch) {
+      double hr[RC][4];
+#pragma unroll
+      for (int r = 0; r < RC; ++r) {
+        const int rr = ch * RC + r;
+        const bool ok = a.hpolys && rr < pp.M;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          hr[r][q] = ok ? a.hpolys[(int64_t)((i * pp.M + rr) * 4 + q) * ld + b] : 0.0;
+      }
+      const bool first = (ch == 0);  // box rows are evaluated with the first chunk
+      for (int j = 0; j < pp.res; ++j) {
+        const double *tb = tab + (size_t)j * 4 * D;
+        double st[4][3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            double acc = 0.0;
+#pragma unroll
+            for (int col = 0; col < D; ++col) acc = __builtin_fma(ct[ax][col], tb[d * D + col], acc);
+            st[d][ax] = acc * (d == 0 ? 1.0 : d == 1 ? rT : d == 2 ? rT2 : rT3);
+          }
+        double cost = 0.0, g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // d cost / d (p,v,a)
+        bool active = false;
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+          const double viol =
+              __builtin_fma(hr[r][0], st[0][0], __builtin_fma(hr[r][1], st[0][1], hr[r][2] * st[0][2])) - hr[r][3];
+          if (__any(viol > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
+            double f, df;
+            smoothed_l1(pp.mu, inv_mu, viol, f, df);
+            cost = __builtin_fma(pp.wc, f, cost);
+            df *= pp.wc;
+            g[0][0] = __builtin_fma(df, hr[r][0], g[0][0]);
+            g[0][1] = __builtin_fma(df, hr[r][1], g[0][1]);
+            g[0][2] = __builtin_fma(df, hr[r][2], g[0][2]);
+            active = true;
+          }
+        }
+        if (first) {
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            const double av = fabs(st[1][ax]) - pp.vmax, aa_ = fabs(st[2][ax]) - pp.amax;
+            if (__any(av > 0.0)) {  // only one of +v, -v can be violated
+              double f, df;
+              smoothed_l1(pp.mu, inv_mu, av, f, df);
+              cost = __builtin_fma(pp.wv, f, cost);
+              g[1][ax] = __builtin_fma(pp.wv * (st[1][ax] < 0.0 ? -1.0 : 1.0), df, g[1][ax]);
+              active = true;
+            }
+            if (__any(aa_ > 0.0)) {
+              double f, df;
+              smoothed_l1(pp.mu, inv_mu, aa_, f, df);
+              cost = __builtin_fma(pp.wa, f, cost);
+              g[2][ax] = __builtin_fma(pp.wa * (st[2][ax] < 0.0 ? -1.0 : 1.0), df, g[2][ax]);
+              active = true;
+            }
+          }
+        }
+        if (__any(active)) {
+          pc = __builtin_fma(step, cost, pc);
+          double dt = 0.0;  // d cost / d t = g_p.v + g_v.a + g_a.j
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) dt = __builtin_fma(g[d][ax], st[d + 1][ax], dt);
+          gT += cost * inv_res + step * dt * ((double)j * inv_res);
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            const double g0 = step * g[0][ax], g1 = step * g[1][ax] * rT, g2 = step * g[2][ax] * rT2;
+#pragma unroll
+            for (int col = 0; col < D; ++col) {
+              double acc = g0 * tb[col];
+              acc = __builtin_fma(g1, tb[D + col], acc);
+              acc = __builtin_fma(g2, tb[2 * D + col], acc);
+              gN[ax][col] += acc;
+            }
+          }
+        }
+      }
+    }
+    {  // d/dc = T^k d/dc~
+      double tk = 1.0;
+#pragma unroll
+      for (int col = D - 1; col >= 0; --col) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) gC[ax][col] = __builtin_fma(gN[ax][col], tk, gC[ax][col]);
+        tk *= Ti;
+      }
+    }
+  }
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+    for (int col = 0; col < D; ++col) a.gdC[(int64_t)((i * 3 + ax) * D + col) * ld + b] = gC[ax][col];
+  a.gdT[(int64_t)i * ld + b] = gT;
+  if (a.pcost) a.pcost[(int64_t)i * ld + b] = pc;
+}
+
+struct PropArgs {
+  const double *T, *coeffs, *gdC, *gdT;
+  double *gradP, *gradT;
+  // optional total cost: cost = energy_in + rho sum T + sum_i pcost_i ; gradT += rho
+  const double *energy_in, *pcost;
+  double *cost;
+  double rho;
+  int64_t B, ld;
+  int N, c;
+};
+
+// MINCO propogateGrad: given the partial gradients (gdC, gdT) of a scalar J(c, T), return its total
+// gradient w.r.t. the interior waypoints and the durations, c = c(waypoints, T) being the minimum-
+// control-effort coefficients.  Adjoint of the Hermite/block-tridiagonal solve:
+//   g_x = Phi' gdC (node-state adjoint), K lam = g_x|free, gradP_k = g_x[k].p - (W lam^)[p rows],
+//   gradT_i = gdT_i + gdC_i.(dPhi_i/dT) x^ - lam^' (dW_i/dT) x^.
+template <int S, int NB, bool NEXACT = false, int NPC = -1>
+__global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
+  constexpr int m = S - 1, D = 2 * S;
+  const int64_t b = (int64_t)blockIdx.x * kSolveBlock + threadIdx.x;
+  if (b >= a.B) return;
+  const int N = NEXACT ? NB : a.N;
+  const int np = NPC >= 0 ? NPC : a.c - 1;
+  const int64_t ld = a.ld;
+
+  Factor<S, NB> F;
+  double gT[NB];
+  double tsum = 0.0, Tlast = 0.0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < N) {
+      const double t = a.T[i * ld + b];
+      F.r[i] = fast_rcp(t);
+      gT[i] = a.gdT[i * ld + b];
+      tsum += t;
+      if (i == N - 1) Tlast = t;
+    }
+  F.factorize(N, np);
+
+#pragma unroll 1
+  for (int ax = 0; ax < 3; ++ax) {
+    double rr[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
+    // ---- node states from the coefficients: x_k[j] = j! c_j(piece k); last node by evaluation
+    double XS[NB + 1][S], GX[NB + 1][S], XA[NB + 1][m];
+#pragma unroll
+    for (int k = 0; k <= NB; ++k)
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        XS[k][j] = 0.0;
+        GX[k][j] = 0.0;
+      }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (k < N) {
+        double fact = 1.0;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          if (j > 0) fact *= (double)j;
+          XS[k][j] = fact * a.coeffs[(int64_t)((k * 3 + ax) * D + (D - 1 - j)) * ld + b];
+        }
+        if (k == N - 1) {
+          double cl[D], tp[D];
+          tp[0] = 1.0;
+#pragma unroll
+          for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Tlast;
+#pragma unroll
+          for (int col = 0; col < D; ++col) cl[col] = a.coeffs[(int64_t)((k * 3 + ax) * D + col) * ld + b];
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int p = j; p < D; ++p) {
+              double f = 1.0;
+#pragma unroll
+              for (int e = 0; e < j; ++e) f *= (double)(p - e);
+              acc = __builtin_fma(f * tp[p - j], cl[D - 1 - p], acc);
+            }
+            XS[k + 1][j] = acc;
+          }
+        }
+      }
+    // ---- g_x = Phi' gdC and the direct dPhi/dT term
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (i < N) {
+        Pw<S> p(rr[i]);
+        double gc[D];
+#pragma unroll
+        for (int col = 0; col < D; ++col) gc[col] = a.gdC[(int64_t)((i * 3 + ax) * D + col) * ld + b];
+        // low powers k < S: c_k = x_i[k]/k!
+        double fact = 1.0;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+          if (k > 0) fact *= (double)k;
+          GX[i][k] = __builtin_fma(gc[D - 1 - k], 1.0 / fact, GX[i][k]);
+        }
+        double h[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) h[q] = gc[S - 1 - q] * p[q];  // gc of power S+q times r^q
+        double dsum = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < 2 * S; ++bb) {
+          const int dg = bb % S;
+          double u = 0.0, qd = 0.0;
+#pragma unroll
+          for (int q = 0; q < S; ++q) {
+            u = __builtin_fma(Tab<S>::BHI[q][bb], h[q], u);
+            qd = __builtin_fma((double)(S + q - dg) * Tab<S>::BHI[q][bb], h[q], qd);
+          }
+          const double sc = p[S - dg];
+          const double xb = (bb < S) ? XS[i][dg] : XS[i + 1][dg];
+          if (bb < S)
+            GX[i][dg] = __builtin_fma(u, sc, GX[i][dg]);
+          else
+            GX[i + 1][dg] = __builtin_fma(u, sc, GX[i + 1][dg]);
+          dsum = __builtin_fma(xb * sc, qd, dsum);
+        }
+        gT[i] = __builtin_fma(-p[1], dsum, gT[i]);
+      }
+    // ---- adjoint solve K lam = g_x|free (pinned rows 0)
+    sweep_forward<S, NB>(F, N, np, rr, XA, [&](int k, double (&y)[m]) {
+#pragma unroll
+      for (int l = 0; l < m; ++l) y[l] = ((k == 0 || k == N) && l < np) ? 0.0 : GX[k][1 + l];
+    });
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
+    sweep_backward<S, NB>(F, N, np, rr, XA, [&](int k, const Pw<S> &p) {
+      // (W_k lam^)[position row of node k]; the row of node k+1 is its negative
+      double wl = 0.0;
+#pragma unroll
+      for (int l = 0; l < m; ++l) {
+        wl = __builtin_fma(Tab<S>::M[0][1 + l] * p[2 * S - 2 - l], XA[k][l], wl);
+        wl = __builtin_fma(Tab<S>::M[0][S + 1 + l] * p[2 * S - 2 - l], XA[k + 1][l], wl);
+      }
+      GX[k][0] -= wl;
+      GX[k + 1][0] += wl;
+      // - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b
+      double xs[2 * S];
+#pragma unroll
+      for (int bb = 0; bb < 2 * S; ++bb)
+        xs[bb] = ((bb < S) ? XS[k][bb % S] : XS[k + 1][bb % S]) * p[S - bb % S];
+      double acc = 0.0;
+#pragma unroll
+      for (int aa = 0; aa < 2 * S; ++aa) {
+        const int da = aa % S;
+        if (da == 0) continue;
+        double row = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < 2 * S; ++bb)
+          row = __builtin_fma(Tab<S>::M[aa][bb] * (double)(2 * S - 1 - da - bb % S), xs[bb], row);
+        const double ls = ((aa < S) ? XA[k][da - 1] : XA[k + 1][da - 1]) * p[S - da];
+        acc = __builtin_fma(ls, row, acc);
+      }
+      gT[k] += acc;
+    });
+#pragma unroll
+    for (int k = 1; k < NB; ++k)
+      if (k < N) a.gradP[(int64_t)((k - 1) * 3 + ax) * ld + b] = GX[k][0];
+  }
+  double csum = 0.0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < N) {
+      a.gradT[i * ld + b] = gT[i] + a.rho;
+      if (a.pcost) csum += a.pcost[i * ld + b];
+    }
+  if (a.cost) a.cost[b] = (a.energy_in ? a.energy_in[b] : 0.0) + a.rho * tsum + csum;
+}
+
+}  // namespace anet
