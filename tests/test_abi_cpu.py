@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     txt = open(os.path.join(ROOT, "include", "allocnet_amd.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(anet_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(anet_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 def test_header_symbols_are_exported():
