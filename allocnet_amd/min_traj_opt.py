@@ -1,0 +1,141 @@
+"""Host mirrors of the reference's training-side QP objects:
+
+  MinTrajOpt  network/utils/min_traj_opt.py:19-178   (params dict, update(...) -> .params=[Q,A,b,G1,h1,G2,h2])
+  OsqpLayer   network/utils/learning/layers.py:35-247 (forward / forward4lstm: solve + loss terms)
+
+Assembly and solve run on the GPU (anet_qp_assemble / anet_qp_solve).  There is no autograd tape here;
+what the reference's backward pass delivers to the segment times is returned explicitly: in layers.py
+the QP solution is a detached leaf (:121,222), so d(objc)/dTimes flows only through Q(T) -- that is
+`OsqpLayer.time_grad` (anet_traj_cost_grad_T / path_length), plus 1/segments from the mean-time term.
+"""
+import numpy as np
+
+from . import qp as _qp
+from .trajectory import traj_cost_grad_T
+
+
+class MinTrajOpt:
+    def __init__(self, params, ctx=None):
+        if not isinstance(params, dict):
+            raise ValueError("pass the parameter dict (the reference reads utils/params.yaml when given [])")
+        self.params_cfg = params
+        self.order = params["planning"]["order"]
+        self.state_dim = params["planning"]["state_dim"]
+        self.dim = params["planning"]["dim"]
+        self.res = params["planning"]["res"]
+        self.D = 2 * self.order
+        self.use_time_factor = params["planning"]["use_time_factor"]
+        if self.use_time_factor:
+            raise NotImplementedError("use_time_factor is false in the reference configuration (utils/params.yaml:24)")
+        self.phy_limits = [params["physical_limits"][k] for k in ("max_vel", "max_acc", "max_jerk")]
+        self.phase1_phy_limits = [params["phase1_physical_limits"][k] for k in ("max_vel", "max_acc", "max_jerk", "inf_dis")]
+        self._ctx = ctx
+
+    def update(self, state, hpolys, time_factor, phase=1, traj_times=None, seq_len=5):
+        """state (9,2): rows px,vx,ax,py,..; col 0 start, col 1 end.  hpolys (rows,4,seq_len) zero padded.
+        time_factor (seq_len,): segment times (network output).  min_traj_opt.py:68-178."""
+        state = np.asarray(state, dtype=np.float64)
+        hpolys = np.asarray(hpolys, dtype=np.float64)
+        tf = np.asarray(time_factor, dtype=np.float64)
+        self.hpolys = []
+        for i in range(seq_len):
+            poly = hpolys[:, :, i]
+            if np.linalg.norm(poly) <= 1.0:          # :78-79 (float32 norm in the reference; same threshold)
+                break
+            for j in range(poly.shape[0]):           # :82-85 strip the zero-padded rows
+                if np.linalg.norm(poly[j, :]) <= 0.0:
+                    poly = poly[0:j, :]
+                    break
+            self.hpolys.append(poly)
+        self.seg = len(self.hpolys)
+        if self.seg == 0:
+            raise ValueError("no polytope survives the zero-padding test")
+        self.start_state = state[:, 0]
+        self.end_state = state[:, 1]
+        self.start = np.array([self.start_state[0], self.start_state[3], self.start_state[6]])
+        self.goal = np.array([self.end_state[0], self.end_state[3], self.end_state[6]])
+        self.var_num = self.seg * self.dim * self.D
+        self.eq_num = (2 * self.state_dim + self.order * (self.seg - 1)) * self.dim
+        const_num = sum(p.shape[0] for p in self.hpolys)
+        self.ineq_num1 = self.res * const_num
+        self.ineq_num2 = self.res * 4 * self.dim * self.seg
+        self.ineq_num = self.ineq_num1 + self.ineq_num2
+        self.Times = tf
+        self.path_length = float(np.linalg.norm(self.goal - self.start))
+        if traj_times is not None:
+            self.ref_time_factor = np.asarray(traj_times, dtype=np.float64)
+        lim = self.phase1_phy_limits if phase == 1 else self.phy_limits
+        ini = self.start_state.reshape(3, 3)
+        fin = self.end_state.reshape(3, 3)
+        Q, A, b, G, h = _qp.qp_assemble(self.order, ini, fin, self.hpolys, tf[:self.seg], res=self.res,
+                                        max_vel=lim[0], max_acc=lim[1], row_order=_qp.ORDER_PYTHON, ctx=self._ctx)
+        n1 = self.ineq_num1
+        self._limits = (lim[0], lim[1])
+        self.params = [Q, A, b, G[:n1], h[:n1], G[n1:], h[n1:]]
+
+
+class OsqpLayer:
+    """Solve + loss terms of layers.py:51-151 (forward) and :153-247 (forward4lstm)."""
+
+    def __init__(self, ctx=None):
+        self._ctx = ctx
+        self.time_grad = None
+
+    def _solve(self, qp_traj):
+        M = max(p.shape[0] for p in qp_traj.hpolys)
+        hp = np.zeros((1, qp_traj.seg, M, 4))
+        for i, p in enumerate(qp_traj.hpolys):
+            hp[0, i, :p.shape[0]] = p
+        ini = qp_traj.start_state.reshape(1, 3, 3)
+        fin = qp_traj.end_state.reshape(1, 3, 3)
+        T = qp_traj.Times[:qp_traj.seg][None]
+        out = _qp.qp_solve(qp_traj.order, ini, fin, hp, T, res=qp_traj.res, max_vel=qp_traj._limits[0],
+                           max_acc=qp_traj._limits[1], ctx=self._ctx)
+        return out, T
+
+    def forward(self, qp_traj):
+        segments = qp_traj.seg
+        Times = qp_traj.Times
+        out, T = self._solve(qp_traj)
+        curr_obj1_val = float(np.sum(Times[:segments]) / (1.0 * segments))
+        zero_segments = 5 - segments
+        curr_padding_loss = float(np.mean(Times[segments:] ** 2)) if zero_segments != 0 else 0.0
+        if out["status"][0] != 1:
+            curr_objt_val = None
+            if hasattr(qp_traj, "ref_time_factor"):
+                curr_objt_val = float(np.mean((Times[:segments] - qp_traj.ref_time_factor[:segments]) ** 2) / segments
+                                      + curr_padding_loss)
+            self.time_grad = None
+            return None, curr_obj1_val, curr_objt_val, None, curr_padding_loss
+        z = out["coeffs"][0].reshape(-1)
+        curr_objc_val = float(out["obj"][0] / qp_traj.path_length)
+        g = traj_cost_grad_T(out["coeffs"], T, m34=1400.0, ctx=self._ctx)[0] / qp_traj.path_length
+        self.time_grad = np.zeros_like(Times)
+        self.time_grad[:segments] = g
+        return z, curr_obj1_val, None, curr_objc_val, curr_padding_loss
+
+    def forward4lstm(self, qp_traj, pred_stop_tokens, seq_len=5):
+        segments = qp_traj.seg
+        Times = qp_traj.Times
+        out, T = self._solve(qp_traj)
+        curr_obj1_val = float(np.sum(Times[:segments]) / (1.0 * segments))
+        pred = np.asarray(pred_stop_tokens, dtype=np.float64)
+        gt = np.concatenate([np.zeros(segments - 1), np.ones(seq_len - segments + 1)])
+        end_penalty, thresh = 5.0, 0.42                                     # layers.py:190-191
+        premature = float(np.sum((pred > thresh) & (gt < thresh)) * end_penalty)
+        late = float(np.sum((pred < thresh) & (gt > thresh)) * end_penalty)
+        eps = 1e-12
+        bce = float(-np.mean(gt * np.log(np.clip(pred, eps, 1)) + (1 - gt) * np.log(np.clip(1 - pred, eps, 1))))
+        stop_token_loss = bce + premature + late
+        if out["status"][0] != 1:
+            curr_objt_val = None
+            if hasattr(qp_traj, "ref_time_factor"):
+                curr_objt_val = float(np.mean((Times[:segments] - qp_traj.ref_time_factor[:segments]) ** 2) / segments)
+            self.time_grad = None
+            return None, curr_obj1_val, curr_objt_val, None, stop_token_loss
+        z = out["coeffs"][0].reshape(-1)
+        curr_objc_val = float(out["obj"][0] / qp_traj.path_length)
+        g = traj_cost_grad_T(out["coeffs"], T, m34=1400.0, ctx=self._ctx)[0] / qp_traj.path_length
+        self.time_grad = np.zeros_like(Times)
+        self.time_grad[:segments] = g
+        return z, curr_obj1_val, None, curr_objc_val, stop_token_loss

@@ -1,0 +1,61 @@
+"""The Python training-side mirrors (MinTrajOpt.update, OsqpLayer.forward) against the fixtures made by
+importing the reference's MinTrajOpt with the same inputs (50x4xseq_len zero-padded polytopes)."""
+import numpy as np
+import pytest
+
+from tests.util import golden_files
+from tests.golden.make_golden import make_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("path", golden_files())
+def test_min_traj_opt_update_matches_reference(anet_ctx, path):
+    import allocnet_amd as aa
+    from tests.test_qp_assembly_gpu import _expand
+    d = np.load(path)
+    s, N, res, phase = int(d["order"]), int(d["N"]), int(d["res"]), int(d["phase"])
+    hp50 = np.zeros((50, 4, N)); hp50[:16] = d["hpolys"]
+    opt = aa.MinTrajOpt(make_params(s, res), ctx=anet_ctx)
+    opt.update(d["state"], hp50, d["T"], phase=phase, seq_len=N)
+    assert opt.seg == N and opt.var_num == 3 * 2 * s * N
+    assert abs(opt.path_length - float(d["path_length"])) < 1e-12
+    Q, A, b, G1, h1, G2, h2 = opt.params
+    Gref, href = _expand(d, N, 2 * s)
+    n1 = d["h1"].shape[0]
+    for got, ref in [(Q, d["Q"]), (A, d["A"]), (b, d["b"]), (G1, Gref[:n1]), (h1, d["h1"]), (G2, Gref[n1:]), (h2, d["h2"])]:
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 4e-16 * max(1.0, np.abs(ref).max())
+
+
+def test_osqp_layer_forward(anet_ctx):
+    import allocnet_amd as aa
+    from tests.test_qp_solve_gpu import _corridor_problem
+    rng = np.random.default_rng(21)
+    ini, fin, hp, T = _corridor_problem(rng, 3, 8)
+    state = np.zeros((9, 2))
+    state[:, 0] = ini.reshape(-1); state[:, 1] = fin.reshape(-1)
+    hp50 = np.zeros((50, 4, 5))
+    for i in range(3):
+        rows = hp[i][np.abs(hp[i]).sum(axis=1) > 0]
+        hp50[:rows.shape[0], :, i] = rows
+    times = np.r_[T, 0.0, 0.0]
+    opt = aa.MinTrajOpt(make_params(4, 10, vmax=3.0, amax=4.0), ctx=anet_ctx)
+    opt.update(state, hp50, times, phase=2, seq_len=5)
+    assert opt.seg == 3
+    layer = aa.OsqpLayer(ctx=anet_ctx)
+    z, obj1, objt, objc, pad = layer.forward(opt)
+    assert z is not None and z.shape == (3 * 3 * 8,) and objt is None
+    assert abs(obj1 - T.sum() / 3) < 1e-12 and pad == 0.0
+    Q = opt.params[0]
+    assert abs(objc - 0.5 * z @ Q @ z / opt.path_length) <= 1e-9 * max(1.0, objc)
+    # time gradient == finite difference of 1/2 z'Q(T)z / path_length with z held fixed (the reference's backward)
+    h = 1e-6
+    for i in range(3):
+        tp = times.copy(); tp[i] += h; tm = times.copy(); tm[i] -= h
+        op = aa.MinTrajOpt(make_params(4, 10, vmax=3.0, amax=4.0), ctx=anet_ctx); op.update(state, hp50, tp, phase=2, seq_len=5)
+        om = aa.MinTrajOpt(make_params(4, 10, vmax=3.0, amax=4.0), ctx=anet_ctx); om.update(state, hp50, tm, phase=2, seq_len=5)
+        fd = (0.5 * z @ op.params[0] @ z - 0.5 * z @ om.params[0] @ z) / (2 * h) / opt.path_length
+        assert abs(fd - layer.time_grad[i]) <= 1e-5 * max(1.0, abs(fd))
+    z2, o1, ot, oc, stl = layer.forward4lstm(opt, np.array([0.1, 0.2, 0.9, 0.95, 0.99]), seq_len=5)
+    assert z2 is not None and stl > 0 and abs(oc - objc) <= 1e-2 * max(1.0, objc)
