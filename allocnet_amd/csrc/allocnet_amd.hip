@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 #include <new>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen()ed
 
 #include "../../include/allocnet_amd.h"
 #include "minco_core.h"
@@ -32,6 +34,9 @@ struct anet_ctx {
   // L-BFGS completion polling: device counter + pinned host mirror
   int *d_counter = nullptr;
   int *h_counter = nullptr;
+  // RCCL communicator for the all-gather of costs
+  ncclComm_t comm = nullptr;
+  int comm_ranks = 0;
 };
 
 namespace {
@@ -254,6 +259,7 @@ void anet_destroy(anet_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->comm) (void)anet_comm_destroy(ctx);
   if (ctx->d_counter) (void)hipFree(ctx->d_counter);
   if (ctx->h_counter) (void)hipHostFree(ctx->h_counter);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1068,6 +1074,93 @@ int anet_traj_cost_grad_T(anet_ctx *ctx, int s, int n_pieces, int64_t batch, con
   rc = anet_traj_cost_grad_T_dev(ctx, s, n_pieces, batch, st.ld, d_co, d_T, m34, d_g, ctx->stream);
   if (rc) return rc;
   return st.download(d_g, n_pieces, gradT);
+}
+
+// ---- RCCL (loaded at run time) -------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+int load_rccl(anet_ctx *ctx) {
+  if (g_rccl.handle) return ANET_OK;
+  const char *env = getenv("ANET_RCCL_PATH");
+  const char *cands[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+  void *h = nullptr;
+  for (const char *c : cands) {
+    if (!c || !*c) continue;
+    h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return fail(ctx, ANET_ERR_UNSUPPORTED, std::string("cannot load librccl.so: ") + dlerror());
+  RcclApi a;
+  a.handle = h;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+  a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy)
+    return fail(ctx, ANET_ERR_UNSUPPORTED, "librccl.so lacks the expected nccl* symbols");
+  g_rccl = a;
+  return ANET_OK;
+}
+int rccl_fail(anet_ctx *ctx, ncclResult_t r, const char *what) {
+  return fail(ctx, ANET_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"));
+}
+}  // namespace
+
+int anet_comm_unique_id(anet_ctx *ctx, unsigned char id[ANET_COMM_ID_BYTES]) {
+  if (!ctx || !id) return fail(ctx, ANET_ERR_INVALID, "anet_comm_unique_id: NULL argument");
+  int rc = load_rccl(ctx);
+  if (rc) return rc;
+  static_assert(sizeof(ncclUniqueId) == ANET_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId u;
+  ncclResult_t r = g_rccl.GetUniqueId(&u);
+  if (r != ncclSuccess) return rccl_fail(ctx, r, "ncclGetUniqueId");
+  memcpy(id, &u, ANET_COMM_ID_BYTES);
+  return ANET_OK;
+}
+
+int anet_comm_init(anet_ctx *ctx, int nranks, int rank, const unsigned char id[ANET_COMM_ID_BYTES]) {
+  if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, ANET_ERR_INVALID, "anet_comm_init: bad argument");
+  if (ctx->comm) return fail(ctx, ANET_ERR_INVALID, "anet_comm_init: communicator already initialised");
+  int rc = load_rccl(ctx);
+  if (rc) return rc;
+  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId u;
+  memcpy(&u, id, ANET_COMM_ID_BYTES);
+  ncclResult_t r = g_rccl.CommInitRank(&ctx->comm, nranks, u, rank);
+  if (r != ncclSuccess) {
+    ctx->comm = nullptr;
+    return rccl_fail(ctx, r, "ncclCommInitRank");
+  }
+  ctx->comm_ranks = nranks;
+  return ANET_OK;
+}
+
+int anet_comm_allgather_costs_dev(anet_ctx *ctx, const double *send, double *recv, int64_t count, void *stream) {
+  if (!ctx || !ctx->comm) return fail(ctx, ANET_ERR_INVALID, "anet_comm_allgather_costs_dev: call anet_comm_init first");
+  if (!send || !recv || count < 0) return fail(ctx, ANET_ERR_INVALID, "anet_comm_allgather_costs_dev: bad argument");
+  if (count == 0) return ANET_OK;
+  ncclResult_t r = g_rccl.AllGather(send, recv, (size_t)count, ncclFloat64, ctx->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) return rccl_fail(ctx, r, "ncclAllGather");
+  return ANET_OK;
+}
+
+int anet_comm_destroy(anet_ctx *ctx) {
+  if (!ctx) return ANET_ERR_INVALID;
+  if (ctx->comm && g_rccl.CommDestroy) {
+    (void)g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_ranks = 0;
+  }
+  return ANET_OK;
 }
 
 }  // extern "C"

@@ -43,3 +43,35 @@ def allgather_costs(local_costs, total, group=None, out=None):
         a, b = shard_bounds(total, world, r)
         res[a:b] = gathered[r * m:r * m + (b - a)]
     return res
+
+
+class NativeComm:
+    """RCCL communicator owned by an allocnet_amd Context (anet_comm_*): the all-gather of costs for
+    hosts that do not run torch.distributed.  The 128-byte unique id made by rank 0 must reach the other
+    ranks through any side channel."""
+
+    def __init__(self, ctx, nranks, rank, unique_id=None):
+        import ctypes
+        self.ctx, self.nranks, self.rank = ctx, int(nranks), int(rank)
+        if unique_id is None:
+            if rank != 0:
+                raise ValueError("only rank 0 may create the unique id")
+            buf = (ctypes.c_ubyte * 128)()
+            ctx.check(ctx.lib.anet_comm_unique_id(ctx.handle, buf))
+            unique_id = bytes(buf)
+        self.unique_id = unique_id
+        buf = (ctypes.c_ubyte * 128).from_buffer_copy(unique_id)
+        ctx.check(ctx.lib.anet_comm_init(ctx.handle, self.nranks, self.rank, buf))
+
+    def allgather_costs(self, send, recv, count, stream=None):
+        """send/recv: torch CUDA float64 tensors (count and nranks*count elements)."""
+        import ctypes
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(send.device).cuda_stream
+        self.ctx.check(self.ctx.lib.anet_comm_allgather_costs_dev(
+            self.ctx.handle, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(recv.data_ptr()), int(count),
+            ctypes.c_void_p(stream)))
+
+    def close(self):
+        self.ctx.check(self.ctx.lib.anet_comm_destroy(self.ctx.handle))

@@ -341,6 +341,21 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                          double *cost, double *coeffs_out, int32_t *status, int32_t *iters,
                          int32_t *evals, void *stream);
 
+/* ---- multi-GPU: all-gather of the per-trajectory costs over RCCL / xGMI --------------------------- */
+/* Trajectories are independent, so a batch shards contiguously across GPUs (one process and one
+ * context per GPU) with no collective inside a solve; the only exchange the path has is this
+ * all-gather of costs (8 B per trajectory: latency-bound).  RCCL is loaded at run time (dlopen of
+ * librccl.so, override with ANET_RCCL_PATH) so single-GPU users carry no dependency.
+ * Usage: rank 0 calls anet_comm_unique_id and ships the 128 bytes to the other ranks by any side
+ * channel (file, socket, MPI, a torch.distributed store), then every rank calls anet_comm_init.       */
+#define ANET_COMM_ID_BYTES 128
+int anet_comm_unique_id(anet_ctx *ctx, unsigned char id[ANET_COMM_ID_BYTES]);
+int anet_comm_init(anet_ctx *ctx, int nranks, int rank, const unsigned char id[ANET_COMM_ID_BYTES]);
+/* recv[r*count + i] = rank r's send[i]; device pointers; asynchronous on `stream`. */
+int anet_comm_allgather_costs_dev(anet_ctx *ctx, const double *send, double *recv, int64_t count,
+                                  void *stream);
+int anet_comm_destroy(anet_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif
