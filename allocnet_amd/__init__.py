@@ -7,7 +7,7 @@ from ._lib import AnetError, load, LIB_PATH  # noqa: F401
 from .context import Context, default_context  # noqa: F401
 from .minco import MINCO, MINCO_S2NU, MINCO_S3NU, MINCO_S4NU, minco_solve, minco_solve_dev, recommended_ld, minco_cost_grad, minco_cost_grad_dev, make_penalty  # noqa: F401
 
-from .trajectory import Piece, Trajectory, traj_eval, traj_cost, traj_cost_grad_T  # noqa: F401
+from .trajectory import Piece, Trajectory, traj_eval, traj_cost, traj_cost_grad_T, traj_max_rate  # noqa: F401
 from . import lbfgs  # noqa: F401
 from .lbfgs import lbfgs_parameter_t, lbfgs_strerror, lbfgs_mvie, lbfgs_minco, lbfgs_minco_dev  # noqa: F401
 from . import qp  # noqa: F401

@@ -40,6 +40,9 @@ PROTOTYPES = {
                                    c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "anet_traj_eval": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
                                c_int, c_void_p, c_int, c_void_p]),
+    "anet_traj_max_rate_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_void_p]),
+    "anet_traj_max_rate": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     "anet_traj_cost_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
                                    c_double, c_void_p, c_void_p]),
     "anet_traj_cost": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_double, c_void_p]),

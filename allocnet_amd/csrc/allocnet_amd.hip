@@ -16,6 +16,7 @@
 #include "minco_core.h"
 #include "minco_kernels.h"
 #include "traj_kernels.h"
+#include "rate_kernels.h"
 #include "lbfgs_kernels.h"
 #include "qp_assemble.h"
 #include "qp_admm.h"
@@ -1161,6 +1162,42 @@ int anet_comm_destroy(anet_ctx *ctx) {
     ctx->comm_ranks = 0;
   }
   return ANET_OK;
+}
+
+int anet_traj_max_rate_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
+                           const double *coeffs, const double *T, int which, double *rate, void *stream) {
+  int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
+  if (rc) return rc;
+  if (which != 1 && which != 2) return fail(ctx, ANET_ERR_INVALID, "anet_traj_max_rate: which must be 1 (velocity) or 2 (acceleration)");
+  if (batch == 0) return ANET_OK;
+  if (!coeffs || !T || !rate || ld < batch) return fail(ctx, ANET_ERR_INVALID, "anet_traj_max_rate_dev: NULL pointer or ld < batch");
+  anet::RateArgs a{coeffs, T, rate, batch, ld, n_pieces, which};
+  const dim3 grid((unsigned)((batch + 63) / 64), (unsigned)n_pieces), block(64);
+  hipStream_t st = (hipStream_t)stream;
+  if (s == 2) hipLaunchKernelGGL(anet::k_piece_max_rate<2>, grid, block, 0, st, a);
+  else if (s == 3) hipLaunchKernelGGL(anet::k_piece_max_rate<3>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(anet::k_piece_max_rate<4>, grid, block, 0, st, a);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+int anet_traj_max_rate(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
+                       const double *T, int which, double *rate) {
+  int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
+  if (rc) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!coeffs || !T || !rate) return fail(ctx, ANET_ERR_INVALID, "anet_traj_max_rate: NULL pointer");
+  const int64_t nco = (int64_t)n_pieces * 3 * 2 * s;
+  Stager st;
+  rc = make_stager(ctx, batch, nco, nco + 2 * (int64_t)n_pieces, &st);
+  if (rc) return rc;
+  double *d_co, *d_T;
+  if ((rc = st.upload(coeffs, nco, &d_co))) return rc;
+  if ((rc = st.upload(T, n_pieces, &d_T))) return rc;
+  double *d_r = st.reserve(n_pieces);
+  rc = anet_traj_max_rate_dev(ctx, s, n_pieces, batch, st.ld, d_co, d_T, which, d_r, ctx->stream);
+  if (rc) return rc;
+  return st.download(d_r, n_pieces, rate);
 }
 
 }  // extern "C"

@@ -58,6 +58,18 @@ def traj_cost_grad_T(coeffs, T, m34=1400.0, ctx=None):
     return out
 
 
+def traj_max_rate(coeffs, T, which, ctx=None):
+    """Per-piece maximum of ||v|| (which=1) or ||a|| (which=2): Piece::getMaxVelRate/getMaxAccRate batched.
+    coeffs (B,N,3,D), T (B,N) -> (B,N)."""
+    ctx = ctx or default_context()
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    B, N, _, D = coeffs.shape
+    out = np.empty((B, N))
+    ctx.check(ctx.lib.anet_traj_max_rate(ctx.handle, D // 2, N, B, _ptr(coeffs), _ptr(T), int(which), _ptr(out)))
+    return out
+
+
 class Piece:
     """Piece<D> (trajectory.hpp:37-316): duration + 3 x (D+1) coefficient matrix, highest power first."""
 
@@ -96,6 +108,19 @@ class Piece:
 
     def getJer(self, t):
         return self._eval(t, 3)
+
+    # trajectory.hpp:177-314
+    def getMaxVelRate(self):
+        return float(traj_max_rate(self.coeffMat[None, None], np.array([[self.duration]]), 1, ctx=self._ctx)[0, 0])
+
+    def getMaxAccRate(self):
+        return float(traj_max_rate(self.coeffMat[None, None], np.array([[self.duration]]), 2, ctx=self._ctx)[0, 0])
+
+    def checkMaxVelRate(self, maxVelRate):
+        return self.getMaxVelRate() < maxVelRate
+
+    def checkMaxAccRate(self, maxAccRate):
+        return self.getMaxAccRate() < maxAccRate
 
 
 class Trajectory:
@@ -167,6 +192,21 @@ class Trajectory:
     def getTrajCost(self, order, m34=1400.0):
         co, T = self._arrays()
         return float(traj_cost(co, T, order, m34, ctx=self._ctx)[0])
+
+    # --- dynamic feasibility (trajectory.hpp:576-630): maximum over the pieces
+    def getMaxVelRate(self):
+        co, T = self._arrays()
+        return float(traj_max_rate(co, T, 1, ctx=self._ctx).max())
+
+    def getMaxAccRate(self):
+        co, T = self._arrays()
+        return float(traj_max_rate(co, T, 2, ctx=self._ctx).max())
+
+    def checkMaxVelRate(self, maxVelRate):
+        return self.getMaxVelRate() < maxVelRate
+
+    def checkMaxAccRate(self, maxAccRate):
+        return self.getMaxAccRate() < maxAccRate
 
     # --- junctions (trajectory.hpp:540-574): direct coefficient reads except at the very end
     def getPositions(self):

@@ -149,6 +149,16 @@ int anet_traj_cost_grad_T_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch,
 int anet_traj_cost_grad_T(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
                           const double *T, double m34, double *gradT);
 
+/* Replaces Piece<D>::getMaxVelRate / getMaxAccRate (gcopter/trajectory.hpp:177-273; root isolation in
+ * gcopter/root_finder.hpp) batched: the maximum of ||v|| (which = 1) or ||a|| (which = 2) over every piece.
+ * Trajectory<D>::getMaxVelRate/getMaxAccRate (:576-604) is the maximum over the pieces, and
+ * checkMaxVelRate/checkMaxAccRate(bound) (:275-314, 606-630) is "max < bound" (both ends and interior).
+ * rate: [N][ld] (dev) / [batch][N] (host).                                                          */
+int anet_traj_max_rate_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
+                           const double *coeffs, const double *T, int which, double *rate, void *stream);
+int anet_traj_max_rate(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
+                       const double *T, int which, double *rate);
+
 /* ---- cost + analytic gradients ----------------------------------------------------------- */
 /* Penalty functional on the reference's own inequality rows (QPSolver::solve step three,
  * planner/qp_solver.hpp:244-296; MinTrajOpt.fill_ineq, network/utils/min_traj_opt.py:535-613):

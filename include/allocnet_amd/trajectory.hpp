@@ -6,8 +6,8 @@
 // getAcc/getJer with the reference's piece location (including the clamp to the last piece);
 // getTrajCost(order) with the reference's constants (m_34 = 1400 by default).  Return types are
 // anet::Vec3 / anet::Matrix which convert to and from Eigen types by duck typing (core.hpp).
-// Not provided: getMax{Vel,Acc}Rate / checkMax{Vel,Acc}Rate (trajectory.hpp:177-314; never called
-// in the reference).
+// getMax{Vel,Acc}Rate / checkMax{Vel,Acc}Rate (trajectory.hpp:177-314, 576-630) are provided through
+// anet_traj_max_rate (Bernstein-subdivision root isolation instead of Sturm sequences, same extrema).
 #pragma once
 #include <algorithm>
 #include <vector>
@@ -46,6 +46,17 @@ class Piece {
   inline anet::Vec3 getVel(const double &t) const { return eval(t, 1); }
   inline anet::Vec3 getAcc(const double &t) const { return eval(t, 2); }
   inline anet::Vec3 getJer(const double &t) const { return eval(t, 3); }
+
+  inline double maxRate(int which) const {
+    double r = 0.0;
+    anet::Context &ctx = anet::Context::thread_default();
+    ctx.check(anet_traj_max_rate(ctx.get(), (D + 1) / 2, 1, 1, coeffMat.data(), &duration, which, &r));
+    return r;
+  }
+  inline double getMaxVelRate() const { return maxRate(1); }
+  inline double getMaxAccRate() const { return maxRate(2); }
+  inline bool checkMaxVelRate(const double &maxVelRate) const { return getMaxVelRate() < maxVelRate; }
+  inline bool checkMaxAccRate(const double &maxAccRate) const { return getMaxAccRate() < maxAccRate; }
 };
 
 template <int D>
@@ -155,6 +166,22 @@ class Trajectory {
     }
     return pieces[juncIdx - 1].getAcc(pieces[juncIdx - 1].getDuration());
   }
+  // trajectory.hpp:576-630: maximum over the pieces (one kernel launch for the whole trajectory)
+  inline double maxRate(int which) const {
+    std::vector<double> co, T;
+    flatten(co, T);
+    std::vector<double> r(T.size());
+    anet::Context &ctx = anet::Context::thread_default();
+    ctx.check(anet_traj_max_rate(ctx.get(), (D + 1) / 2, getPieceNum(), 1, co.data(), T.data(), which, r.data()));
+    double m = 0.0;
+    for (double v : r) m = v > m ? v : m;
+    return m;
+  }
+  inline double getMaxVelRate() const { return maxRate(1); }
+  inline double getMaxAccRate() const { return maxRate(2); }
+  inline bool checkMaxVelRate(const double &maxVelRate) const { return getMaxVelRate() < maxVelRate; }
+  inline bool checkMaxAccRate(const double &maxAccRate) const { return getMaxAccRate() < maxAccRate; }
+
   // 3 x (N+1) junction positions (trajectory.hpp:440-450), column k = junction k
   inline std::vector<anet::Vec3> getPositions() const {
     int N = getPieceNum();

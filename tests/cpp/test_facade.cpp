@@ -103,6 +103,8 @@ int main() {
     printf("\"junc_vel_3\": [%.17g, %.17g, %.17g],\n", copy.getJuncVel(3)(0), copy.getJuncVel(3)(1), copy.getJuncVel(3)(2));
     printf("\"locate\": [%d, %.17g],\n", idx, tloc);
     printf("\"pieces\": %d, \"total\": %.17g,\n", copy.getPieceNum(), copy.getTotalDuration());
+    printf("\"max_vel\": %.17g, \"max_acc\": %.17g, \"check_vel\": %d,\n", copy.getMaxVelRate(), copy.getMaxAccRate(),
+           copy.checkMaxVelRate(1e3) ? 1 : 0);
     // QPSolver exactly as LearningPlanner drives it (learning_planner.hpp:30,36,196-233): 3 pieces, jerk
     {
       QPSolver qp(QPConfig(3.0, 4.0, 10));

@@ -41,6 +41,9 @@ def test_cpp_facade_program():
     assert np.abs(np.array(out["junc_vel_3"]) - onp.piece_eval(co[3], 0.0, 1)).max() < 1e-12
     assert out["locate"][0] == 2 and abs(out["locate"][1] - 0.25) < 1e-15
     assert out["pieces"] == 8 and out["total"] == 8.0
+    assert abs(out["max_vel"] - max(onp.piece_max_rate(co[i], 1.0, 1) for i in range(N))) <= 1e-9 * out["max_vel"]
+    assert abs(out["max_acc"] - max(onp.piece_max_rate(co[i], 1.0, 2) for i in range(N))) <= 1e-9 * out["max_acc"]
+    assert out["check_vel"] == 1
     assert out["lbfgs_default_mem"] == 8 and out["strerror"].startswith("Line search reaches")
 
     # QPSolver facade: solved, ends where asked, inside the velocity box, objective == 1/2 z'Qz of its coefficients
