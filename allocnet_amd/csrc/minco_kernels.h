@@ -333,45 +333,46 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
     double rr[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
-    // ---- node states from the coefficients: x_k[j] = j! c_j(piece k); last node by evaluation
-    double XS[NB + 1][S], GX[NB + 1][S], XA[NB + 1][m];
-#pragma unroll
-    for (int k = 0; k <= NB; ++k)
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        XS[k][j] = 0.0;
-        GX[k][j] = 0.0;
-      }
-#pragma unroll
-    for (int k = 0; k < NB; ++k)
+    // ---- node states are re-read from the coefficients where needed instead of being held:
+    //      x_k[j] = j! c_j(piece k) for k < N; the last node by evaluating piece N-1 at its end
+    // (`cb` is the coefficient base pointer; the second phase passes a laundered copy so that the
+    //  compiler re-reads instead of keeping every node state of the first phase alive)
+    auto node_state = [&](const double *cb, int k, double (&x)[S]) {
       if (k < N) {
         double fact = 1.0;
 #pragma unroll
         for (int j = 0; j < S; ++j) {
           if (j > 0) fact *= (double)j;
-          XS[k][j] = fact * a.coeffs[(int64_t)((k * 3 + ax) * D + (D - 1 - j)) * ld + b];
+          x[j] = fact * cb[(int64_t)((k * 3 + ax) * D + (D - 1 - j)) * ld + b];
         }
-        if (k == N - 1) {
-          double cl[D], tp[D];
-          tp[0] = 1.0;
+      } else {
+        double cl[D], tp[D];
+        tp[0] = 1.0;
 #pragma unroll
-          for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Tlast;
+        for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Tlast;
 #pragma unroll
-          for (int col = 0; col < D; ++col) cl[col] = a.coeffs[(int64_t)((k * 3 + ax) * D + col) * ld + b];
+        for (int col = 0; col < D; ++col) cl[col] = cb[(int64_t)(((N - 1) * 3 + ax) * D + col) * ld + b];
 #pragma unroll
-          for (int j = 0; j < S; ++j) {
-            double acc = 0.0;
+        for (int j = 0; j < S; ++j) {
+          double acc = 0.0;
 #pragma unroll
-            for (int p = j; p < D; ++p) {
-              double f = 1.0;
+          for (int p = j; p < D; ++p) {
+            double f = 1.0;
 #pragma unroll
-              for (int e = 0; e < j; ++e) f *= (double)(p - e);
-              acc = __builtin_fma(f * tp[p - j], cl[D - 1 - p], acc);
-            }
-            XS[k + 1][j] = acc;
+            for (int e = 0; e < j; ++e) f *= (double)(p - e);
+            acc = __builtin_fma(f * tp[p - j], cl[D - 1 - p], acc);
           }
+          x[j] = acc;
         }
       }
+    };
+    double GP[NB + 1], XA[NB + 1][m];  // adjoint of the node positions / of the node derivatives
+#pragma unroll
+    for (int k = 0; k <= NB; ++k) {
+      GP[k] = 0.0;
+#pragma unroll
+      for (int l = 0; l < m; ++l) XA[k][l] = 0.0;
+    }
     // ---- g_x = Phi' gdC and the direct dPhi/dT term
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -381,11 +382,18 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
 #pragma unroll
         for (int col = 0; col < D; ++col) gc[col] = a.gdC[(int64_t)((i * 3 + ax) * D + col) * ld + b];
         // low powers k < S: c_k = x_i[k]/k!
+        double x0[S], x1[S];
+        node_state(a.coeffs, i, x0);
+        node_state(a.coeffs, i + 1, x1);
+        auto addg = [&](int node, int dg, double v) {  // node-state adjoint: slot 0 = position
+          if (dg == 0) GP[node] += v;
+          else XA[node][dg - 1] += v;
+        };
         double fact = 1.0;
 #pragma unroll
         for (int k = 0; k < S; ++k) {
           if (k > 0) fact *= (double)k;
-          GX[i][k] = __builtin_fma(gc[D - 1 - k], 1.0 / fact, GX[i][k]);
+          addg(i, k, gc[D - 1 - k] * (1.0 / fact));
         }
         double h[S];
 #pragma unroll
@@ -401,11 +409,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
             qd = __builtin_fma((double)(S + q - dg) * Tab<S>::BHI[q][bb], h[q], qd);
           }
           const double sc = p[S - dg];
-          const double xb = (bb < S) ? XS[i][dg] : XS[i + 1][dg];
-          if (bb < S)
-            GX[i][dg] = __builtin_fma(u, sc, GX[i][dg]);
-          else
-            GX[i + 1][dg] = __builtin_fma(u, sc, GX[i + 1][dg]);
+          const double xb = (bb < S) ? x0[dg] : x1[dg];
+          addg(bb < S ? i : i + 1, dg, u * sc);
           dsum = __builtin_fma(xb * sc, qd, dsum);
         }
         gT[i] = __builtin_fma(-p[1], dsum, gT[i]);
@@ -413,10 +418,12 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
     // ---- adjoint solve K lam = g_x|free (pinned rows 0)
     sweep_forward<S, NB>(F, N, np, rr, XA, [&](int k, double (&y)[m]) {
 #pragma unroll
-      for (int l = 0; l < m; ++l) y[l] = ((k == 0 || k == N) && l < np) ? 0.0 : GX[k][1 + l];
+      for (int l = 0; l < m; ++l) y[l] = ((k == 0 || k == N) && l < np) ? 0.0 : XA[k][l];
     });
 #pragma unroll
     for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
+    const double *cb2 = a.coeffs;
+    asm volatile("" : "+v"(cb2));
     sweep_backward<S, NB>(F, N, np, rr, XA, [&](int k, const Pw<S> &p) {
       // (W_k lam^)[position row of node k]; the row of node k+1 is its negative
       double wl = 0.0;
@@ -425,13 +432,14 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
         wl = __builtin_fma(Tab<S>::M[0][1 + l] * p[2 * S - 2 - l], XA[k][l], wl);
         wl = __builtin_fma(Tab<S>::M[0][S + 1 + l] * p[2 * S - 2 - l], XA[k + 1][l], wl);
       }
-      GX[k][0] -= wl;
-      GX[k + 1][0] += wl;
+      GP[k] -= wl;
+      GP[k + 1] += wl;
       // - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b
-      double xs[2 * S];
+      double x0[S], x1[S], xs[2 * S];
+      node_state(cb2, k, x0);
+      node_state(cb2, k + 1, x1);
 #pragma unroll
-      for (int bb = 0; bb < 2 * S; ++bb)
-        xs[bb] = ((bb < S) ? XS[k][bb % S] : XS[k + 1][bb % S]) * p[S - bb % S];
+      for (int bb = 0; bb < 2 * S; ++bb) xs[bb] = ((bb < S) ? x0[bb % S] : x1[bb % S]) * p[S - bb % S];
       double acc = 0.0;
 #pragma unroll
       for (int aa = 0; aa < 2 * S; ++aa) {
@@ -448,7 +456,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
     });
 #pragma unroll
     for (int k = 1; k < NB; ++k)
-      if (k < N) a.gradP[(int64_t)((k - 1) * 3 + ax) * ld + b] = GX[k][0];
+      if (k < N) a.gradP[(int64_t)((k - 1) * 3 + ax) * ld + b] = GP[k];
   }
   double csum = 0.0;
 #pragma unroll
