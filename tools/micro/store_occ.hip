@@ -4,7 +4,7 @@
 #include <stdio.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int F, int FIN, int LDSB, int WORK>
+template <int F, int FIN, int LDSB, int WORK, int G = 8>
 __global__ void __launch_bounds__(64) k(const double* __restrict__ in, double* __restrict__ out, long B, long ld) {
   __shared__ double pad[LDSB / 8];
   long b = (long)blockIdx.x * 64 + threadIdx.x;
@@ -14,23 +14,23 @@ __global__ void __launch_bounds__(64) k(const double* __restrict__ in, double* _
 #pragma unroll
   for (int f = 0; f < FIN; ++f) acc += in[f * ld + b];
 #pragma unroll 1
-  for (int g = 0; g < F / 8; ++g) {
-    double v[8];
+  for (int g = 0; g < F / G; ++g) {
+    double v[G];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = acc + q;
+    for (int q = 0; q < G; ++q) v[q] = acc + q;
 #pragma unroll 1
     for (int w = 0; w < WORK; ++w) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = __builtin_fma(v[q], 1.0000001, 0.5);
+      for (int q = 0; q < G; ++q) v[q] = __builtin_fma(v[q], 1.0000001, 0.5);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) out[(g * 8 + q) * ld + b] = v[q];
+    for (int q = 0; q < G; ++q) out[(g * G + q) * ld + b] = v[q];
     acc += v[0];
   }
   if (LDSB > 8 && threadIdx.x == 1001) out[0] = pad[0];
 }
 
-template <int LDSB, int WORK>
+template <int LDSB, int WORK, int G = 8>
 int run(const double* in, double* out, long B, long ld, const char* name) {
   constexpr int F = 192, FIN = 48;
   hipEvent_t e0, e1;
@@ -38,7 +38,7 @@ int run(const double* in, double* out, long B, long ld, const char* name) {
   float best = 1e9;
   for (int it = 0; it < 10; ++it) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k<F, FIN, LDSB, WORK>), dim3(B / 64), dim3(64), 0, 0, in, out, B, ld);
+    hipLaunchKernelGGL((k<F, FIN, LDSB, WORK, G>), dim3(B / 64), dim3(64), 0, 0, in, out, B, ld);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -50,7 +50,7 @@ int run(const double* in, double* out, long B, long ld, const char* name) {
 }
 
 int main() {
-  const long B = 1 << 20, ld = B;
+  const long B = 1 << 20, ld = B + 576;
   double *in, *out;
   CK(hipMalloc(&in, sizeof(double) * 48 * ld));
   CK(hipMalloc(&out, sizeof(double) * 192 * ld));
@@ -64,5 +64,9 @@ int main() {
   run<8, 25>(in, out, B, ld, "occ max, 200 FMA per 8 stores");
   run<13000, 25>(in, out, B, ld, "occ 3/SIMD, 200 FMA per 8 stores");
   run<10000, 25>(in, out, B, ld, "occ 4/SIMD, 200 FMA per 8 stores");
+  run<20000, 25, 64>(in, out, B, ld, "occ 2/SIMD, 1600 FMA per 64 stores");
+  run<40000, 25, 64>(in, out, B, ld, "occ 1/SIMD, 1600 FMA per 64 stores");
+  run<20000, 25, 32>(in, out, B, ld, "occ 2/SIMD, 800 FMA per 32 stores");
+  run<20000, 25, 192>(in, out, B, ld, "occ 2/SIMD, 4800 FMA then 192 stores");
   return 0;
 }
