@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -77,10 +78,43 @@ int ensure_scratch(anet_ctx *ctx, size_t bytes) {
 
 inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Up to this batch the axis-parallel kernel is used (3*B/63 waves still fit the chip's 1024 SIMDs about
+// once); measured crossover on MI355X in DESIGN.md section 4.
+constexpr int64_t kAxisVariantMaxBatchDefault = 16384;
+inline int64_t axis_variant_max_batch() {  // ANET_AXIS_MAX_BATCH overrides (tuning / A-B runs)
+  static const int64_t v = [] {
+    const char *e = getenv("ANET_AXIS_MAX_BATCH");
+    return e ? (int64_t)atoll(e) : kAxisVariantMaxBatchDefault;
+  }();
+  return v;
+}
+
 template <int S>
 int launch_solve(anet_ctx *ctx, const anet::SolveArgs &a, hipStream_t st) {
   const dim3 grid((unsigned)((a.B + anet::kSolveBlock - 1) / anet::kSolveBlock));
   const dim3 block(anet::kSolveBlock);
+  // small batches: lane per (trajectory, axis) -- three times the waves, ~2.4x shorter dependent chains
+  if (a.B <= axis_variant_max_batch()) {
+    const dim3 g3((unsigned)((a.B + 20) / 21));
+    bool done = true;
+    if constexpr (S == 4) {
+      if (a.N == 8 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_solve_axis<4, 8, true, 2>), g3, block, 0, st, a);
+      else if (a.N == 8 && a.c == 4) hipLaunchKernelGGL((anet::k_minco_solve_axis<4, 8, true, 3>), g3, block, 0, st, a);
+      else done = false;
+    } else if constexpr (S == 3) {
+      if (a.N == 16 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_solve_axis<3, 16, true, 2>), g3, block, 0, st, a);
+      else done = false;
+    } else {
+      done = false;
+    }
+    if (!done) {
+      if (a.N <= 4) hipLaunchKernelGGL((anet::k_minco_solve_axis<S, 4>), g3, block, 0, st, a);
+      else if (a.N <= 8) hipLaunchKernelGGL((anet::k_minco_solve_axis<S, 8>), g3, block, 0, st, a);
+      else hipLaunchKernelGGL((anet::k_minco_solve_axis<S, 16>), g3, block, 0, st, a);
+    }
+    ANET_HIP(ctx, hipGetLastError());
+    return ANET_OK;
+  }
   // fully specialised instantiations for the shapes the benchmarks and the reference use
   if constexpr (S == 4) {
     if (a.N == 8 && a.c == 3) {
