@@ -93,3 +93,19 @@ def test_stride_larger_than_batch(anet_ctx):
     got = co[:, :B].T.cpu().numpy().reshape(B, N, 3, 8)
     assert rel_err(got, cc) < 1e-9 and rel_err(en[:B].cpu().numpy(), ec) < 1e-9
     assert (co[:, B:] == -7.0).all() and (en[B:] == -7.0).all()
+
+
+@pytest.mark.parametrize("s,c,N", [(4, 3, 5), (3, 3, 12), (4, 4, 16), (3, 2, 3), (4, 3, 8)])
+def test_lane_per_trajectory_kernels_above_the_axis_threshold(anet_ctx, s, c, N):
+    """Batches above 16384 use the lane-per-trajectory kernels (generic and specialised instantiations);
+    smaller ones the axis-parallel kernels.  Both must agree with the oracle and with each other."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(7 * N + s)
+    B = 16384 + 700
+    head, tail, wps, T = random_problem(rng, B, N, c)
+    co, en = aa.minco_solve(head, tail, wps, T, s, ctx=anet_ctx)
+    idx = np.arange(0, B, 997)
+    cc, ec = cbind.minco_solve_batch(s, head[idx], tail[idx], wps[idx], T[idx])
+    assert rel_err(co[idx], cc) < 1e-9 and rel_err(en[idx], ec) < 1e-9
+    co2, en2 = aa.minco_solve(head[:3000], tail[:3000], wps[:3000], T[:3000], s, ctx=anet_ctx)   # axis-parallel path
+    assert rel_err(co2, co[:3000]) < 1e-11 and rel_err(en2, en[:3000]) < 1e-11
