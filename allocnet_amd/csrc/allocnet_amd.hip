@@ -36,6 +36,9 @@ struct anet_ctx {
   // L-BFGS completion polling: device counter + pinned host mirror
   int *d_counter = nullptr;
   int *h_counter = nullptr;
+  // pinned host staging for single-trajectory calls (inputs are packed and sent with ONE copy)
+  double *h_pack = nullptr;
+  size_t h_pack_doubles = 0;
   // RCCL communicator for the all-gather of costs
   ncclComm_t comm = nullptr;
   int comm_ranks = 0;
@@ -297,6 +300,7 @@ void anet_destroy(anet_ctx *ctx) {
   if (ctx->comm) (void)anet_comm_destroy(ctx);
   if (ctx->d_counter) (void)hipFree(ctx->d_counter);
   if (ctx->h_counter) (void)hipHostFree(ctx->h_counter);
+  if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -396,51 +400,7 @@ int anet_minco_solve_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
 
 int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
                      const double *tail, const double *wps, const double *T, double *coeffs,
-                     double *energy) {
-  int rc = check_solve_args(ctx, s, c, n_pieces, batch);
-  if (rc) return rc;
-  if (batch == 0) return ANET_OK;
-  if (!head || !tail || !T || (n_pieces > 1 && !wps))
-    return fail(ctx, ANET_ERR_INVALID, "anet_minco_solve: NULL input");
-  ANET_HIP(ctx, hipSetDevice(ctx->device));
-  const int N = n_pieces, D = 2 * s;
-  const int64_t ld = anet_recommended_ld(batch);
-  const int64_t n_in = 3 * c * 2 + (int64_t)(N - 1) * 3 + N;  // fields in per trajectory
-  const int64_t n_co = (int64_t)N * 3 * D;
-  const int64_t n_stage = (n_in > n_co ? n_in : n_co);
-  // scratch: [stage: batch*n_stage][soa_in: n_in*ld][soa_co: n_co*ld][energy: ld]
-  const size_t bytes = sizeof(double) * (size_t)(batch * n_stage + (n_in + n_co + 1) * ld);
-  rc = ensure_scratch(ctx, bytes);
-  if (rc) return rc;
-  double *stage = (double *)ctx->scratch;
-  double *s_head = stage + batch * n_stage;
-  double *s_tail = s_head + 3 * c * ld;
-  double *s_wps = s_tail + 3 * c * ld;
-  double *s_T = s_wps + (int64_t)(N - 1) * 3 * ld;
-  double *s_co = s_T + (int64_t)N * ld;
-  double *s_en = s_co + n_co * ld;
-  hipStream_t st = ctx->stream;
-  struct In { const double *h; double *d; int64_t nf; } ins[4] = {
-      {head, s_head, 3 * c}, {tail, s_tail, 3 * c}, {wps, s_wps, (int64_t)(N - 1) * 3}, {T, s_T, N}};
-  for (auto &in : ins) {
-    if (in.nf == 0) continue;
-    ANET_HIP(ctx, hipMemcpyAsync(stage, in.h, sizeof(double) * batch * in.nf, hipMemcpyHostToDevice, st));
-    rc = anet_to_batch_minor_dev(ctx, batch, in.nf, ld, stage, in.d, st);
-    if (rc) return rc;
-  }
-  rc = anet_minco_solve_dev(ctx, s, c, N, batch, ld, s_head, s_tail, s_wps, s_T, coeffs ? s_co : nullptr,
-                            s_en, st);
-  if (rc) return rc;
-  if (coeffs) {
-    rc = anet_to_traj_major_dev(ctx, batch, n_co, ld, s_co, stage, st);
-    if (rc) return rc;
-    ANET_HIP(ctx, hipMemcpyAsync(coeffs, stage, sizeof(double) * batch * n_co, hipMemcpyDeviceToHost, st));
-  }
-  if (energy)
-    ANET_HIP(ctx, hipMemcpyAsync(energy, s_en, sizeof(double) * batch, hipMemcpyDeviceToHost, st));
-  ANET_HIP(ctx, hipStreamSynchronize(st));
-  return ANET_OK;
-}
+                     double *energy);
 
 int anet_traj_eval_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
                        const double *coeffs, const double *T, int nq, const double *tq, int deriv,
@@ -487,16 +447,55 @@ struct Stager {
     *dev = cursor;
     cursor += nf * ld;
     if (nf == 0) return ANET_OK;
+    if (batch == 1) {
+      // one trajectory: both layouts coincide (ld = 1), no transpose kernel; the inputs are packed into
+      // pinned memory and go out with a single copy when the first output region is reserved
+      if (!pack_base) pack_base = *dev;
+      const size_t off = (size_t)(*dev - pack_base);
+      if (off + (size_t)nf > ctx->h_pack_doubles) {
+        const size_t want = (off + (size_t)nf) * 2 + 1024;
+        double *np_ = nullptr;
+        hipError_t e1 = hipHostMalloc((void **)&np_, sizeof(double) * want, hipHostMallocDefault);
+        if (e1 != hipSuccess) return hip_fail(ctx, e1, "hipHostMalloc(pack)");
+        if (ctx->h_pack) {
+          memcpy(np_, ctx->h_pack, sizeof(double) * off);
+          (void)hipHostFree(ctx->h_pack);
+        }
+        ctx->h_pack = np_;
+        ctx->h_pack_doubles = want;
+      }
+      memcpy(ctx->h_pack + off, host, sizeof(double) * nf);
+      pack_doubles = off + (size_t)nf;
+      return ANET_OK;
+    }
     hipError_t e = hipMemcpyAsync(stage, host, sizeof(double) * batch * nf, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpyAsync(H2D)");
     return anet_to_batch_minor_dev(ctx, batch, nf, ld, stage, *dev, ctx->stream);
   }
-  double *reserve(int64_t nf) {
+  double *pack_base = nullptr;
+  size_t pack_doubles = 0;
+  int flush() {  // send the packed single-trajectory inputs (no-op otherwise)
+    if (pack_base && pack_doubles) {
+      hipError_t e = hipMemcpyAsync(pack_base, ctx->h_pack, sizeof(double) * pack_doubles, hipMemcpyHostToDevice, ctx->stream);
+      pack_doubles = 0;
+      if (e != hipSuccess) return hip_fail(ctx, e, "hipMemcpyAsync(H2D packed)");
+    }
+    return ANET_OK;
+  }
+  double *reserve(int64_t nf) {  // called after all uploads and before the kernels in every entry point
+    (void)flush();
     double *p = cursor;
     cursor += nf * ld;
     return p;
   }
   int download(const double *dev, int64_t nf, double *host) {
+    if (batch == 1) {
+      hipError_t e1 = hipMemcpyAsync(host, dev, sizeof(double) * nf, hipMemcpyDeviceToHost, ctx->stream);
+      if (e1 != hipSuccess) return hip_fail(ctx, e1, "hipMemcpyAsync(D2H)");
+      e1 = hipStreamSynchronize(ctx->stream);
+      if (e1 != hipSuccess) return hip_fail(ctx, e1, "hipStreamSynchronize");
+      return ANET_OK;
+    }
     int rc = anet_to_traj_major_dev(ctx, batch, nf, ld, dev, stage, ctx->stream);
     if (rc) return rc;
     hipError_t e = hipMemcpyAsync(host, stage, sizeof(double) * batch * nf, hipMemcpyDeviceToHost, ctx->stream);
@@ -509,15 +508,46 @@ struct Stager {
 };
 int make_stager(anet_ctx *ctx, int64_t batch, int64_t max_field, int64_t total_fields, Stager *st) {
   ANET_HIP(ctx, hipSetDevice(ctx->device));
-  const int64_t ld = anet_recommended_ld(batch);
+  const int64_t ld = batch == 1 ? 1 : anet_recommended_ld(batch);
   int rc = ensure_scratch(ctx, sizeof(double) * (size_t)(batch * max_field + total_fields * ld));
   if (rc) return rc;
   st->ctx = ctx; st->batch = batch; st->ld = ld;
   st->stage = (double *)ctx->scratch;
   st->cursor = st->stage + batch * max_field;
+  st->pack_base = nullptr;
+  st->pack_doubles = 0;
   return ANET_OK;
 }
 }  // namespace
+
+int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
+                     const double *tail, const double *wps, const double *T, double *coeffs,
+                     double *energy) {
+  int rc = check_solve_args(ctx, s, c, n_pieces, batch);
+  if (rc) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!head || !tail || !T || (n_pieces > 1 && !wps))
+    return fail(ctx, ANET_ERR_INVALID, "anet_minco_solve: NULL input");
+  const int N = n_pieces;
+  const int64_t n_in = 6 * (int64_t)c + (int64_t)(N - 1) * 3 + N;
+  const int64_t n_co = (int64_t)N * 3 * 2 * s;
+  Stager st;
+  rc = make_stager(ctx, batch, n_in > n_co ? n_in : n_co, n_in + n_co + 1, &st);
+  if (rc) return rc;
+  double *d_head, *d_tail, *d_wps, *d_T;
+  if ((rc = st.upload(head, 3 * c, &d_head))) return rc;
+  if ((rc = st.upload(tail, 3 * c, &d_tail))) return rc;
+  if ((rc = st.upload(wps, (int64_t)(N - 1) * 3, &d_wps))) return rc;
+  if ((rc = st.upload(T, N, &d_T))) return rc;
+  double *d_co = st.reserve(n_co), *d_en = st.reserve(1);
+  rc = anet_minco_solve_dev(ctx, s, c, N, batch, st.ld, d_head, d_tail, d_wps, d_T, coeffs ? d_co : nullptr, d_en,
+                            ctx->stream);
+  if (rc) return rc;
+  if (energy) ANET_HIP(ctx, hipMemcpyAsync(energy, d_en, sizeof(double) * batch, hipMemcpyDeviceToHost, ctx->stream));
+  if (coeffs) return st.download(d_co, n_co, coeffs);
+  ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ANET_OK;
+}
 
 int anet_traj_eval(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
                    const double *T, int nq, const double *tq, int deriv, double *out) {
