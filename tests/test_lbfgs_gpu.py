@@ -157,3 +157,33 @@ def test_mvie_large_batch_uses_lane_kernel(anet_ctx):
     xs, fs, ss, its, evs = aa.lbfgs_mvie(A[:2000], x0[:2000], param=aa.lbfgs_parameter_t(**prm), ctx=anet_ctx)
     assert np.array_equal(ss, status[:2000]) and np.array_equal(its, iters[:2000]) and np.array_equal(evs, evals[:2000])
     assert np.abs(xs - x[:2000]).max() <= 1e-4        # reduction order differs (shuffle tree vs sequential)
+
+
+@pytest.mark.parametrize("opt_name", ["waypoints", "times"])
+def test_minco_lbfgs_partial_variable_sets(anet_ctx, opt_name):
+    """ANET_OPT_WAYPOINTS / ANET_OPT_TIMES alone: the other block of variables is left untouched and the
+    cost still decreases; the result is a stationary point of the restricted problem."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(77)
+    s, c, N, M, B = 3, 3, 6, 6, 40
+    head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
+    hp = make_corridors(rng, head, tail, wps, M, tight=2.0)
+    pen = aa.make_penalty(rho=30.0, w_corridor=1e3, w_vel=1e2, w_acc=1e2, smooth_mu=1e-2, max_vel=3.0, max_acc=4.0,
+                          res=8, poly_rows=M)
+    c0, gP0, gT0 = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, ctx=anet_ctx)
+    opt = aa.lbfgs.OPT_WAYPOINTS if opt_name == "waypoints" else aa.lbfgs.OPT_TIMES
+    out = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, opt=opt,
+                         param=aa.lbfgs_parameter_t(g_epsilon=1e-7, delta=1e-10, max_iterations=400), ctx=anet_ctx)
+    assert (out["cost"] < c0).all()
+    if opt_name == "waypoints":
+        assert np.array_equal(out["T"], T) and not np.array_equal(out["wps"], wps)
+    else:
+        assert np.array_equal(out["wps"], wps) and not np.array_equal(out["T"], T)
+        assert (out["T"] > 0).all()
+    c1, gP1, gT1 = aa.minco_cost_grad(head, tail, out["wps"], out["T"], s, hpolys=hp, penalty=pen, ctx=anet_ctx)
+    assert np.abs(c1 - out["cost"]).max() <= 1e-9 * np.abs(c1).max()
+    g1 = gP1 if opt_name == "waypoints" else gT1
+    g0 = gP0 if opt_name == "waypoints" else gT0
+    ok = out["status"] >= 0
+    assert ok.mean() > 0.5
+    assert np.abs(g1[ok]).max() < 1e-2 * np.abs(g0[ok]).max()      # (much) closer to stationarity than the start

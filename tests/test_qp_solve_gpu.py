@@ -114,3 +114,25 @@ def test_qpsolver_class_mirror(anet_ctx):
         hp3[0, i, :p.shape[0]] = p
     r = aa.qp_solve(3, ini[None], fin_bad[None], hp3, T[None], res=10, max_vel=3.0, max_acc=4.0, ctx=anet_ctx)
     assert r["status"][0] == -3 and r["iters"][0] < 4000          # OSQP_PRIMAL_INFEASIBLE, detected early
+
+
+def test_qp_solve_size_limits(anet_ctx):
+    """The block factor must fit the 160 KB LDS: snap up to 12 pieces at res 20, jerk up to 16; a 16-piece
+    snap problem does not fit and the entry point refuses (ANET_ERR_UNSUPPORTED) instead of computing
+    something else."""
+    import allocnet_amd as aa
+    from allocnet_amd import _lib
+    rng = np.random.default_rng(3)
+    for s, N in [(4, 12), (3, 16)]:
+        probs = [_corridor_problem(rng, N, 7, margin=2.0) for _ in range(2)]
+        ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
+        hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs]) * 1.5
+        r = aa.qp_solve(s, ini, fin, hp, T, res=6, max_vel=6.0, max_acc=8.0, ctx=anet_ctx)
+        assert (r["status"] == 1).all(), (s, N, r["status"], r["iters"])
+        for bb in range(2):
+            co = r["coeffs"][bb]
+            assert np.abs(onp.piece_eval(co[0], 0.0, 0) - ini[bb][:, 0]).max() < 2e-2
+            assert np.abs(onp.piece_eval(co[N - 1], T[bb, N - 1], 0) - fin[bb][:, 0]).max() < 5e-2
+    with pytest.raises(aa.AnetError) as ei:
+        aa.qp_solve(4, np.zeros((1, 3, 3)), np.zeros((1, 3, 3)), np.zeros((1, 16, 6, 4)), np.ones((1, 16)), res=20, ctx=anet_ctx)
+    assert ei.value.code == _lib.ANET_ERR_UNSUPPORTED
