@@ -1049,7 +1049,7 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
   if (!(st_.rho > 0) || !(st_.sigma > 0) || !(st_.alpha > 0 && st_.alpha < 2) || st_.max_iter < 1 ||
       st_.check_termination < 1 || st_.eps_abs < 0 || st_.eps_rel < 0 || st_.adaptive_rho_interval < 0)
     return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad settings");
-  const size_t lds = (s == 4) ? anet::qp_admm_lds_bytes<4>(n_pieces, res) : anet::qp_admm_lds_bytes<3>(n_pieces, res);
+  const size_t lds = (s == 4) ? anet::qp_admm_lds_bytes<4>(n_pieces, res, M) : anet::qp_admm_lds_bytes<3>(n_pieces, res, M);
   if (lds > 160 * 1024)
     return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_qp_solve: the block factor of this many pieces does not fit the 160 KB LDS");
   const int64_t m = 3 * (6 + (int64_t)s * (n_pieces - 1)) + (int64_t)n_pieces * res * (M + 12);

@@ -64,6 +64,8 @@ __device__ __forceinline__ double fallf(int k, int d) {
   return r;
 }
 
+constexpr size_t kAdmmHpLdsBytes = 16 * 1024;  // polytope rows are copied to LDS when they take less than this
+
 template <int S>
 __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   constexpr int D = 2 * S, NB = 3 * D;
@@ -90,12 +92,19 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   double *Sp = G12 + D * D;                 // [N][9]  sum_q a_q a_q'
   double *Tn = Sp + (size_t)N * 9;          // [N]
   double *red = Tn + N;                     // [12] reductions / broadcast
+  double *hp_l = red + 12;                  // [N*M*4] polytope rows (only when they fit the budget below)
 
   const double *Tg = a.T + b * N;
   const double *hp = a.hpolys + b * (int64_t)N * M * 4;
   const double *st = a.state + b * 18;
   double *zg = a.z + b * mtot, *yg = a.y + b * mtot;
 
+  const bool hp_in_lds = (size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes;
+  const double *hpl = hp;
+  if (hp_in_lds) {
+    for (int e = tid; e < N * M * 4; e += nt) hp_l[e] = hp[e];
+    hpl = hp_l;
+  }
   // ---- tables -------------------------------------------------------------------------------
   for (int e = tid; e < R * 3 * D; e += nt) {
     const int j = e / (3 * D), d = (e / D) % 3, col = e % D, k = D - 1 - col;
@@ -386,51 +395,78 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gy[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
       double gd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
       const double Ti = Tn[i];
-      for (int q = 0; q < rows_per_sample; ++q) {
-        double zt, axn, hv, c0 = 0, c1 = 0, c2 = 0;
-        int dsel = 0, axsel = 0;
-        double sgn = 1.0;
-        if (q < M) {
-          const double *hq = hp + ((int64_t)i * M + q) * 4;
-          c0 = hq[0]; c1 = hq[1]; c2 = hq[2];
-          hv = hq[3];
-          zt = c0 * s3[0][0] + c1 * s3[0][1] + c2 * s3[0][2];
-          axn = c0 * s3n[0][0] + c1 * s3n[0][1] + c2 * s3n[0][2];
-        } else {
-          const int qq = q - M;
-          axsel = qq / 4;
-          const int w4 = qq % 4;
-          dsel = 1 + (w4 & 1);
-          sgn = (w4 < 2) ? 1.0 : -1.0;
-          hv = (dsel == 1) ? a.vmax * Ti : a.amax * Ti * Ti;
-          zt = sgn * s3[dsel][axsel];
-          axn = sgn * s3n[dsel][axsel];
-        }
-        const double zo = zg[r0 + q * NS], yo = yg[r0 + q * NS];
+      // one ADMM row update; returns w = rho z+ - y+ and (at check iterations) y+ and dy
+      auto row_update = [&](double zt, double axn, double hv, double zo, double yo, double &zn, double &yn) {
         const double zr = alpha * zt + (1.0 - alpha) * zo;
-        const double zn = fmin(zr + yo / rho, hv);  // l = -inf
-        const double yn = yo + rho * (zr - zn);
-        zg[r0 + q * NS] = zn;
-        yg[r0 + q * NS] = yn;
-        const double w = rho * zn - yn;
-        const double dy = yn - yo;
-        if (q < M) {
-          g[0][0] += w * c0; g[0][1] += w * c1; g[0][2] += w * c2;
-          if (check) {
-            gy[0][0] += yn * c0; gy[0][1] += yn * c1; gy[0][2] += yn * c2;
-            gd[0][0] += dy * c0; gd[0][1] += dy * c1; gd[0][2] += dy * c2;
-          }
-        } else {
-          g[dsel][axsel] += sgn * w;
-          if (check) { gy[dsel][axsel] += sgn * yn; gd[dsel][axsel] += sgn * dy; }
-        }
+        zn = fmin(zr + yo / rho, hv);  // l = -inf
+        yn = yo + rho * (zr - zn);
         if (check) {
+          const double dy = yn - yo;
           l_rp = fmax(l_rp, fabs(axn - zn));
           l_ax = fmax(l_ax, fabs(axn));
           l_z = fmax(l_z, fabs(zn));
           // l = -inf: only the positive part of dy can certify (a negative part makes the support +inf)
           l_dy = fmax(l_dy, fabs(dy));
           l_sup += (dy > 0.0) ? hv * dy : (dy < 0.0 ? 1e300 : 0.0);
+        }
+      };
+      // ---- corridor rows, four at a time so that their z / y loads are in flight together
+      for (int q0 = 0; q0 < M; q0 += 4) {
+        double zo[4], yo[4], cf[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + u;
+          const bool ok = q < M;
+          zo[u] = ok ? zg[r0 + q * NS] : 0.0;
+          yo[u] = ok ? yg[r0 + q * NS] : 0.0;
+          const double *hq = hpl + ((int64_t)i * M + (ok ? q : 0)) * 4;
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) cf[u][w4] = ok ? hq[w4] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + u;
+          if (q < M) {
+            const double c0 = cf[u][0], c1 = cf[u][1], c2 = cf[u][2];
+            const double zt = c0 * s3[0][0] + c1 * s3[0][1] + c2 * s3[0][2];
+            const double axn = c0 * s3n[0][0] + c1 * s3n[0][1] + c2 * s3n[0][2];
+            double zn, yn;
+            row_update(zt, axn, cf[u][3], zo[u], yo[u], zn, yn);
+            zg[r0 + q * NS] = zn;
+            yg[r0 + q * NS] = yn;
+            const double w = rho * zn - yn;
+            g[0][0] += w * c0; g[0][1] += w * c1; g[0][2] += w * c2;
+            if (check) {
+              const double dy = yn - yo[u];
+              gy[0][0] += yn * c0; gy[0][1] += yn * c1; gy[0][2] += yn * c2;
+              gd[0][0] += dy * c0; gd[0][1] += dy * c1; gd[0][2] += dy * c2;
+            }
+          }
+        }
+      }
+      // ---- the 12 box rows (+v, +a, -v, -a per axis), all loads up front
+      {
+        double zo[12], yo[12];
+#pragma unroll
+        for (int qq = 0; qq < 12; ++qq) {
+          zo[qq] = zg[r0 + (M + qq) * NS];
+          yo[qq] = yg[r0 + (M + qq) * NS];
+        }
+#pragma unroll
+        for (int qq = 0; qq < 12; ++qq) {
+          const int axsel = qq / 4, w4 = qq % 4, dsel = 1 + (w4 & 1);
+          const double sgn = (w4 < 2) ? 1.0 : -1.0;
+          const double hv = (dsel == 1) ? a.vmax * Ti : a.amax * Ti * Ti;
+          double zn, yn;
+          row_update(sgn * s3[dsel][axsel], sgn * s3n[dsel][axsel], hv, zo[qq], yo[qq], zn, yn);
+          zg[r0 + (M + qq) * NS] = zn;
+          yg[r0 + (M + qq) * NS] = yn;
+          const double w = rho * zn - yn;
+          g[dsel][axsel] += sgn * w;
+          if (check) {
+            gy[dsel][axsel] += sgn * yn;
+            gd[dsel][axsel] += sgn * (yn - yo[qq]);
+          }
         }
       }
       for (int axx = 0; axx < 3; ++axx)
@@ -522,7 +558,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
             for (int q = 0; q < rows_per_sample; ++q) {
               const double w = rho * zg[r0 + q * NS] - yg[r0 + q * NS];
               if (q < M) {
-                const double *hq = hp + ((int64_t)i * M + q) * 4;
+                const double *hq = hpl + ((int64_t)i * M + q) * 4;
                 g[0][0] += w * hq[0]; g[0][1] += w * hq[1]; g[0][2] += w * hq[2];
               } else {
                 const int qq = q - M, w4 = qq % 4;
@@ -567,10 +603,11 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
 }
 
 template <int S>
-inline size_t qp_admm_lds_bytes(int N, int R) {
+inline size_t qp_admm_lds_bytes(int N, int R, int M) {
   constexpr int D = 2 * S, NB = 3 * D;
   const size_t n = (size_t)NB * N;
-  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 5 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 12);
+  const size_t hp = (size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes ? (size_t)N * M * 4 : 0;
+  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 5 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 12 + hp);
 }
 
 }  // namespace anet
