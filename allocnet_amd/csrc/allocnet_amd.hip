@@ -1049,7 +1049,12 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
   if (!(st_.rho > 0) || !(st_.sigma > 0) || !(st_.alpha > 0 && st_.alpha < 2) || st_.max_iter < 1 ||
       st_.check_termination < 1 || st_.eps_abs < 0 || st_.eps_rel < 0 || st_.adaptive_rho_interval < 0)
     return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad settings");
-  const size_t lds = (s == 4) ? anet::qp_admm_lds_bytes<4>(n_pieces, res, M) : anet::qp_admm_lds_bytes<3>(n_pieces, res, M);
+  size_t lds = (s == 4) ? anet::qp_admm_lds_bytes<4>(n_pieces, res, M, true) : anet::qp_admm_lds_bytes<3>(n_pieces, res, M, true);
+  int zy_in_lds = 1;
+  if (lds > 160 * 1024) {
+    zy_in_lds = 0;
+    lds = (s == 4) ? anet::qp_admm_lds_bytes<4>(n_pieces, res, M, false) : anet::qp_admm_lds_bytes<3>(n_pieces, res, M, false);
+  }
   if (lds > 160 * 1024)
     return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_qp_solve: the block factor of this many pieces does not fit the 160 KB LDS");
   const int64_t m = 3 * (6 + (int64_t)s * (n_pieces - 1)) + (int64_t)n_pieces * res * (M + 12);
@@ -1058,7 +1063,8 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
   anet::AdmmArgs a{state, T, hpolys, work, work + m * batch, coeffs, obj, status, iters,
                    residuals ? residuals : work + 2 * m * batch, batch, n_pieces, res, M, max_vel, max_acc, m34,
                    anet::AdmmParams{st_.rho, st_.sigma, st_.alpha, st_.eps_abs, st_.eps_rel, st_.max_iter,
-                                    st_.check_termination, adapt}};
+                                    st_.check_termination, adapt},
+                   zy_in_lds};
   hipStream_t st = (hipStream_t)stream;
   if (s == 4) {
     ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_admm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -39,6 +39,7 @@ struct AdmmArgs {
   int N, R, M;
   double vmax, amax, m34;
   AdmmParams p;
+  int zy_in_lds;  // z, y live in LDS (small problems) instead of the global workspace
 };
 
 __device__ __forceinline__ double atomic_max_pos(double *addr, double v) {  // v >= 0
@@ -93,11 +94,14 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   double *Tn = Sp + (size_t)N * 9;          // [N]
   double *red = Tn + N;                     // [12] reductions / broadcast
   double *hp_l = red + 12;                  // [N*M*4] polytope rows (only when they fit the budget below)
+  double *gs = hp_l + ((size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes ? (size_t)N * M * 4 : 0);  // [N*R][9]
+  double *zy_l = gs + (size_t)N * R * 9;    // [2*mtot] when a.zy_in_lds
 
   const double *Tg = a.T + b * N;
   const double *hp = a.hpolys + b * (int64_t)N * M * 4;
   const double *st = a.state + b * 18;
-  double *zg = a.z + b * mtot, *yg = a.y + b * mtot;
+  double *zg = a.zy_in_lds ? zy_l : a.z + b * mtot;
+  double *yg = a.zy_in_lds ? zy_l + mtot : a.y + b * mtot;
 
   const bool hp_in_lds = (size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes;
   const double *hpl = hp;
@@ -469,11 +473,16 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
           }
         }
       }
+      // A'w of this sample: the 3x3 block g goes to LDS and is contracted with the basis table by the
+      // threads that own the n outputs after the barrier (no 20-way contended atomics every iteration)
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int axx = 0; axx < 3; ++axx) gs[(size_t)smp * 9 + d * 3 + axx] = g[d][axx];
+      if (check)
       for (int axx = 0; axx < 3; ++axx)
         for (int col = 0; col < D; ++col) {
-          const double v = g[0][axx] * bj[col] + g[1][axx] * bj[D + col] + g[2][axx] * bj[2 * D + col];
-          if (v != 0.0) atomicAdd(&rhs[i * NB + axx * D + col], v);
-          if (check) {
+          {
             const double vy = gy[0][axx] * bj[col] + gy[1][axx] * bj[D + col] + gy[2][axx] * bj[2 * D + col];
             if (vy != 0.0) atomicAdd(&aty[i * NB + axx * D + col], vy);
             const double vd = gd[0][axx] * bj[col] + gd[1][axx] * bj[D + col] + gd[2][axx] * bj[2 * D + col];
@@ -487,6 +496,17 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       atomic_max_pos(&red[2], l_z);
       atomic_max_pos(&red[6], l_dy);
       if (l_sup != 0.0) atomicAdd(&red[7], fmin(l_sup, 1e300));
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += nt) {
+      const int i = e / NB, axx = (e % NB) / D, col = e % D;
+      double acc = 0.0;
+      for (int j = 0; j < R; ++j) {
+        const double *gj = gs + (size_t)(i * R + j) * 9;
+        const double *bj = be + (size_t)j * 3 * D;
+        acc += gj[axx] * bj[col] + gj[3 + axx] * bj[D + col] + gj[6 + axx] * bj[2 * D + col];
+      }
+      rhs[e] += acc;
     }
     __syncthreads();
     if (check) {
@@ -602,12 +622,15 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   }
 }
 
+// LDS bytes without / with z, y resident; the launcher keeps z, y in LDS when the larger figure fits.
 template <int S>
-inline size_t qp_admm_lds_bytes(int N, int R, int M) {
+inline size_t qp_admm_lds_bytes(int N, int R, int M, bool zy_in_lds) {
   constexpr int D = 2 * S, NB = 3 * D;
   const size_t n = (size_t)NB * N;
   const size_t hp = (size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes ? (size_t)N * M * 4 : 0;
-  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 5 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 12 + hp);
+  const size_t mtot = (size_t)(3 * (6 + S * (N - 1))) + (size_t)N * R * (M + 12);
+  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 5 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 12 + hp +
+                           (size_t)N * R * 9 + (zy_in_lds ? 2 * mtot : 0));
 }
 
 }  // namespace anet
