@@ -59,10 +59,11 @@ __device__ __forceinline__ double qblk1(int j, int k, double m34) {  // cost blo
   return m[j][k];
 }
 
+// k!/(k-d)! for k <= 7, d <= 3 (0 when k < d)
 __device__ __forceinline__ double fallf(int k, int d) {
-  double r = 1.0;
-  for (int e = 0; e < d; ++e) r *= (double)(k - e);
-  return r;
+  constexpr double tab[8][4] = {{1, 0, 0, 0},   {1, 1, 0, 0},    {1, 2, 2, 0},    {1, 3, 6, 6},
+                                {1, 4, 12, 24}, {1, 5, 20, 60}, {1, 6, 30, 120}, {1, 7, 42, 210}};
+  return tab[k & 7][d & 3];
 }
 
 constexpr size_t kAdmmHpLdsBytes = 16 * 1024;  // polytope rows are copied to LDS when they take less than this
@@ -94,7 +95,9 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   double *Tn = Sp + (size_t)N * 9;          // [N]
   double *red = Tn + N;                     // [12] reductions / broadcast
   double *hp_l = red + 12;                  // [N*M*4] polytope rows (only when they fit the budget below)
-  double *gs = hp_l + ((size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes ? (size_t)N * M * 4 : 0);  // [N*R][9]
+  double *eqb = hp_l + ((size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes ? (size_t)N * M * 4 : 0);  // [me] rhs b
+  double *eqc = eqb + me;                    // [me] coefficient of the right-hand piece (continuity rows)
+  double *gs = eqc + me;                     // [N*R][9] per-sample A'w blocks
   double *zy_l = gs + (size_t)N * R * 9;    // [2*mtot] when a.zy_in_lds
 
   const double *Tg = a.T + b * N;
@@ -122,6 +125,18 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   }
   for (int i = tid; i < N; i += nt) Tn[i] = Tg[i];
   __syncthreads();
+  for (int r = tid; r < me; r += nt) {  // per-row constants of the equality block (do not change per iteration)
+    double bv = 0.0, cf = 0.0;
+    if (r < 18) {
+      const int ax = r / 6, q = r % 6, d = q % 3, i0 = q < 3 ? 0 : N - 1;
+      bv = st[(q < 3 ? 0 : 9) + ax * 3 + d] * pow(Tn[i0], (double)d);
+    } else {
+      const int rr = r - 18, i0 = rr / (3 * S), d = rr % S;
+      cf = -fallf(d, d) * pow(Tn[i0] / Tn[i0 + 1], (double)d);
+    }
+    eqb[r] = bv;
+    eqc[r] = cf;
+  }
   for (int e = tid; e < D * D; e += nt) {
     const int c1 = e / D, c2 = e % D;
     double g0 = 0.0, g12 = 0.0;
@@ -298,7 +313,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   double rp = 0.0, rd = 0.0;
   for (it = 1; it <= a.p.max_iter; ++it) {
     const bool check = (it % a.p.check_every) == 0;
-    const double rho_e = 1.0e3 * rho;
+    const double rho_e = 1.0e3 * rho, inv_rho = 1.0 / rho;
     solve();
     // x+ = alpha x~ + (1-alpha) x ; next rhs starts as sigma x+
     for (int e = tid; e < n; e += nt) {
@@ -322,7 +337,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
         kind = q < 3 ? 0 : 1;
         d = q % 3;
         i0 = kind == 0 ? 0 : N - 1;
-        bval = st[(kind == 0 ? 0 : 9) + ax * 3 + d] * pow(Tn[i0], (double)d);
+        bval = eqb[r];
       } else {
         const int rr = r - 18;
         i0 = rr / (3 * S);
@@ -330,7 +345,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
         d = rr % S;
         kind = 2;
       }
-      const double cf2 = (kind == 2) ? -fallf(d, d) * pow(Tn[i0] / Tn[i0 + 1], (double)d) : 0.0;
+      const double cf2 = eqc[r];
       if (kind == 0) {
         zt = fallf(d, d) * xt[ax * D + (D - 1 - d)];
         ax_new = fallf(d, d) * x[ax * D + (D - 1 - d)];
@@ -402,7 +417,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       // one ADMM row update; returns w = rho z+ - y+ and (at check iterations) y+ and dy
       auto row_update = [&](double zt, double axn, double hv, double zo, double yo, double &zn, double &yn) {
         const double zr = alpha * zt + (1.0 - alpha) * zo;
-        zn = fmin(zr + yo / rho, hv);  // l = -inf
+        zn = fmin(zr + yo * inv_rho, hv);  // l = -inf
         yn = yo + rho * (zr - zn);
         if (check) {
           const double dy = yn - yo;
@@ -567,7 +582,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
             if (kind == 0) atomicAdd(&rhs[ax * D + (D - 1 - d)], fallf(d, d) * w);
             else {
               for (int col = 0; col < D; ++col) { const int k = D - 1 - col; if (k >= d) atomicAdd(&rhs[i0 * NB + ax * D + col], fallf(k, d) * w); }
-              if (kind == 2) atomicAdd(&rhs[(i0 + 1) * NB + ax * D + (D - 1 - d)], -fallf(d, d) * pow(Tn[i0] / Tn[i0 + 1], (double)d) * w);
+              if (kind == 2) atomicAdd(&rhs[(i0 + 1) * NB + ax * D + (D - 1 - d)], eqc[r] * w);
             }
           }
           for (int smp = tid; smp < N * R; smp += nt) {
@@ -629,7 +644,7 @@ inline size_t qp_admm_lds_bytes(int N, int R, int M, bool zy_in_lds) {
   const size_t n = (size_t)NB * N;
   const size_t hp = (size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes ? (size_t)N * M * 4 : 0;
   const size_t mtot = (size_t)(3 * (6 + S * (N - 1))) + (size_t)N * R * (M + 12);
-  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 5 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 12 + hp +
+  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 5 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 12 + hp + 2 * (size_t)(3 * (6 + S * (N - 1))) +
                            (size_t)N * R * 9 + (zy_in_lds ? 2 * mtot : 0));
 }
 
