@@ -97,7 +97,8 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   double *hp_l = red + 12;                  // [N*M*4] polytope rows (only when they fit the budget below)
   double *eqb = hp_l + ((size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes ? (size_t)N * M * 4 : 0);  // [me] rhs b
   double *eqc = eqb + me;                    // [me] coefficient of the right-hand piece (continuity rows)
-  double *gs = eqc + me;                     // [N*R][9] per-sample A'w blocks
+  double *eqs = eqc + me;                    // [me] 1/T^d: undoes the row scaling of the normalisation
+  double *gs = eqs + me;                     // [N*R][9] per-sample A'w blocks
   double *zy_l = gs + (size_t)N * R * 9;    // [2*mtot] when a.zy_in_lds
 
   const double *Tg = a.T + b * N;
@@ -136,6 +137,12 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
     }
     eqb[r] = bv;
     eqc[r] = cf;
+    {
+      int i0, d;
+      if (r < 18) { const int q = r % 6; d = q % 3; i0 = q < 3 ? 0 : N - 1; }
+      else { const int rr = r - 18; i0 = rr / (3 * S); d = rr % S; }
+      eqs[r] = pow(Tn[i0], (double)(-d));
+    }
   }
   for (int e = tid; e < D * D; e += nt) {
     const int c1 = e / D, c2 = e % D;
@@ -382,9 +389,11 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       scatter(rhs, w);
       if (check) {
         scatter(aty, yn);
-        l_rp = fmax(l_rp, fabs(ax_new - zn));
-        l_ax = fmax(l_ax, fabs(ax_new));
-        l_z = fmax(l_z, fabs(zn));
+        // OSQP tests the UNSCALED residuals: this row was scaled by T^d when the QP was normalised
+        const double un = eqs[r];
+        l_rp = fmax(l_rp, fabs(ax_new - zn) * un);
+        l_ax = fmax(l_ax, fabs(ax_new) * un);
+        l_z = fmax(l_z, fabs(zn) * un);
         const double dy = yn - yo;  // certificate terms: l = u = b for equality rows
         scatter(ady, dy);
         l_dy = fmax(l_dy, fabs(dy));
@@ -413,17 +422,17 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       const int64_t NS = (int64_t)N * R;
       double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gy[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
       double gd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-      const double Ti = Tn[i];
+      const double Ti = Tn[i], rTi = 1.0 / Tn[i];
       // one ADMM row update; returns w = rho z+ - y+ and (at check iterations) y+ and dy
-      auto row_update = [&](double zt, double axn, double hv, double zo, double yo, double &zn, double &yn) {
+      auto row_update = [&](double zt, double axn, double hv, double zo, double yo, double un, double &zn, double &yn) {
         const double zr = alpha * zt + (1.0 - alpha) * zo;
         zn = fmin(zr + yo * inv_rho, hv);  // l = -inf
         yn = yo + rho * (zr - zn);
         if (check) {
           const double dy = yn - yo;
-          l_rp = fmax(l_rp, fabs(axn - zn));
-          l_ax = fmax(l_ax, fabs(axn));
-          l_z = fmax(l_z, fabs(zn));
+          l_rp = fmax(l_rp, fabs(axn - zn) * un);  // un: 1 (corridor), 1/T (velocity), 1/T^2 (acceleration)
+          l_ax = fmax(l_ax, fabs(axn) * un);
+          l_z = fmax(l_z, fabs(zn) * un);
           // l = -inf: only the positive part of dy can certify (a negative part makes the support +inf)
           l_dy = fmax(l_dy, fabs(dy));
           l_sup += (dy > 0.0) ? hv * dy : (dy < 0.0 ? 1e300 : 0.0);
@@ -450,7 +459,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
             const double zt = c0 * s3[0][0] + c1 * s3[0][1] + c2 * s3[0][2];
             const double axn = c0 * s3n[0][0] + c1 * s3n[0][1] + c2 * s3n[0][2];
             double zn, yn;
-            row_update(zt, axn, cf[u][3], zo[u], yo[u], zn, yn);
+            row_update(zt, axn, cf[u][3], zo[u], yo[u], 1.0, zn, yn);
             zg[r0 + q * NS] = zn;
             yg[r0 + q * NS] = yn;
             const double w = rho * zn - yn;
@@ -477,7 +486,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
           const double sgn = (w4 < 2) ? 1.0 : -1.0;
           const double hv = (dsel == 1) ? a.vmax * Ti : a.amax * Ti * Ti;
           double zn, yn;
-          row_update(sgn * s3[dsel][axsel], sgn * s3n[dsel][axsel], hv, zo[qq], yo[qq], zn, yn);
+          row_update(sgn * s3[dsel][axsel], sgn * s3n[dsel][axsel], hv, zo[qq], yo[qq], (dsel == 1) ? rTi : rTi * rTi, zn, yn);
           zg[r0 + (M + qq) * NS] = zn;
           yg[r0 + (M + qq) * NS] = yn;
           const double w = rho * zn - yn;
@@ -535,9 +544,10 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
           const double *xb = x + (e - cr);
           for (int k = 0; k < S; ++k) px += qs * qblk1<S>(cr, k, a.m34) * xb[k];
         }
-        l_rd = fmax(l_rd, fabs(px + aty[e]));
-        l_px = fmax(l_px, fabs(px));
-        l_aty = fmax(l_aty, fabs(aty[e]));
+        const double und = pow(Tn[i], (double)(D - 1 - cr)) / cobj;  // back to the reference's variables and objective
+        l_rd = fmax(l_rd, fabs(px + aty[e]) * und);
+        l_px = fmax(l_px, fabs(px) * und);
+        l_aty = fmax(l_aty, fabs(aty[e]) * und);
         l_ady = fmax(l_ady, fabs(ady[e]));
       }
       atomic_max_pos(&red[3], l_rd);
@@ -644,7 +654,7 @@ inline size_t qp_admm_lds_bytes(int N, int R, int M, bool zy_in_lds) {
   const size_t n = (size_t)NB * N;
   const size_t hp = (size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes ? (size_t)N * M * 4 : 0;
   const size_t mtot = (size_t)(3 * (6 + S * (N - 1))) + (size_t)N * R * (M + 12);
-  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 5 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 12 + hp + 2 * (size_t)(3 * (6 + S * (N - 1))) +
+  return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 5 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 12 + hp + 3 * (size_t)(3 * (6 + S * (N - 1))) +
                            (size_t)N * R * 9 + (zy_in_lds ? 2 * mtot : 0));
 }
 
