@@ -1025,7 +1025,7 @@ int anet_qp_assemble(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res,
 void anet_qp_default_settings(anet_qp_settings *s) {
   if (!s) return;
   s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
-  s->max_iter = 4000; s->check_termination = 25; s->adaptive_rho_interval = 100;
+  s->max_iter = 4000; s->check_termination = 25; s->adaptive_rho_interval = 100; s->scaled_termination = 0;
 }
 
 int64_t anet_qp_solve_workspace(int s, int n_pieces, int64_t batch, int res, int M) {
@@ -1063,7 +1063,7 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
   anet::AdmmArgs a{state, T, hpolys, work, work + m * batch, coeffs, obj, status, iters,
                    residuals ? residuals : work + 2 * m * batch, batch, n_pieces, res, M, max_vel, max_acc, m34,
                    anet::AdmmParams{st_.rho, st_.sigma, st_.alpha, st_.eps_abs, st_.eps_rel, st_.max_iter,
-                                    st_.check_termination, adapt},
+                                    st_.check_termination, adapt, st_.scaled_termination ? 1 : 0},
                    zy_in_lds};
   hipStream_t st = (hipStream_t)stream;
   if (s == 4) {

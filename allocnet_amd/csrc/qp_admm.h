@@ -23,7 +23,7 @@ namespace anet {
 
 struct AdmmParams {
   double rho, sigma, alpha, eps_abs, eps_rel;
-  int max_iter, check_every, adapt_every;
+  int max_iter, check_every, adapt_every, scaled_termination;
 };
 
 struct AdmmArgs {
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       if (check) {
         scatter(aty, yn);
         // OSQP tests the UNSCALED residuals: this row was scaled by T^d when the QP was normalised
-        const double un = eqs[r];
+        const double un = a.p.scaled_termination ? 1.0 : eqs[r];
         l_rp = fmax(l_rp, fabs(ax_new - zn) * un);
         l_ax = fmax(l_ax, fabs(ax_new) * un);
         l_z = fmax(l_z, fabs(zn) * un);
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       const int64_t NS = (int64_t)N * R;
       double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, gy[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
       double gd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-      const double Ti = Tn[i], rTi = 1.0 / Tn[i];
+      const double Ti = Tn[i], rTi = a.p.scaled_termination ? 1.0 : 1.0 / Tn[i];
       // one ADMM row update; returns w = rho z+ - y+ and (at check iterations) y+ and dy
       auto row_update = [&](double zt, double axn, double hv, double zo, double yo, double un, double &zn, double &yn) {
         const double zr = alpha * zt + (1.0 - alpha) * zo;
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
           const double *xb = x + (e - cr);
           for (int k = 0; k < S; ++k) px += qs * qblk1<S>(cr, k, a.m34) * xb[k];
         }
-        const double und = pow(Tn[i], (double)(D - 1 - cr)) / cobj;  // back to the reference's variables and objective
+        const double und = a.p.scaled_termination ? 1.0 : pow(Tn[i], (double)(D - 1 - cr)) / cobj;  // back to the reference's variables and objective
         l_rd = fmax(l_rd, fabs(px + aty[e]) * und);
         l_px = fmax(l_px, fabs(px) * und);
         l_aty = fmax(l_aty, fabs(aty[e]) * und);

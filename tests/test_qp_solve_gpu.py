@@ -136,3 +136,19 @@ def test_qp_solve_size_limits(anet_ctx):
     with pytest.raises(aa.AnetError) as ei:
         aa.qp_solve(4, np.zeros((1, 3, 3)), np.zeros((1, 3, 3)), np.zeros((1, 16, 6, 4)), np.ones((1, 16)), res=20, ctx=anet_ctx)
     assert ei.value.code == _lib.ANET_ERR_UNSUPPORTED
+
+
+def test_scaled_termination_setting(anet_ctx):
+    """scaled_termination = 1 stops on the residuals of the normalised problem: fewer iterations, same
+    optimum within the (looser) tolerance."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(31)
+    probs = [_corridor_problem(rng, 4, 8, margin=1.5) for _ in range(16)]
+    ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
+    hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs])
+    a = aa.qp_solve(4, ini, fin, hp, T, res=8, max_vel=4.0, max_acc=6.0, ctx=anet_ctx)
+    b = aa.qp_solve(4, ini, fin, hp, T, res=8, max_vel=4.0, max_acc=6.0, settings=aa.qp_settings(scaled_termination=1), ctx=anet_ctx)
+    both = (a["status"] == 1) & (b["status"] == 1)
+    assert both.sum() >= 10
+    assert b["iters"][both].mean() <= a["iters"][both].mean()
+    assert np.median(np.abs(a["obj"][both] - b["obj"][both]) / np.maximum(1e-9, a["obj"][both])) < 0.1
