@@ -261,6 +261,9 @@ __device__ __forceinline__ double wave_max(double v) {
 // product / norm is a wavefront shuffle reduction, scalars are computed redundantly by all lanes
 // (no divergence: a wave holds one problem).  Used for small batches, where one lane per problem
 // leaves the chip idle and serialises ~16 n-long dependent loops per accepted step.
+// history slots the wave kernel keeps in registers (default mem_size 8, FIRI's 18)
+constexpr int LBFGS_WAVE_MREG = 20;
+
 __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
   const int64_t b = blockIdx.x;
   const int lane = threadIdx.x;
@@ -383,7 +386,7 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
           const int64_t js = (vs == 1) ? ps : (int64_t)n * vs;             // stride between history slots
           double *se = lms + (int64_t)end * js, *ye = lmy + (int64_t)end * js;
           // this lane's variable(s) live in registers for the whole two-loop recursion (n <= 128)
-          double dv[2] = {0.0, 0.0};
+          double dv[2] = {0.0, 0.0}, sreg[2] = {0.0, 0.0}, yreg[2] = {0.0, 0.0};
           double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
           int q = 0;
           for (int i = lane; i < n; i += 64, ++q) {
@@ -391,6 +394,8 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
             const double si = x[i * ld] - xp[i * vs], yi = gi - gpi;
             se[i * vs] = si;
             ye[i * vs] = yi;
+            sreg[q] = si;
+            yreg[q] = yi;
             ys = __builtin_fma(yi, si, ys);
             yy = __builtin_fma(yi, yi, yy);
             ss = __builtin_fma(si, si, ss);
@@ -405,41 +410,90 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
             bound = m < bound ? m : bound;
             const int newest = end;
             end = (end + 1) % m;
-            int j = end;
-            double alpha = 0.0;  // lane `it` keeps alpha of the it-th visited slot (mem_size <= 64, host-checked)
-            for (int it = 0; it < bound; ++it) {
-              j = (j + m - 1) % m;
-              const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
-              double sd = 0.0, yv[2] = {0.0, 0.0};
-              q = 0;
-              for (int i = lane; i < n; i += 64, ++q) {
-                sd = __builtin_fma(sj[i * vs], dv[q], sd);
-                yv[q] = yj[i * vs];
+            if (m <= LBFGS_WAVE_MREG) {
+              // Whole history in registers: the 2*bound loads go out together instead of one
+              // dependent load per reduction (same operations in the same order as below).
+              double hs[LBFGS_WAVE_MREG][2], hy[LBFGS_WAVE_MREG][2], hys[LBFGS_WAVE_MREG];
+#pragma unroll
+              for (int it = 0; it < LBFGS_WAVE_MREG; ++it) {
+                hs[it][0] = hs[it][1] = hy[it][0] = hy[it][1] = 0.0;
+                hys[it] = 1.0;
+                if (it == 0) {
+                  hs[0][0] = sreg[0]; hs[0][1] = sreg[1];
+                  hy[0][0] = yreg[0]; hy[0][1] = yreg[1];
+                  hys[0] = ys;
+                } else if (it < bound) {
+                  const int jj = (end - 1 - it + m) % m;
+                  const double *sj = lms + (int64_t)jj * js, *yj = lmy + (int64_t)jj * js;
+                  if (lane < n) { hs[it][0] = sj[lane * vs]; hy[it][0] = yj[lane * vs]; }
+                  if (lane + 64 < n) { hs[it][1] = sj[(lane + 64) * vs]; hy[it][1] = yj[(lane + 64) * vs]; }
+                  hys[it] = a.lm_ys[(int64_t)jj * ld + b];
+                }
               }
-              sd = wave_sum(sd);
-              const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
-              const double al = sd / ysj;
-              alpha = (lane == it) ? al : alpha;
-              dv[0] = __builtin_fma(-al, yv[0], dv[0]);
-              dv[1] = __builtin_fma(-al, yv[1], dv[1]);
-            }
-            const double sc = ys / yy;
-            dv[0] *= sc;
-            dv[1] *= sc;
-            for (int it = 0; it < bound; ++it) {
-              const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
-              double yd = 0.0, sv[2] = {0.0, 0.0};
-              q = 0;
-              for (int i = lane; i < n; i += 64, ++q) {
-                yd = __builtin_fma(yj[i * vs], dv[q], yd);
-                sv[q] = sj[i * vs];
+              double alpha = 0.0;
+#pragma unroll
+              for (int it = 0; it < LBFGS_WAVE_MREG; ++it) {
+                if (it < bound) {
+                  double sd = __builtin_fma(hs[it][0], dv[0], 0.0);
+                  sd = __builtin_fma(hs[it][1], dv[1], sd);
+                  sd = wave_sum(sd);
+                  const double al = sd / hys[it];
+                  alpha = (lane == it) ? al : alpha;
+                  dv[0] = __builtin_fma(-al, hy[it][0], dv[0]);
+                  dv[1] = __builtin_fma(-al, hy[it][1], dv[1]);
+                }
               }
-              yd = wave_sum(yd);
-              const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
-              const double cf = __shfl(alpha, bound - 1 - it) - yd / ysj;
-              dv[0] = __builtin_fma(cf, sv[0], dv[0]);
-              dv[1] = __builtin_fma(cf, sv[1], dv[1]);
-              j = (j + 1) % m;
+              const double sc = ys / yy;
+              dv[0] *= sc;
+              dv[1] *= sc;
+#pragma unroll
+              for (int k = LBFGS_WAVE_MREG - 1; k >= 0; --k) {
+                if (k < bound) {
+                  double yd = __builtin_fma(hy[k][0], dv[0], 0.0);
+                  yd = __builtin_fma(hy[k][1], dv[1], yd);
+                  yd = wave_sum(yd);
+                  const double cf = __shfl(alpha, k) - yd / hys[k];
+                  dv[0] = __builtin_fma(cf, hs[k][0], dv[0]);
+                  dv[1] = __builtin_fma(cf, hs[k][1], dv[1]);
+                }
+              }
+            } else {
+              int j = end;
+              double alpha = 0.0;  // lane `it` keeps alpha of the it-th visited slot (mem_size <= 64, host-checked)
+              for (int it = 0; it < bound; ++it) {
+                j = (j + m - 1) % m;
+                const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
+                double sd = 0.0, yv[2] = {0.0, 0.0};
+                q = 0;
+                for (int i = lane; i < n; i += 64, ++q) {
+                  sd = __builtin_fma(sj[i * vs], dv[q], sd);
+                  yv[q] = yj[i * vs];
+                }
+                sd = wave_sum(sd);
+                const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
+                const double al = sd / ysj;
+                alpha = (lane == it) ? al : alpha;
+                dv[0] = __builtin_fma(-al, yv[0], dv[0]);
+                dv[1] = __builtin_fma(-al, yv[1], dv[1]);
+              }
+              const double sc = ys / yy;
+              dv[0] *= sc;
+              dv[1] *= sc;
+              for (int it = 0; it < bound; ++it) {
+                const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
+                double yd = 0.0, sv[2] = {0.0, 0.0};
+                q = 0;
+                for (int i = lane; i < n; i += 64, ++q) {
+                  yd = __builtin_fma(yj[i * vs], dv[q], yd);
+                  sv[q] = sj[i * vs];
+                }
+                yd = wave_sum(yd);
+                const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
+                const double cf = __shfl(alpha, bound - 1 - it) - yd / ysj;
+                dv[0] = __builtin_fma(cf, sv[0], dv[0]);
+                dv[1] = __builtin_fma(cf, sv[1], dv[1]);
+                j = (j + 1) % m;
+              }
             }
           }
           q = 0;

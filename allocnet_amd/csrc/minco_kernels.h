@@ -353,6 +353,145 @@ struct PropArgs {
   int N, c;
 };
 
+// One axis of the adjoint: accumulates this axis' share of dJ/dT into gT and stores its gradP rows.
+template <int S, int NB>
+__device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int N, const int np, const PropArgs &a,
+                                               const int64_t b, const int ax, const double Tlast,
+                                               double (&gT)[NB], const bool store) {
+  constexpr int m = S - 1, D = 2 * S;
+  const int64_t ld = a.ld;
+  // per-axis base pointers: every later offset is wave-uniform also when ax differs per lane
+  const double *ca = a.coeffs + (int64_t)(ax * D) * ld + b, *ga = a.gdC + (int64_t)(ax * D) * ld + b;
+  double *gp = a.gradP + (int64_t)ax * ld + b;
+  double rr[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
+  // ---- node states are re-read from the coefficients where needed instead of being held:
+  //      x_k[j] = j! c_j(piece k) for k < N; the last node by evaluating piece N-1 at its end
+  // (`cb` is this axis' coefficient base pointer; the second phase passes a laundered copy so that the
+  //  compiler re-reads instead of keeping every node state of the first phase alive)
+  auto node_state = [&](const double *cb, int k, double (&x)[S]) {
+    if (k < N) {
+      double fact = 1.0;
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        if (j > 0) fact *= (double)j;
+        x[j] = fact * cb[(int64_t)(k * 3 * D + (D - 1 - j)) * ld];
+      }
+    } else {
+      double cl[D], tp[D];
+      tp[0] = 1.0;
+#pragma unroll
+      for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Tlast;
+#pragma unroll
+      for (int col = 0; col < D; ++col) cl[col] = cb[(int64_t)((N - 1) * 3 * D + col) * ld];
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int p = j; p < D; ++p) {
+          double f = 1.0;
+#pragma unroll
+          for (int e = 0; e < j; ++e) f *= (double)(p - e);
+          acc = __builtin_fma(f * tp[p - j], cl[D - 1 - p], acc);
+        }
+        x[j] = acc;
+      }
+    }
+  };
+  double GP[NB + 1], XA[NB + 1][m];  // adjoint of the node positions / of the node derivatives
+#pragma unroll
+  for (int k = 0; k <= NB; ++k) {
+    GP[k] = 0.0;
+#pragma unroll
+    for (int l = 0; l < m; ++l) XA[k][l] = 0.0;
+  }
+  // ---- g_x = Phi' gdC and the direct dPhi/dT term
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < N) {
+      Pw<S> p(rr[i]);
+      double gc[D];
+#pragma unroll
+      for (int col = 0; col < D; ++col) gc[col] = ga[(int64_t)(i * 3 * D + col) * ld];
+      // low powers k < S: c_k = x_i[k]/k!
+      double x0[S], x1[S];
+      node_state(ca, i, x0);
+      node_state(ca, i + 1, x1);
+      auto addg = [&](int node, int dg, double v) {  // node-state adjoint: slot 0 = position
+        if (dg == 0) GP[node] += v;
+        else XA[node][dg - 1] += v;
+      };
+      double fact = 1.0;
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        if (k > 0) fact *= (double)k;
+        addg(i, k, gc[D - 1 - k] * (1.0 / fact));
+      }
+      double h[S];
+#pragma unroll
+      for (int q = 0; q < S; ++q) h[q] = gc[S - 1 - q] * p[q];  // gc of power S+q times r^q
+      double dsum = 0.0;
+#pragma unroll
+      for (int bb = 0; bb < 2 * S; ++bb) {
+        const int dg = bb % S;
+        double u = 0.0, qd = 0.0;
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+          u = __builtin_fma(Tab<S>::BHI[q][bb], h[q], u);
+          qd = __builtin_fma((double)(S + q - dg) * Tab<S>::BHI[q][bb], h[q], qd);
+        }
+        const double sc = p[S - dg];
+        const double xb = (bb < S) ? x0[dg] : x1[dg];
+        addg(bb < S ? i : i + 1, dg, u * sc);
+        dsum = __builtin_fma(xb * sc, qd, dsum);
+      }
+      gT[i] = __builtin_fma(-p[1], dsum, gT[i]);
+    }
+  // ---- adjoint solve K lam = g_x|free (pinned rows 0)
+  sweep_forward<S, NB>(F, N, np, rr, XA, [&](int k, double (&y)[m]) {
+#pragma unroll
+    for (int l = 0; l < m; ++l) y[l] = ((k == 0 || k == N) && l < np) ? 0.0 : XA[k][l];
+  });
+#pragma unroll
+  for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
+  const double *cb2 = ca;
+  asm volatile("" : "+v"(cb2));
+  sweep_backward<S, NB>(F, N, np, rr, XA, [&](int k, const Pw<S> &p) {
+    // (W_k lam^)[position row of node k]; the row of node k+1 is its negative
+    double wl = 0.0;
+#pragma unroll
+    for (int l = 0; l < m; ++l) {
+      wl = __builtin_fma(Tab<S>::M[0][1 + l] * p[2 * S - 2 - l], XA[k][l], wl);
+      wl = __builtin_fma(Tab<S>::M[0][S + 1 + l] * p[2 * S - 2 - l], XA[k + 1][l], wl);
+    }
+    GP[k] -= wl;
+    GP[k + 1] += wl;
+    // - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b
+    double x0[S], x1[S], xs[2 * S];
+    node_state(cb2, k, x0);
+    node_state(cb2, k + 1, x1);
+#pragma unroll
+    for (int bb = 0; bb < 2 * S; ++bb) xs[bb] = ((bb < S) ? x0[bb % S] : x1[bb % S]) * p[S - bb % S];
+    double acc = 0.0;
+#pragma unroll
+    for (int aa = 0; aa < 2 * S; ++aa) {
+      const int da = aa % S;
+      if (da == 0) continue;
+      double row = 0.0;
+#pragma unroll
+      for (int bb = 0; bb < 2 * S; ++bb)
+        row = __builtin_fma(Tab<S>::M[aa][bb] * (double)(2 * S - 1 - da - bb % S), xs[bb], row);
+      const double ls = ((aa < S) ? XA[k][da - 1] : XA[k + 1][da - 1]) * p[S - da];
+      acc = __builtin_fma(ls, row, acc);
+    }
+    gT[k] += acc;
+  });
+#pragma unroll
+  for (int k = 1; k < NB; ++k)
+    if (k < N && store) gp[(int64_t)((k - 1) * 3) * ld] = GP[k];
+}
+
 // MINCO propogateGrad: given the partial gradients (gdC, gdT) of a scalar J(c, T), return its total
 // gradient w.r.t. the interior waypoints and the durations, c = c(waypoints, T) being the minimum-
 // control-effort coefficients.  Adjoint of the Hermite/block-tridiagonal solve:
@@ -382,135 +521,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
   F.factorize(N, np);
 
 #pragma unroll 1
-  for (int ax = 0; ax < 3; ++ax) {
-    double rr[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
-    // ---- node states are re-read from the coefficients where needed instead of being held:
-    //      x_k[j] = j! c_j(piece k) for k < N; the last node by evaluating piece N-1 at its end
-    // (`cb` is the coefficient base pointer; the second phase passes a laundered copy so that the
-    //  compiler re-reads instead of keeping every node state of the first phase alive)
-    auto node_state = [&](const double *cb, int k, double (&x)[S]) {
-      if (k < N) {
-        double fact = 1.0;
-#pragma unroll
-        for (int j = 0; j < S; ++j) {
-          if (j > 0) fact *= (double)j;
-          x[j] = fact * cb[(int64_t)((k * 3 + ax) * D + (D - 1 - j)) * ld + b];
-        }
-      } else {
-        double cl[D], tp[D];
-        tp[0] = 1.0;
-#pragma unroll
-        for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Tlast;
-#pragma unroll
-        for (int col = 0; col < D; ++col) cl[col] = cb[(int64_t)(((N - 1) * 3 + ax) * D + col) * ld + b];
-#pragma unroll
-        for (int j = 0; j < S; ++j) {
-          double acc = 0.0;
-#pragma unroll
-          for (int p = j; p < D; ++p) {
-            double f = 1.0;
-#pragma unroll
-            for (int e = 0; e < j; ++e) f *= (double)(p - e);
-            acc = __builtin_fma(f * tp[p - j], cl[D - 1 - p], acc);
-          }
-          x[j] = acc;
-        }
-      }
-    };
-    double GP[NB + 1], XA[NB + 1][m];  // adjoint of the node positions / of the node derivatives
-#pragma unroll
-    for (int k = 0; k <= NB; ++k) {
-      GP[k] = 0.0;
-#pragma unroll
-      for (int l = 0; l < m; ++l) XA[k][l] = 0.0;
-    }
-    // ---- g_x = Phi' gdC and the direct dPhi/dT term
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (i < N) {
-        Pw<S> p(rr[i]);
-        double gc[D];
-#pragma unroll
-        for (int col = 0; col < D; ++col) gc[col] = a.gdC[(int64_t)((i * 3 + ax) * D + col) * ld + b];
-        // low powers k < S: c_k = x_i[k]/k!
-        double x0[S], x1[S];
-        node_state(a.coeffs, i, x0);
-        node_state(a.coeffs, i + 1, x1);
-        auto addg = [&](int node, int dg, double v) {  // node-state adjoint: slot 0 = position
-          if (dg == 0) GP[node] += v;
-          else XA[node][dg - 1] += v;
-        };
-        double fact = 1.0;
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-          if (k > 0) fact *= (double)k;
-          addg(i, k, gc[D - 1 - k] * (1.0 / fact));
-        }
-        double h[S];
-#pragma unroll
-        for (int q = 0; q < S; ++q) h[q] = gc[S - 1 - q] * p[q];  // gc of power S+q times r^q
-        double dsum = 0.0;
-#pragma unroll
-        for (int bb = 0; bb < 2 * S; ++bb) {
-          const int dg = bb % S;
-          double u = 0.0, qd = 0.0;
-#pragma unroll
-          for (int q = 0; q < S; ++q) {
-            u = __builtin_fma(Tab<S>::BHI[q][bb], h[q], u);
-            qd = __builtin_fma((double)(S + q - dg) * Tab<S>::BHI[q][bb], h[q], qd);
-          }
-          const double sc = p[S - dg];
-          const double xb = (bb < S) ? x0[dg] : x1[dg];
-          addg(bb < S ? i : i + 1, dg, u * sc);
-          dsum = __builtin_fma(xb * sc, qd, dsum);
-        }
-        gT[i] = __builtin_fma(-p[1], dsum, gT[i]);
-      }
-    // ---- adjoint solve K lam = g_x|free (pinned rows 0)
-    sweep_forward<S, NB>(F, N, np, rr, XA, [&](int k, double (&y)[m]) {
-#pragma unroll
-      for (int l = 0; l < m; ++l) y[l] = ((k == 0 || k == N) && l < np) ? 0.0 : XA[k][l];
-    });
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
-    const double *cb2 = a.coeffs;
-    asm volatile("" : "+v"(cb2));
-    sweep_backward<S, NB>(F, N, np, rr, XA, [&](int k, const Pw<S> &p) {
-      // (W_k lam^)[position row of node k]; the row of node k+1 is its negative
-      double wl = 0.0;
-#pragma unroll
-      for (int l = 0; l < m; ++l) {
-        wl = __builtin_fma(Tab<S>::M[0][1 + l] * p[2 * S - 2 - l], XA[k][l], wl);
-        wl = __builtin_fma(Tab<S>::M[0][S + 1 + l] * p[2 * S - 2 - l], XA[k + 1][l], wl);
-      }
-      GP[k] -= wl;
-      GP[k + 1] += wl;
-      // - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b
-      double x0[S], x1[S], xs[2 * S];
-      node_state(cb2, k, x0);
-      node_state(cb2, k + 1, x1);
-#pragma unroll
-      for (int bb = 0; bb < 2 * S; ++bb) xs[bb] = ((bb < S) ? x0[bb % S] : x1[bb % S]) * p[S - bb % S];
-      double acc = 0.0;
-#pragma unroll
-      for (int aa = 0; aa < 2 * S; ++aa) {
-        const int da = aa % S;
-        if (da == 0) continue;
-        double row = 0.0;
-#pragma unroll
-        for (int bb = 0; bb < 2 * S; ++bb)
-          row = __builtin_fma(Tab<S>::M[aa][bb] * (double)(2 * S - 1 - da - bb % S), xs[bb], row);
-        const double ls = ((aa < S) ? XA[k][da - 1] : XA[k + 1][da - 1]) * p[S - da];
-        acc = __builtin_fma(ls, row, acc);
-      }
-      gT[k] += acc;
-    });
-#pragma unroll
-    for (int k = 1; k < NB; ++k)
-      if (k < N) a.gradP[(int64_t)((k - 1) * 3 + ax) * ld + b] = GP[k];
-  }
+  for (int ax = 0; ax < 3; ++ax) propagate_axis<S, NB>(F, N, np, a, b, ax, Tlast, gT, true);
   double csum = 0.0;
 #pragma unroll
   for (int i = 0; i < NB; ++i)
@@ -519,6 +530,49 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
       if (a.pcost) csum += a.pcost[i * ld + b];
     }
   if (a.cost) a.cost[b] = (a.energy_in ? a.energy_in[b] : 0.0) + a.rho * tsum + csum;
+}
+
+// Small-batch variant of the above, one lane per (trajectory, axis) like k_minco_solve_axis: the three
+// lanes of a trajectory refactorise the shared system and propagate their own axis; dJ/dT is the
+// 3-lane shuffle sum of the per-axis shares.
+template <int S, int NB, bool NEXACT = false, int NPC = -1>
+__global__ void __launch_bounds__(kSolveBlock) k_minco_propagate_axis(PropArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * 63 + threadIdx.x;
+  const int64_t b = gid / 3;
+  const int ax = (int)(gid % 3);
+  const bool live = threadIdx.x < 63 && b < a.B;
+  const int N = NEXACT ? NB : a.N;
+  const int np = NPC >= 0 ? NPC : a.c - 1;
+  const int64_t ld = a.ld;
+  const int64_t bb = live ? b : 0;
+
+  Factor<S, NB> F;
+  double gT[NB];
+  double tsum = 0.0, Tlast = 0.0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    gT[i] = 0.0;
+    if (i < N) {
+      const double t = a.T[i * ld + bb];
+      F.r[i] = fast_rcp(t);
+      tsum += t;
+      if (i == N - 1) Tlast = t;
+    }
+  }
+  F.factorize(N, np);
+  propagate_axis<S, NB>(F, N, np, a, bb, ax, Tlast, gT, live);
+
+  double csum = 0.0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < N) {
+      const double tot = gT[i] + __shfl_down(gT[i], 1) + __shfl_down(gT[i], 2);
+      if (live && ax == 0) {
+        a.gradT[i * ld + bb] = a.gdT[i * ld + bb] + tot + a.rho;
+        if (a.pcost) csum += a.pcost[i * ld + bb];
+      }
+    }
+  if (a.cost && live && ax == 0) a.cost[bb] = (a.energy_in ? a.energy_in[bb] : 0.0) + a.rho * tsum + csum;
 }
 
 }  // namespace anet

@@ -109,3 +109,27 @@ def test_lane_per_trajectory_kernels_above_the_axis_threshold(anet_ctx, s, c, N)
     assert rel_err(co[idx], cc) < 1e-9 and rel_err(en[idx], ec) < 1e-9
     co2, en2 = aa.minco_solve(head[:3000], tail[:3000], wps[:3000], T[:3000], s, ctx=anet_ctx)   # axis-parallel path
     assert rel_err(co2, co[:3000]) < 1e-11 and rel_err(en2, en[:3000]) < 1e-11
+
+
+@pytest.mark.parametrize("s,c,N", [(4, 3, 8), (3, 3, 16), (4, 4, 3), (3, 2, 6), (2, 2, 12)])
+def test_gradient_propagation_lane_and_axis_kernels_agree(anet_ctx, s, c, N):
+    """propogateGrad has the same two launch shapes as the solve: lane per trajectory above 16384,
+    lane per (trajectory, axis) below.  The small-batch result is pinned against the numpy oracle in
+    test_grad_gpu.py; here the two shapes are compared on the same trajectories."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(91 * N + s)
+    B = 16384 + 300
+    head, tail, wps, T = random_problem(rng, B, N, c)
+    pen = aa.make_penalty(rho=1.3, w_vel=20.0, w_acc=8.0, smooth_mu=0.05, max_vel=1.0, max_acc=1.5, res=5)
+    cost, gP, gT = aa.minco_cost_grad(head, tail, wps, T, s, penalty=pen, ctx=anet_ctx)            # lane kernels
+    n = 2000
+    cost2, gP2, gT2 = aa.minco_cost_grad(head[:n], tail[:n], wps[:n], T[:n], s, penalty=pen, ctx=anet_ctx)
+    assert np.isfinite(cost).all() and np.isfinite(gT).all()
+    assert rel_err(cost2, cost[:n]) < 1e-12
+    assert np.abs(gP2 - gP[:n]).max() <= 1e-10 * max(1.0, np.abs(gP).max())
+    assert np.abs(gT2 - gT[:n]).max() <= 1e-10 * max(1.0, np.abs(gT).max())
+    # rows past the batch in the last, partly filled wave stay untouched (idle lanes store nothing)
+    odd = 21 * 5 + 4
+    c3, gP3, gT3 = aa.minco_cost_grad(head[:odd], tail[:odd], wps[:odd], T[:odd], s, penalty=pen, ctx=anet_ctx)
+    assert np.abs(gT3 - gT[:odd]).max() <= 1e-10 * max(1.0, np.abs(gT).max())
+    assert np.abs(gP3 - gP[:odd]).max() <= 1e-10 * max(1.0, np.abs(gP).max())
