@@ -226,7 +226,7 @@ static int ensure_counter(anet_ctx *ctx) {
 // problem by one evaluation per pass and polls the number of unfinished problems every `poll` passes.
 template <class Eval>
 static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfgs_params &prm, int max_evals,
-                       hipStream_t st, Eval &&eval) {
+                       hipStream_t st, Eval &&eval, double *map_T = nullptr, int map_nw = 0) {
   int rc = ensure_counter(ctx);
   if (rc) return rc;
   ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * L.ld, st));
@@ -235,7 +235,7 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
   // large batches: one lane per problem (internal vectors batch-minor)
   const bool wave = B <= 32768 && L.n <= 128 && prm.mem_size <= 64;
   anet::LbfgsArgs a{L.n, B, L.ld, L.x, L.g, L.xp, L.gp, L.d, L.lm_s, L.lm_y, L.lm_ys, L.lm_alpha, L.pf, L.ds,
-                    L.feval, L.is, to_kernel_params(prm), nullptr, wave ? 1 : L.ld, wave ? L.n : 1};
+                    L.feval, L.is, to_kernel_params(prm), nullptr, wave ? 1 : L.ld, wave ? L.n : 1, map_T, map_nw};
   const dim3 grid(wave ? (unsigned)B : (unsigned)((B + 63) / 64)), block(64);
   const int poll = 8;
   for (int it = 0; it < max_evals; ++it) {
@@ -243,10 +243,25 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
     const bool check = ((it + 1) % poll == 0) || it + 1 == max_evals;
     if (check) ANET_HIP(ctx, hipMemsetAsync(ctx->d_counter, 0, sizeof(int), st));
     a.n_active = check ? ctx->d_counter : nullptr;
-    if (wave)
-      hipLaunchKernelGGL(anet::k_lbfgs_update_wave, grid, block, 0, st, a);
-    else
+    if (wave) {
+      auto shape = [&](int waves, dim3 &g, dim3 &bl) {
+        g = dim3((unsigned)((B + waves - 1) / waves));
+        bl = dim3(64u * waves);
+      };
+      dim3 gw, bw;
+      if (a.p.mem_size <= 8) {
+        shape(anet::LbfgsWaveShape<8>::kWaves, gw, bw);
+        hipLaunchKernelGGL(anet::k_lbfgs_update_wave<8>, gw, bw, 0, st, a);
+      } else if (a.p.mem_size <= 20) {
+        shape(anet::LbfgsWaveShape<20>::kWaves, gw, bw);
+        hipLaunchKernelGGL(anet::k_lbfgs_update_wave<20>, gw, bw, 0, st, a);
+      } else {
+        shape(anet::LbfgsWaveShape<0>::kWaves, gw, bw);
+        hipLaunchKernelGGL(anet::k_lbfgs_update_wave<0>, gw, bw, 0, st, a);
+      }
+    } else {
       hipLaunchKernelGGL(anet::k_lbfgs_update, grid, block, 0, st, a);
+    }
     ANET_HIP(ctx, hipGetLastError());
     if (check) {
       ANET_HIP(ctx, hipMemcpyAsync(ctx->h_counter, ctx->d_counter, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -655,11 +670,12 @@ int64_t anet_minco_cost_grad_workspace(int s, int n_pieces, int64_t ld) {
   return ((int64_t)n_pieces * 3 * 2 * s * 2 + 2 * (int64_t)n_pieces + 1) * ld;
 }
 
-int anet_minco_cost_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
-                             const double *head, const double *tail, const double *wps,
-                             const double *T, const double *hpolys, const anet_penalty *pen,
-                             double *work, double *cost, double *gradP, double *gradT,
-                             double *coeffs_out, void *stream) {
+// tau != nullptr: the durations are T = forward_T(tau) and gradT is returned as dJ/dtau (L-BFGS driver)
+static int cost_grad_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                              const double *head, const double *tail, const double *wps,
+                              const double *T, const double *hpolys, const anet_penalty *pen,
+                              double *work, double *cost, double *gradP, double *gradT,
+                              double *coeffs_out, void *stream, const double *tau) {
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
   if ((rc = check_penalty(ctx, pen))) return rc;
@@ -678,8 +694,17 @@ int anet_minco_cost_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t 
                                     w_pc, stream);
   if (rc) return rc;
   anet::PropArgs a{T, w_co, w_gdC, w_gdT, gradP, gradT, w_en, pen ? w_pc : nullptr, cost,
-                   pen ? pen->rho : 0.0, batch, ld, n_pieces, c};
+                   pen ? pen->rho : 0.0, batch, ld, n_pieces, c, tau};
   return do_propagate(ctx, s, a, (hipStream_t)stream);
+}
+
+int anet_minco_cost_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                             const double *head, const double *tail, const double *wps,
+                             const double *T, const double *hpolys, const anet_penalty *pen,
+                             double *work, double *cost, double *gradP, double *gradT,
+                             double *coeffs_out, void *stream) {
+  return cost_grad_dev_impl(ctx, s, c, n_pieces, batch, ld, head, tail, wps, T, hpolys, pen, work, cost, gradP, gradT,
+                            coeffs_out, stream, nullptr);
 }
 
 int anet_minco_cost_grad(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
@@ -859,26 +884,20 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
   double *w_gT = w_gP + (int64_t)3 * (N - 1) * ld;
   hipStream_t st = (hipStream_t)stream;
   const dim3 g256((unsigned)((batch + 255) / 256)), b256(256);
-  anet::MapArgs mp{L.x, L.g, wps, T, w_gP, w_gT, batch, ld, nw, nt, 0};
+  anet::MapArgs mp{L.x, wps, T, batch, ld, nw, nt, 0};
   const dim3 gmap(g256.x, (unsigned)n);
   hipLaunchKernelGGL(anet::k_minco_map, gmap, b256, 0, st, mp);
   ANET_HIP(ctx, hipGetLastError());
-  bool first = true;
+  // No per-evaluation mapping launches: the optimised waypoints ARE the first nw rows of x (same layout),
+  // their gradient goes straight into g, the update kernel writes T = forward_T(tau) next to x, and the
+  // propagate kernel applies dT/dtau to the duration gradient.
+  const double *wps_eval = nw ? L.x : wps;
+  double *gP_out = nw ? L.g : w_gP, *gT_out = nt ? L.g + (int64_t)nw * ld : w_gT;
+  const double *tau = nt ? L.x + (int64_t)nw * ld : nullptr;
   rc = lbfgs_drive(ctx, L, batch, *params, max_evals, st, [&]() -> int {
-    if (!first) {
-      mp.mode = 1;
-      hipLaunchKernelGGL(anet::k_minco_map, gmap, b256, 0, st, mp);
-      ANET_HIP(ctx, hipGetLastError());
-    }
-    first = false;
-    int r = anet_minco_cost_grad_dev(ctx, s, c, N, batch, ld, head, tail, wps, T, hpolys, pen, w_cg, L.feval,
-                                     w_gP, w_gT, nullptr, st);
-    if (r) return r;
-    mp.mode = 2;
-    hipLaunchKernelGGL(anet::k_minco_map, gmap, b256, 0, st, mp);
-    ANET_HIP(ctx, hipGetLastError());
-    return ANET_OK;
-  });
+    return cost_grad_dev_impl(ctx, s, c, N, batch, ld, head, tail, wps_eval, T, hpolys, pen, w_cg, L.feval, gP_out,
+                              gT_out, nullptr, st, tau);
+  }, nt ? T : nullptr, nw);
   if (rc) return rc;
   // final parameters (x may have been reverted by a failed line search) and outputs
   mp.mode = 1;

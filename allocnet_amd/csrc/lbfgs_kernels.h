@@ -36,7 +36,15 @@ struct LbfgsArgs {
   LbfgsP p;
   int *n_active;
   int64_t vs, ps;  // internal vectors (xp, gp, d, lm_s, lm_y): element i of problem b at [i*vs + b*ps]
+  // MINCO objective: variables [map_nw, n) are tau of the durations; wherever x is written the mapped
+  // duration T = forward_T(tau) is written too (saves a launch per evaluation).  nullptr: no mapping.
+  double *map_T = nullptr;
+  int map_nw = 0;
 };
+__device__ __forceinline__ void store_x(const LbfgsArgs &a, int64_t b, int i, double v) {
+  a.x[(int64_t)i * a.ld + b] = v;
+  if (a.map_T && i >= a.map_nw) a.map_T[(int64_t)(i - a.map_nw) * a.ld + b] = forward_T(v);
+}
 
 // One lane per problem.  Every launch consumes ONE objective evaluation (f = feval[b], gradient in
 // g, both taken at the point currently in x) and leaves in x the next point to evaluate.  The
@@ -132,13 +140,13 @@ __global__ void __launch_bounds__(64) k_lbfgs_update(LbfgsArgs a) {
     if (err) {
       // revert to the previous point; the reported f stays the last trial's (lbfgs.hpp:570-577,713)
       for (int i = 0; i < n; ++i) {
-        x[i * ld] = xp[i * ld];
+        store_x(a, b, i, xp[i * ld]);
         g[i * ld] = gp[i * ld];
       }
       fx = f;
       finish = err;
     } else if (!success) {
-      for (int i = 0; i < n; ++i) x[i * ld] = __builtin_fma(step, d[i * ld], xp[i * ld]);
+      for (int i = 0; i < n; ++i) store_x(a, b, i, __builtin_fma(step, d[i * ld], xp[i * ld]));
       ds[DS_MU * ld] = mu;
       ds[DS_NU * ld] = nu;
       is[IS_COUNT * ld] = count;
@@ -231,7 +239,7 @@ __global__ void __launch_bounds__(64) k_lbfgs_update(LbfgsArgs a) {
       is[IS_COUNT * ld] = 0;
       is[IS_BRACKT * ld] = 0;
       is[IS_TOUCHED * ld] = 0;
-      for (int i = 0; i < n; ++i) x[i * ld] = __builtin_fma(step, d[i * ld], xp[i * ld]);
+      for (int i = 0; i < n; ++i) store_x(a, b, i, __builtin_fma(step, d[i * ld], xp[i * ld]));
     }
   }
   ds[DS_FX * ld] = fx;
@@ -246,36 +254,82 @@ __global__ void __launch_bounds__(64) k_lbfgs_update(LbfgsArgs a) {
 }
 
 
+// Wave-wide reductions on the DPP path: in-row inclusive scan by row_shr 1/2/4/8, row_bcast:15 /
+// row_bcast:31 to chain the four rows, total read from lane 63 as a wave-uniform scalar.  About 20 VALU
+// ops, where the ds_bpermute butterfly of __shfl_xor costs several hundred cycles per reduction --
+// the two-loop recursion is a chain of 2*mem_size dependent reductions.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);  // masked rows / missing sources read 0
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double last_lane(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                          __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// a value every lane holds identically (loaded from a wave-uniform address) -> SGPR pair
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_f64<0x111>(v);
+  v += dpp_f64<0x112>(v);
+  v += dpp_f64<0x114>(v);
+  v += dpp_f64<0x118>(v);
+  v += dpp_f64<0x142, 0xa>(v);
+  v += dpp_f64<0x143, 0xc>(v);
+  return last_lane(v);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
+// maximum of NON-NEGATIVE values (0 is the fill of masked / missing lanes)
+__device__ __forceinline__ double wave_max_nonneg(double v) {
+  v = fmax(v, dpp_f64<0x111>(v));
+  v = fmax(v, dpp_f64<0x112>(v));
+  v = fmax(v, dpp_f64<0x114>(v));
+  v = fmax(v, dpp_f64<0x118>(v));
+  v = fmax(v, dpp_f64<0x142, 0xa>(v));
+  v = fmax(v, dpp_f64<0x143, 0xc>(v));
+  return last_lane(v);
 }
 
-// Same state machine, ONE WAVE per problem: the n variables are spread over the 64 lanes, every dot
-// product / norm is a wavefront shuffle reduction, scalars are computed redundantly by all lanes
-// (no divergence: a wave holds one problem).  Used for small batches, where one lane per problem
-// leaves the chip idle and serialises ~16 n-long dependent loops per accepted step.
-// history slots the wave kernel keeps in registers (default mem_size 8, FIRI's 18)
-constexpr int LBFGS_WAVE_MREG = 20;
-
-__global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
-  const int64_t b = blockIdx.x;
-  const int lane = threadIdx.x;
+// Same state machine, ONE WAVE per problem: the n <= 128 variables are spread over the 64 lanes (two
+// per lane, held in registers for the whole tick), every dot product / norm is a wave reduction,
+// scalars are wave-uniform.  Used for small batches, where one lane per problem leaves the chip idle
+// and serialises ~16 n-long dependent loops per accepted step.
+// Memory round trips per tick: (1) state + the lane's x, g, d, xp, gp; (2) history + past-f ring
+// (speculatively, the accepted-step branch is the common one); then only stores.
+// LBFGS_WAVE_MREG: history slots kept in registers -- instantiated for 8 (the default mem_size;
+// 4 waves/SIMD), 20 (FIRI's 18; 2 waves/SIMD) and 0 (any mem_size, history re-read per slot).
+// A workgroup is 4 to 16 waves (by register budget) = ADJACENT problems: x, g and the state
+// are batch-minor, so one 128-byte line holds the same variable of 16 neighbouring problems -- on one
+// CU they share it in L1; as separate workgroups they were dealt round-robin to the 8 XCDs and every
+// line was fetched 16 times.
+template <int LBFGS_WAVE_MREG>
+struct LbfgsWaveShape {
+  static constexpr int kWaves = (LBFGS_WAVE_MREG > 8) ? 4 : (LBFGS_WAVE_MREG > 0) ? 8 : 16;  // register budget
+};
+template <int LBFGS_WAVE_MREG>
+__global__ void __launch_bounds__(64 * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves)
+k_lbfgs_update_wave(LbfgsArgs a) {
+  constexpr int MR = LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1;
+  const int64_t b = (int64_t)blockIdx.x * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= a.B) return;  // whole waves only: the reductions below need all 64 lanes
   const int64_t ld = a.ld;
   int *is = a.is + b;
-  if (is[IS_DONE * ld]) return;
   double *ds = a.ds + b;
   const int n = a.n, m = a.p.mem_size;
   const LbfgsP &P = a.p;
   const int64_t vs = a.vs, ps = a.ps;
   double *x = a.x + b, *g = a.g + b;                       // batch-minor (shared with the objective)
   double *xp = a.xp + b * ps, *gp = a.gp + b * ps, *d = a.d + b * ps;
+  const bool h[2] = {lane < n, lane + 64 < n};
+  const int64_t iv[2] = {lane, lane + 64};                  // this lane's variable indices
+
+  // ---- round trip 1
+  const int done = is[IS_DONE * ld];
   const double f = a.feval[b];
   double fx = ds[DS_FX * ld];
   double step = ds[DS_STEP * ld];
@@ -285,30 +339,71 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
   int count = is[IS_COUNT * ld], brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
   double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
   double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
+  double xr[2], gr[2], dr[2], xpr[2], gpr[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    xr[q] = h[q] ? x[iv[q] * ld] : 0.0;
+    gr[q] = h[q] ? g[iv[q] * ld] : 0.0;
+    dr[q] = h[q] ? d[iv[q] * vs] : 0.0;
+    xpr[q] = h[q] ? xp[iv[q] * vs] : 0.0;
+    gpr[q] = h[q] ? gp[iv[q] * vs] : 0.0;
+  }
+  if (done) return;
+  // the scalars are the same in every lane: make that visible (scalar branches, SGPR operands)
+  k = __builtin_amdgcn_readfirstlane(k);
+  end = __builtin_amdgcn_readfirstlane(end);
+  bound = __builtin_amdgcn_readfirstlane(bound);
+  phase = __builtin_amdgcn_readfirstlane(phase);
+
+  // ---- round trip 2 (speculative): history slots other than the one this tick writes, past-f entry
+  double *lms = a.lm_s + b * ps * m, *lmy = a.lm_y + b * ps * m;  // [j][i] at (j*js + i*vs)
+  const int64_t js = (vs == 1) ? ps : (int64_t)n * vs;             // stride between history slots
+  const bool hist_in_regs = LBFGS_WAVE_MREG > 0 && m <= LBFGS_WAVE_MREG;
+  double hs[MR][2], hy[MR][2], hys[MR];
+  double pf_old = 0.0;
+  if (phase != 0) {
+    if (0 < P.past && P.past <= k) pf_old = a.pf[(int64_t)(k % P.past) * ld + b];
+    if (hist_in_regs) {
+      const int nb = (bound + 1 < m) ? bound + 1 : m;  // bound after an accepted step
+#pragma unroll
+      for (int it = 1; it < MR; ++it) {
+        hs[it][0] = hs[it][1] = hy[it][0] = hy[it][1] = 0.0;
+        hys[it] = 1.0;
+        if (it < nb) {
+          const int jj = (end - it + m) % m;  // it-th slot behind the new one
+          const double *sj = lms + (int64_t)jj * js, *yj = lmy + (int64_t)jj * js;
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            if (h[q]) {
+              hs[it][q] = sj[iv[q] * vs];
+              hy[it][q] = yj[iv[q] * vs];
+            }
+          hys[it] = uniform_f64(a.lm_ys[(int64_t)jj * ld + b]);
+        }
+      }
+    }
+  }
+
   bool start_ls = false;
   int finish = 0x7fffffff;
-
+  auto dot = [&](const double (&u)[2], const double (&v)[2]) {
+    return wave_sum(__builtin_fma(u[1], v[1], __builtin_fma(u[0], v[0], 0.0)));
+  };
   auto conv_test = [&]() {
-    double gn = 0.0, xn = 0.0;
-    for (int i = lane; i < n; i += 64) {
-      gn = fmax(gn, fabs(g[i * ld]));
-      xn = fmax(xn, fabs(x[i * ld]));
-    }
-    gn = wave_max(gn);
-    xn = wave_max(xn);
+    const double gn = wave_max_nonneg(fmax(fabs(gr[0]), fabs(gr[1])));
+    const double xn = wave_max_nonneg(fmax(fabs(xr[0]), fabs(xr[1])));
     return gn / fmax(1.0, xn) < P.g_epsilon;
   };
 
   if (phase == 0) {
     fx = f;
     if (lane == 0) a.pf[b] = fx;
-    double dd = 0.0;
-    for (int i = lane; i < n; i += 64) {
-      const double gi = g[i * ld];
-      d[i * vs] = -gi;
-      dd = __builtin_fma(gi, gi, dd);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      dr[q] = -gr[q];
+      if (h[q]) d[iv[q] * vs] = dr[q];
     }
-    dd = wave_sum(dd);
+    const double dd = dot(gr, gr);
     if (conv_test()) {
       finish = LB_CONVERGENCE;
     } else {
@@ -330,9 +425,7 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
         nu = step;
         brackt = 1;
       } else {
-        double dg = 0.0;
-        for (int i = lane; i < n; i += 64) dg = __builtin_fma(g[i * ld], d[i * vs], dg);
-        dg = wave_sum(dg);
+        const double dg = dot(gr, dr);
         if (dg < dstest)
           mu = step;
         else
@@ -359,14 +452,18 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
       }
     }
     if (err) {
-      for (int i = lane; i < n; i += 64) {
-        x[i * ld] = xp[i * vs];
-        g[i * ld] = gp[i * vs];
-      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (h[q]) {
+          store_x(a, b, (int)iv[q], xpr[q]);
+          g[iv[q] * ld] = gpr[q];
+        }
       fx = f;
       finish = err;
     } else if (!success) {
-      for (int i = lane; i < n; i += 64) x[i * ld] = __builtin_fma(step, d[i * vs], xp[i * vs]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (h[q]) store_x(a, b, (int)iv[q], __builtin_fma(step, dr[q], xpr[q]));
     } else {
       fx = f;
       if (conv_test()) {
@@ -374,7 +471,7 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
       } else {
         if (0 < P.past) {
           if (P.past <= k) {
-            const double rate = fabs(a.pf[(int64_t)(k % P.past) * ld + b] - fx) / fmax(1.0, fabs(fx));
+            const double rate = fabs(pf_old - fx) / fmax(1.0, fabs(fx));
             if (rate < P.delta) finish = LB_STOP;
           }
           if (finish == 0x7fffffff && lane == 0) a.pf[(int64_t)(k % P.past) * ld + b] = fx;
@@ -382,27 +479,19 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
         if (finish == 0x7fffffff && P.max_iterations != 0 && P.max_iterations <= k) finish = LBERR_MAXIMUMITERATION;
         if (finish == 0x7fffffff) {
           ++k;
-          double *lms = a.lm_s + b * ps * m, *lmy = a.lm_y + b * ps * m;  // [j][i] at (j*n_stride + i*vs)
-          const int64_t js = (vs == 1) ? ps : (int64_t)n * vs;             // stride between history slots
           double *se = lms + (int64_t)end * js, *ye = lmy + (int64_t)end * js;
-          // this lane's variable(s) live in registers for the whole two-loop recursion (n <= 128)
-          double dv[2] = {0.0, 0.0}, sreg[2] = {0.0, 0.0}, yreg[2] = {0.0, 0.0};
-          double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
-          int q = 0;
-          for (int i = lane; i < n; i += 64, ++q) {
-            const double gi = g[i * ld], gpi = gp[i * vs];
-            const double si = x[i * ld] - xp[i * vs], yi = gi - gpi;
-            se[i * vs] = si;
-            ye[i * vs] = yi;
-            sreg[q] = si;
-            yreg[q] = yi;
-            ys = __builtin_fma(yi, si, ys);
-            yy = __builtin_fma(yi, yi, yy);
-            ss = __builtin_fma(si, si, ss);
-            gpgp = __builtin_fma(gpi, gpi, gpgp);
-            dv[q] = -gi;
+          double sreg[2], yreg[2], dv[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            sreg[q] = xr[q] - xpr[q];
+            yreg[q] = gr[q] - gpr[q];
+            dv[q] = -gr[q];
+            if (h[q]) {
+              se[iv[q] * vs] = sreg[q];
+              ye[iv[q] * vs] = yreg[q];
+            }
           }
-          ys = wave_sum(ys); yy = wave_sum(yy); ss = wave_sum(ss); gpgp = wave_sum(gpgp);
+          const double ys = dot(yreg, sreg), yy = dot(yreg, yreg), ss = dot(sreg, sreg), gpgp = dot(gpr, gpr);
           if (lane == 0) a.lm_ys[(int64_t)end * ld + b] = ys;
           const double cau = ss * sqrt(gpgp) * P.cautious_factor;
           if (ys > cau) {
@@ -410,51 +499,29 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
             bound = m < bound ? m : bound;
             const int newest = end;
             end = (end + 1) % m;
-            if (m <= LBFGS_WAVE_MREG) {
-              // Whole history in registers: the 2*bound loads go out together instead of one
-              // dependent load per reduction (same operations in the same order as below).
-              double hs[LBFGS_WAVE_MREG][2], hy[LBFGS_WAVE_MREG][2], hys[LBFGS_WAVE_MREG];
+            if (hist_in_regs) {
+              hs[0][0] = sreg[0]; hs[0][1] = sreg[1];
+              hy[0][0] = yreg[0]; hy[0][1] = yreg[1];
+              hys[0] = ys;
+              double alpha[MR];
 #pragma unroll
-              for (int it = 0; it < LBFGS_WAVE_MREG; ++it) {
-                hs[it][0] = hs[it][1] = hy[it][0] = hy[it][1] = 0.0;
-                hys[it] = 1.0;
-                if (it == 0) {
-                  hs[0][0] = sreg[0]; hs[0][1] = sreg[1];
-                  hy[0][0] = yreg[0]; hy[0][1] = yreg[1];
-                  hys[0] = ys;
-                } else if (it < bound) {
-                  const int jj = (end - 1 - it + m) % m;
-                  const double *sj = lms + (int64_t)jj * js, *yj = lmy + (int64_t)jj * js;
-                  if (lane < n) { hs[it][0] = sj[lane * vs]; hy[it][0] = yj[lane * vs]; }
-                  if (lane + 64 < n) { hs[it][1] = sj[(lane + 64) * vs]; hy[it][1] = yj[(lane + 64) * vs]; }
-                  hys[it] = a.lm_ys[(int64_t)jj * ld + b];
-                }
-              }
-              double alpha = 0.0;
-#pragma unroll
-              for (int it = 0; it < LBFGS_WAVE_MREG; ++it) {
+              for (int it = 0; it < MR; ++it) {
+                alpha[it] = 0.0;
                 if (it < bound) {
-                  double sd = __builtin_fma(hs[it][0], dv[0], 0.0);
-                  sd = __builtin_fma(hs[it][1], dv[1], sd);
-                  sd = wave_sum(sd);
-                  const double al = sd / hys[it];
-                  alpha = (lane == it) ? al : alpha;
-                  dv[0] = __builtin_fma(-al, hy[it][0], dv[0]);
-                  dv[1] = __builtin_fma(-al, hy[it][1], dv[1]);
+                  alpha[it] = dot(hs[it], dv) / hys[it];
+                  dv[0] = __builtin_fma(-alpha[it], hy[it][0], dv[0]);
+                  dv[1] = __builtin_fma(-alpha[it], hy[it][1], dv[1]);
                 }
               }
               const double sc = ys / yy;
               dv[0] *= sc;
               dv[1] *= sc;
 #pragma unroll
-              for (int k = LBFGS_WAVE_MREG - 1; k >= 0; --k) {
-                if (k < bound) {
-                  double yd = __builtin_fma(hy[k][0], dv[0], 0.0);
-                  yd = __builtin_fma(hy[k][1], dv[1], yd);
-                  yd = wave_sum(yd);
-                  const double cf = __shfl(alpha, k) - yd / hys[k];
-                  dv[0] = __builtin_fma(cf, hs[k][0], dv[0]);
-                  dv[1] = __builtin_fma(cf, hs[k][1], dv[1]);
+              for (int it = MR - 1; it >= 0; --it) {
+                if (it < bound) {
+                  const double cf = alpha[it] - dot(hy[it], dv) / hys[it];
+                  dv[0] = __builtin_fma(cf, hs[it][0], dv[0]);
+                  dv[1] = __builtin_fma(cf, hs[it][1], dv[1]);
                 }
               }
             } else {
@@ -463,15 +530,15 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
               for (int it = 0; it < bound; ++it) {
                 j = (j + m - 1) % m;
                 const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
-                double sd = 0.0, yv[2] = {0.0, 0.0};
-                q = 0;
-                for (int i = lane; i < n; i += 64, ++q) {
-                  sd = __builtin_fma(sj[i * vs], dv[q], sd);
-                  yv[q] = yj[i * vs];
-                }
-                sd = wave_sum(sd);
+                double sv[2] = {0.0, 0.0}, yv[2] = {0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                  if (h[q]) {
+                    sv[q] = sj[iv[q] * vs];
+                    yv[q] = yj[iv[q] * vs];
+                  }
                 const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
-                const double al = sd / ysj;
+                const double al = dot(sv, dv) / ysj;
                 alpha = (lane == it) ? al : alpha;
                 dv[0] = __builtin_fma(-al, yv[0], dv[0]);
                 dv[1] = __builtin_fma(-al, yv[1], dv[1]);
@@ -481,23 +548,26 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
               dv[1] *= sc;
               for (int it = 0; it < bound; ++it) {
                 const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
-                double yd = 0.0, sv[2] = {0.0, 0.0};
-                q = 0;
-                for (int i = lane; i < n; i += 64, ++q) {
-                  yd = __builtin_fma(yj[i * vs], dv[q], yd);
-                  sv[q] = sj[i * vs];
-                }
-                yd = wave_sum(yd);
+                double sv[2] = {0.0, 0.0}, yv[2] = {0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                  if (h[q]) {
+                    sv[q] = sj[iv[q] * vs];
+                    yv[q] = yj[iv[q] * vs];
+                  }
                 const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
-                const double cf = __shfl(alpha, bound - 1 - it) - yd / ysj;
+                const double cf = __shfl(alpha, bound - 1 - it) - dot(yv, dv) / ysj;
                 dv[0] = __builtin_fma(cf, sv[0], dv[0]);
                 dv[1] = __builtin_fma(cf, sv[1], dv[1]);
                 j = (j + 1) % m;
               }
             }
           }
-          q = 0;
-          for (int i = lane; i < n; i += 64, ++q) d[i * vs] = dv[q];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            dr[q] = dv[q];
+            if (h[q]) d[iv[q] * vs] = dv[q];
+          }
           step = 1.0;
           start_ls = true;
         }
@@ -505,14 +575,13 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
     }
   }
   if (start_ls) {
-    double dginit = 0.0;
-    for (int i = lane; i < n; i += 64) {
-      const double xi = x[i * ld], gi = g[i * ld];
-      xp[i * vs] = xi;
-      gp[i * vs] = gi;
-      dginit = __builtin_fma(gi, d[i * vs], dginit);
-    }
-    dginit = wave_sum(dginit);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (h[q]) {
+        xp[iv[q] * vs] = xr[q];
+        gp[iv[q] * vs] = gr[q];
+      }
+    const double dginit = dot(gr, dr);
     if (!(step > 0.0)) {
       finish = LBERR_INVALIDPARAMETERS;
     } else if (0.0 < dginit) {
@@ -526,7 +595,9 @@ __global__ void __launch_bounds__(64) k_lbfgs_update_wave(LbfgsArgs a) {
       count = 0;
       brackt = 0;
       touched = 0;
-      for (int i = lane; i < n; i += 64) x[i * ld] = __builtin_fma(step, d[i * vs], xp[i * vs]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (h[q]) store_x(a, b, (int)iv[q], __builtin_fma(step, dr[q], xr[q]));
     }
   }
   if (lane == 0) {
@@ -605,27 +676,15 @@ __global__ void __launch_bounds__(64) k_mvie_eval(MvieArgs a) {
   a.f[b] = cost;
 }
 
-// GCOPTER's smooth bijection R -> (0, inf) for the durations (upstream gcopter.hpp forwardT /
-// backwardT; not part of the reference tree): T = tau>0 ? (tau/2+1)tau+1 : 1/((tau/2-1)tau+1).
-__device__ __forceinline__ double forward_T(double tau) {
-  return tau > 0.0 ? (0.5 * tau + 1.0) * tau + 1.0 : 1.0 / ((0.5 * tau - 1.0) * tau + 1.0);
-}
-__device__ __forceinline__ double dforward_T(double tau) {
-  if (tau > 0.0) return tau + 1.0;
-  const double den = (0.5 * tau - 1.0) * tau + 1.0;
-  return (1.0 - tau) / (den * den);
-}
-__device__ __forceinline__ double backward_T(double T) {
-  return T > 1.0 ? sqrt(2.0 * T - 1.0) - 1.0 : 1.0 - sqrt(2.0 / T - 1.0);
-}
 struct MapArgs {
-  double *x, *g;             // optimisation variables / gradient [n][ld]
+  double *x;                 // optimisation variables [n][ld]
   double *wps, *T;           // trajectory parameters
-  const double *gradP, *gradT;
   int64_t B, ld;
   int nw, nt;                // optimised waypoint coordinates (0 or 3(N-1)), optimised durations (0 or N)
-  int mode;                  // 0: params -> x (init), 1: x -> params, 2: (gradP, gradT) -> g
+  int mode;                  // 0: params -> x (before the first evaluation), 1: x -> params (results)
 };
+// Only at the two ends of a run: during it the waypoint rows of x are read in place, the update kernel
+// writes T = forward_T(tau) (store_x) and the propagate kernel applies dT/dtau (PropArgs::tau).
 __global__ void __launch_bounds__(256) k_minco_map(MapArgs a) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= a.B) return;
@@ -634,13 +693,11 @@ __global__ void __launch_bounds__(256) k_minco_map(MapArgs a) {
   if (v < a.nw) {
     const int64_t i = (int64_t)v * ld + b;
     if (a.mode == 0) a.x[i] = a.wps[i];
-    else if (a.mode == 1) a.wps[i] = a.x[i];
-    else a.g[i] = a.gradP[i];
+    else a.wps[i] = a.x[i];
   } else {
     const int64_t xi = (int64_t)v * ld + b, ti = (int64_t)(v - a.nw) * ld + b;
     if (a.mode == 0) a.x[xi] = backward_T(a.T[ti]);
-    else if (a.mode == 1) a.T[ti] = forward_T(a.x[xi]);
-    else a.g[xi] = a.gradT[ti] * dforward_T(a.x[xi]);
+    else a.T[ti] = forward_T(a.x[xi]);
   }
 }
 

@@ -398,4 +398,18 @@ __device__ __forceinline__ double solve_axis(const Factor<S, NB> &F, int N, int 
   return energy;
 }
 
+// GCOPTER's smooth bijection R -> (0, inf) for the durations (upstream gcopter.hpp forwardT /
+// backwardT; not part of the reference tree): T = tau>0 ? (tau/2+1)tau+1 : 1/((tau/2-1)tau+1).
+__device__ __forceinline__ double forward_T(double tau) {
+  return tau > 0.0 ? (0.5 * tau + 1.0) * tau + 1.0 : 1.0 / ((0.5 * tau - 1.0) * tau + 1.0);
+}
+__device__ __forceinline__ double dforward_T(double tau) {
+  if (tau > 0.0) return tau + 1.0;
+  const double den = (0.5 * tau - 1.0) * tau + 1.0;
+  return (1.0 - tau) / (den * den);
+}
+__device__ __forceinline__ double backward_T(double T) {
+  return T > 1.0 ? sqrt(2.0 * T - 1.0) - 1.0 : 1.0 - sqrt(2.0 / T - 1.0);
+}
+
 }  // namespace anet

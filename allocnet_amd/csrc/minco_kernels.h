@@ -351,6 +351,8 @@ struct PropArgs {
   double rho;
   int64_t B, ld;
   int N, c;
+  // optional chain rule for durations parametrised as T = forward_T(tau): gradT is written as dJ/dtau
+  const double *tau = nullptr;
 };
 
 // One axis of the adjoint: accumulates this axis' share of dJ/dT into gT and stores its gradP rows.
@@ -526,7 +528,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate(PropArgs a) {
 #pragma unroll
   for (int i = 0; i < NB; ++i)
     if (i < N) {
-      a.gradT[i * ld + b] = gT[i] + a.rho;
+      const double gt = gT[i] + a.rho;
+      a.gradT[i * ld + b] = a.tau ? gt * dforward_T(a.tau[i * ld + b]) : gt;
       if (a.pcost) csum += a.pcost[i * ld + b];
     }
   if (a.cost) a.cost[b] = (a.energy_in ? a.energy_in[b] : 0.0) + a.rho * tsum + csum;
@@ -568,7 +571,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate_axis(PropArgs a
     if (i < N) {
       const double tot = gT[i] + __shfl_down(gT[i], 1) + __shfl_down(gT[i], 2);
       if (live && ax == 0) {
-        a.gradT[i * ld + bb] = a.gdT[i * ld + bb] + tot + a.rho;
+        const double gt = a.gdT[i * ld + bb] + tot + a.rho;
+        a.gradT[i * ld + bb] = a.tau ? gt * dforward_T(a.tau[i * ld + bb]) : gt;
         if (a.pcost) csum += a.pcost[i * ld + bb];
       }
     }

@@ -59,6 +59,25 @@ def test_mvie_matches_oracle(anet_ctx):
         assert (np.linalg.norm(Ab @ L, axis=1) + Ab @ x[b, :3] - 1.0).max() < 2e-2   # ellipsoid inside
 
 
+@pytest.mark.parametrize("mem", [3, 8, 24])
+def test_mvie_history_lengths(anet_ctx, mem):
+    """The wave-per-problem kernel has three instantiations by history length (registers for
+    mem_size <= 8 and <= 20, re-read from memory above); mem_size 3 also wraps the ring buffer
+    inside the fixed budget.  Counters exact, iterates to rounding, as in (a) above."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(30 + mem)
+    B, M = 40, 12
+    A, x0, k = _mvie_batch(rng, B, M)
+    kw = dict(mem_size=mem, g_epsilon=0.0, min_step=1e-32, past=3, delta=1e-7, max_iterations=9)
+    x, f, status, iters, evals = aa.lbfgs_mvie(A, x0, param=aa.lbfgs_parameter_t(**kw), ctx=anet_ctx)
+    prm = cbind.lbfgs_default_param(**kw)
+    for b in range(0, B, 2):
+        ret, xo, fo, it, ev = cbind.lbfgs_mvie(A[b, :k[b]], 1e-2, 1e3, x0[b], prm)
+        assert (status[b], iters[b], evals[b]) == (ret, it, ev), b
+        assert np.abs(x[b] - xo).max() <= 1e-7 * max(1.0, np.abs(xo).max()), b
+        assert abs(f[b] - fo) <= 1e-7 * max(1.0, abs(fo))
+
+
 def test_mvie_error_codes_and_budget(anet_ctx):
     import allocnet_amd as aa
     rng = np.random.default_rng(4)

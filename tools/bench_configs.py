@@ -54,7 +54,7 @@ def main():
     # ---- config 3: B=4096 x 8-seg min-snap, corridor penalties + time gradients -------------------
     for B in (4096, 1 << 17):
         s, c, N, M = 4, 3, 8, 16
-        ld = (B + 63) // 64 * 64
+        ld = aa.recommended_ld(B) if os.environ.get("ANET_CFG_LD", "rec") == "rec" else (B + 63) // 64 * 64
         rng = np.random.default_rng(1)
         head, tail, wps, T, hp = synth(rng, B, N, c, M)
         pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0,
@@ -73,7 +73,7 @@ def main():
                                            "active_penalty_frac": float((cost[:B].cpu().numpy() > 0).mean())}
     # ---- config 4: B=4096 x 16-seg min-jerk, full L-BFGS to convergence ---------------------------
     B, s, c, N, M = 4096, 3, 3, 16, 16
-    ld = B
+    ld = aa.recommended_ld(B) if os.environ.get("ANET_CFG_LD", "rec") == "rec" else B
     rng = np.random.default_rng(2)
     head, tail, wps, T, hp = synth(rng, B, N, c, M)
     pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0,
