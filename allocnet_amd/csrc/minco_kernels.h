@@ -141,6 +141,16 @@ __device__ __forceinline__ void smoothed_l1(double mu, double inv_mu, double x, 
   df = neg ? 0.0 : (hi ? 1.0 : dm);
 }
 
+// The same function without selects (the penalty kernel evaluates this for every row x sample):
+// with xc = clamp(x, 0, mu) the cubic piece gives 0 below 0 and mu/2, slope 1 at mu, so
+//   f = cubic(xc) + max(x - mu, 0),  df = cubic'(xc).
+__device__ __forceinline__ void smoothed_l1_clamped(double mu, double inv_mu, double x, double &f, double &df) {
+  const double xc = fmin(fmax(x, 0.0), mu);
+  const double xd = xc * inv_mu, sq = xd * xd, mm = __builtin_fma(-0.5, xc, mu);
+  f = __builtin_fma(mm * sq, xd, fmax(x - mu, 0.0));
+  df = sq * __builtin_fma(-0.5, xd, (3.0 * inv_mu) * mm);
+}
+
 struct PieceGradArgs {
   const double *coeffs, *T, *hpolys;
   double *gdC, *gdT, *pcost;
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(256) k_piece_grad(PieceGradArgs a) {
               __builtin_fma(hr[r][0], st[0][0], __builtin_fma(hr[r][1], st[0][1], hr[r][2] * st[0][2])) - hr[r][3];
           if (__any(viol > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
             double f, df;
-            smoothed_l1(pp.mu, inv_mu, viol, f, df);
+            smoothed_l1_clamped(pp.mu, inv_mu, viol, f, df);
             cost = __builtin_fma(pp.wc, f, cost);
             df *= pp.wc;
             g[0][0] = __builtin_fma(df, hr[r][0], g[0][0]);
@@ -288,14 +298,14 @@ __global__ void __launch_bounds__(256) k_piece_grad(PieceGradArgs a) {
             const double av = fabs(st[1][ax]) - pp.vmax, aa_ = fabs(st[2][ax]) - pp.amax;
             if (__any(av > 0.0)) {  // only one of +v, -v can be violated
               double f, df;
-              smoothed_l1(pp.mu, inv_mu, av, f, df);
+              smoothed_l1_clamped(pp.mu, inv_mu, av, f, df);
               cost = __builtin_fma(pp.wv, f, cost);
               g[1][ax] = __builtin_fma(pp.wv * (st[1][ax] < 0.0 ? -1.0 : 1.0), df, g[1][ax]);
               active = true;
             }
             if (__any(aa_ > 0.0)) {
               double f, df;
-              smoothed_l1(pp.mu, inv_mu, aa_, f, df);
+              smoothed_l1_clamped(pp.mu, inv_mu, aa_, f, df);
               cost = __builtin_fma(pp.wa, f, cost);
               g[2][ax] = __builtin_fma(pp.wa * (st[2][ax] < 0.0 ? -1.0 : 1.0), df, g[2][ax]);
               active = true;
