@@ -22,27 +22,7 @@ def to_bm(torch, a, B, ld, device):
     return t
 
 
-def synth(rng, B, N, c, M):
-    """SURVEY 8(d) config 3 generator: random-walk waypoints, axis-aligned box around each segment
-    inflated by U(0.5,3) plus k~U{0,6} random tangent half-spaces, rows normalised, a.x <= b, padded to M."""
-    from tests.util import random_problem
-    head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
-    pts = np.concatenate([head[:, None, :, 0], wps, tail[:, None, :, 0]], axis=1)
-    hp = np.zeros((B, N, M, 4))
-    lo = np.minimum(pts[:, :-1], pts[:, 1:]) - rng.uniform(0.5, 3.0, size=(B, N, 3))
-    hi = np.maximum(pts[:, :-1], pts[:, 1:]) + rng.uniform(0.5, 3.0, size=(B, N, 3))
-    for ax in range(3):
-        hp[:, :, 2 * ax, ax] = 1.0; hp[:, :, 2 * ax, 3] = hi[:, :, ax]
-        hp[:, :, 2 * ax + 1, ax] = -1.0; hp[:, :, 2 * ax + 1, 3] = -lo[:, :, ax]
-    k = rng.integers(0, min(6, M - 6) + 1, size=(B, N))
-    mid = 0.5 * (pts[:, :-1] + pts[:, 1:])
-    for r in range(min(6, M - 6)):
-        a = rng.normal(size=(B, N, 3)); a /= np.linalg.norm(a, axis=2, keepdims=True)
-        b = np.einsum("bnk,bnk->bn", a, mid) + rng.uniform(1.0, 3.0, size=(B, N))
-        use = (k > r)[..., None]
-        hp[:, :, 6 + r, :3] = np.where(use, a, 0.0)
-        hp[:, :, 6 + r, 3] = np.where(use[..., 0], b, 0.0)
-    return head, tail, wps, T, hp
+from tests.util import corridor_problem as synth  # noqa: E402  (SURVEY 8(d) config 3/5 generator)
 
 
 def main():
