@@ -67,6 +67,10 @@ PROTOTYPES = {
     "anet_qp_solve_workspace": (c_int64, [c_int, c_int, c_int64, c_int, c_int]),
     "anet_qp_solve_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double]
                           + [c_void_p] * 11),
+    "anet_qp_solve_time_grad": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double]
+                                + [c_void_p] * 10),
+    "anet_qp_solve_time_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double,
+                                            c_double] + [c_void_p] * 12),
     "anet_comm_unique_id": (c_int, [c_void_p, c_void_p]),
     "anet_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "anet_comm_allgather_costs_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

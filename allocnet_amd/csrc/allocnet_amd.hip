@@ -1061,10 +1061,11 @@ int64_t anet_qp_solve_workspace(int s, int n_pieces, int64_t batch, int res, int
   return 2 * m * batch + 2 * batch;  // z, y, residuals
 }
 
-int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
-                      double max_acc, double m34, const double *state, const double *T,
-                      const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
-                      double *obj, int32_t *status, int32_t *iters, double *residuals, void *stream) {
+static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                             double max_acc, double m34, const double *state, const double *T,
+                             const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
+                             double *obj, int32_t *status, int32_t *iters, double *residuals, double *grad_T,
+                             void *stream) {
   if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
   if (s != 3 && s != 4) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: order must be 3 (jerk) or 4 (snap)");
   if (n_pieces < 1 || batch < 0 || res < 1 || M < 0) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad argument");
@@ -1092,7 +1093,7 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
                    residuals ? residuals : work + 2 * m * batch, batch, n_pieces, res, M, max_vel, max_acc, m34,
                    anet::AdmmParams{st_.rho, st_.sigma, st_.alpha, st_.eps_abs, st_.eps_rel, st_.max_iter,
                                     st_.check_termination, adapt, st_.scaled_termination ? 1 : 0},
-                   zy_in_lds};
+                   zy_in_lds, grad_T};
   hipStream_t st = (hipStream_t)stream;
   if (s == 4) {
     ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_admm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1105,10 +1106,28 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
   return ANET_OK;
 }
 
-int anet_qp_solve(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
-                  double max_acc, double m34, const double *state, const double *T, const double *hpolys,
-                  const anet_qp_settings *settings, double *coeffs, double *obj, int32_t *status,
-                  int32_t *iters, double *residuals) {
+int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                      double max_acc, double m34, const double *state, const double *T,
+                      const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
+                      double *obj, int32_t *status, int32_t *iters, double *residuals, void *stream) {
+  return qp_solve_dev_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, state, T, hpolys, settings, work,
+                           coeffs, obj, status, iters, residuals, nullptr, stream);
+}
+
+int anet_qp_solve_time_grad_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                                double max_acc, double m34, const double *state, const double *T,
+                                const double *hpolys, const anet_qp_settings *settings, double *work,
+                                double *coeffs, double *obj, int32_t *status, int32_t *iters, double *residuals,
+                                double *grad_T, void *stream) {
+  if (ctx && batch > 0 && !grad_T) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve_time_grad: grad_T is NULL");
+  return qp_solve_dev_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, state, T, hpolys, settings, work,
+                           coeffs, obj, status, iters, residuals, grad_T, stream);
+}
+
+static int qp_solve_host_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                              double max_acc, double m34, const double *state, const double *T,
+                              const double *hpolys, const anet_qp_settings *settings, double *coeffs, double *obj,
+                              int32_t *status, int32_t *iters, double *residuals, double *grad_T) {
   if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
   if ((s != 3 && s != 4) || n_pieces < 1 || batch < 0 || res < 1 || M < 0)
     return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad argument");
@@ -1119,18 +1138,20 @@ int anet_qp_solve(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, in
   const size_t n_state = 18 * (size_t)batch, n_T = (size_t)n_pieces * batch, n_hp = (size_t)batch * n_pieces * M * 4;
   const size_t n_work = (size_t)anet_qp_solve_workspace(s, n_pieces, batch, res, M);
   const size_t n_int = (size_t)batch;  // 2 int32 arrays fit in `batch` doubles
-  int rc = ensure_scratch(ctx, sizeof(double) * (n_state + n_T + n_hp + n_work + n * batch + 3 * batch + n_int + 8));
+  int rc = ensure_scratch(ctx, sizeof(double) * (n_state + n_T + n_hp + n_work + n * batch + 3 * batch + n_int + n_T + 8));
   if (rc) return rc;
   double *d_state = (double *)ctx->scratch, *d_T = d_state + n_state, *d_hp = d_T + n_T, *d_work = d_hp + n_hp;
   double *d_co = d_work + n_work, *d_obj = d_co + n * batch, *d_res = d_obj + batch;
   int32_t *d_status = (int32_t *)(d_res + 2 * batch), *d_iters = d_status + batch;
+  double *d_gT = d_res + 2 * batch + n_int;
   hipStream_t st = ctx->stream;
   ANET_HIP(ctx, hipMemcpyAsync(d_state, state, sizeof(double) * n_state, hipMemcpyHostToDevice, st));
   ANET_HIP(ctx, hipMemcpyAsync(d_T, T, sizeof(double) * n_T, hipMemcpyHostToDevice, st));
   if (n_hp) ANET_HIP(ctx, hipMemcpyAsync(d_hp, hpolys, sizeof(double) * n_hp, hipMemcpyHostToDevice, st));
-  rc = anet_qp_solve_dev(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, d_state, d_T, d_hp, settings, d_work,
-                         d_co, d_obj, d_status, d_iters, d_res, st);
+  rc = qp_solve_dev_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, d_state, d_T, d_hp, settings, d_work,
+                         d_co, d_obj, d_status, d_iters, d_res, grad_T ? d_gT : nullptr, st);
   if (rc) return rc;
+  if (grad_T) ANET_HIP(ctx, hipMemcpyAsync(grad_T, d_gT, sizeof(double) * n_T, hipMemcpyDeviceToHost, st));
   ANET_HIP(ctx, hipMemcpyAsync(coeffs, d_co, sizeof(double) * n * batch, hipMemcpyDeviceToHost, st));
   if (obj) ANET_HIP(ctx, hipMemcpyAsync(obj, d_obj, sizeof(double) * batch, hipMemcpyDeviceToHost, st));
   if (status) ANET_HIP(ctx, hipMemcpyAsync(status, d_status, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, st));
@@ -1138,6 +1159,23 @@ int anet_qp_solve(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, in
   if (residuals) ANET_HIP(ctx, hipMemcpyAsync(residuals, d_res, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, st));
   ANET_HIP(ctx, hipStreamSynchronize(st));
   return ANET_OK;
+}
+
+int anet_qp_solve(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                  double max_acc, double m34, const double *state, const double *T, const double *hpolys,
+                  const anet_qp_settings *settings, double *coeffs, double *obj, int32_t *status,
+                  int32_t *iters, double *residuals) {
+  return qp_solve_host_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, state, T, hpolys, settings, coeffs,
+                            obj, status, iters, residuals, nullptr);
+}
+
+int anet_qp_solve_time_grad(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                            double max_acc, double m34, const double *state, const double *T,
+                            const double *hpolys, const anet_qp_settings *settings, double *coeffs, double *obj,
+                            int32_t *status, int32_t *iters, double *residuals, double *grad_T) {
+  if (ctx && batch > 0 && !grad_T) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve_time_grad: grad_T is NULL");
+  return qp_solve_host_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, state, T, hpolys, settings, coeffs,
+                            obj, status, iters, residuals, grad_T);
 }
 
 int anet_traj_cost_grad_T_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,

@@ -40,6 +40,7 @@ struct AdmmArgs {
   double vmax, amax, m34;
   AdmmParams p;
   int zy_in_lds;  // z, y live in LDS (small problems) instead of the global workspace
+  double *gradT;  // optional [B][N]: d(optimal 1/2 z'Qz)/dT_i (envelope theorem, see the end of the kernel)
 };
 
 __device__ __forceinline__ double atomic_max_pos(double *addr, double v) {  // v >= 0
@@ -623,6 +624,55 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
     __syncthreads();
   }
   if (it > a.p.max_iter) it = a.p.max_iter;
+  __syncthreads();
+  // ---- implicit time gradient of the optimal cost (layers.py:120-147) -------
+  // The loss the reference back-propagates is the QP objective itself, J*(T) = min 1/2 z'Q(T)z.  For a
+  // value function no KKT solve is needed: dJ*/dT_i = dL/dT_i at the optimum (envelope theorem),
+  // L = J + (y/cobj)'(A x - u) in the variables of THIS kernel (normalised time), where only
+  //   J_i = T_i^(1-2s) 1/2 x_i'Q1 x_i,  the start/end values b = state T^d,  the continuity coefficient
+  //   -d!(T_i/T_i+1)^d,  and the box bounds vmax T_i, amax T_i^2
+  // depend on T; the corridor rows do not.  (y/cobj: the duals belong to the cobj-scaled objective.)
+  if (a.gradT) {
+    for (int i = tid; i < N; i += nt) {
+      const double qs = pow(Tn[i], (double)(1 - 2 * S));
+      double Ji = 0.0;
+      for (int axx = 0; axx < 3; ++axx) {
+        const double *xb = x + i * NB + axx * D;
+        for (int j = 0; j < S; ++j)
+          for (int k = 0; k < S; ++k) Ji += 0.5 * qs * qblk1<S>(j, k, a.m34) * xb[j] * xb[k];
+      }
+      rhs[i] = (double)(1 - 2 * S) * Ji / Tn[i];  // rhs is free now: accumulator [N]
+    }
+    __syncthreads();
+    const double inv_c = 1.0 / cobj;
+    for (int r = tid; r < me; r += nt) {
+      int i0, ax, d, kind;
+      if (r < 18) { ax = r / 6; const int q = r % 6; kind = q < 3 ? 0 : 1; d = q % 3; i0 = kind == 0 ? 0 : N - 1; }
+      else { const int rr = r - 18; i0 = rr / (3 * S); ax = (rr / S) % 3; d = rr % S; kind = 2; }
+      if (d == 0) continue;
+      const double yr = yg[r] * inv_c;
+      if (kind != 2) {
+        atomicAdd(&rhs[i0], -yr * (double)d * eqb[r] / Tn[i0]);
+      } else {
+        const double t = yr * (double)d * eqc[r] * x[(i0 + 1) * NB + ax * D + (D - 1 - d)];
+        atomicAdd(&rhs[i0], t / Tn[i0]);
+        atomicAdd(&rhs[i0 + 1], -t / Tn[i0 + 1]);
+      }
+    }
+    for (int smp = tid; smp < N * R; smp += nt) {
+      const int i = smp / R;
+      const int64_t r0 = me + smp, NS = (int64_t)N * R;
+      double sv = 0.0, sa = 0.0;
+      for (int qq = 0; qq < 12; ++qq) {
+        const double yv = yg[r0 + (M + qq) * NS];
+        if ((qq % 4) & 1) sa += yv;
+        else sv += yv;
+      }
+      if (sv != 0.0 || sa != 0.0) atomicAdd(&rhs[i], -inv_c * (a.vmax * sv + 2.0 * a.amax * Tn[i] * sa));
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += nt) a.gradT[b * N + i] = rhs[i];
+  }
   // ---- unscale and report ---------------------------------------------------------------------
   __syncthreads();
   for (int e = tid; e < n; e += nt) {

@@ -79,7 +79,8 @@ class OsqpLayer:
 
     def __init__(self, ctx=None):
         self._ctx = ctx
-        self.time_grad = None
+        self.time_grad = None             # what the reference's autograd delivers (z detached): 1/2 z'(dQ/dT)z
+        self.implicit_time_grad = None    # d(optimal objc)/dTimes through the QP (anet_qp_solve_time_grad)
 
     def _solve(self, qp_traj):
         M = max(p.shape[0] for p in qp_traj.hpolys)
@@ -90,7 +91,7 @@ class OsqpLayer:
         fin = qp_traj.end_state.reshape(1, 3, 3)
         T = qp_traj.Times[:qp_traj.seg][None]
         out = _qp.qp_solve(qp_traj.order, ini, fin, hp, T, res=qp_traj.res, max_vel=qp_traj._limits[0],
-                           max_acc=qp_traj._limits[1], ctx=self._ctx)
+                           max_acc=qp_traj._limits[1], time_grad=True, ctx=self._ctx)
         return out, T
 
     def forward(self, qp_traj):
@@ -106,12 +107,15 @@ class OsqpLayer:
                 curr_objt_val = float(np.mean((Times[:segments] - qp_traj.ref_time_factor[:segments]) ** 2) / segments
                                       + curr_padding_loss)
             self.time_grad = None
+            self.implicit_time_grad = None
             return None, curr_obj1_val, curr_objt_val, None, curr_padding_loss
         z = out["coeffs"][0].reshape(-1)
         curr_objc_val = float(out["obj"][0] / qp_traj.path_length)
         g = traj_cost_grad_T(out["coeffs"], T, m34=1400.0, ctx=self._ctx)[0] / qp_traj.path_length
         self.time_grad = np.zeros_like(Times)
         self.time_grad[:segments] = g
+        self.implicit_time_grad = np.zeros_like(Times)
+        self.implicit_time_grad[:segments] = out["grad_T"][0] / qp_traj.path_length
         return z, curr_obj1_val, None, curr_objc_val, curr_padding_loss
 
     def forward4lstm(self, qp_traj, pred_stop_tokens, seq_len=5):
@@ -132,10 +136,13 @@ class OsqpLayer:
             if hasattr(qp_traj, "ref_time_factor"):
                 curr_objt_val = float(np.mean((Times[:segments] - qp_traj.ref_time_factor[:segments]) ** 2) / segments)
             self.time_grad = None
+            self.implicit_time_grad = None
             return None, curr_obj1_val, curr_objt_val, None, stop_token_loss
         z = out["coeffs"][0].reshape(-1)
         curr_objc_val = float(out["obj"][0] / qp_traj.path_length)
         g = traj_cost_grad_T(out["coeffs"], T, m34=1400.0, ctx=self._ctx)[0] / qp_traj.path_length
         self.time_grad = np.zeros_like(Times)
         self.time_grad[:segments] = g
+        self.implicit_time_grad = np.zeros_like(Times)
+        self.implicit_time_grad[:segments] = out["grad_T"][0] / qp_traj.path_length
         return z, curr_obj1_val, None, curr_objc_val, stop_token_loss

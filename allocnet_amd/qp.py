@@ -87,9 +87,11 @@ def qp_settings(**over):
 
 
 def qp_solve(order, iniPVA, finPVA, hPolys, times, res=20, max_vel=4.0, max_acc=6.0, m34=1400.0,
-             settings=None, ctx=None):
+             settings=None, time_grad=False, ctx=None):
     """Batched QPSolver::solve.  iniPVA/finPVA (B,3,3); hPolys (B,N,M,4) rows a.x <= b (zero rows =
-    padding); times (B,N).  Returns dict(coeffs (B,N,3,2s), obj (B,), status, iters, residuals (B,2))."""
+    padding); times (B,N).  Returns dict(coeffs (B,N,3,2s), obj (B,), status, iters, residuals (B,2));
+    with time_grad=True also grad_T (B,N) = d(obj)/d(times), the derivative of the optimal cost through
+    the inequality QP (anet_qp_solve_time_grad: envelope theorem on the solver's multipliers)."""
     ctx = ctx or default_context()
     hp = np.ascontiguousarray(hPolys, dtype=np.float64)
     B, N, M, _ = hp.shape
@@ -101,11 +103,17 @@ def qp_solve(order, iniPVA, finPVA, hPolys, times, res=20, max_vel=4.0, max_acc=
     D = 2 * order
     coeffs = np.empty((B, N, 3, D)); obj = np.empty(B)
     status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); resid = np.empty((B, 2))
-    ctx.check(ctx.lib.anet_qp_solve(ctx.handle, int(order), N, B, int(res), M, float(max_vel), float(max_acc),
-                                    float(m34), _p(state), _p(T), _p(hp),
-                                    ctypes.cast(ctypes.pointer(settings), ctypes.c_void_p) if settings is not None else None,
-                                    _p(coeffs), _p(obj), _p(status), _p(iters), _p(resid)))
-    return dict(coeffs=coeffs, obj=obj, status=status, iters=iters, residuals=resid)
+    sp = ctypes.cast(ctypes.pointer(settings), ctypes.c_void_p) if settings is not None else None
+    args = (ctx.handle, int(order), N, B, int(res), M, float(max_vel), float(max_acc), float(m34), _p(state), _p(T),
+            _p(hp), sp, _p(coeffs), _p(obj), _p(status), _p(iters), _p(resid))
+    out = dict(coeffs=coeffs, obj=obj, status=status, iters=iters, residuals=resid)
+    if time_grad:
+        gT = np.empty((B, N))
+        ctx.check(ctx.lib.anet_qp_solve_time_grad(*args, _p(gT)))
+        out["grad_T"] = gT
+    else:
+        ctx.check(ctx.lib.anet_qp_solve(*args))
+    return out
 
 
 class QPConfig:

@@ -294,6 +294,24 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
                       const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
                       double *obj, int32_t *status, int32_t *iters, double *residuals, void *stream);
 
+/* The same solve plus grad_T [batch][N] = d(obj)/dT_i, the derivative of the OPTIMAL cost 1/2 z*'Q z*
+ * with respect to the segment durations -- the "time-allocation gradient" the reference's training loop
+ * is after (network/layers.py:120-147 installs a -J^-1 grad KKT hook for it, a dense (n+m)^2 solve per
+ * sample).  Because the loss IS the QP objective, no KKT solve is needed: by the
+ * envelope theorem the derivative is dL/dT at the optimum, assembled inside the ADMM kernel from the
+ * solution and its multipliers (allocnet_amd/csrc/qp_admm.h).  Exact at the optimum of a problem with a
+ * stable active set; its accuracy follows the solve tolerance.  Not what the reference's autograd
+ * delivers today (its z is a detached leaf: that quantity is anet_traj_cost_grad_T) -- see DESIGN.md 8b. */
+int anet_qp_solve_time_grad(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                            double max_acc, double m34, const double *state, const double *T,
+                            const double *hpolys, const anet_qp_settings *settings, double *coeffs, double *obj,
+                            int32_t *status, int32_t *iters, double *residuals, double *grad_T);
+int anet_qp_solve_time_grad_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                                double max_acc, double m34, const double *state, const double *T,
+                                const double *hpolys, const anet_qp_settings *settings, double *work,
+                                double *coeffs, double *obj, int32_t *status, int32_t *iters, double *residuals,
+                                double *grad_T, void *stream);
+
 /* ---- batched L-BFGS ------------------------------------------------------------------------ */
 /* lbfgs::lbfgs_parameter_t, same fields and defaults (gcopter/lbfgs.hpp:15-129). */
 typedef struct anet_lbfgs_params {

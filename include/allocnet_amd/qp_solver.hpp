@@ -37,6 +37,7 @@ class QPSolver {
   int order_ = 3;
   double obj_cost_ = -1;
   int last_status_ = 0, last_iters_ = 0;
+  std::vector<double> time_grad_;
   double m34_ = 1400.0;  // the reference's snap-block constant (qp_solver.hpp:212)
 
  public:
@@ -46,6 +47,9 @@ class QPSolver {
   inline void setOrder(const int &order) { order_ = order; }
   inline double getObjCost() { return obj_cost_; }
   inline int getIterations() const { return last_iters_; }
+  // Extension (not in the reference): d(getObjCost())/d(times(i)) of the last successful solve, the
+  // derivative of the optimal cost through the inequality QP (anet_qp_solve_time_grad).
+  inline const std::vector<double> &getTimeGrad() const { return time_grad_; }
 
   template <typename MatA, typename MatB, typename Poly, typename Times, typename Sol>
   inline bool solve(const MatA &iniPVA,  // 3*3
@@ -69,8 +73,10 @@ class QPSolver {
     double obj = 0.0;
     int32_t status = 0, iters = 0;
     anet::Context &ctx = anet::Context::thread_default();
-    ctx.check(anet_qp_solve(ctx.get(), order_, seg, 1, config.ConstRes, M, config.MaxVelBox, config.MaxAccBox, m34_,
-                            state.data(), T.data(), hp.data(), nullptr, co.data(), &obj, &status, &iters, nullptr));
+    time_grad_.assign(seg, 0.0);
+    ctx.check(anet_qp_solve_time_grad(ctx.get(), order_, seg, 1, config.ConstRes, M, config.MaxVelBox, config.MaxAccBox,
+                                      m34_, state.data(), T.data(), hp.data(), nullptr, co.data(), &obj, &status,
+                                      &iters, nullptr, time_grad_.data()));
     last_status_ = status;
     last_iters_ = iters;
     const float result = (float)obj;

@@ -144,6 +144,7 @@ int main() {
       printf("\"qp_end\": [%.17g, %.17g, %.17g],\n", qe(0), qe(1), qe(2));
       printf("\"qp_vel\": [%.17g, %.17g, %.17g],\n", qv(0), qv(1), qv(2));
       print_vec("qp_coeffs", flatten_coffmats.a);
+      print_vec("qp_time_grad", qp.getTimeGrad());
     }
     lbfgs::lbfgs_parameter_t prm;
     printf("\"lbfgs_default_mem\": %d, \"strerror\": \"%s\"\n", prm.mem_size, lbfgs::lbfgs_strerror(lbfgs::LBFGSERR_MAXIMUMLINESEARCH));

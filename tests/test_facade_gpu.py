@@ -52,3 +52,6 @@ def test_cpp_facade_program():
     assert np.abs(np.array(out["qp_vel"])).max() <= 3.0 + 5e-2
     zc = np.array(out["qp_coeffs"]).reshape(3, 3, 6)
     assert abs(onp.traj_cost(zc, np.array([2.0, 1.5, 2.0]), 3) - out["qp_obj"]) <= 1e-9 * max(1.0, out["qp_obj"])
+    # getTimeGrad (extension): one entry per segment; giving a rest-to-rest trajectory more time lowers its cost
+    gT = np.array(out["qp_time_grad"])
+    assert gT.shape == (3,) and np.isfinite(gT).all() and gT.sum() < 0

@@ -57,5 +57,17 @@ def test_osqp_layer_forward(anet_ctx):
         om = aa.MinTrajOpt(make_params(4, 10, vmax=3.0, amax=4.0), ctx=anet_ctx); om.update(state, hp50, tm, phase=2, seq_len=5)
         fd = (0.5 * z @ op.params[0] @ z - 0.5 * z @ om.params[0] @ z) / (2 * h) / opt.path_length
         assert abs(fd - layer.time_grad[i]) <= 1e-5 * max(1.0, abs(fd))
+    # implicit gradient == finite difference of the OPTIMAL objc (z re-solved), to the solve tolerance
+    imp = layer.implicit_time_grad.copy()
+    assert imp.shape == times.shape and (imp[3:] == 0).all()
+    h = 1e-3
+    for i in range(3):
+        vals = []
+        for sg in (+1, -1):
+            tt = times.copy(); tt[i] += sg * h
+            o = aa.MinTrajOpt(make_params(4, 10, vmax=3.0, amax=4.0), ctx=anet_ctx); o.update(state, hp50, tt, phase=2, seq_len=5)
+            vals.append(aa.OsqpLayer(ctx=anet_ctx).forward(o)[3])
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - imp[i]) <= 0.1 * np.abs(imp[:3]).max() + 1e-3, (i, fd, imp)
     z2, o1, ot, oc, stl = layer.forward4lstm(opt, np.array([0.1, 0.2, 0.9, 0.95, 0.99]), seq_len=5)
     assert z2 is not None and stl > 0 and abs(oc - objc) <= 1e-2 * max(1.0, objc)
