@@ -29,7 +29,7 @@ def _corridor_problem(rng, N, M, margin=1.0):
     return ini, fin, hp, T
 
 
-def _dense(s, ini, fin, hp, T, res, vmax, amax):
+def _dense(s, ini, fin, hp, T, res, vmax, amax, keep=None, want_keep=False):
     N, M = hp.shape[0], hp.shape[1]
     state = np.zeros((9, 2))
     for ax in range(3):
@@ -47,7 +47,10 @@ def _dense(s, ini, fin, hp, T, res, vmax, amax):
             for j in range(3):
                 G[r + r2:r + r2 + 4, i * 3 * D + j * D:i * 3 * D + (j + 1) * D] = G2[r2:r2 + 4]; r2 += 4
     hh = np.r_[h1, h2]
-    keep = (np.abs(G).sum(axis=1) > 0) | (hh != 0)      # drop the inert 0.x <= 0 padding rows for the oracle
+    if keep is None:
+        keep = (np.abs(G).sum(axis=1) > 0) | (hh != 0)  # drop the inert 0.x <= 0 padding rows for the oracle
+    if want_keep:
+        return Q, A, b, G[keep], hh[keep], keep
     return Q, A, b, G[keep], hh[keep]
 
 
@@ -191,3 +194,36 @@ def test_time_gradient_of_the_optimal_cost(anet_ctx, s, N, M, res):
     # what the reference's autograd delivers instead (z held fixed, 1/2 z'(dQ/dT)z) is a different quantity
     eff = aa.traj_cost_grad_T(out["coeffs"], T, m34=1400.0, ctx=anet_ctx)
     assert (np.abs(eff - fd).max(axis=1) > 0.5 * scale[:, 0]).all()
+
+
+def test_time_gradient_matches_the_oracle_lagrangian(anet_ctx):
+    """The same derivative from independent ingredients: the interior-point oracle's (z, lambda, nu) on
+    the reference-pinned dense matrices, and dL/dT_i by central differences of those MATRICES with
+    (z, lambda, nu) held fixed -- the envelope theorem in the reference's own (unnormalised) variables."""
+    import allocnet_amd as aa
+    s, N, M, res, vmax, amax = 4, 3, 9, 6, 3.0, 4.0
+    rng = np.random.default_rng(10 * s + N)
+    probs = [_corridor_problem(rng, N, M, margin=0.6) for _ in range(6)]
+    ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
+    hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs])
+    out = aa.qp_solve(s, ini, fin, hp, T, res=res, max_vel=vmax, max_acc=amax, time_grad=True,
+                      settings=aa.qp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000), ctx=anet_ctx)
+    checked = 0
+    for bb in range(len(probs)):
+        Q, A, b, G, h, keep = _dense(s, ini[bb], fin[bb], hp[bb], T[bb], res, vmax, amax, want_keep=True)
+        z, lam, nu, fo, it = qp_np.qp_ipm(Q, A, b, G, h)
+        if it >= 199 or qp_np.kkt_violation(Q, A, b, G, h, z) > 1e-7:
+            continue
+        checked += 1
+
+        def lagr(Tt):
+            Q1, A1, b1, G1, h1 = _dense(s, ini[bb], fin[bb], hp[bb], Tt, res, vmax, amax, keep=keep)
+            return 0.5 * z @ Q1 @ z + nu @ (A1 @ z - b1) + lam @ (G1 @ z - h1)
+        g0 = np.zeros(N)
+        e = 1e-6
+        for i in range(N):
+            Tp = T[bb].copy(); Tp[i] += e
+            Tm = T[bb].copy(); Tm[i] -= e
+            g0[i] = (lagr(Tp) - lagr(Tm)) / (2 * e)
+        assert np.abs(out["grad_T"][bb] - g0).max() <= 1e-4 * np.abs(g0).max(), (bb, out["grad_T"][bb], g0)
+    assert checked >= 3
