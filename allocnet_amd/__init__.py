@@ -13,5 +13,7 @@ from .lbfgs import lbfgs_parameter_t, lbfgs_strerror, lbfgs_mvie, lbfgs_minco, l
 from . import qp  # noqa: F401
 from .qp import qp_assemble, qp_dims, qp_solve, qp_settings, QPSolver, QPConfig  # noqa: F401
 from .min_traj_opt import MinTrajOpt, OsqpLayer  # noqa: F401
+from . import firi as _firi_mod  # noqa: F401
+from .firi import firi, firi_params, convex_cover  # noqa: F401
 
 __version__ = "0.1.0"

@@ -71,6 +71,8 @@ PROTOTYPES = {
                                 + [c_void_p] * 10),
     "anet_qp_solve_time_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double,
                                             c_double] + [c_void_p] * 12),
+    "anet_firi_default_params": (None, [c_void_p]),
+    "anet_firi": (c_int, [c_void_p, c_int64, c_int, c_int, c_int] + [c_void_p] * 10),
     "anet_comm_unique_id": (c_int, [c_void_p, c_void_p]),
     "anet_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "anet_comm_allgather_costs_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -95,6 +97,12 @@ class QpSettings(ctypes.Structure):
     _fields_ = [("rho", c_double), ("sigma", c_double), ("alpha", c_double), ("eps_abs", c_double),
                 ("eps_rel", c_double), ("max_iter", ctypes.c_int32), ("check_termination", ctypes.c_int32),
                 ("adaptive_rho_interval", ctypes.c_int32), ("scaled_termination", ctypes.c_int32)]
+
+
+class FiriParams(ctypes.Structure):
+    """struct anet_firi_params (defaults of firi::firi / maxVolInsEllipsoid)."""
+    _fields_ = [("iterations", ctypes.c_int32), ("epsilon", c_double), ("smooth_eps", c_double),
+                ("penalty_wt", c_double), ("mvie_max_evals", ctypes.c_int32)]
 
 
 class QpDims(ctypes.Structure):

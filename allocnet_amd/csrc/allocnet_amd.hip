@@ -19,6 +19,7 @@
 #include "traj_kernels.h"
 #include "rate_kernels.h"
 #include "lbfgs_kernels.h"
+#include "firi_kernels.h"
 #include "qp_assemble.h"
 #include "qp_admm.h"
 #include "layout_kernels.h"
@@ -226,11 +227,13 @@ static int ensure_counter(anet_ctx *ctx) {
 // problem by one evaluation per pass and polls the number of unfinished problems every `poll` passes.
 template <class Eval>
 static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfgs_params &prm, int max_evals,
-                       hipStream_t st, Eval &&eval, double *map_T = nullptr, int map_nw = 0) {
+                       hipStream_t st, Eval &&eval, double *map_T = nullptr, int map_nw = 0, bool reset = true) {
   int rc = ensure_counter(ctx);
   if (rc) return rc;
-  ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * L.ld, st));
-  ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_ * L.ld, st));
+  if (reset) {  // (a caller that pre-marks problems as finished resets the state itself)
+    ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * L.ld, st));
+    ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_ * L.ld, st));
+  }
   // small batches: one wave per problem (shuffle reductions, internal vectors problem-major);
   // large batches: one lane per problem (internal vectors batch-minor)
   const bool wave = B <= 32768 && L.n <= 128 && prm.mem_size <= 64;
@@ -848,6 +851,96 @@ int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A, double
   if (evals) ANET_HIP(ctx, hipMemcpyAsync(evals, d_res + 2 * st.ld, sizeof(int) * batch, hipMemcpyDeviceToHost, s0));
   if (f) ANET_HIP(ctx, hipMemcpyAsync(f, L.feval, sizeof(double) * batch, hipMemcpyDeviceToHost, s0));
   return st.download(L.x, n, x);
+}
+
+// ---- batched FIRI -------------------------------------------------------------------------------
+void anet_firi_default_params(anet_firi_params *p) {
+  if (!p) return;
+  p->iterations = 4;       // firi.hpp:273
+  p->epsilon = 1.0e-6;     // firi.hpp:274
+  p->smooth_eps = 1.0e-2;  // firi.hpp:218
+  p->penalty_wt = 1.0e+3;  // firi.hpp:219
+  p->mvie_max_evals = 2000;
+}
+
+int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
+              const double *pc, const int32_t *n_points, const double *a, const double *b,
+              const anet_firi_params *params, double *hpoly, int32_t *n_rows, int32_t *ok, double *ellipsoid) {
+  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  anet_firi_params P;
+  anet_firi_default_params(&P);
+  if (params) P = *params;
+  if (batch < 0 || n_bd < 1 || n_bd > 64 || max_points < 0 || max_rows < 4 || P.iterations < 1 || !(P.epsilon >= 0.0) ||
+      !(P.smooth_eps > 0.0) || P.mvie_max_evals < 1)
+    return fail(ctx, ANET_ERR_INVALID, "anet_firi: bad argument (1 <= n_bd <= 64, max_rows >= 4, iterations >= 1)");
+  if (batch == 0) return ANET_OK;
+  if (!bd || (max_points > 0 && (!pc || !n_points)) || !a || !b || !hpoly || !n_rows)
+    return fail(ctx, ANET_ERR_INVALID, "anet_firi: NULL pointer");
+  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  const int H = max_rows, Np = max_points > 0 ? max_points : 1;
+  if ((size_t)H * 4 * sizeof(double) > 60 * 1024) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_firi: max_rows too large");
+  // firi.hpp:212-217
+  anet_lbfgs_params lp;
+  anet_lbfgs_default_params(&lp);
+  lp.mem_size = 18; lp.g_epsilon = 0.0; lp.min_step = 1.0e-32; lp.past = 3; lp.delta = 1.0e-7;
+  const int n = 9, m = lp.mem_size, npf = lp.past;
+  const int64_t ld = anet_recommended_ld(batch);
+  const int64_t w_l = LbfgsLayout::doubles(n, m, npf, ld);
+  // device scratch (doubles): bd, pc, a, b, ell, fpc, hpoly, A, lbfgs | ints: npts, flag, nh, ok, mvie_ok
+  const size_t n_bdv = (size_t)batch * n_bd * 4, n_pc = (size_t)batch * Np * 3, n_ab = (size_t)batch * 3;
+  const size_t n_ell = (size_t)batch * anet::kFiriEll, n_fpc = (size_t)batch * Np * 4, n_hp = (size_t)batch * H * 4;
+  const size_t n_A = (size_t)3 * H * ld;
+  const size_t n_int = (size_t)batch * (4 + (size_t)Np);
+  int rc = ensure_scratch(ctx, sizeof(double) * (n_bdv + n_pc + 2 * n_ab + n_ell + n_fpc + n_hp + n_A + (size_t)w_l + n_int / 2 + 16));
+  if (rc) return rc;
+  double *d_bd = (double *)ctx->scratch, *d_pc = d_bd + n_bdv, *d_a = d_pc + n_pc, *d_b = d_a + n_ab, *d_ell = d_b + n_ab;
+  double *d_fpc = d_ell + n_ell, *d_hp = d_fpc + n_fpc, *d_A = d_hp + n_hp, *d_l = d_A + n_A;
+  int *d_np = (int *)(d_l + w_l), *d_flag = d_np + batch, *d_nh = d_flag + (size_t)batch * Np, *d_ok = d_nh + batch,
+      *d_mok = d_ok + batch;
+  hipStream_t st = ctx->stream;
+  ANET_HIP(ctx, hipMemcpyAsync(d_bd, bd, sizeof(double) * n_bdv, hipMemcpyHostToDevice, st));
+  if (max_points > 0) {
+    ANET_HIP(ctx, hipMemcpyAsync(d_pc, pc, sizeof(double) * n_pc, hipMemcpyHostToDevice, st));
+    ANET_HIP(ctx, hipMemcpyAsync(d_np, n_points, sizeof(int) * batch, hipMemcpyHostToDevice, st));
+  } else {
+    ANET_HIP(ctx, hipMemsetAsync(d_np, 0, sizeof(int) * batch, st));
+  }
+  ANET_HIP(ctx, hipMemcpyAsync(d_a, a, sizeof(double) * n_ab, hipMemcpyHostToDevice, st));
+  ANET_HIP(ctx, hipMemcpyAsync(d_b, b, sizeof(double) * n_ab, hipMemcpyHostToDevice, st));
+  ANET_HIP(ctx, hipMemsetAsync(d_hp, 0, sizeof(double) * n_hp, st));
+  anet::FiriArgs fa{d_bd, d_pc, d_np, d_a, d_b, d_ell, d_fpc, d_flag, d_hp, d_nh, d_ok, batch, n_bd, Np, H, P.epsilon};
+  const dim3 g64((unsigned)((batch + 63) / 64)), b64(64), gB((unsigned)batch), b256(256);
+  hipLaunchKernelGGL(anet::k_firi_init, g64, b64, 0, st, fa);
+  ANET_HIP(ctx, hipGetLastError());
+  LbfgsLayout L{n, m, npf, ld};
+  L.carve(d_l);
+  anet::FiriMvieArgs ma{d_hp, d_nh, d_ok, d_ell, d_A, L.x, L.is + (int64_t)anet::IS_DONE * ld, L.is + (int64_t)anet::IS_RET * ld,
+                        d_mok, batch, ld, H};
+  anet::MvieArgs ev{d_A, L.x, L.feval, L.g, L.is, batch, ld, H, P.smooth_eps, P.penalty_wt};
+  for (int loop = 0; loop < P.iterations; ++loop) {
+    hipLaunchKernelGGL(anet::k_firi_planes, gB, b256, 0, st, fa);
+    ANET_HIP(ctx, hipGetLastError());
+    if (loop == P.iterations - 1) break;
+    ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * ld, st));
+    ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_ * ld, st));
+    hipLaunchKernelGGL(anet::k_firi_mvie_setup, gB, b256, sizeof(double) * H * 4, st, ma);
+    ANET_HIP(ctx, hipGetLastError());
+    rc = lbfgs_drive(ctx, L, batch, lp, P.mvie_max_evals, st, [&]() -> int {
+      hipLaunchKernelGGL(anet::k_mvie_eval, g64, b64, 0, st, ev);
+      ANET_HIP(ctx, hipGetLastError());
+      return ANET_OK;
+    }, nullptr, 0, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(anet::k_firi_mvie_finish, g64, b64, 0, st, ma);
+    ANET_HIP(ctx, hipGetLastError());
+  }
+  ANET_HIP(ctx, hipMemcpyAsync(hpoly, d_hp, sizeof(double) * n_hp, hipMemcpyDeviceToHost, st));
+  ANET_HIP(ctx, hipMemcpyAsync(n_rows, d_nh, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
+  if (ok) ANET_HIP(ctx, hipMemcpyAsync(ok, d_ok, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
+  if (ellipsoid) ANET_HIP(ctx, hipMemcpy2DAsync(ellipsoid, sizeof(double) * 15, d_ell, sizeof(double) * anet::kFiriEll,
+                                                sizeof(double) * 15, batch, hipMemcpyDeviceToHost, st));
+  ANET_HIP(ctx, hipStreamSynchronize(st));
+  return ANET_OK;
 }
 
 int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_lbfgs_params *params) {

@@ -1,0 +1,114 @@
+"""Corridor generation: batched firi::firi (gcopter/firi.hpp:268-416) and the convexCover loop around it
+(gcopter/sfc_gen.hpp:116-186).  Polytopes are in GCOPTER's raw form, rows h with h.[x;1] <= 0;
+`to_planner_form` is the normalise-and-negate step LearningPlanner applies before the QP
+(learning_planner.hpp:293-299)."""
+import ctypes
+
+import numpy as np
+
+from .context import default_context
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def firi_params(**over):
+    from ._lib import FiriParams, load
+    p = FiriParams()
+    load().anet_firi_default_params(ctypes.byref(p))
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def firi(bd, pc, a, b, n_points=None, max_rows=64, params=None, ctx=None):
+    """Batched firi::firi.  bd (B,Mb,4); pc (B,Np,3) with n_points (B,) valid points each (default: all);
+    a, b (B,3).  Returns dict(hpoly (B,max_rows,4) zero-padded, n_rows (B,), ok (B,), ellipsoid (B,15))."""
+    ctx = ctx or default_context()
+    bd = np.ascontiguousarray(bd, dtype=np.float64)
+    a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    B, Mb, _ = bd.shape
+    pc = np.ascontiguousarray(pc, dtype=np.float64).reshape(B, -1, 3)
+    Np = pc.shape[1]
+    npts = np.full(B, Np, dtype=np.int32) if n_points is None else np.ascontiguousarray(n_points, dtype=np.int32)
+    if a.shape != (B, 3) or b.shape != (B, 3) or npts.shape != (B,) or (npts > Np).any() or (npts < 0).any():
+        raise ValueError("shape mismatch")
+    hp = np.zeros((B, max_rows, 4)); nh = np.zeros(B, dtype=np.int32); ok = np.zeros(B, dtype=np.int32)
+    ell = np.zeros((B, 15))
+    pp = ctypes.cast(ctypes.pointer(params), ctypes.c_void_p) if params is not None else None
+    ctx.check(ctx.lib.anet_firi(ctx.handle, B, Mb, Np, int(max_rows), _p(bd), _p(pc) if Np else None,
+                                _p(npts) if Np else None, _p(a), _p(b), pp, _p(hp), _p(nh), _p(ok), _p(ell)))
+    return dict(hpoly=hp, n_rows=nh, ok=ok, ellipsoid=ell)
+
+
+def to_planner_form(hpoly, n_rows):
+    """learning_planner.hpp:293-299: rows divided by the norm of their normal, offset negated: a.x <= b."""
+    out = np.zeros_like(hpoly)
+    for i, k in enumerate(n_rows):
+        nrm = np.linalg.norm(hpoly[i, :k, :3], axis=1, keepdims=True)
+        out[i, :k, :3] = hpoly[i, :k, :3] / nrm
+        out[i, :k, 3] = -hpoly[i, :k, 3] / nrm[:, 0]
+    return out
+
+
+def convex_cover(path, points, low_corner, high_corner, progress, rng_range, eps=1.0e-6, max_rows=64, ctx=None):
+    """sfc_gen::convexCover (sfc_gen.hpp:116-186): walk the path in steps of at most `progress`, one FIRI
+    polytope per step inside the box [segment -/+ range] clipped to the map, plus a gap polytope where
+    consecutive ones barely overlap at the shared point.  The segments are independent, so all FIRI calls
+    of a path run as ONE batch (then one more batch for the gap polytopes).  Returns a list of (n_i,4)
+    arrays in raw form."""
+    path = [np.asarray(p, dtype=np.float64) for p in path]
+    points = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    lo_c = np.asarray(low_corner, dtype=np.float64); hi_c = np.asarray(high_corner, dtype=np.float64)
+    segs = []
+    bq = path[0]
+    i = 1
+    while i < len(path):
+        aq = bq
+        if np.linalg.norm(aq - path[i]) > progress:
+            d = path[i] - aq
+            bq = d / np.linalg.norm(d) * progress + aq
+        else:
+            bq = path[i]
+            i += 1
+        segs.append((aq, bq))
+    if not segs:
+        return []
+    B = len(segs)
+    bd = np.zeros((B, 6, 4)); sel = []
+    for k, (aq, bq) in enumerate(segs):
+        hi = np.minimum(np.maximum(aq, bq) + rng_range, hi_c)
+        lo = np.maximum(np.minimum(aq, bq) - rng_range, lo_c)
+        for ax in range(3):
+            bd[k, 2 * ax, ax] = 1.0; bd[k, 2 * ax, 3] = -hi[ax]
+            bd[k, 2 * ax + 1, ax] = -1.0; bd[k, 2 * ax + 1, 3] = lo[ax]
+        inside = ((points @ bd[k, :, :3].T + bd[k, :, 3]).max(axis=1) < 0.0) if len(points) else np.zeros(0, dtype=bool)
+        sel.append(points[inside])
+    Np = max(1, max(len(s) for s in sel))
+    pc = np.zeros((B, Np, 3)); npts = np.zeros(B, dtype=np.int32)
+    for k, s in enumerate(sel):
+        pc[k, :len(s)] = s; npts[k] = len(s)
+    A = np.array([s[0] for s in segs]); Bv = np.array([s[1] for s in segs])
+    main = firi(bd, pc, A, Bv, n_points=npts, max_rows=max_rows, ctx=ctx)
+    polys = [main["hpoly"][k, :main["n_rows"][k]] for k in range(B)]
+    # gap polytopes (sfc_gen.hpp:171-179): decided from consecutive results, built in one more batch
+    need = []
+    for k in range(1, B):
+        ah = np.r_[segs[k][0], 1.0]
+        if 3 <= int((polys[k] @ ah > -eps).sum()) + int((polys[k - 1] @ ah > -eps).sum()):
+            need.append(k)
+    gaps = {}
+    if need:
+        g = firi(bd[need], pc[need], A[need], A[need], n_points=npts[need], max_rows=max_rows,
+                 params=firi_params(iterations=1), ctx=ctx)
+        for q, k in enumerate(need):
+            gaps[k] = g["hpoly"][q, :g["n_rows"][q]]
+    out = []
+    for k in range(B):
+        if k in gaps:
+            out.append(gaps[k])
+        out.append(polys[k])
+    return out

@@ -372,6 +372,33 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                          double *cost, double *coeffs_out, int32_t *status, int32_t *iters,
                          int32_t *evals, void *stream);
 
+/* ---- corridor generation: batched FIRI ------------------------------------ */
+/* firi::firi + firi::maxVolInsEllipsoid (gcopter/firi.hpp:159-416), the inner step of
+ * sfc_gen::convexCover (gcopter/sfc_gen.hpp:116-186): for each corridor segment (a, b), obstacle points
+ * pc and bounding half-spaces bd, alternate `iterations` times between the polytope that separates the
+ * current ellipsoid from the obstacles and the maximum-volume ellipsoid inscribed in that polytope
+ * (L-BFGS on costMVIE with the call-site parameters of firi.hpp:212-217).
+ * bd [batch][n_bd][4] and hpoly [batch][max_rows][4] rows h: h0 x + h1 y + h2 z + h3 <= 0 (GCOPTER's raw
+ * form; LearningPlanner normalises and negates it into a.x <= b, learning_planner.hpp:293-299);
+ * pc [batch][max_points][3] with n_points[batch] valid points each; a, b [batch][3].
+ * n_rows [batch] rows written per corridor (the rest of hpoly is zero);
+ * ok [batch]: 1 = done, 0 = a or b violates bd (firi returns false, firi.hpp:282-286),
+ *            -1 = the polytope needs more than max_rows rows;   ellipsoid [batch][15] (optional) =
+ * R row-major, p, r of the last inscribed ellipsoid.  All HOST pointers.
+ * sdlp::linprog<4> and Eigen::JacobiSVD, third-party pieces of the reference, are replaced by exact
+ * equivalents (allocnet_amd/csrc/firi_kernels.h).                                                   */
+typedef struct anet_firi_params {
+  int32_t iterations;     /* 4     firi.hpp:273 */
+  double epsilon;         /* 1e-6  firi.hpp:274 */
+  double smooth_eps;      /* 1e-2  firi.hpp:218 */
+  double penalty_wt;      /* 1e3   firi.hpp:219 */
+  int32_t mvie_max_evals; /* 2000  evaluation budget of one MVIE optimisation (the reference has none) */
+} anet_firi_params;
+void anet_firi_default_params(anet_firi_params *p);
+int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
+              const double *pc, const int32_t *n_points, const double *a, const double *b,
+              const anet_firi_params *params, double *hpoly, int32_t *n_rows, int32_t *ok, double *ellipsoid);
+
 /* ---- multi-GPU: all-gather of the per-trajectory costs over RCCL / xGMI --------------------------- */
 /* Trajectories are independent, so a batch shards contiguously across GPUs (one process and one
  * context per GPU) with no collective inside a solve; the only exchange the path has is this

@@ -1,0 +1,140 @@
+"""Batched FIRI on the GPU vs the numpy restatement of firi.hpp (oracle/firi_np.py; parity unpinned by the
+reference, see its header) and through the properties the algorithm guarantees."""
+import numpy as np
+import pytest
+
+from oracle import firi_np as F
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(rng, n_pts, clearance=0.5, box=3.0):
+    a = rng.uniform(-2, 2, size=3)
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    b = a + d * rng.uniform(0.5, 2.5)
+    lo = np.minimum(a, b) - box; hi = np.maximum(a, b) + box
+    bd = np.zeros((6, 4))
+    for ax in range(3):
+        bd[2 * ax, ax] = 1.0; bd[2 * ax, 3] = -hi[ax]
+        bd[2 * ax + 1, ax] = -1.0; bd[2 * ax + 1, 3] = lo[ax]
+    pts = rng.uniform(lo + 1e-3, hi - 1e-3, size=(4 * n_pts, 3))
+    dd = b - a
+    t = np.clip(((pts - a) @ dd) / (dd @ dd), 0, 1)
+    dist = np.linalg.norm(pts - (a + t[:, None] * dd), axis=1)
+    pts = pts[dist > clearance][:n_pts]
+    return bd, pts, a, b
+
+
+def pack(cases):
+    B = len(cases)
+    Np = max(1, max(len(c[1]) for c in cases))
+    bd = np.array([c[0] for c in cases]); a = np.array([c[2] for c in cases]); b = np.array([c[3] for c in cases])
+    pc = np.zeros((B, Np, 3)); npts = np.zeros(B, dtype=np.int32)
+    for i, c in enumerate(cases):
+        pc[i, :len(c[1])] = c[1]; npts[i] = len(c[1])
+    return bd, pc, npts, a, b
+
+
+def check_properties(hp, bd, pts, a, b, eps=1e-6):
+    assert (hp @ np.r_[a, 1.0]).max() <= eps and (hp @ np.r_[b, 1.0]).max() <= eps         # contains the segment
+    if len(pts):
+        assert ((pts @ hp[:, :3].T + hp[:, 3]).max(axis=1) > -2 * eps).all()              # no obstacle point strictly inside
+
+
+def test_planes_match_oracle_exactly(anet_ctx):
+    """iterations = 1: the polytope around the unit ball at the segment midpoint -- no optimisation involved,
+    so rows, their order and their count must agree to rounding."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(5)
+    cases = [make_case(rng, n) for n in (0, 1, 7, 60, 300, 300, 1000, 257)]
+    bd, pc, npts, a, b = pack(cases)
+    out = aa.firi(bd, pc, a, b, n_points=npts, max_rows=96, params=aa.firi_params(iterations=1), ctx=anet_ctx)
+    assert (out["ok"] == 1).all()
+    for i, c in enumerate(cases):
+        ok, hp0 = F.firi(c[0], c[1], c[2], c[3], iterations=1)
+        k = out["n_rows"][i]
+        assert ok and k == hp0.shape[0], (i, k, hp0.shape)
+        assert np.abs(out["hpoly"][i, :k] - hp0).max() <= 1e-12 * max(1.0, np.abs(hp0).max()), i
+        assert (out["hpoly"][i, k:] == 0).all()
+        check_properties(hp0, *c)
+
+
+def test_full_firi_against_oracle_and_properties(anet_ctx):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(11)
+    cases = [make_case(rng, n) for n in (40, 120, 400, 400, 800, 25)]
+    bd, pc, npts, a, b = pack(cases)
+    vols = []
+    for iters in (2, 4):
+        out = aa.firi(bd, pc, a, b, n_points=npts, max_rows=96, params=aa.firi_params(iterations=iters), ctx=anet_ctx)
+        assert (out["ok"] == 1).all()
+        v = []
+        for i, c in enumerate(cases):
+            k = out["n_rows"][i]
+            hp = out["hpoly"][i, :k]
+            check_properties(hp, *c)
+            tr = []
+            ok, hp0 = F.firi(c[0], c[1], c[2], c[3], iterations=iters, trace=tr)
+            R = out["ellipsoid"][i, :9].reshape(3, 3); p = out["ellipsoid"][i, 9:12]; r = out["ellipsoid"][i, 12:15]
+            assert abs(np.linalg.det(R) - 1.0) < 1e-9 and np.abs(R @ R.T - np.eye(3)).max() < 1e-9
+            # the ellipsoid the last polytope was built around is the oracle's, to the optimiser's tolerance
+            R0, p0, r0 = tr[-1]["R"], tr[-1]["p"], tr[-1]["r"]
+            Q = R @ np.diag(r * r) @ R.T; Q0 = R0 @ np.diag(r0 * r0) @ R0.T
+            assert np.abs(Q - Q0).max() <= 2e-2 * np.abs(Q0).max(), (iters, i)
+            assert np.abs(p - p0).max() <= 2e-2 * max(1.0, np.abs(r0).max()), (iters, i)
+            assert abs(np.prod(r) - np.prod(r0)) <= 2e-2 * np.prod(r0)
+            # the inscribed ellipsoid lies inside the polytope it was inscribed in (previous pass): support function
+            if iters == 2:
+                hprev = tr[0]["hPoly"]
+                nrm = np.linalg.norm(hprev[:, :3] @ R @ np.diag(r), axis=1)
+                assert (nrm + hprev[:, :3] @ p + hprev[:, 3]).max() <= 2e-2
+            v.append(np.prod(r))
+        vols.append(np.array(v))
+    assert (vols[1] >= vols[0] * (1 - 1e-3)).all()  # inflation is monotone
+
+
+def test_failure_codes_and_edge_cases(anet_ctx):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(2)
+    cases = [make_case(rng, 50) for _ in range(4)]
+    bd, pc, npts, a, b = pack(cases)
+    a2 = a.copy(); a2[1] += np.array([100.0, 0, 0])            # a outside the bounding box: firi returns false
+    out = aa.firi(bd, pc, a2, b, n_points=npts, max_rows=64, ctx=anet_ctx)
+    assert list(out["ok"]) == [1, 0, 1, 1] and out["n_rows"][1] == 0
+    out = aa.firi(bd, pc, a, b, n_points=npts, max_rows=6, params=aa.firi_params(iterations=1), ctx=anet_ctx)
+    assert (out["ok"] == -1).all()                              # 6 box planes + at least one point: does not fit
+    # no obstacle points at all: the polytope is the bounding box
+    out = aa.firi(bd, np.zeros((4, 0, 3)), a, b, max_rows=16, ctx=anet_ctx)
+    assert (out["ok"] == 1).all() and (out["n_rows"] == 6).all()
+    for i in range(4):
+        got = out["hpoly"][i, :6]
+        nrm = np.linalg.norm(got[:, :3], axis=1, keepdims=True)
+        want = {tuple(np.round(r, 9)) for r in bd[i]}
+        assert {tuple(np.round(r, 9)) for r in got / nrm} == want
+    with pytest.raises(aa.AnetError):
+        aa.firi(bd, pc, a, b, max_rows=2, ctx=anet_ctx)
+
+
+def test_convex_cover_batches_the_path(anet_ctx):
+    """sfc_gen::convexCover mirror: consecutive polytopes overlap (share the junction point), every
+    polytope contains its own segment, obstacle points stay outside."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(3)
+    path = [np.array([0.0, 0.0, 1.0]), np.array([4.0, 1.0, 1.5]), np.array([6.0, 4.0, 1.0]), np.array([9.0, 4.5, 2.0])]
+    pts = rng.uniform([-3, -3, 0], [12, 8, 4], size=(3000, 3))
+    keep = np.ones(len(pts), dtype=bool)
+    for p0, p1 in zip(path[:-1], path[1:]):
+        d = p1 - p0
+        t = np.clip(((pts - p0) @ d) / (d @ d), 0, 1)
+        keep &= np.linalg.norm(pts - (p0 + t[:, None] * d), axis=1) > 0.6
+    pts = pts[keep]
+    polys = aa.convex_cover(path, pts, [-3, -3, 0], [12, 8, 4], progress=2.0, rng_range=3.0, ctx=anet_ctx)
+    assert len(polys) >= 6
+    for hp in polys:
+        assert hp.shape[1] == 4 and hp.shape[0] >= 4
+        assert ((pts @ hp[:, :3].T + hp[:, 3]).max(axis=1) > -2e-6).all()
+    # the walk of convexCover: every junction point lies in some pair of consecutive polytopes
+    q = path[0]
+    for hp in polys[:1]:
+        assert (hp @ np.r_[q, 1.0]).max() <= 1e-6
+    assert (polys[-1] @ np.r_[path[-1], 1.0]).max() <= 1e-6
