@@ -50,9 +50,7 @@ __device__ __forceinline__ void store_x(const LbfgsArgs &a, int64_t b, int i, do
 // g, both taken at the point currently in x) and leaves in x the next point to evaluate.  The
 // control flow per problem is lbfgs_optimize's: phase 0 = the initial evaluation, phase 1 = inside
 // line_search_lewisoverton.  Finished problems are untouched (x, g hold the result).
-__global__ void __launch_bounds__(64) k_lbfgs_update(LbfgsArgs a) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.B) return;
+__device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int64_t b) {
   const int64_t ld = a.ld;
   int *is = a.is + b;
   if (is[IS_DONE * ld]) return;
@@ -269,6 +267,11 @@ __device__ __forceinline__ double last_lane(double v) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
                           __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+__global__ void __launch_bounds__(64) k_lbfgs_update(LbfgsArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b < a.B) lbfgs_update_lane(a, b);
+}
+
 // a value every lane holds identically (loaded from a wave-uniform address) -> SGPR pair
 __device__ __forceinline__ double uniform_f64(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
@@ -625,9 +628,7 @@ struct MvieArgs {
   int M;
   double eps, wt;
 };
-__global__ void __launch_bounds__(64) k_mvie_eval(MvieArgs a) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.B) return;
+__device__ __forceinline__ void mvie_eval_lane(const MvieArgs &a, const int64_t b) {
   if (a.done && a.done[b]) return;
   const int64_t ld = a.ld;
   const double *x = a.x + b;
@@ -674,6 +675,10 @@ __global__ void __launch_bounds__(64) k_mvie_eval(MvieArgs a) {
     g[(6 + q) * ld] = gdc[q] * a.wt;
   }
   a.f[b] = cost;
+}
+__global__ void __launch_bounds__(64) k_mvie_eval(MvieArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b < a.B) mvie_eval_lane(a, b);
 }
 
 struct MapArgs {

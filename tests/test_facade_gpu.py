@@ -55,3 +55,15 @@ def test_cpp_facade_program():
     # getTimeGrad (extension): one entry per segment; giving a rest-to-rest trajectory more time lowers its cost
     gT = np.array(out["qp_time_grad"])
     assert gT.shape == (3,) and np.isfinite(gT).all() and gT.sum() < 0
+    # firi::firi facade: polytope around the segment (0,0,1)-(2,.5,1.2), lattice points outside, a outside bd -> false
+    assert out["firi_ok"] == 1 and out["firi_rows"] >= 6 and out["firi_outside"] == 0
+    hp = np.array(out["firi_hpoly"]).reshape(-1, 4); pts = np.array(out["firi_pts"]).reshape(-1, 3)
+    assert (hp @ np.array([0.0, 0.0, 1.0, 1.0])).max() <= 1e-6 and (hp @ np.array([2.0, 0.5, 1.2, 1.0])).max() <= 1e-6
+    assert ((pts @ hp[:, :3].T + hp[:, 3]).max(axis=1) > -2e-6).all()
+    from oracle import firi_np as F
+    bd = np.zeros((6, 4)); lo = [-3.0, -3.0, -2.0]; hi = [5.0, 3.5, 4.0]
+    for ax in range(3):
+        bd[2 * ax, ax] = 1.0; bd[2 * ax, 3] = -hi[ax]; bd[2 * ax + 1, ax] = -1.0; bd[2 * ax + 1, 3] = lo[ax]
+    tr = []
+    ok0, hp0 = F.firi(bd, pts, np.array([0.0, 0.0, 1.0]), np.array([2.0, 0.5, 1.2]), trace=tr)
+    assert ok0 and abs(hp.shape[0] - hp0.shape[0]) <= 2
