@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_firi_planes(FiriArgs g) {
   __shared__ double s_row[4], s_red_d[4], s_fw[9], s_p[3], s_fa[3], s_fb[3];
   __shared__ int s_red_j[4], s_state[4];  // [0] completed, [1] nH, [2] overflow
   if (g.ok[b] != 1) return;
-  const int N = g.npts[b], M = g.Mb;
+  const int N = min(max(g.npts[b], 0), g.Np), M = g.Mb;  // counts beyond the padded capacity are clamped
   const double *E = g.ell + b * kFiriEll;
   const double eps = g.eps;
   double R[9], p[3], r[3];
