@@ -138,3 +138,25 @@ def test_convex_cover_batches_the_path(anet_ctx):
     for hp in polys[:1]:
         assert (hp @ np.r_[q, 1.0]).max() <= 1e-6
     assert (polys[-1] @ np.r_[path[-1], 1.0]).max() <= 1e-6
+
+
+def test_random_scenes_keep_the_guarantees(anet_ctx):
+    """300 random scenes, sparse to dense, obstacles from 5 cm off the segment outwards: every polytope
+    contains its segment, excludes every obstacle point, and is bounded by the box."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(99)
+    cases = []
+    for i in range(300):
+        n = int(rng.choice([3, 20, 100, 400, 1200]))
+        cases.append(make_case(rng, n, clearance=float(rng.choice([0.05, 0.2, 0.6])), box=float(rng.uniform(1.0, 3.0))))
+    bd, pc, npts, a, b = pack(cases)
+    out = aa.firi(bd, pc, a, b, n_points=npts, max_rows=128, ctx=anet_ctx)
+    assert (out["ok"] == 1).all(), np.unique(out["ok"], return_counts=True)
+    for i, c in enumerate(cases):
+        k = out["n_rows"][i]
+        assert 4 <= k <= 128
+        hp = out["hpoly"][i, :k]
+        assert np.isfinite(hp).all()
+        check_properties(hp, *c)
+        r = out["ellipsoid"][i, 12:15]
+        assert np.isfinite(out["ellipsoid"][i]).all() and (r > 0).all()
