@@ -30,7 +30,7 @@ struct AdmmArgs {
   const double *state;   // [B][2][3][3]
   const double *T;       // [B][N]
   const double *hpolys;  // [B][N][M][4]
-  double *z, *y;         // [B][m] workspace / duals (scaled problem), m = me + N*R*(M+12)
+  double *z, *y;         // z: [B][m] workspace, ONE value per constraint row (see `wg` in the kernel), m = me + N*R*(M+12); y: unused
   double *coeffs;        // [B][n]  (piece, axis, highest power first) -- the reference's flatten order
   double *obj;           // [B]  1/2 z'Qz in original units (QPSolver::getObjCost)
   int *status, *iters;   // [B]  1 = solved, 0 = max_iter reached, -3 = primal infeasible (OSQP codes)
@@ -39,7 +39,7 @@ struct AdmmArgs {
   int N, R, M;
   double vmax, amax, m34;
   AdmmParams p;
-  int zy_in_lds;  // z, y live in LDS (small problems) instead of the global workspace
+  int zy_in_lds;  // the per-row state lives in LDS (it fits for <= 8-piece snap at M = 16) instead of the global workspace
   double *gradT;  // optional [B][N]: d(optimal 1/2 z'Qz)/dT_i (envelope theorem, see the end of the kernel)
 };
 
@@ -100,13 +100,16 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   double *eqc = eqb + me;                    // [me] coefficient of the right-hand piece (continuity rows)
   double *eqs = eqc + me;                    // [me] 1/T^d: undoes the row scaling of the normalisation
   double *gs = eqs + me;                     // [N*R][9] per-sample A'w blocks
-  double *zy_l = gs + (size_t)N * R * 9;    // [2*mtot] when a.zy_in_lds
+  double *zy_l = gs + (size_t)N * R * 9;    // [mtot] when a.zy_in_lds
 
   const double *Tg = a.T + b * N;
   const double *hp = a.hpolys + b * (int64_t)N * M * 4;
   const double *st = a.state + b * 18;
-  double *zg = a.zy_in_lds ? zy_l : a.z + b * mtot;
-  double *yg = a.zy_in_lds ? zy_l + mtot : a.y + b * mtot;
+  // ADMM state per constraint row: OSQP keeps z and y; both are functions of the single number
+  //   w = alpha (A x~) + (1-alpha) z_prev + y_prev/rho      (the argument of the projection):
+  //   z = Pi(w) = min(w, u) [b for an equality row],   y = rho (w - z).
+  // Storing w alone halves the row traffic and lets the state of an 8-piece snap problem sit in LDS.
+  double *wg = a.zy_in_lds ? zy_l : a.z + b * mtot;
 
   const bool hp_in_lds = (size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes;
   const double *hpl = hp;
@@ -313,7 +316,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
 
   // ---- init -----------------------------------------------------------------------------------
   for (int e = tid; e < n; e += nt) { x[e] = 0.0; rhs[e] = 0.0; }
-  for (int64_t e = tid; e < mtot; e += nt) { zg[e] = 0.0; yg[e] = 0.0; }
+  for (int64_t e = tid; e < mtot; e += nt) wg[e] = 0.0;  // (the first iteration reads z = y = 0 regardless: cold start)
   factorize();
   __syncthreads();
 
@@ -321,6 +324,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   double rp = 0.0, rd = 0.0;
   for (it = 1; it <= a.p.max_iter; ++it) {
     const bool check = (it % a.p.check_every) == 0;
+    const bool first = it == 1;  // cold start: z = y = 0 whatever the stored row state says
     const double rho_e = 1.0e3 * rho, inv_rho = 1.0 / rho;
     solve();
     // x+ = alpha x~ + (1-alpha) x ; next rhs starts as sigma x+
@@ -368,12 +372,13 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
           ax_new += cf2 * x[(i0 + 1) * NB + ax * D + (D - 1 - d)];
         }
       }
-      const double zo = zg[r], yo = yg[r];
+      const double wo = wg[r];
+      const double zo = first ? 0.0 : bval, yo = first ? 0.0 : rho_e * (wo - bval);
       const double zr = alpha * zt + (1.0 - alpha) * zo;
       const double zn = bval;  // l = u = b
-      const double yn = yo + rho_e * (zr - zn);
-      zg[r] = zn;
-      yg[r] = yn;
+      const double wn = zr + yo / rho_e;
+      const double yn = rho_e * (wn - zn);
+      wg[r] = wn;
       const double w = rho_e * zn - yn;
       // scatter A' w (and A' y at check iterations)
       auto scatter = [&](double *dst, double wv) {
@@ -425,12 +430,15 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       double gd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
       const double Ti = Tn[i], rTi = a.p.scaled_termination ? 1.0 : 1.0 / Tn[i];
       // one ADMM row update; returns w = rho z+ - y+ and (at check iterations) y+ and dy
-      auto row_update = [&](double zt, double axn, double hv, double zo, double yo, double un, double &zn, double &yn) {
+      auto row_update = [&](double zt, double axn, double hv, double wo, double un, double &wn, double &zn, double &yn,
+                            double &dy) {
+        const double zo = first ? 0.0 : fmin(wo, hv), yo = first ? 0.0 : rho * (wo - zo);
         const double zr = alpha * zt + (1.0 - alpha) * zo;
-        zn = fmin(zr + yo * inv_rho, hv);  // l = -inf
-        yn = yo + rho * (zr - zn);
+        wn = zr + yo * inv_rho;
+        zn = fmin(wn, hv);  // l = -inf
+        yn = rho * (wn - zn);
+        dy = yn - yo;
         if (check) {
-          const double dy = yn - yo;
           l_rp = fmax(l_rp, fabs(axn - zn) * un);  // un: 1 (corridor), 1/T (velocity), 1/T^2 (acceleration)
           l_ax = fmax(l_ax, fabs(axn) * un);
           l_z = fmax(l_z, fabs(zn) * un);
@@ -439,15 +447,14 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
           l_sup += (dy > 0.0) ? hv * dy : (dy < 0.0 ? 1e300 : 0.0);
         }
       };
-      // ---- corridor rows, four at a time so that their z / y loads are in flight together
+      // ---- corridor rows, four at a time so that their state loads are in flight together
       for (int q0 = 0; q0 < M; q0 += 4) {
-        double zo[4], yo[4], cf[4][4];
+        double wo[4], cf[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int q = q0 + u;
           const bool ok = q < M;
-          zo[u] = ok ? zg[r0 + q * NS] : 0.0;
-          yo[u] = ok ? yg[r0 + q * NS] : 0.0;
+          wo[u] = ok ? wg[r0 + q * NS] : 0.0;
           const double *hq = hpl + ((int64_t)i * M + (ok ? q : 0)) * 4;
 #pragma unroll
           for (int w4 = 0; w4 < 4; ++w4) cf[u][w4] = ok ? hq[w4] : 0.0;
@@ -459,14 +466,12 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
             const double c0 = cf[u][0], c1 = cf[u][1], c2 = cf[u][2];
             const double zt = c0 * s3[0][0] + c1 * s3[0][1] + c2 * s3[0][2];
             const double axn = c0 * s3n[0][0] + c1 * s3n[0][1] + c2 * s3n[0][2];
-            double zn, yn;
-            row_update(zt, axn, cf[u][3], zo[u], yo[u], 1.0, zn, yn);
-            zg[r0 + q * NS] = zn;
-            yg[r0 + q * NS] = yn;
+            double wn, zn, yn, dy;
+            row_update(zt, axn, cf[u][3], wo[u], 1.0, wn, zn, yn, dy);
+            wg[r0 + q * NS] = wn;
             const double w = rho * zn - yn;
             g[0][0] += w * c0; g[0][1] += w * c1; g[0][2] += w * c2;
             if (check) {
-              const double dy = yn - yo[u];
               gy[0][0] += yn * c0; gy[0][1] += yn * c1; gy[0][2] += yn * c2;
               gd[0][0] += dy * c0; gd[0][1] += dy * c1; gd[0][2] += dy * c2;
             }
@@ -475,26 +480,22 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       }
       // ---- the 12 box rows (+v, +a, -v, -a per axis), all loads up front
       {
-        double zo[12], yo[12];
+        double wo[12];
 #pragma unroll
-        for (int qq = 0; qq < 12; ++qq) {
-          zo[qq] = zg[r0 + (M + qq) * NS];
-          yo[qq] = yg[r0 + (M + qq) * NS];
-        }
+        for (int qq = 0; qq < 12; ++qq) wo[qq] = wg[r0 + (M + qq) * NS];
 #pragma unroll
         for (int qq = 0; qq < 12; ++qq) {
           const int axsel = qq / 4, w4 = qq % 4, dsel = 1 + (w4 & 1);
           const double sgn = (w4 < 2) ? 1.0 : -1.0;
           const double hv = (dsel == 1) ? a.vmax * Ti : a.amax * Ti * Ti;
-          double zn, yn;
-          row_update(sgn * s3[dsel][axsel], sgn * s3n[dsel][axsel], hv, zo[qq], yo[qq], (dsel == 1) ? rTi : rTi * rTi, zn, yn);
-          zg[r0 + (M + qq) * NS] = zn;
-          yg[r0 + (M + qq) * NS] = yn;
+          double wn, zn, yn, dy;
+          row_update(sgn * s3[dsel][axsel], sgn * s3n[dsel][axsel], hv, wo[qq], (dsel == 1) ? rTi : rTi * rTi, wn, zn, yn, dy);
+          wg[r0 + (M + qq) * NS] = wn;
           const double w = rho * zn - yn;
           g[dsel][axsel] += sgn * w;
           if (check) {
             gy[dsel][axsel] += sgn * yn;
-            gd[dsel][axsel] += sgn * (yn - yo[qq]);
+            gd[dsel][axsel] += sgn * dy;
           }
         }
       }
@@ -578,7 +579,9 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
         double rho_new = rho * sqrt(np_ / fmax(nd_, 1e-300));
         rho_new = fmin(fmax(rho_new, 1e-6), 1e6);
         if (rho_new > 5.0 * rho || rho_new < 0.2 * rho) {
-          // rhs was accumulated with the old rho: rebuild it for the new one from z, y
+          // rhs was accumulated with the old rho: rebuild it for the new one from z, y (decoded from the row
+          // state with the OLD rho, re-encoded with the new one: y does not change when rho does)
+          const double rho_old = rho;
           rho = rho_new;
           __syncthreads();
           factorize();
@@ -589,7 +592,9 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
             int i0, ax, d, kind;
             if (r < 18) { ax = r / 6; const int q = r % 6; kind = q < 3 ? 0 : 1; d = q % 3; i0 = kind == 0 ? 0 : N - 1; }
             else { const int rr = r - 18; i0 = rr / (3 * S); ax = (rr / S) % 3; d = rr % S; kind = 2; }
-            const double w = rho_e2 * zg[r] - yg[r];
+            const double zo = eqb[r], yo = 1.0e3 * rho_old * (wg[r] - zo);
+            const double w = rho_e2 * zo - yo;
+            wg[r] = zo + yo / rho_e2;
             if (kind == 0) atomicAdd(&rhs[ax * D + (D - 1 - d)], fallf(d, d) * w);
             else {
               for (int col = 0; col < D; ++col) { const int k = D - 1 - col; if (k >= d) atomicAdd(&rhs[i0 * NB + ax * D + col], fallf(k, d) * w); }
@@ -602,12 +607,16 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
             const int64_t r0 = me + smp, NS = (int64_t)N * R;
             double g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
             for (int q = 0; q < rows_per_sample; ++q) {
-              const double w = rho * zg[r0 + q * NS] - yg[r0 + q * NS];
+              const double *hq = hpl + ((int64_t)i * M + (q < M ? q : 0)) * 4;
+              const int qq = q - M, w4 = qq % 4;
+              const double hv = (q < M) ? hq[3] : (((w4 & 1) == 0) ? a.vmax * Tn[i] : a.amax * Tn[i] * Tn[i]);
+              const double wo = wg[r0 + q * NS];
+              const double zo = fmin(wo, hv), yo = rho_old * (wo - zo);
+              const double w = rho * zo - yo;
+              wg[r0 + q * NS] = zo + yo / rho;
               if (q < M) {
-                const double *hq = hpl + ((int64_t)i * M + q) * 4;
                 g[0][0] += w * hq[0]; g[0][1] += w * hq[1]; g[0][2] += w * hq[2];
               } else {
-                const int qq = q - M, w4 = qq % 4;
                 g[1 + (w4 & 1)][qq / 4] += ((w4 < 2) ? 1.0 : -1.0) * w;
               }
             }
@@ -650,7 +659,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       if (r < 18) { ax = r / 6; const int q = r % 6; kind = q < 3 ? 0 : 1; d = q % 3; i0 = kind == 0 ? 0 : N - 1; }
       else { const int rr = r - 18; i0 = rr / (3 * S); ax = (rr / S) % 3; d = rr % S; kind = 2; }
       if (d == 0) continue;
-      const double yr = yg[r] * inv_c;
+      const double yr = 1.0e3 * rho * (wg[r] - eqb[r]) * inv_c;
       if (kind != 2) {
         atomicAdd(&rhs[i0], -yr * (double)d * eqb[r] / Tn[i0]);
       } else {
@@ -664,8 +673,10 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
       const int64_t r0 = me + smp, NS = (int64_t)N * R;
       double sv = 0.0, sa = 0.0;
       for (int qq = 0; qq < 12; ++qq) {
-        const double yv = yg[r0 + (M + qq) * NS];
-        if ((qq % 4) & 1) sa += yv;
+        const bool acc = (qq % 4) & 1;
+        const double hv = acc ? a.amax * Tn[i] * Tn[i] : a.vmax * Tn[i];
+        const double yv = rho * fmax(wg[r0 + (M + qq) * NS] - hv, 0.0);
+        if (acc) sa += yv;
         else sv += yv;
       }
       if (sv != 0.0 || sa != 0.0) atomicAdd(&rhs[i], -inv_c * (a.vmax * sv + 2.0 * a.amax * Tn[i] * sa));
@@ -705,7 +716,7 @@ inline size_t qp_admm_lds_bytes(int N, int R, int M, bool zy_in_lds) {
   const size_t hp = (size_t)N * M * 4 * sizeof(double) <= kAdmmHpLdsBytes ? (size_t)N * M * 4 : 0;
   const size_t mtot = (size_t)(3 * (6 + S * (N - 1))) + (size_t)N * R * (M + 12);
   return sizeof(double) * ((size_t)2 * N * NB * NB + NB * NB + 5 * n + (size_t)R * 3 * D + 2 * D * D + (size_t)N * 9 + N + 12 + hp + 3 * (size_t)(3 * (6 + S * (N - 1))) +
-                           (size_t)N * R * 9 + (zy_in_lds ? 2 * mtot : 0));
+                           (size_t)N * R * 9 + (zy_in_lds ? mtot : 0));
 }
 
 }  // namespace anet

@@ -206,3 +206,42 @@ def test_minco_lbfgs_partial_variable_sets(anet_ctx, opt_name):
     ok = out["status"] >= 0
     assert ok.mean() > 0.5
     assert np.abs(g1[ok]).max() < 1e-2 * np.abs(g0[ok]).max()      # (much) closer to stationarity than the start
+
+
+def test_minco_s2nu_16_segments_lbfgs(anet_ctx):
+    """BASELINE.json labels config 4 "16-segment min-jerk (MINCO_S2NU)"; SURVEY 8(d) reads it as s = 3
+    (covered above and by tools/bench_configs.py).  The other reading, s = 2 (MINCO_S2NU, minimum
+    acceleration) with 16 segments, through the same driver: gradient checked by central differences of
+    the GPU cost (the numpy oracle covers the reference's orders s >= 3), L-BFGS lowers the cost and
+    stops at a point where the gradient has dropped."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(202)
+    s, c, N, M, B = 2, 2, 16, 6, 24
+    head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
+    hp = make_corridors(rng, head, tail, wps, M, tight=2.0)
+    pen = aa.make_penalty(rho=20.0, w_corridor=1e3, w_vel=1e2, w_acc=1e2, smooth_mu=1e-2, max_vel=3.0, max_acc=4.0,
+                          res=8, poly_rows=M)
+    c0, gP0, gT0 = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, ctx=anet_ctx)
+    h = 1e-6
+    for (k, ax) in [(0, 0), (7, 1), (14, 2)]:
+        wp = wps.copy(); wp[:, k, ax] += h
+        wm = wps.copy(); wm[:, k, ax] -= h
+        fd = (aa.minco_cost_grad(head, tail, wp, T, s, hpolys=hp, penalty=pen, ctx=anet_ctx)[0]
+              - aa.minco_cost_grad(head, tail, wm, T, s, hpolys=hp, penalty=pen, ctx=anet_ctx)[0]) / (2 * h)
+        assert np.abs(fd - gP0[:, k, ax]).max() <= 1e-4 * max(1.0, np.abs(gP0[:, k, ax]).max())
+    for i in (0, 9, 15):
+        tp = T.copy(); tp[:, i] += h
+        tm = T.copy(); tm[:, i] -= h
+        fd = (aa.minco_cost_grad(head, tail, wps, tp, s, hpolys=hp, penalty=pen, ctx=anet_ctx)[0]
+              - aa.minco_cost_grad(head, tail, wps, tm, s, hpolys=hp, penalty=pen, ctx=anet_ctx)[0]) / (2 * h)
+        assert np.abs(fd - gT0[:, i]).max() <= 1e-4 * max(1.0, np.abs(gT0[:, i]).max())
+    out = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=aa.lbfgs_parameter_t(), max_evals=3000,
+                         ctx=anet_ctx)
+    assert (out["cost"] < c0).all() and (out["status"] >= 0).all()
+    c1, gP1, gT1 = aa.minco_cost_grad(head, tail, out["wps"], out["T"], s, hpolys=hp, penalty=pen, ctx=anet_ctx)
+    fin = out["status"] <= 1          # converged / stopped (a problem still running at max_evals holds a trial point)
+    assert fin.sum() >= B // 2
+    assert np.abs(c1 - out["cost"])[fin].max() <= 1e-9 * np.abs(c1).max()
+    g0 = np.sqrt((gP0 ** 2).sum(axis=(1, 2)) + (gT0 ** 2).sum(axis=1))
+    g1 = np.sqrt((gP1 ** 2).sum(axis=(1, 2)) + (gT1 ** 2).sum(axis=1))
+    assert (g1[fin] < 0.2 * g0[fin]).all()
