@@ -96,7 +96,8 @@ class QpSettings(ctypes.Structure):
     """struct anet_qp_settings (OSQP defaults)."""
     _fields_ = [("rho", c_double), ("sigma", c_double), ("alpha", c_double), ("eps_abs", c_double),
                 ("eps_rel", c_double), ("max_iter", ctypes.c_int32), ("check_termination", ctypes.c_int32),
-                ("adaptive_rho_interval", ctypes.c_int32), ("scaled_termination", ctypes.c_int32)]
+                ("adaptive_rho_interval", ctypes.c_int32), ("scaled_termination", ctypes.c_int32),
+                ("method", ctypes.c_int32)]
 
 
 class FiriParams(ctypes.Structure):

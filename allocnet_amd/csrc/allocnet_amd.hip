@@ -22,6 +22,7 @@
 #include "firi_kernels.h"
 #include "qp_assemble.h"
 #include "qp_admm.h"
+#include "qp_ipm.h"
 #include "layout_kernels.h"
 
 // ------------------------------------------------------------------------------------------
@@ -1147,6 +1148,7 @@ void anet_qp_default_settings(anet_qp_settings *s) {
   if (!s) return;
   s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
   s->max_iter = 4000; s->check_termination = 25; s->adaptive_rho_interval = 100; s->scaled_termination = 0;
+  s->method = ANET_QP_METHOD_ADMM;
 }
 
 int64_t anet_qp_solve_workspace(int s, int n_pieces, int64_t batch, int res, int M) {
@@ -1171,6 +1173,30 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
   if (!(st_.rho > 0) || !(st_.sigma > 0) || !(st_.alpha > 0 && st_.alpha < 2) || st_.max_iter < 1 ||
       st_.check_termination < 1 || st_.eps_abs < 0 || st_.eps_rel < 0 || st_.adaptive_rho_interval < 0)
     return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad settings");
+  if (st_.method != ANET_QP_METHOD_ADMM && st_.method != ANET_QP_METHOD_INTERIOR_POINT)
+    return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: unknown method");
+  if (st_.method == ANET_QP_METHOD_INTERIOR_POINT) {
+    if (grad_T) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_qp_solve_time_grad: the time gradient is computed by the ADMM method");
+    const size_t ldsb = (s == 4) ? anet::qp_ipm_lds_bytes<4>(n_pieces, res, M) : anet::qp_ipm_lds_bytes<3>(n_pieces, res, M);
+    if (ldsb > 160 * 1024)
+      return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_qp_solve: problem too large for the 160 KB LDS (interior-point method)");
+    const int64_t mi = (int64_t)n_pieces * res * (M + 12);
+    double tol = st_.eps_rel < st_.eps_abs ? st_.eps_rel : st_.eps_abs;
+    if (!(tol > 0.0) || tol > 1e-6) tol = 1e-6;   // Newton's method: the last digits cost one or two steps
+    anet::IpmArgs ia{state, T, hpolys, work, work + mi * batch, coeffs, obj, status, iters,
+                     residuals ? residuals : work + 2 * mi * batch, nullptr, batch, n_pieces, res, M, max_vel, max_acc, m34,
+                     tol, st_.max_iter < 200 ? st_.max_iter : 200};
+    hipStream_t sti = (hipStream_t)stream;
+    if (s == 4) {
+      ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_ipm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      hipLaunchKernelGGL((anet::k_qp_ipm<4>), dim3((unsigned)batch), dim3(256), ldsb, sti, ia);
+    } else {
+      ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_ipm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      hipLaunchKernelGGL((anet::k_qp_ipm<3>), dim3((unsigned)batch), dim3(256), ldsb, sti, ia);
+    }
+    ANET_HIP(ctx, hipGetLastError());
+    return ANET_OK;
+  }
   size_t lds = (s == 4) ? anet::qp_admm_lds_bytes<4>(n_pieces, res, M, true) : anet::qp_admm_lds_bytes<3>(n_pieces, res, M, true);
   int zy_in_lds = 1;
   if (lds > 160 * 1024) {

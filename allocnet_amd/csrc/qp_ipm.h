@@ -1,0 +1,634 @@
+// Interior-point solve of the reference's inequality QP (planner/qp_solver.hpp:119-360), an alternative to
+// the OSQP-faithful ADMM kernel (qp_admm.h) for callers who want the optimum rather than OSQP's iterates:
+// same problem, same solution, 10-20 Newton steps instead of ~10^3 ADMM iterations.
+//
+// MI355X-first formulation (one 256-thread workgroup per trajectory, everything but the row state in LDS):
+//  * normalised time per piece (as in qp_admm.h) AND Hermite coordinates: the unknowns are the node states
+//    y_k = (p, p', .., p^(s-1)) T^d at the N+1 knots.  The reference's equality block -- C^(s-1) continuity and
+//    the start/end PVA rows -- then holds by construction (fixed components are pinned), so the QP has
+//    inequality rows only and its Newton matrix is SPD block tridiagonal with one 3s x 3s block per knot,
+//    the shape the MINCO solve already uses (minco_core.h).
+//  * piece i sees u_i = [y_i ; (T_i/T_i+1)^d y_i+1]; every row of the QP is a Hermite basis function (or a
+//    derivative) at tau_j = j/res contracted with a 3-vector, so A'WA is assembled from per-sample 3x3 /
+//    3-vector weights and one table of 3*res*2s numbers; Q, A, G are never formed.
+//  * Mehrotra predictor-corrector; the two solves of a step share one block Cholesky, done by wave 0 in LDS
+//    while the other waves wait (12 x 12 blocks: too small to split further).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "qp_admm.h"  // qblk1, fallf
+
+namespace anet {
+
+struct IpmArgs {
+  const double *state;   // [B][2][3][3]
+  const double *T;       // [B][N]
+  const double *hpolys;  // [B][N][M][4]
+  double *sl, *lam;      // [B][m] slacks / multipliers of the inequality rows, m = N*R*(M+12), sample index minor
+  double *coeffs;        // [B][n]
+  double *obj;           // [B]
+  int *status, *iters;   // [B]
+  double *res;           // [B][2] primal / dual residual at exit (relative)
+  double *gradT;         // optional [B][N]
+  int64_t B;
+  int N, R, M;
+  double vmax, amax, m34, tol;
+  int max_iter;
+};
+
+template <int S>
+inline size_t qp_ipm_lds_bytes(int N, int R, int M) {
+  constexpr int D = 2 * S, NB = 3 * D, BK = 3 * S;
+  const size_t NS = (size_t)N * R;
+  return sizeof(double) * ((size_t)(N + 1) * BK * 4 + (size_t)(N + 1) * BK * BK + (size_t)N * BK * BK + 3 * (size_t)N * NB +
+                           (size_t)R * 3 * D + 2 * D * D + (size_t)N * D + NS * 30 + (size_t)N * M * 4 + 2 * N + 32);
+}
+
+template <int S>
+__global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
+  constexpr int D = 2 * S, NB = 3 * D, BK = 3 * S;
+  const int N = a.N, R = a.R, M = a.M;
+  const int NS = N * R, RPS = M + 12;
+  const int64_t mtot = (int64_t)NS * RPS;
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int NY = (N + 1) * BK;
+
+  extern __shared__ double lds[];
+  double *yv = lds;                       // [NY] node states (scaled by T^d of the piece to their right)
+  double *dya = yv + NY;                  // [NY] affine direction
+  double *dyc = dya + NY;                 // [NY] final direction
+  double *rhs = dyc + NY;                 // [NY]
+  double *Dg = rhs + NY;                  // [(N+1)][BK*BK] diagonal blocks -> their Cholesky factors
+  double *Of = Dg + (size_t)(N + 1) * BK * BK;  // [N][BK*BK] block (k+1,k) -> L_{k+1,k}
+  double *uu = Of + (size_t)N * BK * BK;  // [N][NB] u_i of y
+  double *dua = uu + (size_t)N * NB;      // [N][NB] u_i of the affine direction
+  double *duc = dua + (size_t)N * NB;     // [N][NB] u_i of the final direction
+  double *ht = duc + (size_t)N * NB;      // [R][3][D] Hermite basis (derivative d) at tau_j
+  double *Hobj = ht + (size_t)R * 3 * D;  // [D][D] cost block in Hermite coordinates (per axis, T = 1)
+  double *Hm = Hobj + D * D;              // [D][D] c~ = Hm u
+  double *sc = Hm + D * D;                // [N][D] 1 for the start half, (T_i/T_i+1)^d for the end half
+  double *acc = sc + (size_t)N * D;       // [NS][30]: 0-5 Wa (sym), 6-8 Wv, 9-11 Wacc, 12-20 gamma[d][ax], 21-29 gamma_lambda
+  double *hp_l = acc + (size_t)NS * 30;   // [N*M*4]
+  double *Tn = hp_l + (size_t)N * M * 4;  // [N]
+  double *red = Tn + N;                   // [32]
+  double *qsv = red + 32;                 // [N] T_i^(1-2s)
+
+  const double *Tg = a.T + b * N;
+  const double *hp = a.hpolys + b * (int64_t)N * M * 4;
+  const double *st = a.state + b * 18;
+  double *slg = a.sl + b * mtot, *lmg = a.lam + b * mtot;
+
+  for (int e = tid; e < N * M * 4; e += nt) hp_l[e] = hp[e];
+  for (int i = tid; i < N; i += nt) {
+    Tn[i] = Tg[i];
+    qsv[i] = pow(Tg[i], (double)(1 - 2 * S));
+  }
+  // ---- Hermite matrix: E[row][col] = value of derivative d of the monomial col at tau = 0 / 1; Hm = E^-1
+  if (tid == 0) {
+    double *E = acc;  // [D][2D] scratch in LDS (acc is not in use yet)
+    constexpr int W = 2 * D;
+    for (int r = 0; r < D; ++r)
+      for (int col = 0; col < D; ++col) {
+        const int d = r % S, k = D - 1 - col;
+        double v = 0.0;
+        if (k >= d) v = (r < S) ? (k == d ? fallf(k, d) : 0.0) : fallf(k, d);
+        E[r * W + col] = v;
+        E[r * W + D + col] = (r == col) ? 1.0 : 0.0;
+      }
+    for (int c = 0; c < D; ++c) {  // Gauss-Jordan with partial pivoting
+      int pv = c;
+      for (int r = c + 1; r < D; ++r)
+        if (fabs(E[r * W + c]) > fabs(E[pv * W + c])) pv = r;
+      for (int k = 0; k < W; ++k) { const double t = E[c * W + k]; E[c * W + k] = E[pv * W + k]; E[pv * W + k] = t; }
+      const double ip = 1.0 / E[c * W + c];
+      for (int k = 0; k < W; ++k) E[c * W + k] *= ip;
+      for (int r = 0; r < D; ++r)
+        if (r != c) {
+          const double f = E[r * W + c];
+          if (f != 0.0)
+            for (int k = 0; k < W; ++k) E[r * W + k] -= f * E[c * W + k];
+        }
+    }
+    for (int r = 0; r < D; ++r)
+      for (int c = 0; c < D; ++c) Hm[r * D + c] = E[r * W + D + c];  // Hm[col][m]
+  }
+  __syncthreads();
+  for (int e = tid; e < R * 3 * D; e += nt) {
+    const int j = e / (3 * D), d = (e / D) % 3, m = e % D;
+    const double tau = (double)j / (double)R;
+    double v = 0.0;
+    for (int col = 0; col < D; ++col) {
+      const int k = D - 1 - col;
+      if (k >= d) {
+        double bv = fallf(k, d);
+        for (int q = 0; q < k - d; ++q) bv *= tau;
+        v += bv * Hm[col * D + m];
+      }
+    }
+    ht[e] = v;
+  }
+  for (int e = tid; e < D * D; e += nt) {
+    const int m = e / D, m2 = e % D;
+    double v = 0.0;
+    for (int c1 = 0; c1 < S; ++c1)
+      for (int c2 = 0; c2 < S; ++c2) v += Hm[c1 * D + m] * qblk1<S>(c1, c2, a.m34) * Hm[c2 * D + m2];
+    Hobj[e] = v;
+  }
+  for (int e = tid; e < N * D; e += nt) {
+    const int i = e / D, m = e % D;
+    double v = 1.0;
+    if (m >= S && i < N - 1) v = pow(Tn[i] / Tn[i + 1], (double)(m - S));
+    sc[e] = v;
+  }
+  // ---- starting point: boundary values pinned, interior knot positions on the chord, derivatives zero
+  for (int e = tid; e < NY; e += nt) {
+    const int k = e / BK, ax = (e / S) % 3, d = e % S;
+    double v = 0.0;
+    if (k == 0 && d < 3) v = st[ax * 3 + d] * pow(Tn[0], (double)d);
+    else if (k == N && d < 3) v = st[9 + ax * 3 + d] * pow(Tn[N - 1], (double)d);
+    else if (d == 0) {
+      double tsum = 0.0, tk = 0.0;
+      for (int i = 0; i < N; ++i) { tsum += Tn[i]; if (i < k) tk += Tn[i]; }
+      const double f = tk / tsum;
+      v = (1.0 - f) * st[ax * 3] + f * st[9 + ax * 3];
+    }
+    yv[e] = v;
+    dya[e] = 0.0;
+    dyc[e] = 0.0;
+  }
+  __syncthreads();
+  auto pinned = [&](int k, int d) { return (k == 0 || k == N) && d < 3; };
+  // u_i of a node vector
+  auto to_u = [&](const double *y, double *u) {
+    for (int e = tid; e < N * NB; e += nt) {
+      const int i = e / NB, ax = (e % NB) / D, m = e % D;
+      u[e] = (m < S) ? y[i * BK + ax * S + m] : sc[i * D + m] * y[(i + 1) * BK + ax * S + (m - S)];
+    }
+  };
+  to_u(yv, uu);
+  __syncthreads();
+
+  // state rows (derivative d, axis ax) of a u-vector at sample (i, j)
+  auto state_of = [&](const double *u, int i, int j, double (&s3)[3][3]) {
+    const double *hj = ht + (size_t)j * 3 * D, *ui = u + (size_t)i * NB;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        double v = 0.0;
+        for (int m = 0; m < D; ++m) v += hj[d * D + m] * ui[ax * D + m];
+        s3[d][ax] = v;
+      }
+  };
+  // Visit the live rows of a sample of piece i: fn(q, dsel, c0, c1, c2, bound) with the row = (c0,c1,c2).(derivative
+  // dsel of the three axes).  The box rows are unrolled so that dsel and the axis are compile-time constants
+  // inside fn (private arrays indexed by them stay in registers); all-zero corridor rows are inert padding.
+  auto for_rows = [&](int i, auto &&fn) {
+    for (int q = 0; q < M; ++q) {
+      const double *hq = hp_l + ((size_t)i * M + q) * 4;
+      const double c0 = hq[0], c1 = hq[1], c2 = hq[2];
+      if (c0 == 0.0 && c1 == 0.0 && c2 == 0.0) continue;
+      fn(q, 0, c0, c1, c2, hq[3]);
+    }
+    const double hvv = a.vmax * Tn[i], hva = a.amax * Tn[i] * Tn[i];
+#pragma unroll
+    for (int qq = 0; qq < 12; ++qq) {
+      const int axsel = qq / 4, w4 = qq % 4, dsel = 1 + (w4 & 1);
+      const double sgn = (w4 < 2) ? 1.0 : -1.0;
+      fn(M + qq, dsel, axsel == 0 ? sgn : 0.0, axsel == 1 ? sgn : 0.0, axsel == 2 ? sgn : 0.0, dsel == 1 ? hvv : hva);
+    }
+  };
+  auto block_reduce = [&](double v, int slot, bool is_min) {  // red[slot] must have been initialised before a barrier
+    for (int o = 32; o > 0; o >>= 1) {
+      const double w = __shfl_xor(v, o);
+      v = is_min ? fmin(v, w) : v + w;
+    }
+    if ((tid & 63) == 0) {
+      if (is_min) atomic_max_pos(&red[slot], 1.0 / fmax(v, 1e-300));  // min of positives via max of reciprocals
+      else atomicAdd(&red[slot], v);
+    }
+  };
+
+  // ---- initial slacks / multipliers
+  int64_t nrows_local = 0;
+  for (int smp = tid; smp < NS; smp += nt) {
+    const int i = smp / R, j = smp % R;
+    double s3[3][3];
+    state_of(uu, i, j, s3);
+    for (int q = 0; q < RPS; ++q) {  // inert rows keep s = 1, lambda = 0 and are never visited again
+      slg[smp + (int64_t)q * NS] = 1.0;
+      lmg[smp + (int64_t)q * NS] = 0.0;
+    }
+    for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
+      const double gy = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2];
+      slg[smp + (int64_t)q * NS] = fmax(hv - gy, 1.0);
+      lmg[smp + (int64_t)q * NS] = 1.0;
+      ++nrows_local;
+    });
+  }
+  if (tid < 32) red[tid] = 0.0;
+  __syncthreads();
+  block_reduce((double)nrows_local, 0, false);
+  __syncthreads();
+  const double mrows = fmax(red[0], 1.0);
+  __syncthreads();
+
+  // assemble the node-space vector  out_k = sum over the pieces touching knot k of sc * (qs Hobj u + sum_j gamma_j h_j)
+  // (gamma at acc offset `goff`; with_obj adds the cost gradient); pinned components are zeroed
+  auto node_vector = [&](double *out, int goff, bool with_obj, const double *u) {
+    for (int e = tid; e < NY; e += nt) {
+      const int k = e / BK, ax = (e / S) % 3, d = e % S;
+      double v = 0.0;
+      if (!pinned(k, d)) {
+        for (int side = 0; side < 2; ++side) {
+          const int i = side == 0 ? k : k - 1;  // piece whose start (side 0) / end (side 1) is knot k
+          if (i < 0 || i >= N) continue;
+          const int m = side == 0 ? d : S + d;
+          double g = 0.0;
+          if (with_obj) {
+            const double qs = qsv[i];
+            const double *ui = u + (size_t)i * NB + ax * D;
+            for (int m2 = 0; m2 < D; ++m2) g += qs * Hobj[m * D + m2] * ui[m2];
+          }
+          for (int j = 0; j < R; ++j) {
+            const double *ga = acc + (size_t)(i * R + j) * 30 + goff;
+            const double *hj = ht + (size_t)j * 3 * D;
+            g += ga[ax] * hj[m] + ga[3 + ax] * hj[D + m] + ga[6 + ax] * hj[2 * D + m];
+          }
+          v += sc[i * D + m] * g;
+        }
+      }
+      out[e] = v;
+    }
+  };
+
+  // block Cholesky of (Dg, Of) in place and block forward/backward substitution, by wave 0 alone (LDS
+  // operations of one wave execute in order; no workgroup barrier inside)
+  auto wave0_factor = [&]() {
+    if (tid < 64) {
+      const int lane = tid;
+      for (int k = 0; k <= N; ++k) {
+        double *Dk = Dg + (size_t)k * BK * BK;
+        if (k > 0) {  // Schur update with L_{k,k-1}
+          const double *Lo = Of + (size_t)(k - 1) * BK * BK;
+          for (int e = lane; e < BK * BK; e += 64) {
+            const int r = e / BK, c = e % BK;
+            if (c <= r) {
+              double v = 0.0;
+              for (int q = 0; q < BK; ++q) v += Lo[r * BK + q] * Lo[c * BK + q];
+              Dk[e] -= v;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        for (int c = 0; c < BK; ++c) {  // Cholesky, column by column; lane = row
+          if (lane == c) Dk[c * BK + c] = sqrt(fmax(Dk[c * BK + c], 1e-300));
+          __builtin_amdgcn_wave_barrier();
+          const double piv = Dk[c * BK + c];
+          if (lane > c && lane < BK) Dk[lane * BK + c] /= piv;
+          __builtin_amdgcn_wave_barrier();
+          for (int e = lane; e < BK * BK; e += 64) {
+            const int r = e / BK, c2 = e % BK;
+            if (c2 > c && r >= c2) Dk[e] -= Dk[r * BK + c] * Dk[c2 * BK + c];
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (k < N) {  // L_{k+1,k} = A_{k+1,k} L_k^-T : row r of Of by forward substitution over the columns; lane = row
+          double *Lo = Of + (size_t)k * BK * BK;
+          if (lane < BK) {
+            for (int c = 0; c < BK; ++c) {
+              double v = Lo[lane * BK + c];
+              for (int q = 0; q < c; ++q) v -= Lo[lane * BK + q] * Dk[c * BK + q];
+              Lo[lane * BK + c] = v / Dk[c * BK + c];
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  };
+  auto wave0_solve = [&](double *x) {  // x <- K^-1 x
+    if (tid < 64) {
+      const int lane = tid;
+      for (int k = 0; k <= N; ++k) {  // forward: L z = x
+        const double *Dk = Dg + (size_t)k * BK * BK;
+        double *xk = x + k * BK;
+        if (k > 0) {
+          const double *Lo = Of + (size_t)(k - 1) * BK * BK;
+          const double *xp = x + (k - 1) * BK;
+          double v = 0.0;
+          if (lane < BK)
+            for (int q = 0; q < BK; ++q) v += Lo[lane * BK + q] * xp[q];
+          __builtin_amdgcn_wave_barrier();
+          if (lane < BK) xk[lane] -= v;
+          __builtin_amdgcn_wave_barrier();
+        }
+        for (int c = 0; c < BK; ++c) {
+          if (lane == c) xk[c] /= Dk[c * BK + c];
+          __builtin_amdgcn_wave_barrier();
+          const double xc = xk[c];
+          if (lane > c && lane < BK) xk[lane] -= Dk[lane * BK + c] * xc;
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      for (int k = N; k >= 0; --k) {  // backward: L' x = z
+        const double *Dk = Dg + (size_t)k * BK * BK;
+        double *xk = x + k * BK;
+        if (k < N) {
+          const double *Lo = Of + (size_t)k * BK * BK;  // L_{k+1,k}
+          const double *xn = x + (k + 1) * BK;
+          double v = 0.0;
+          if (lane < BK)
+            for (int q = 0; q < BK; ++q) v += Lo[q * BK + lane] * xn[q];
+          __builtin_amdgcn_wave_barrier();
+          if (lane < BK) xk[lane] -= v;
+          __builtin_amdgcn_wave_barrier();
+        }
+        for (int c = BK - 1; c >= 0; --c) {
+          if (lane == c) xk[c] /= Dk[c * BK + c];
+          __builtin_amdgcn_wave_barrier();
+          const double xc = xk[c];
+          if (lane < c) xk[lane] -= Dk[c * BK + lane] * xc;
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  };
+
+  int it = 0, status = 0;
+  double pres = 0.0, dres = 0.0, mu = 0.0, mu0 = 0.0;
+  for (it = 0; it < a.max_iter; ++it) {
+    // ---- pass A: residuals, weights, right-hand-side pieces per sample ---------------------------
+    if (tid < 32) red[tid] = 0.0;
+    __syncthreads();
+    double l_mu = 0.0, l_pres = 0.0, l_h = 0.0;
+    for (int smp = tid; smp < NS; smp += nt) {
+      const int i = smp / R, j = smp % R;
+      double s3[3][3];
+      state_of(uu, i, j, s3);
+      double A_[30];
+#pragma unroll
+      for (int q = 0; q < 30; ++q) A_[q] = 0.0;
+      for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
+        const double gy = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2];
+        const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
+        const double rg = gy + sl - hv, w = lm / sl, t = lm + w * (gy - hv);
+        l_mu += sl * lm;
+        l_pres = fmax(l_pres, fabs(rg));
+        l_h = fmax(l_h, fabs(hv));
+        if (dsel == 0) {
+          A_[0] += w * c0 * c0; A_[1] += w * c0 * c1; A_[2] += w * c0 * c2;
+          A_[3] += w * c1 * c1; A_[4] += w * c1 * c2; A_[5] += w * c2 * c2;
+        } else {
+          A_[3 + dsel * 3 + 0] += w * c0 * c0;
+          A_[3 + dsel * 3 + 1] += w * c1 * c1;
+          A_[3 + dsel * 3 + 2] += w * c2 * c2;
+        }
+        A_[12 + dsel * 3 + 0] += t * c0; A_[12 + dsel * 3 + 1] += t * c1; A_[12 + dsel * 3 + 2] += t * c2;
+        A_[21 + dsel * 3 + 0] += lm * c0; A_[21 + dsel * 3 + 1] += lm * c1; A_[21 + dsel * 3 + 2] += lm * c2;
+      });
+      double *as = acc + (size_t)smp * 30;
+#pragma unroll
+      for (int q = 0; q < 30; ++q) as[q] = A_[q];
+    }
+    block_reduce(l_mu, 0, false);
+    block_reduce(1.0 / fmax(l_pres, 1e-300), 1, true);  // max via min of reciprocals -> stored as max
+    block_reduce(1.0 / fmax(l_h, 1e-300), 2, true);
+    __syncthreads();
+    mu = red[0] / mrows;
+    if (it == 0) mu0 = mu;
+    pres = red[1] / fmax(1.0, red[2]);
+    // ---- dual residual (node space) and the Newton matrix -------------------------------------------
+    node_vector(rhs, 21, true, uu);  // P y + q + G'lambda
+    __syncthreads();
+    {
+      double l_rd = 0.0;
+      for (int e = tid; e < NY; e += nt) l_rd = fmax(l_rd, fabs(rhs[e]));
+      if (tid < 32) red[8 + (tid & 7)] = 0.0;
+      __syncthreads();
+      block_reduce(1.0 / fmax(l_rd, 1e-300), 8, true);
+      // scale of the dual residual: |P y| in node space
+      double l_py = 0.0;
+      for (int e = tid; e < NY; e += nt) {
+        const int k = e / BK, ax = (e / S) % 3, d = e % S;
+        double v = 0.0;
+        for (int side = 0; side < 2; ++side) {
+          const int i = side == 0 ? k : k - 1;
+          if (i < 0 || i >= N) continue;
+          const int m = side == 0 ? d : S + d;
+          const double qs = qsv[i];
+          const double *ui = uu + (size_t)i * NB + ax * D;
+          double g = 0.0;
+          for (int m2 = 0; m2 < D; ++m2) g += qs * Hobj[m * D + m2] * ui[m2];
+          v += sc[i * D + m] * g;
+        }
+        l_py = fmax(l_py, fabs(v));
+      }
+      block_reduce(1.0 / fmax(l_py, 1e-300), 9, true);
+      // y'Py, the scale of the complementarity test
+      double l_obj = 0.0;
+      for (int e = tid; e < N * NB; e += nt) {
+        const int i = e / NB, ax = (e % NB) / D, m = e % D;
+        const double *ui = uu + (size_t)i * NB + ax * D;
+        double g = 0.0;
+        for (int m2 = 0; m2 < D; ++m2) g += Hobj[m * D + m2] * ui[m2];
+        l_obj += qsv[i] * ui[m] * g;
+      }
+      block_reduce(l_obj, 10, false);
+      __syncthreads();
+      dres = red[8] / fmax(1.0, red[9]);
+    }
+    const double objn = red[10];
+    // (the duality gap is mu * rows: that, not mu, is what bounds the distance of the objective from the optimum)
+    if (pres < a.tol && dres < a.tol && mu * mrows < a.tol * fmax(1.0, 0.5 * fabs(objn))) { status = 1; break; }
+    if (!(mu == mu) || mu > 1e12 * fmax(mu0, 1.0)) { status = -3; break; }  // diverging: no strictly feasible point
+    __syncthreads();
+    // Newton matrix blocks: entry (r, c) of diagonal block k and of the sub-diagonal block (k+1, k)
+    for (int e = tid; e < (2 * N + 1) * BK * BK; e += nt) {
+      const int blk = e / (BK * BK), r = (e % (BK * BK)) / BK, c = e % BK;
+      const bool diag = blk <= N;
+      const int k = diag ? blk : blk - (N + 1);  // diag: knot k ; off: block (k+1, k)
+      const int axr = r / S, dr = r % S, axc = c / S, dc = c % S;
+      double v = 0.0;
+      const int nside = diag ? 2 : 1;
+      for (int side = 0; side < nside; ++side) {
+        int i, mr, mc;
+        if (diag) { i = side == 0 ? k : k - 1; mr = side == 0 ? dr : S + dr; mc = side == 0 ? dc : S + dc; }
+        else { i = k; mr = S + dr; mc = dc; }  // row = end half (knot k+1), column = start half (knot k)
+        if (i < 0 || i >= N) continue;
+        double g = 0.0;
+        if (axr == axc) g += qsv[i] * Hobj[mr * D + mc];
+        const int wa = axr <= axc ? (axr == 0 ? axc : (axr == 1 ? 2 + axc : 5)) : (axc == 0 ? axr : (axc == 1 ? 2 + axr : 5));
+        for (int j = 0; j < R; ++j) {
+          const double *as = acc + (size_t)(i * R + j) * 30;
+          const double *hj = ht + (size_t)j * 3 * D;
+          double t = as[wa] * hj[mr] * hj[mc];
+          if (axr == axc) t += as[6 + axr] * hj[D + mr] * hj[D + mc] + as[9 + axr] * hj[2 * D + mr] * hj[2 * D + mc];
+          g += t;
+        }
+        v += sc[i * D + mr] * sc[i * D + mc] * g;
+      }
+      const int kr = diag ? k : k + 1, kc = k;
+      if (pinned(kr, dr) || pinned(kc, dc)) v = (diag && r == c) ? 1.0 : 0.0;
+      if (diag) {
+        if (r == c) v += 1e-13 * fabs(v) + 1e-300;
+        Dg[(size_t)k * BK * BK + r * BK + c] = v;
+      } else {
+        Of[(size_t)k * BK * BK + r * BK + c] = v;
+      }
+    }
+    // affine right-hand side: -(P y + q) - G'(lambda + w (Gy - h))
+    node_vector(dya, 12, true, uu);
+    __syncthreads();
+    for (int e = tid; e < NY; e += nt) dya[e] = -dya[e];
+    __syncthreads();
+    wave0_factor();
+    __syncthreads();
+    wave0_solve(dya);
+    __syncthreads();
+    to_u(dya, dua);
+    if (tid < 32) red[tid] = 0.0;
+    __syncthreads();
+    // ---- pass B: affine step length and the three sums of (s + a ds)'(lambda + a dlambda) -----------------
+    {
+      double l_ap = 1e300, l_s1 = 0.0, l_s2 = 0.0;
+      for (int smp = tid; smp < NS; smp += nt) {
+        const int i = smp / R, j = smp % R;
+        double s3[3][3], d3[3][3];
+        state_of(uu, i, j, s3);
+        state_of(dua, i, j, d3);
+        for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
+          const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
+          const double rg = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2] + sl - hv;
+          const double ds = -rg - (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
+          const double dl = -lm - (lm / sl) * ds;
+          if (ds < 0.0) l_ap = fmin(l_ap, -sl / ds);
+          if (dl < 0.0) l_ap = fmin(l_ap, -lm / dl);
+          l_s1 += sl * dl + lm * ds;
+          l_s2 += ds * dl;
+        });
+      }
+      block_reduce(l_ap, 3, true);
+      block_reduce(l_s1, 4, false);
+      block_reduce(l_s2, 5, false);
+    }
+    __syncthreads();
+    const double a_aff = fmin(1.0, red[3] > 0.0 ? 1.0 / red[3] : 1.0);
+    const double mu_aff = (mu * mrows + a_aff * red[4] + a_aff * a_aff * red[5]) / mrows;
+    double sigma = mu_aff / mu;
+    sigma = sigma * sigma * sigma;
+    __syncthreads();
+    // ---- pass C: corrector right-hand side (same factor) ----------------------------------------------
+    for (int smp = tid; smp < NS; smp += nt) {
+      const int i = smp / R, j = smp % R;
+      double s3[3][3], d3[3][3], G_[9];
+      state_of(uu, i, j, s3);
+      state_of(dua, i, j, d3);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) G_[q] = 0.0;
+      for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
+        const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
+        const double rg = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2] + sl - hv;
+        const double ds = -rg - (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
+        const double dl = -lm - (lm / sl) * ds;
+        const double rc = sl * lm + ds * dl - sigma * mu;
+        const double t = lm + (lm * rg - rc) / sl;
+        G_[dsel * 3 + 0] += t * c0; G_[dsel * 3 + 1] += t * c1; G_[dsel * 3 + 2] += t * c2;
+      });
+      double *as = acc + (size_t)smp * 30 + 12;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) as[q] = G_[q];
+    }
+    __syncthreads();
+    node_vector(dyc, 12, true, uu);
+    __syncthreads();
+    for (int e = tid; e < NY; e += nt) dyc[e] = -dyc[e];
+    __syncthreads();
+    wave0_solve(dyc);
+    __syncthreads();
+    to_u(dyc, duc);
+    if (tid < 32) red[tid] = 0.0;
+    __syncthreads();
+    // ---- pass D: step length of the combined direction -----------------------------------------------
+    // slack / multiplier directions of the combined step for one row
+    auto final_dir = [&](int dsel, double c0, double c1, double c2, double hv, const double (&s3)[3][3], const double (&d3)[3][3],
+                         const double (&e3)[3][3], double sl, double lm, double &ds, double &dl) {
+      const double rg = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2] + sl - hv;
+      const double dsa = -rg - (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
+      const double dla = -lm - (lm / sl) * dsa;
+      const double rc = sl * lm + dsa * dla - sigma * mu;
+      ds = -rg - (c0 * e3[dsel][0] + c1 * e3[dsel][1] + c2 * e3[dsel][2]);
+      dl = (-rc - lm * ds) / sl;
+    };
+    {
+      double l_a = 1e300;
+      for (int smp = tid; smp < NS; smp += nt) {
+        const int i = smp / R, j = smp % R;
+        double s3[3][3], d3[3][3], e3[3][3];
+        state_of(uu, i, j, s3);
+        state_of(dua, i, j, d3);
+        state_of(duc, i, j, e3);
+        for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
+          const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
+          double ds, dl;
+          final_dir(dsel, c0, c1, c2, hv, s3, d3, e3, sl, lm, ds, dl);
+          if (ds < 0.0) l_a = fmin(l_a, -sl / ds);
+          if (dl < 0.0) l_a = fmin(l_a, -lm / dl);
+        });
+      }
+      block_reduce(l_a, 6, true);
+    }
+    __syncthreads();
+    const double alpha = fmin(1.0, 0.99 * (red[6] > 0.0 ? 1.0 / red[6] : 1e300));
+    __syncthreads();
+    // ---- pass E: update ----------------------------------------------------------------------------------
+    for (int smp = tid; smp < NS; smp += nt) {
+      const int i = smp / R, j = smp % R;
+      double s3[3][3], d3[3][3], e3[3][3];
+      state_of(uu, i, j, s3);
+      state_of(dua, i, j, d3);
+      state_of(duc, i, j, e3);
+      for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
+        const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
+        double ds, dl;
+        final_dir(dsel, c0, c1, c2, hv, s3, d3, e3, sl, lm, ds, dl);
+        slg[smp + (int64_t)q * NS] = sl + alpha * ds;
+        lmg[smp + (int64_t)q * NS] = lm + alpha * dl;
+      });
+    }
+    __syncthreads();
+    for (int e = tid; e < NY; e += nt) yv[e] += alpha * dyc[e];
+    __syncthreads();
+    to_u(yv, uu);
+    __syncthreads();
+  }
+  __syncthreads();
+  // ---- report: coefficients c = Hm u / T^k, objective in original units ---------------------------------
+  for (int e = tid; e < N * NB; e += nt) {
+    const int i = e / NB, ax = (e % NB) / D, col = e % D, k = D - 1 - col;
+    const double *ui = uu + (size_t)i * NB + ax * D;
+    double v = 0.0;
+    for (int m = 0; m < D; ++m) v += Hm[col * D + m] * ui[m];
+    a.coeffs[b * (int64_t)N * NB + e] = v * pow(Tn[i], (double)(-k));
+  }
+  if (tid == 0) {
+    double obj = 0.0;
+    for (int i = 0; i < N; ++i) {
+      const double qs = qsv[i];
+      for (int ax = 0; ax < 3; ++ax) {
+        const double *ui = uu + (size_t)i * NB + ax * D;
+        for (int m = 0; m < D; ++m)
+          for (int m2 = 0; m2 < D; ++m2) obj += 0.5 * qs * ui[m] * Hobj[m * D + m2] * ui[m2];
+      }
+    }
+    a.obj[b] = obj;
+    a.status[b] = status;
+    a.iters[b] = it;
+    a.res[b * 2] = pres;
+    a.res[b * 2 + 1] = dres;
+  }
+}
+
+}  // namespace anet

@@ -73,6 +73,10 @@ def qp_assemble(order, iniPVA, finPVA, hPolys, times, res=20, max_vel=4.0, max_a
 # -------------------------------------------------------------------------------------------------
 # the solve: QPSolver (planner/qp_solver.hpp:28-366)
 # -------------------------------------------------------------------------------------------------
+QP_METHOD_ADMM = 0             # OSQP's algorithm (default)
+QP_METHOD_INTERIOR_POINT = 1   # primal-dual interior point in Hermite node coordinates (csrc/qp_ipm.h)
+
+
 def qp_settings(**over):
     """OSQP's default settings as the reference uses them (it never overrides any:
     qp_solver.hpp:299-302, layers.py:79)."""

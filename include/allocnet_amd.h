@@ -274,7 +274,15 @@ typedef struct anet_qp_settings {
   int32_t scaled_termination;    /* 0: OSQP's rule -- residuals of the reference's own (unscaled) QP;
                                     1: residuals of the internally normalised QP (like OSQP's
                                     scaled_termination): ~2-3x fewer iterations, looser on stiff problems */
+  int32_t method;                /* ANET_QP_METHOD_ADMM (default): OSQP's algorithm, settings above.
+                                    ANET_QP_METHOD_INTERIOR_POINT: primal-dual interior point on the same QP in
+                                    Hermite node coordinates (allocnet_amd/csrc/qp_ipm.h) -- the optimum to
+                                    min(eps, 1e-6) in 10-20 Newton steps; uses only eps_abs/eps_rel and max_iter
+                                    (capped at 200) of the fields above; infeasible problems are reported
+                                    PRIMAL_INFEASIBLE when the iteration diverges, MAX_ITER_REACHED otherwise */
 } anet_qp_settings;
+#define ANET_QP_METHOD_ADMM 0
+#define ANET_QP_METHOD_INTERIOR_POINT 1
 void anet_qp_default_settings(anet_qp_settings *s);
 #define ANET_QP_SOLVED 1          /* OSQP_SOLVED                 */
 #define ANET_QP_MAX_ITER_REACHED 0 /* the reference treats anything but Solved as failure (qp_solver.hpp:346-350) */

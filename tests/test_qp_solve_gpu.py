@@ -227,3 +227,82 @@ def test_time_gradient_matches_the_oracle_lagrangian(anet_ctx):
             g0[i] = (lagr(Tp) - lagr(Tm)) / (2 * e)
         assert np.abs(out["grad_T"][bb] - g0).max() <= 1e-4 * np.abs(g0).max(), (bb, out["grad_T"][bb], g0)
     assert checked >= 3
+
+
+@pytest.mark.parametrize("s,N,M,res", [(4, 3, 9, 6), (3, 4, 8, 5), (4, 1, 7, 8), (3, 2, 7, 10)])
+def test_interior_point_method_matches_the_oracle_optimum(anet_ctx, s, N, M, res):
+    """settings.method = ANET_QP_METHOD_INTERIOR_POINT: the same QP solved by a primal-dual interior-point
+    method in Hermite node coordinates (csrc/qp_ipm.h).  The optimum of the convex QP is unique: compared with
+    the CPU interior-point oracle on the reference-pinned dense matrices (coefficients, objective, KKT)."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(10 * s + N)
+    B = 6
+    probs = [_corridor_problem(rng, N, M) for _ in range(B)]
+    ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
+    hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs])
+    vmax, amax = 3.0, 4.0
+    out = aa.qp_solve(s, ini, fin, hp, T, res=res, max_vel=vmax, max_acc=amax,
+                      settings=aa.qp_settings(method=aa.qp.QP_METHOD_INTERIOR_POINT), ctx=anet_ctx)
+    feasible = 0
+    for bb in range(B):
+        Q, A, b, G, h = _dense(s, ini[bb], fin[bb], hp[bb], T[bb], res, vmax, amax)
+        z, lam, nu, fo, it = qp_np.qp_ipm(Q, A, b, G, h)
+        if it >= 199 or qp_np.kkt_violation(Q, A, b, G, h, z) > 1e-7:
+            # the numpy oracle (monomial basis, unnormalised time) gave up on this instance; if the kernel
+            # reports a solution it must at least be feasible (its optimality is covered by the ADMM check below)
+            if out["status"][bb] == 1:
+                zg = out["coeffs"][bb].reshape(-1)
+                assert np.abs(A @ zg - b).max() <= 1e-8 * max(1.0, np.abs(b).max())
+                assert (G @ zg - h).max() <= 1e-6 * max(1.0, np.abs(h).max())
+            continue
+        feasible += 1
+        assert out["status"][bb] == 1 and out["iters"][bb] <= 40, (bb, out["status"][bb], out["iters"][bb])
+        zg = out["coeffs"][bb].reshape(-1)
+        assert abs(out["obj"][bb] - 0.5 * zg @ Q @ zg) <= 1e-9 * max(1.0, fo)
+        assert abs(out["obj"][bb] - fo) <= 1e-5 * max(1.0, fo), (bb, out["obj"][bb], fo)
+        assert np.abs(A @ zg - b).max() <= 1e-8 * max(1.0, np.abs(b).max())     # equalities hold by construction
+        assert (G @ zg - h).max() <= 1e-6 * max(1.0, np.abs(h).max())
+        assert np.abs(zg - z).max() <= 1e-3 * np.abs(z).max()
+    assert feasible >= 3
+    # same answer as the OSQP-faithful method run to tight tolerances
+    admm = aa.qp_solve(s, ini, fin, hp, T, res=res, max_vel=vmax, max_acc=amax,
+                       settings=aa.qp_settings(eps_abs=1e-9, eps_rel=1e-9, max_iter=100000), ctx=anet_ctx)
+    both = (admm["status"] == 1) & (out["status"] == 1)
+    assert np.abs(admm["obj"][both] - out["obj"][both]).max() <= 1e-5 * max(1.0, np.abs(out["obj"][both]).max())
+
+
+def test_interior_point_reports_infeasible_problems(anet_ctx):
+    import allocnet_amd as aa
+    rng = np.random.default_rng(4)
+    ini, fin, hp, T = _corridor_problem(rng, 3, 8)
+    st = aa.qp_settings(method=aa.qp.QP_METHOD_INTERIOR_POINT)
+    ok = aa.qp_solve(4, ini[None], fin[None], hp[None], T[None], res=8, max_vel=3.0, max_acc=4.0, settings=st, ctx=anet_ctx)
+    bad = aa.qp_solve(4, ini[None], fin[None], hp[None], T[None] * 0.02, res=8, max_vel=3.0, max_acc=4.0, settings=st,
+                      ctx=anet_ctx)               # 50x less time: the velocity box cannot be met
+    assert ok["status"][0] == 1 and bad["status"][0] in (-3, 0)
+    with pytest.raises(aa.AnetError):
+        aa.qp_solve(4, ini[None], fin[None], hp[None], T[None], res=8, settings=st, time_grad=True, ctx=anet_ctx)
+    with pytest.raises(aa.AnetError):
+        aa.qp_solve(4, ini[None], fin[None], hp[None], T[None], res=8, settings=aa.qp_settings(method=7), ctx=anet_ctx)
+
+
+@pytest.mark.parametrize("s,N,M,res", [(4, 8, 16, 20), (3, 16, 12, 20), (4, 12, 8, 10)])
+def test_interior_point_matches_admm_at_the_reference_sizes(anet_ctx, s, N, M, res):
+    """8-piece snap / 16-piece jerk at res 20: too large for the dense numpy oracle in a
+    test, so the two independent GPU methods are compared with each other -- same status, same optimum."""
+    import allocnet_amd as aa
+    from tests.util import corridor_problem
+    B = 24
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(5 * N + s), B, N, 3, M)
+    T = T * 1.5
+    kw = dict(res=res, max_vel=4.0, max_acc=6.0, ctx=anet_ctx)
+    ipm = aa.qp_solve(s, head, tail, hp, T, settings=aa.qp_settings(method=aa.qp.QP_METHOD_INTERIOR_POINT), **kw)
+    admm = aa.qp_solve(s, head, tail, hp, T, settings=aa.qp_settings(eps_abs=1e-8, eps_rel=1e-8, max_iter=200000), **kw)
+    both = (ipm["status"] == 1) & (admm["status"] == 1)
+    assert both.sum() >= B // 2
+    assert ((ipm["status"] == 1) == (admm["status"] == 1)).mean() >= 0.9          # feasibility verdicts agree
+    assert (ipm["iters"][both] <= 40).all()
+    rel = np.abs(ipm["obj"][both] - admm["obj"][both]) / np.maximum(1e-3, np.abs(admm["obj"][both]))
+    assert rel.max() <= 1e-4, rel
+    dc = np.abs(ipm["coeffs"][both] - admm["coeffs"][both]).max(axis=(1, 2, 3)) / np.abs(admm["coeffs"][both]).max(axis=(1, 2, 3))
+    assert dc.max() <= 1e-2, dc
