@@ -264,47 +264,62 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     }
   };
 
-  // block Cholesky of (Dg, Of) in place and block forward/backward substitution, by wave 0 alone (LDS
-  // operations of one wave execute in order; no workgroup barrier inside)
+  // Block Cholesky of (Dg, Of) in place and block forward/backward substitution, by wave 0 alone, IN REGISTERS:
+  // lane r holds row r of the current block, values of other lanes arrive as wave-uniform scalars through
+  // v_readlane (lane indices are compile-time constants after unrolling).  The blocks are 9x9 / 12x12 and every
+  // step depends on the previous one: going through LDS (write, read back) for each column cost ~10x more.
+  auto rl = [](double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+  };
   auto wave0_factor = [&]() {
     if (tid < 64) {
       const int lane = tid;
+      const bool act = lane < BK;
+      double Lp[BK];  // row `lane` of L_{k,k-1}
+#pragma unroll
+      for (int q = 0; q < BK; ++q) Lp[q] = 0.0;
       for (int k = 0; k <= N; ++k) {
         double *Dk = Dg + (size_t)k * BK * BK;
-        if (k > 0) {  // Schur update with L_{k,k-1}
-          const double *Lo = Of + (size_t)(k - 1) * BK * BK;
-          for (int e = lane; e < BK * BK; e += 64) {
-            const int r = e / BK, c = e % BK;
-            if (c <= r) {
-              double v = 0.0;
-              for (int q = 0; q < BK; ++q) v += Lo[r * BK + q] * Lo[c * BK + q];
-              Dk[e] -= v;
-            }
+        double Dr[BK];
+#pragma unroll
+        for (int c = 0; c < BK; ++c) Dr[c] = act ? Dk[lane * BK + c] : (c == 0 ? 1.0 : 0.0);
+        if (k > 0) {  // Schur update: D_k -= L_{k,k-1} L_{k,k-1}'
+#pragma unroll
+          for (int c = 0; c < BK; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < BK; ++q) v += Lp[q] * rl(Lp[q], c);
+            Dr[c] -= v;
           }
-          __builtin_amdgcn_wave_barrier();
         }
-        for (int c = 0; c < BK; ++c) {  // Cholesky, column by column; lane = row
-          if (lane == c) Dk[c * BK + c] = sqrt(fmax(Dk[c * BK + c], 1e-300));
-          __builtin_amdgcn_wave_barrier();
-          const double piv = Dk[c * BK + c];
-          if (lane > c && lane < BK) Dk[lane * BK + c] /= piv;
-          __builtin_amdgcn_wave_barrier();
-          for (int e = lane; e < BK * BK; e += 64) {
-            const int r = e / BK, c2 = e % BK;
-            if (c2 > c && r >= c2) Dk[e] -= Dk[r * BK + c] * Dk[c2 * BK + c];
-          }
-          __builtin_amdgcn_wave_barrier();
+        double dinv[BK];  // 1 / L[c][c], wave-uniform
+#pragma unroll
+        for (int c = 0; c < BK; ++c) {
+          const double piv = sqrt(fmax(rl(Dr[c], c), 1e-300));
+          dinv[c] = 1.0 / piv;
+          Dr[c] = (lane == c) ? piv : Dr[c] * dinv[c];  // column c of L (rows > c); upper part is never read
+#pragma unroll
+          for (int c2 = c + 1; c2 < BK; ++c2) Dr[c2] -= Dr[c] * rl(Dr[c], c2);
         }
-        if (k < N) {  // L_{k+1,k} = A_{k+1,k} L_k^-T : row r of Of by forward substitution over the columns; lane = row
+        if (act) {
+#pragma unroll
+          for (int c = 0; c < BK; ++c) Dk[lane * BK + c] = Dr[c];
+        }
+        if (k < N) {  // L_{k+1,k} = A_{k+1,k} L_k^-T, row by row (forward substitution over the columns)
           double *Lo = Of + (size_t)k * BK * BK;
-          if (lane < BK) {
-            for (int c = 0; c < BK; ++c) {
-              double v = Lo[lane * BK + c];
-              for (int q = 0; q < c; ++q) v -= Lo[lane * BK + q] * Dk[c * BK + q];
-              Lo[lane * BK + c] = v / Dk[c * BK + c];
-            }
+#pragma unroll
+          for (int c = 0; c < BK; ++c) Lp[c] = act ? Lo[lane * BK + c] : 0.0;
+#pragma unroll
+          for (int c = 0; c < BK; ++c) {
+            double v = Lp[c];
+#pragma unroll
+            for (int q = 0; q < c; ++q) v -= Lp[q] * rl(Dr[q], c);  // L_k[c][q] lives in lane c
+            Lp[c] = v * dinv[c];
           }
-          __builtin_amdgcn_wave_barrier();
+          if (act) {
+#pragma unroll
+            for (int c = 0; c < BK; ++c) Lo[lane * BK + c] = Lp[c];
+          }
         }
       }
     }
@@ -312,47 +327,52 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
   auto wave0_solve = [&](double *x) {  // x <- K^-1 x
     if (tid < 64) {
       const int lane = tid;
+      const bool act = lane < BK;
+      double zp = 0.0;
       for (int k = 0; k <= N; ++k) {  // forward: L z = x
         const double *Dk = Dg + (size_t)k * BK * BK;
-        double *xk = x + k * BK;
+        double xr = act ? x[k * BK + lane] : 0.0;
+        double Dr[BK];
+#pragma unroll
+        for (int c = 0; c < BK; ++c) Dr[c] = act ? Dk[lane * BK + c] : (c == 0 ? 1.0 : 0.0);
         if (k > 0) {
           const double *Lo = Of + (size_t)(k - 1) * BK * BK;
-          const double *xp = x + (k - 1) * BK;
-          double v = 0.0;
-          if (lane < BK)
-            for (int q = 0; q < BK; ++q) v += Lo[lane * BK + q] * xp[q];
-          __builtin_amdgcn_wave_barrier();
-          if (lane < BK) xk[lane] -= v;
-          __builtin_amdgcn_wave_barrier();
+          double Or[BK];
+#pragma unroll
+          for (int q = 0; q < BK; ++q) Or[q] = act ? Lo[lane * BK + q] : 0.0;
+#pragma unroll
+          for (int q = 0; q < BK; ++q) xr -= Or[q] * rl(zp, q);
         }
+#pragma unroll
         for (int c = 0; c < BK; ++c) {
-          if (lane == c) xk[c] /= Dk[c * BK + c];
-          __builtin_amdgcn_wave_barrier();
-          const double xc = xk[c];
-          if (lane > c && lane < BK) xk[lane] -= Dk[lane * BK + c] * xc;
-          __builtin_amdgcn_wave_barrier();
+          const double zc = rl(xr, c) / rl(Dr[c], c);
+          xr = (lane == c) ? zc : (lane > c ? xr - Dr[c] * zc : xr);
         }
+        zp = xr;
+        if (act) x[k * BK + lane] = xr;
       }
+      double xn = 0.0;
       for (int k = N; k >= 0; --k) {  // backward: L' x = z
         const double *Dk = Dg + (size_t)k * BK * BK;
-        double *xk = x + k * BK;
+        double xr = act ? x[k * BK + lane] : 0.0;
+        double Dc[BK];  // column `lane` of L_k: Dc[c] = L_k[c][lane]
+#pragma unroll
+        for (int c = 0; c < BK; ++c) Dc[c] = act ? Dk[c * BK + lane] : (c == 0 ? 1.0 : 0.0);
         if (k < N) {
           const double *Lo = Of + (size_t)k * BK * BK;  // L_{k+1,k}
-          const double *xn = x + (k + 1) * BK;
-          double v = 0.0;
-          if (lane < BK)
-            for (int q = 0; q < BK; ++q) v += Lo[q * BK + lane] * xn[q];
-          __builtin_amdgcn_wave_barrier();
-          if (lane < BK) xk[lane] -= v;
-          __builtin_amdgcn_wave_barrier();
+          double Oc[BK];
+#pragma unroll
+          for (int q = 0; q < BK; ++q) Oc[q] = act ? Lo[q * BK + lane] : 0.0;
+#pragma unroll
+          for (int q = 0; q < BK; ++q) xr -= Oc[q] * rl(xn, q);
         }
+#pragma unroll
         for (int c = BK - 1; c >= 0; --c) {
-          if (lane == c) xk[c] /= Dk[c * BK + c];
-          __builtin_amdgcn_wave_barrier();
-          const double xc = xk[c];
-          if (lane < c) xk[lane] -= Dk[c * BK + lane] * xc;
-          __builtin_amdgcn_wave_barrier();
+          const double xc = rl(xr, c) / rl(Dc[c], c);   // lane c holds L_k[c][c] in Dc[c]
+          xr = (lane == c) ? xc : (lane < c ? xr - Dc[c] * xc : xr);
         }
+        xn = xr;
+        if (act) x[k * BK + lane] = xr;
       }
     }
   };
