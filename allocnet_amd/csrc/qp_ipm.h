@@ -465,39 +465,47 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     if (pres < a.tol && dres < a.tol && mu * mrows < a.tol * fmax(1.0, 0.5 * fabs(objn))) { status = 1; break; }
     if (!(mu == mu) || mu > 1e12 * fmax(mu0, 1.0)) { status = -3; break; }  // diverging: no strictly feasible point
     __syncthreads();
-    // Newton matrix blocks: entry (r, c) of diagonal block k and of the sub-diagonal block (k+1, k)
-    for (int e = tid; e < (2 * N + 1) * BK * BK; e += nt) {
+    // Newton matrix: per piece and pair (m, m') of Hermite basis functions the twelve weighted sums over the
+    // samples (six corridor 3x3 entries, three velocity, three acceleration weights) are formed once and
+    // scattered to the nine axis pairs of the node blocks -- 18 LDS reads per 12 results, where one thread per
+    // matrix entry needed 9 per result.
+    for (int e = tid; e < (2 * N + 1) * BK * BK; e += nt) Dg[e] = 0.0;  // Of follows Dg
+    __syncthreads();
+    for (int w = tid; w < N * D * D; w += nt) {
+      const int i = w / (D * D), m = (w / D) % D, m2 = w % D;
+      if (m < S && m2 >= S) continue;  // upper off-diagonal block: the transpose of the stored one
+      double Sa[6] = {0, 0, 0, 0, 0, 0}, Sd[3] = {0, 0, 0};
+      for (int j = 0; j < R; ++j) {
+        const double *as = acc + (size_t)(i * R + j) * 30;
+        const double *hj = ht + (size_t)j * 3 * D;
+        const double p0 = hj[m] * hj[m2], p1 = hj[D + m] * hj[D + m2], p2 = hj[2 * D + m] * hj[2 * D + m2];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Sa[q] += as[q] * p0;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) Sd[ax] += as[6 + ax] * p1 + as[9 + ax] * p2;
+      }
+      const double scale = sc[i * D + m] * sc[i * D + m2], ob = qsv[i] * Hobj[m * D + m2];
+#pragma unroll
+      for (int axr = 0; axr < 3; ++axr)
+#pragma unroll
+        for (int axc = 0; axc < 3; ++axc) {
+          const int wa = axr <= axc ? (axr == 0 ? axc : (axr == 1 ? 2 + axc : 5)) : (axc == 0 ? axr : (axc == 1 ? 2 + axr : 5));
+          const double v = scale * (Sa[wa] + (axr == axc ? Sd[axr] + ob : 0.0));
+          if (m < S) atomicAdd(&Dg[(size_t)i * BK * BK + (axr * S + m) * BK + axc * S + m2], v);
+          else if (m2 >= S) atomicAdd(&Dg[(size_t)(i + 1) * BK * BK + (axr * S + m - S) * BK + axc * S + (m2 - S)], v);
+          else Of[(size_t)i * BK * BK + (axr * S + m - S) * BK + axc * S + m2] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < (2 * N + 1) * BK * BK; e += nt) {  // pinned components, diagonal regularisation
       const int blk = e / (BK * BK), r = (e % (BK * BK)) / BK, c = e % BK;
       const bool diag = blk <= N;
-      const int k = diag ? blk : blk - (N + 1);  // diag: knot k ; off: block (k+1, k)
-      const int axr = r / S, dr = r % S, axc = c / S, dc = c % S;
-      double v = 0.0;
-      const int nside = diag ? 2 : 1;
-      for (int side = 0; side < nside; ++side) {
-        int i, mr, mc;
-        if (diag) { i = side == 0 ? k : k - 1; mr = side == 0 ? dr : S + dr; mc = side == 0 ? dc : S + dc; }
-        else { i = k; mr = S + dr; mc = dc; }  // row = end half (knot k+1), column = start half (knot k)
-        if (i < 0 || i >= N) continue;
-        double g = 0.0;
-        if (axr == axc) g += qsv[i] * Hobj[mr * D + mc];
-        const int wa = axr <= axc ? (axr == 0 ? axc : (axr == 1 ? 2 + axc : 5)) : (axc == 0 ? axr : (axc == 1 ? 2 + axr : 5));
-        for (int j = 0; j < R; ++j) {
-          const double *as = acc + (size_t)(i * R + j) * 30;
-          const double *hj = ht + (size_t)j * 3 * D;
-          double t = as[wa] * hj[mr] * hj[mc];
-          if (axr == axc) t += as[6 + axr] * hj[D + mr] * hj[D + mc] + as[9 + axr] * hj[2 * D + mr] * hj[2 * D + mc];
-          g += t;
-        }
-        v += sc[i * D + mr] * sc[i * D + mc] * g;
-      }
+      const int k = diag ? blk : blk - (N + 1);
       const int kr = diag ? k : k + 1, kc = k;
-      if (pinned(kr, dr) || pinned(kc, dc)) v = (diag && r == c) ? 1.0 : 0.0;
-      if (diag) {
-        if (r == c) v += 1e-13 * fabs(v) + 1e-300;
-        Dg[(size_t)k * BK * BK + r * BK + c] = v;
-      } else {
-        Of[(size_t)k * BK * BK + r * BK + c] = v;
-      }
+      double v = Dg[e];
+      if (pinned(kr, r % S) || pinned(kc, c % S)) v = (diag && r == c) ? 1.0 : 0.0;
+      if (diag && r == c) v += 1e-13 * fabs(v) + 1e-300;
+      Dg[e] = v;
     }
     // affine right-hand side: -(P y + q) - G'(lambda + w (Gy - h))
     node_vector(dya, 12, true, uu);
