@@ -17,7 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "qp_admm.h"  // qblk1, fallf
+#include "minco_core.h"  // fast_rcp
+#include "qp_admm.h"    // qblk1, fallf
 
 namespace anet {
 
@@ -41,7 +42,7 @@ template <int S>
 inline size_t qp_ipm_lds_bytes(int N, int R, int M) {
   constexpr int D = 2 * S, NB = 3 * D, BK = 3 * S;
   const size_t NS = (size_t)N * R;
-  return sizeof(double) * ((size_t)(N + 1) * BK * 4 + (size_t)(N + 1) * BK * BK + (size_t)N * BK * BK + 3 * (size_t)N * NB +
+  return sizeof(double) * ((size_t)(N + 1) * BK * 5 + (size_t)(N + 1) * BK * BK + (size_t)N * BK * BK + 3 * (size_t)N * NB +
                            (size_t)R * 3 * D + 2 * D * D + (size_t)N * D + NS * 30 + (size_t)N * M * 4 + 2 * N + 32);
 }
 
@@ -74,6 +75,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
   double *Tn = hp_l + (size_t)N * M * 4;  // [N]
   double *red = Tn + N;                   // [32]
   double *qsv = red + 32;                 // [N] T_i^(1-2s)
+  double *dinvd = qsv + N;                // [NY] reciprocals of the diagonal of the block Cholesky factor
 
   const double *Tg = a.T + b * N;
   const double *hp = a.hpolys + b * (int64_t)N * M * 4;
@@ -305,6 +307,10 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
 #pragma unroll
           for (int c = 0; c < BK; ++c) Dk[lane * BK + c] = Dr[c];
         }
+        if (lane == 0) {
+#pragma unroll
+          for (int c = 0; c < BK; ++c) dinvd[k * BK + c] = dinv[c];
+        }
         if (k < N) {  // L_{k+1,k} = A_{k+1,k} L_k^-T, row by row (forward substitution over the columns)
           double *Lo = Of + (size_t)k * BK * BK;
 #pragma unroll
@@ -341,11 +347,11 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
 #pragma unroll
           for (int q = 0; q < BK; ++q) Or[q] = act ? Lo[lane * BK + q] : 0.0;
 #pragma unroll
-          for (int q = 0; q < BK; ++q) xr -= Or[q] * rl(zp, q);
+          for (int q = 0; q < BK; ++q) xr -= Or[q] * x[(k - 1) * BK + q];
         }
 #pragma unroll
         for (int c = 0; c < BK; ++c) {
-          const double zc = rl(xr, c) / rl(Dr[c], c);
+          const double zc = rl(xr, c) * dinvd[k * BK + c];
           xr = (lane == c) ? zc : (lane > c ? xr - Dr[c] * zc : xr);
         }
         zp = xr;
@@ -364,11 +370,11 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
 #pragma unroll
           for (int q = 0; q < BK; ++q) Oc[q] = act ? Lo[q * BK + lane] : 0.0;
 #pragma unroll
-          for (int q = 0; q < BK; ++q) xr -= Oc[q] * rl(xn, q);
+          for (int q = 0; q < BK; ++q) xr -= Oc[q] * x[(k + 1) * BK + q];
         }
 #pragma unroll
         for (int c = BK - 1; c >= 0; --c) {
-          const double xc = rl(xr, c) / rl(Dc[c], c);   // lane c holds L_k[c][c] in Dc[c]
+          const double xc = rl(xr, c) * dinvd[k * BK + c];
           xr = (lane == c) ? xc : (lane < c ? xr - Dc[c] * xc : xr);
         }
         xn = xr;
@@ -394,7 +400,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
       for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
         const double gy = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2];
         const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
-        const double rg = gy + sl - hv, w = lm / sl, t = lm + w * (gy - hv);
+        const double rg = gy + sl - hv, w = lm * fast_rcp(sl), t = lm + w * (gy - hv);
         l_mu += sl * lm;
         l_pres = fmax(l_pres, fabs(rg));
         l_h = fmax(l_h, fabs(hv));
@@ -521,7 +527,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     // ---- pass B: affine step length and the three sums of (s + a ds)'(lambda + a dlambda) -----------------
     {
-      double l_ap = 1e300, l_s1 = 0.0, l_s2 = 0.0;
+      double l_ap = 0.0, l_s1 = 0.0, l_s2 = 0.0;  // l_ap: max of -ds/s, -dl/lambda = 1 / (step to the boundary)
       for (int smp = tid; smp < NS; smp += nt) {
         const int i = smp / R, j = smp % R;
         double s3[3][3], d3[3][3];
@@ -531,14 +537,14 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
           const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
           const double rg = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2] + sl - hv;
           const double ds = -rg - (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
-          const double dl = -lm - (lm / sl) * ds;
-          if (ds < 0.0) l_ap = fmin(l_ap, -sl / ds);
-          if (dl < 0.0) l_ap = fmin(l_ap, -lm / dl);
+          const double dl = -lm - (lm * fast_rcp(sl)) * ds;
+          // step to the boundary: the largest of -ds/s, -dl/lambda over the rows is 1/alpha (no division per row)
+          l_ap = fmax(l_ap, fmax(-ds * fast_rcp(sl), -dl * fast_rcp(lm)));
           l_s1 += sl * dl + lm * ds;
           l_s2 += ds * dl;
         });
       }
-      block_reduce(l_ap, 3, true);
+      block_reduce(1.0 / fmax(l_ap, 1e-300), 3, true);
       block_reduce(l_s1, 4, false);
       block_reduce(l_s2, 5, false);
     }
@@ -560,9 +566,10 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
         const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
         const double rg = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2] + sl - hv;
         const double ds = -rg - (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
-        const double dl = -lm - (lm / sl) * ds;
+        const double isl = fast_rcp(sl);
+        const double dl = -lm - (lm * isl) * ds;
         const double rc = sl * lm + ds * dl - sigma * mu;
-        const double t = lm + (lm * rg - rc) / sl;
+        const double t = lm + (lm * rg - rc) * isl;
         G_[dsel * 3 + 0] += t * c0; G_[dsel * 3 + 1] += t * c1; G_[dsel * 3 + 2] += t * c2;
       });
       double *as = acc + (size_t)smp * 30 + 12;
@@ -585,13 +592,14 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
                          const double (&e3)[3][3], double sl, double lm, double &ds, double &dl) {
       const double rg = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2] + sl - hv;
       const double dsa = -rg - (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
-      const double dla = -lm - (lm / sl) * dsa;
+      const double isl = fast_rcp(sl);
+      const double dla = -lm - (lm * isl) * dsa;
       const double rc = sl * lm + dsa * dla - sigma * mu;
       ds = -rg - (c0 * e3[dsel][0] + c1 * e3[dsel][1] + c2 * e3[dsel][2]);
-      dl = (-rc - lm * ds) / sl;
+      dl = (-rc - lm * ds) * isl;
     };
     {
-      double l_a = 1e300;
+      double l_a = 0.0;  // 1 / (step to the boundary)
       for (int smp = tid; smp < NS; smp += nt) {
         const int i = smp / R, j = smp % R;
         double s3[3][3], d3[3][3], e3[3][3];
@@ -602,11 +610,10 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
           const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
           double ds, dl;
           final_dir(dsel, c0, c1, c2, hv, s3, d3, e3, sl, lm, ds, dl);
-          if (ds < 0.0) l_a = fmin(l_a, -sl / ds);
-          if (dl < 0.0) l_a = fmin(l_a, -lm / dl);
+          l_a = fmax(l_a, fmax(-ds * fast_rcp(sl), -dl * fast_rcp(lm)));
         });
       }
-      block_reduce(l_a, 6, true);
+      block_reduce(1.0 / fmax(l_a, 1e-300), 6, true);
     }
     __syncthreads();
     const double alpha = fmin(1.0, 0.99 * (red[6] > 0.0 ? 1.0 / red[6] : 1e300));
