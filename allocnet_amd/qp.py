@@ -136,6 +136,13 @@ class QPSolver:
         self.order_ = None
         self.obj_cost_ = -1.0
         self._ctx = ctx
+        self._method = QP_METHOD_ADMM
+
+    def setMethod(self, method):
+        """Extension: QP_METHOD_ADMM (default, OSQP's algorithm and tolerances) or QP_METHOD_INTERIOR_POINT."""
+        if method not in (QP_METHOD_ADMM, QP_METHOD_INTERIOR_POINT):
+            raise ValueError("unknown method")
+        self._method = method
 
     def setOrder(self, order):
         if order not in (3, 4):
@@ -156,6 +163,7 @@ class QPSolver:
         t = np.asarray(times, dtype=np.float64)[:seg]
         out = qp_solve(self.order_, np.asarray(iniPVA)[None], np.asarray(finPVA)[None], hp, t[None],
                        res=self.config.ConstRes, max_vel=self.config.MaxVelBox, max_acc=self.config.MaxAccBox,
+                       settings=qp_settings(method=self._method) if self._method != QP_METHOD_ADMM else None,
                        ctx=self._ctx)
         result = float(np.float32(out["obj"][0]))          # the reference reads the objective into a float
         if result > 5000 or result < -0.01 or out["status"][0] != 1:

@@ -157,6 +157,10 @@ int main() {
       printf("\"qp_vel\": [%.17g, %.17g, %.17g],\n", qv(0), qv(1), qv(2));
       print_vec("qp_coeffs", flatten_coffmats.a);
       print_vec("qp_time_grad", qp.getTimeGrad());
+      qp.setMethod(ANET_QP_METHOD_INTERIOR_POINT);
+      VecX sol_ipm;
+      const bool ok_ipm = qp.solve(ini, fin, hPolys, times, sol_ipm);
+      printf("\"qp_ipm_ok\": %d, \"qp_ipm_obj\": %.17g, \"qp_ipm_iters\": %d,\n", ok_ipm ? 1 : 0, qp.getObjCost(), qp.getIterations());
     }
     {
       // firi::firi as sfc_gen::convexCover calls it (sfc_gen.hpp:163): box bd, a lattice of obstacle points

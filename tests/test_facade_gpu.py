@@ -55,6 +55,9 @@ def test_cpp_facade_program():
     # getTimeGrad (extension): one entry per segment; giving a rest-to-rest trajectory more time lowers its cost
     gT = np.array(out["qp_time_grad"])
     assert gT.shape == (3,) and np.isfinite(gT).all() and gT.sum() < 0
+    # setMethod(interior point): same optimum (OSQP's 1e-3 tolerances leave the ADMM objective within a few 1e-3 of it)
+    assert out["qp_ipm_ok"] == 1 and out["qp_ipm_iters"] <= 40
+    assert abs(out["qp_ipm_obj"] - out["qp_obj"]) <= 2e-2 * max(1.0, out["qp_obj"])
     # firi::firi facade: polytope around the segment (0,0,1)-(2,.5,1.2), lattice points outside, a outside bd -> false
     assert out["firi_ok"] == 1 and out["firi_rows"] >= 6 and out["firi_outside"] == 0
     hp = np.array(out["firi_hpoly"]).reshape(-1, 4); pts = np.array(out["firi_pts"]).reshape(-1, 3)
