@@ -1176,7 +1176,6 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
   if (st_.method != ANET_QP_METHOD_ADMM && st_.method != ANET_QP_METHOD_INTERIOR_POINT)
     return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: unknown method");
   if (st_.method == ANET_QP_METHOD_INTERIOR_POINT) {
-    if (grad_T) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_qp_solve_time_grad: the time gradient is computed by the ADMM method");
     const size_t ldsb = (s == 4) ? anet::qp_ipm_lds_bytes<4>(n_pieces, res, M) : anet::qp_ipm_lds_bytes<3>(n_pieces, res, M);
     if (ldsb > 160 * 1024)
       return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_qp_solve: problem too large for the 160 KB LDS (interior-point method)");
@@ -1184,7 +1183,7 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     double tol = st_.eps_rel < st_.eps_abs ? st_.eps_rel : st_.eps_abs;
     if (!(tol > 0.0) || tol > 1e-6) tol = 1e-6;   // Newton's method: the last digits cost one or two steps
     anet::IpmArgs ia{state, T, hpolys, work, work + mi * batch, coeffs, obj, status, iters,
-                     residuals ? residuals : work + 2 * mi * batch, nullptr, batch, n_pieces, res, M, max_vel, max_acc, m34,
+                     residuals ? residuals : work + 2 * mi * batch, grad_T, batch, n_pieces, res, M, max_vel, max_acc, m34,
                      tol, st_.max_iter < 200 ? st_.max_iter : 200};
     hipStream_t sti = (hipStream_t)stream;
     if (s == 4) {

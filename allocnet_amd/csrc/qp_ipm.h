@@ -640,6 +640,53 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     __syncthreads();
   }
   __syncthreads();
+  // ---- time gradient of the optimal cost (anet_qp_solve_time_grad): envelope theorem in these coordinates ----
+  // L = sum_i q_i 1/2 u_i'H_obj u_i + lambda'(G u - h) at fixed (y, lambda) depends on T through q_i = T_i^(1-2s),
+  // the end halves u_i[S+d] = (T_i/T_i+1)^d y_i+1[d], the pinned boundary values y_0[d] = ini_d T_0^d,
+  // y_N[d] = fin_d T_N-1^d, and the box bounds vmax T_i, amax T_i^2.  (acc[21..29] holds G'lambda per sample
+  // for the iterate the loop stopped at.)
+  if (a.gradT) {
+    for (int i = tid; i < N; i += nt) rhs[i] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < N * NB; e += nt) {
+      const int i = e / NB, ax = (e % NB) / D, m = e % D, d = m % S;
+      const double *ui = uu + (size_t)i * NB + ax * D;
+      double hu = 0.0;
+      for (int m2 = 0; m2 < D; ++m2) hu += Hobj[m * D + m2] * ui[m2];
+      atomicAdd(&rhs[i], (double)(1 - 2 * S) * 0.5 * qsv[i] * ui[m] * hu / Tn[i]);  // (1-2s) J_i / T_i
+      if (d == 0) continue;
+      double g = qsv[i] * hu;
+      for (int j = 0; j < R; ++j) {
+        const double *ga = acc + (size_t)(i * R + j) * 30 + 21;
+        const double *hj = ht + (size_t)j * 3 * D;
+        g += ga[ax] * hj[m] + ga[3 + ax] * hj[D + m] + ga[6 + ax] * hj[2 * D + m];
+      }
+      const double c = g * ui[m] * (double)d;
+      if (m >= S) {
+        if (i < N - 1) {
+          atomicAdd(&rhs[i], c / Tn[i]);
+          atomicAdd(&rhs[i + 1], -c / Tn[i + 1]);
+        } else if (d < 3) {
+          atomicAdd(&rhs[i], c / Tn[i]);
+        }
+      } else if (i == 0 && d < 3) {
+        atomicAdd(&rhs[0], c / Tn[0]);
+      }
+    }
+    for (int smp = tid; smp < NS; smp += nt) {
+      const int i = smp / R;
+      double sv = 0.0, sa = 0.0;
+      for (int qq = 0; qq < 12; ++qq) {
+        const double lm = lmg[smp + (int64_t)(M + qq) * NS];
+        if ((qq % 4) & 1) sa += lm;
+        else sv += lm;
+      }
+      atomicAdd(&rhs[i], -(a.vmax * sv + 2.0 * a.amax * Tn[i] * sa));
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += nt) a.gradT[b * N + i] = rhs[i];
+    __syncthreads();
+  }
   // ---- report: coefficients c = Hm u / T^k, objective in original units ---------------------------------
   for (int e = tid; e < N * NB; e += nt) {
     const int i = e / NB, ax = (e % NB) / D, col = e % D, k = D - 1 - col;

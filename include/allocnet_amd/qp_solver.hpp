@@ -51,8 +51,8 @@ class QPSolver {
   // Extension (not in the reference): d(getObjCost())/d(times(i)) of the last successful solve, the
   // derivative of the optimal cost through the inequality QP (anet_qp_solve_time_grad).
   inline const std::vector<double> &getTimeGrad() const { return time_grad_; }
-  // Extension: ANET_QP_METHOD_ADMM (default: OSQP's algorithm and tolerances, getTimeGrad available) or
-  // ANET_QP_METHOD_INTERIOR_POINT (the optimum to 1e-6 in ~10 Newton steps, ~5x lower latency; no time gradient).
+  // Extension: ANET_QP_METHOD_ADMM (default: OSQP's algorithm and tolerances) or
+  // ANET_QP_METHOD_INTERIOR_POINT (the optimum to 1e-6 in ~10 Newton steps, ~5x lower latency).
   inline void setMethod(int method) { method_ = method; }
 
   template <typename MatA, typename MatB, typename Poly, typename Times, typename Sol>
@@ -78,17 +78,12 @@ class QPSolver {
     int32_t status = 0, iters = 0;
     anet::Context &ctx = anet::Context::thread_default();
     time_grad_.assign(seg, 0.0);
-    if (method_ == ANET_QP_METHOD_INTERIOR_POINT) {
-      anet_qp_settings st;
-      anet_qp_default_settings(&st);
-      st.method = ANET_QP_METHOD_INTERIOR_POINT;
-      ctx.check(anet_qp_solve(ctx.get(), order_, seg, 1, config.ConstRes, M, config.MaxVelBox, config.MaxAccBox, m34_,
-                              state.data(), T.data(), hp.data(), &st, co.data(), &obj, &status, &iters, nullptr));
-    } else {
-      ctx.check(anet_qp_solve_time_grad(ctx.get(), order_, seg, 1, config.ConstRes, M, config.MaxVelBox, config.MaxAccBox,
-                                        m34_, state.data(), T.data(), hp.data(), nullptr, co.data(), &obj, &status,
-                                        &iters, nullptr, time_grad_.data()));
-    }
+    anet_qp_settings st;
+    anet_qp_default_settings(&st);
+    st.method = method_;
+    ctx.check(anet_qp_solve_time_grad(ctx.get(), order_, seg, 1, config.ConstRes, M, config.MaxVelBox, config.MaxAccBox,
+                                      m34_, state.data(), T.data(), hp.data(), &st, co.data(), &obj, &status, &iters,
+                                      nullptr, time_grad_.data()));
     last_status_ = status;
     last_iters_ = iters;
     const float result = (float)obj;
