@@ -77,8 +77,11 @@ class MinTrajOpt:
 class OsqpLayer:
     """Solve + loss terms of layers.py:51-151 (forward) and :153-247 (forward4lstm)."""
 
-    def __init__(self, ctx=None):
+    def __init__(self, ctx=None, method=_qp.QP_METHOD_ADMM):
+        """method: QP_METHOD_ADMM (default: OSQP's algorithm and tolerances, as layers.py:77-81 runs them) or
+        QP_METHOD_INTERIOR_POINT (same optimum to 1e-6, an order of magnitude faster)."""
         self._ctx = ctx
+        self._settings = _qp.qp_settings(method=method) if method != _qp.QP_METHOD_ADMM else None
         self.time_grad = None             # what the reference's autograd delivers (z detached): 1/2 z'(dQ/dT)z
         self.implicit_time_grad = None    # d(optimal objc)/dTimes through the QP (anet_qp_solve_time_grad)
 
@@ -91,7 +94,7 @@ class OsqpLayer:
         fin = qp_traj.end_state.reshape(1, 3, 3)
         T = qp_traj.Times[:qp_traj.seg][None]
         out = _qp.qp_solve(qp_traj.order, ini, fin, hp, T, res=qp_traj.res, max_vel=qp_traj._limits[0],
-                           max_acc=qp_traj._limits[1], time_grad=True, ctx=self._ctx)
+                           max_acc=qp_traj._limits[1], settings=self._settings, time_grad=True, ctx=self._ctx)
         return out, T
 
     def forward(self, qp_traj):

@@ -69,5 +69,10 @@ def test_osqp_layer_forward(anet_ctx):
             vals.append(aa.OsqpLayer(ctx=anet_ctx).forward(o)[3])
         fd = (vals[0] - vals[1]) / (2 * h)
         assert abs(fd - imp[i]) <= 0.1 * np.abs(imp[:3]).max() + 1e-3, (i, fd, imp)
+    # the interior-point method behind the same layer: same objective (to OSQP's tolerance), sharper gradient
+    lay2 = aa.OsqpLayer(ctx=anet_ctx, method=aa.qp.QP_METHOD_INTERIOR_POINT)
+    zi, _, _, objc_i, _ = lay2.forward(opt)
+    assert zi is not None and abs(objc_i - objc) <= 2e-2 * max(1.0, objc)
+    assert np.abs(lay2.implicit_time_grad[:3] - imp[:3]).max() <= 0.1 * np.abs(imp[:3]).max() + 1e-3
     z2, o1, ot, oc, stl = layer.forward4lstm(opt, np.array([0.1, 0.2, 0.9, 0.95, 0.99]), seq_len=5)
     assert z2 is not None and stl > 0 and abs(oc - objc) <= 1e-2 * max(1.0, objc)
