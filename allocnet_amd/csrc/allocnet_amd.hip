@@ -918,6 +918,9 @@ int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_ro
   anet::FiriMvieArgs ma{d_hp, d_nh, d_ok, d_ell, d_A, L.x, L.is + (int64_t)anet::IS_DONE * ld, L.is + (int64_t)anet::IS_RET * ld,
                         d_mok, batch, ld, H};
   anet::MvieArgs ev{d_A, L.x, L.feval, L.g, L.is, batch, ld, H, P.smooth_eps, P.penalty_wt};
+  // wave-per-problem layout of the internal vectors (element i of problem b at [i + b*n]), no "still running" counter
+  anet::LbfgsArgs la{L.n, batch, L.ld, L.x, L.g, L.xp, L.gp, L.d, L.lm_s, L.lm_y, L.lm_ys, L.lm_alpha, L.pf, L.ds,
+                     L.feval, L.is, to_kernel_params(lp), nullptr, 1, L.n, nullptr, 0};
   for (int loop = 0; loop < P.iterations; ++loop) {
     hipLaunchKernelGGL(anet::k_firi_planes, gB, b256, 0, st, fa);
     ANET_HIP(ctx, hipGetLastError());
@@ -926,12 +929,12 @@ int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_ro
     ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_ * ld, st));
     hipLaunchKernelGGL(anet::k_firi_mvie_setup, gB, b256, sizeof(double) * H * 4, st, ma);
     ANET_HIP(ctx, hipGetLastError());
-    rc = lbfgs_drive(ctx, L, batch, lp, P.mvie_max_evals, st, [&]() -> int {
-      hipLaunchKernelGGL(anet::k_mvie_eval, g64, b64, 0, st, ev);
+    {  // the whole MVIE optimisation in one launch, one wave per corridor
+      constexpr int kw = anet::LbfgsWaveShape<20>::kWaves;
+      hipLaunchKernelGGL(anet::k_lbfgs_mvie_persistent<20>, dim3((unsigned)((batch + kw - 1) / kw)), dim3(64u * kw), 0, st, la, ev,
+                         P.mvie_max_evals);
       ANET_HIP(ctx, hipGetLastError());
-      return ANET_OK;
-    }, nullptr, 0, false);
-    if (rc) return rc;
+    }
     hipLaunchKernelGGL(anet::k_firi_mvie_finish, g64, b64, 0, st, ma);
     ANET_HIP(ctx, hipGetLastError());
   }

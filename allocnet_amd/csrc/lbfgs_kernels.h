@@ -314,12 +314,8 @@ struct LbfgsWaveShape {
   static constexpr int kWaves = (LBFGS_WAVE_MREG > 8) ? 4 : (LBFGS_WAVE_MREG > 0) ? 8 : 16;  // register budget
 };
 template <int LBFGS_WAVE_MREG>
-__global__ void __launch_bounds__(64 * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves)
-k_lbfgs_update_wave(LbfgsArgs a) {
+__device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const int64_t b, const int lane) {
   constexpr int MR = LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1;
-  const int64_t b = (int64_t)blockIdx.x * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (b >= a.B) return;  // whole waves only: the reductions below need all 64 lanes
   const int64_t ld = a.ld;
   int *is = a.is + b;
   double *ds = a.ds + b;
@@ -618,6 +614,14 @@ k_lbfgs_update_wave(LbfgsArgs a) {
   }
 }
 
+template <int LBFGS_WAVE_MREG>
+__global__ void __launch_bounds__(64 * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves)
+k_lbfgs_update_wave(LbfgsArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves + (threadIdx.x >> 6);
+  if (b >= a.B) return;  // whole waves only: the reductions need all 64 lanes
+  lbfgs_update_wave_body<LBFGS_WAVE_MREG>(a, b, threadIdx.x & 63);
+}
+
 // firi::costMVIE (gcopter/firi.hpp:86-157): x = [p, rtd, cde], A is M x 3 column-major per problem
 // (field k*M + r), the reference's optData packing (firi.hpp:186-200).
 struct MvieArgs {
@@ -679,6 +683,86 @@ __device__ __forceinline__ void mvie_eval_lane(const MvieArgs &a, const int64_t 
 __global__ void __launch_bounds__(64) k_mvie_eval(MvieArgs a) {
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b < a.B) mvie_eval_lane(a, b);
+}
+
+// costMVIE with one WAVE per problem: the rows of A are spread over the lanes, the ten sums (cost, nine gradient
+// parts) are wave reductions.  Same quantities as mvie_eval_lane, summed in a different order.
+__device__ __forceinline__ void mvie_eval_wave(const MvieArgs &a, const int64_t b, const int lane) {
+  const int64_t ld = a.ld;
+  const double *x = a.x + b;
+  double p[3], rtd[3], cde[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    p[q] = x[q * ld];
+    rtd[q] = x[(3 + q) * ld];
+    cde[q] = x[(6 + q) * ld];
+  }
+  const double L00 = rtd[0] * rtd[0] + 2.220446049250313e-16, L11 = rtd[1] * rtd[1] + 2.220446049250313e-16,
+               L22 = rtd[2] * rtd[2] + 2.220446049250313e-16;
+  const double L10 = cde[0], L21 = cde[1], L20 = cde[2];
+  double cost = 0.0, gdp[3] = {0, 0, 0}, gdr[3] = {0, 0, 0}, gdc[3] = {0, 0, 0};
+  const double inv_mu = 1.0 / a.eps;
+  for (int r = lane; r < a.M; r += 64) {
+    const double a0 = a.A[(int64_t)r * ld + b], a1 = a.A[(int64_t)(a.M + r) * ld + b],
+                 a2 = a.A[(int64_t)(2 * a.M + r) * ld + b];
+    const double al0 = a0 * L00 + a1 * L10 + a2 * L20, al1 = a1 * L11 + a2 * L21, al2 = a2 * L22;
+    const double nrm = sqrt(al0 * al0 + al1 * al1 + al2 * al2);
+    const double viol = nrm + (a0 * p[0] + a1 * p[1] + a2 * p[2]) - 1.0;
+    if (viol >= 0.0) {
+      double c, dc;
+      smoothed_l1(a.eps, inv_mu, viol, c, dc);
+      const double inv = 1.0 / nrm;
+      const double adj0 = al0 * inv, adj1 = al1 * inv, adj2 = al2 * inv;
+      const double v0 = dc * a0, v1 = dc * a1, v2 = dc * a2;
+      cost += c;
+      gdp[0] += v0; gdp[1] += v1; gdp[2] += v2;
+      gdr[0] += adj0 * v0; gdr[1] += adj1 * v1; gdr[2] += adj2 * v2;
+      gdc[0] += adj0 * v1;
+      gdc[1] += adj1 * v2;
+      gdc[2] += adj0 * v2;
+    }
+  }
+  cost = wave_sum(cost);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    gdp[q] = wave_sum(gdp[q]);
+    gdr[q] = wave_sum(gdr[q]);
+    gdc[q] = wave_sum(gdc[q]);
+  }
+  cost *= a.wt;
+  cost -= log(L00) + log(L11) + log(L22);
+  const double Ld[3] = {L00, L11, L22};
+  if (lane == 0) {
+    double *g = a.g + b;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      g[q * ld] = gdp[q] * a.wt;
+      g[(3 + q) * ld] = (gdr[q] * a.wt - 1.0 / Ld[q]) * 2.0 * rtd[q];
+      g[(6 + q) * ld] = gdc[q] * a.wt;
+    }
+    a.f[b] = cost;
+  }
+}
+
+// A whole MVIE optimisation in ONE launch: one wave per problem loops evaluation + L-BFGS update (the same
+// update body as k_lbfgs_update_wave, state in the same arrays).  The launch-per-evaluation driver spends a
+// corridor search of a handful of segments almost entirely on launch latency (hundreds of evaluations of a
+// 9-variable problem); here an evaluation costs a few memory round trips.  The fences order the cross-lane
+// traffic through global memory inside the wave (workgroup scope: the lanes share one L1).
+template <int LBFGS_WAVE_MREG>
+__global__ void __launch_bounds__(64 * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves)
+k_lbfgs_mvie_persistent(LbfgsArgs la, MvieArgs ma, int max_evals) {
+  const int64_t b = (int64_t)blockIdx.x * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves + (threadIdx.x >> 6);
+  if (b >= la.B) return;
+  const int lane = threadIdx.x & 63;
+  const int *done = la.is + (int64_t)IS_DONE * la.ld + b;
+  for (int e = 0; e < max_evals; ++e) {
+    if (__builtin_amdgcn_readfirstlane(*(volatile const int *)done)) break;
+    mvie_eval_wave(ma, b, lane);
+    __threadfence_block();
+    lbfgs_update_wave_body<LBFGS_WAVE_MREG>(la, b, lane);
+    __threadfence_block();
+  }
 }
 
 struct MapArgs {
