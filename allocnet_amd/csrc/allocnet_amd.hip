@@ -838,12 +838,27 @@ int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A, double
   ANET_HIP(ctx, hipMemcpyAsync(L.x, d_x0, sizeof(double) * n * st.ld, hipMemcpyDeviceToDevice, s0));
   anet::MvieArgs ma{d_A, L.x, L.feval, L.g, L.is, batch, st.ld, M, smooth_eps, penalty_wt};
   const dim3 grid((unsigned)((batch + 63) / 64)), block(64);
-  rc = lbfgs_drive(ctx, L, batch, *params, max_evals, s0, [&]() -> int {
-    hipLaunchKernelGGL(anet::k_mvie_eval, grid, block, 0, s0, ma);
+  if (batch <= 32768 && params->mem_size <= 64) {
+    // small batches: one wave per problem, the whole optimisation in one launch (k_lbfgs_mvie_persistent)
+    ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * L.ld, s0));
+    ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_ * L.ld, s0));
+    anet::LbfgsArgs la{L.n, batch, L.ld, L.x, L.g, L.xp, L.gp, L.d, L.lm_s, L.lm_y, L.lm_ys, L.lm_alpha, L.pf, L.ds,
+                       L.feval, L.is, to_kernel_params(*params), nullptr, 1, L.n, nullptr, 0};
+    auto launch = [&](auto kernel, int waves) {
+      hipLaunchKernelGGL(kernel, dim3((unsigned)((batch + waves - 1) / waves)), dim3(64u * waves), 0, s0, la, ma, max_evals);
+    };
+    if (m <= 8) launch(anet::k_lbfgs_mvie_persistent<8>, anet::LbfgsWaveShape<8>::kWaves);
+    else if (m <= 20) launch(anet::k_lbfgs_mvie_persistent<20>, anet::LbfgsWaveShape<20>::kWaves);
+    else launch(anet::k_lbfgs_mvie_persistent<0>, anet::LbfgsWaveShape<0>::kWaves);
     ANET_HIP(ctx, hipGetLastError());
-    return ANET_OK;
-  });
-  if (rc) return rc;
+  } else {
+    rc = lbfgs_drive(ctx, L, batch, *params, max_evals, s0, [&]() -> int {
+      hipLaunchKernelGGL(anet::k_mvie_eval, grid, block, 0, s0, ma);
+      ANET_HIP(ctx, hipGetLastError());
+      return ANET_OK;
+    });
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(k_lbfgs_results, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, s0, L.is, L.ds, batch,
                      st.ld, d_res, d_res + st.ld, d_res + 2 * st.ld, L.feval);
   ANET_HIP(ctx, hipGetLastError());
