@@ -308,3 +308,42 @@ def test_interior_point_matches_admm_at_the_reference_sizes(anet_ctx, s, N, M, r
     assert rel.max() <= 1e-4, rel
     dc = np.abs(ipm["coeffs"][both] - admm["coeffs"][both]).max(axis=(1, 2, 3)) / np.abs(admm["coeffs"][both]).max(axis=(1, 2, 3))
     assert dc.max() <= 1e-2, dc
+
+
+def test_interior_point_edge_cases(anet_ctx):
+    """No corridor rows at all (only the velocity / acceleration boxes), a single piece, all-padding polytopes,
+    and the largest sizes the kernel accepts: same optimum as the ADMM method where that one runs."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(8)
+    ipm = aa.qp_settings(method=aa.qp.QP_METHOD_INTERIOR_POINT)
+    tight = aa.qp_settings(eps_abs=1e-9, eps_rel=1e-9, max_iter=100000)
+    for (s, N) in [(3, 1), (4, 1), (3, 3), (4, 4)]:
+        B = 5
+        ini = np.zeros((B, 3, 3)); fin = np.zeros((B, 3, 3))
+        fin[:, :, 0] = rng.uniform(1.0, 3.0, size=(B, 3)) * N
+        T = rng.uniform(2.0, 4.0, size=(B, N))
+        hp0 = np.zeros((B, N, 3, 4))                     # three all-zero rows per piece: inert padding only
+        a = aa.qp_solve(s, ini, fin, hp0, T, res=10, max_vel=2.0, max_acc=3.0, settings=ipm, ctx=anet_ctx)
+        c = aa.qp_solve(s, ini, fin, hp0, T, res=10, max_vel=2.0, max_acc=3.0, settings=tight, ctx=anet_ctx)
+        both = (a["status"] == 1) & (c["status"] == 1)
+        assert np.array_equal(a["status"] == 1, c["status"] == 1) and both.sum() >= 2, (s, N, a["status"], c["status"])
+        assert np.abs(a["obj"][both] - c["obj"][both]).max() <= 1e-5 * max(1.0, np.abs(c["obj"][both]).max())
+        # loose limits: the boxes are inactive and the optimum is the equality-constrained minimiser (closed form)
+        f = aa.qp_solve(s, ini, fin, hp0, T, res=10, max_vel=1e3, max_acc=1e3, settings=ipm, ctx=anet_ctx)
+        assert (f["status"] == 1).all() and (f["iters"] <= 12).all()
+        for bb in range(B):
+            hp_dense = np.zeros((N, 1, 4))
+            Q, A, b_, G, h = _dense(s, ini[bb], fin[bb], hp_dense, T[bb], 10, 1e3, 1e3)
+            n = Q.shape[0]; me = A.shape[0]
+            K = np.block([[Q + 1e-12 * np.eye(n), A.T], [A, np.zeros((me, me))]])
+            z = np.linalg.solve(K, np.r_[np.zeros(n), b_])[:n]
+            fo = 0.5 * z @ Q @ z
+            assert abs(f["obj"][bb] - fo) <= 1e-6 * max(1.0, fo), (s, N, bb, f["obj"][bb], fo)
+    # size limits: 16-piece jerk at M = 16, res 20 runs (the ADMM factor does not fit there); 17 pieces are refused
+    from tests.util import corridor_problem
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(2), 3, 16, 3, 16)
+    r = aa.qp_solve(3, head, tail, hp, T * 1.5, res=20, settings=ipm, ctx=anet_ctx)
+    assert (r["status"] != 0).all() and (r["status"] == 1).any()
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(2), 2, 40, 3, 16)
+    with pytest.raises(aa.AnetError):
+        aa.qp_solve(3, head, tail, hp, T, res=20, settings=ipm, ctx=anet_ctx)
