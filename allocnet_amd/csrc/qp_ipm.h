@@ -285,12 +285,13 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
         double Dr[BK];
 #pragma unroll
         for (int c = 0; c < BK; ++c) Dr[c] = act ? Dk[lane * BK + c] : (c == 0 ? 1.0 : 0.0);
-        if (k > 0) {  // Schur update: D_k -= L_{k,k-1} L_{k,k-1}'
+        if (k > 0) {  // Schur update: D_k -= L_{k,k-1} L_{k,k-1}' (the other rows of L_{k,k-1}: LDS broadcast reads)
+          const double *Lq = Of + (size_t)(k - 1) * BK * BK;
 #pragma unroll
           for (int c = 0; c < BK; ++c) {
             double v = 0.0;
 #pragma unroll
-            for (int q = 0; q < BK; ++q) v += Lp[q] * rl(Lp[q], c);
+            for (int q = 0; q < BK; ++q) v += Lp[q] * Lq[c * BK + q];
             Dr[c] -= v;
           }
         }
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
           for (int c = 0; c < BK; ++c) {
             double v = Lp[c];
 #pragma unroll
-            for (int q = 0; q < c; ++q) v -= Lp[q] * rl(Dr[q], c);  // L_k[c][q] lives in lane c
+            for (int q = 0; q < c; ++q) v -= Lp[q] * Dk[c * BK + q];  // L_k[c][q], just stored: LDS broadcast read
             Lp[c] = v * dinv[c];
           }
           if (act) {
