@@ -63,3 +63,64 @@ def test_route_to_corridor_to_trajectory(anet_ctx):
         P = np.array([traj.getPos(t) for t in ts])
         dmin = np.min(np.linalg.norm(P[:, None, :] - pts[None, ::7, :], axis=2))
         assert dmin > 0.05
+
+
+def test_route_to_corridor_to_minco_lbfgs(anet_ctx):
+    """The north-star formulation on the same corridor: waypoints and durations are the variables, corridor and
+    limit rows a smoothed penalty, L-BFGS outer loop (anet_lbfgs_minco).  From the junction points of the corridor
+    the optimiser lowers the cost, and the result stays within a few centimetres of the corridor."""
+    import allocnet_amd as aa
+    from allocnet_amd.firi import to_planner_form
+    rng = np.random.default_rng(17)
+    route = [np.array([0.0, 0.0, 1.0]), np.array([3.5, 1.0, 1.5]), np.array([6.0, 4.0, 1.0]), np.array([9.0, 4.5, 2.0])]
+    pts = rng.uniform([-3, -3, 0], [12, 8, 4], size=(4000, 3))
+    keep = np.ones(len(pts), dtype=bool)
+    for p0, p1 in zip(route[:-1], route[1:]):
+        d = p1 - p0
+        t = np.clip(((pts - p0) @ d) / (d @ d), 0, 1)
+        keep &= np.linalg.norm(pts - (p0 + t[:, None] * d), axis=1) > 0.7
+    pts = pts[keep]
+    # one polytope per straight step of the route (no gap polytopes needed for this check): FIRI directly
+    steps = []
+    b = route[0]
+    i = 1
+    while i < len(route):
+        a = b
+        if np.linalg.norm(a - route[i]) > 2.5:
+            b = (route[i] - a) / np.linalg.norm(route[i] - a) * 2.5 + a
+        else:
+            b = route[i]; i += 1
+        steps.append((a, b))
+    N = len(steps)
+    bd = np.zeros((N, 6, 4)); A = np.array([s_[0] for s_ in steps]); Bv = np.array([s_[1] for s_ in steps])
+    for k in range(N):
+        hi = np.minimum(np.maximum(A[k], Bv[k]) + 3.0, [12, 8, 4]); lo = np.maximum(np.minimum(A[k], Bv[k]) - 3.0, [-3, -3, 0])
+        for ax in range(3):
+            bd[k, 2 * ax, ax] = 1.0; bd[k, 2 * ax, 3] = -hi[ax]; bd[k, 2 * ax + 1, ax] = -1.0; bd[k, 2 * ax + 1, 3] = lo[ax]
+    out = aa.firi(bd, np.broadcast_to(pts, (N,) + pts.shape).copy(), A, Bv, max_rows=64, ctx=anet_ctx)
+    assert (out["ok"] == 1).all()
+    M = int(out["n_rows"].max())
+    hp = to_planner_form(out["hpoly"][:, :M], out["n_rows"])[None]            # (1, N, M, 4)
+    head = np.zeros((1, 3, 3)); tail = np.zeros((1, 3, 3))
+    head[0, :, 0] = route[0]; tail[0, :, 0] = route[-1]
+    wps = Bv[None, :-1].copy()                                                   # junction points: inside both neighbours
+    T = np.full((1, N), 2.5 / 1.0)
+    pen = aa.make_penalty(rho=30.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=3.0, max_acc=4.0,
+                          res=20, poly_rows=M)
+    c0 = aa.minco_cost_grad(head, tail, wps, T, 4, hpolys=hp, penalty=pen, ctx=anet_ctx)[0]
+    res = aa.lbfgs_minco(head, tail, wps, T, 4, hpolys=hp, penalty=pen, param=aa.lbfgs_parameter_t(), max_evals=3000,
+                         ctx=anet_ctx)
+    assert res["status"][0] >= 0 and res["cost"][0] < c0[0]
+    traj = aa.Trajectory()
+    for i in range(N):
+        traj.emplace_back(res["T"][0, i], res["coeffs"][0, i])
+    assert np.abs(traj.getPos(0.0) - route[0]).max() < 1e-9 and np.abs(traj.getPos(traj.getTotalDuration()) - route[-1]).max() < 1e-9
+    t0 = 0.0
+    worst = 0.0
+    for i in range(N):
+        k = out["n_rows"][i]
+        for j in range(20):
+            p = traj.getPos(t0 + j * res["T"][0, i] / 20)
+            worst = max(worst, float((hp[0, i, :k, :3] @ p - hp[0, i, :k, 3]).max()))
+        t0 += res["T"][0, i]
+    assert worst <= 0.05, worst                                                  # soft constraint: centimetres, not metres
