@@ -44,6 +44,9 @@ struct anet_ctx {
   // RCCL communicator for the all-gather of costs
   ncclComm_t comm = nullptr;
   int comm_ranks = 0;
+  // basis table of k_piece_grad for the last (order, res) used
+  double *d_tab = nullptr;
+  int tab_s = 0, tab_res = 0, tab_cap = 0;
 };
 
 namespace {
@@ -327,6 +330,7 @@ void anet_destroy(anet_ctx *ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->comm) (void)anet_comm_destroy(ctx);
   if (ctx->d_counter) (void)hipFree(ctx->d_counter);
+  if (ctx->d_tab) (void)hipFree(ctx->d_tab);
   if (ctx->h_counter) (void)hipHostFree(ctx->h_counter);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -647,11 +651,26 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
                                pen->max_vel, pen->max_acc, pen->res, pen->poly_rows};
   const dim3 grid((unsigned)((batch + 255) / 256), (unsigned)n_pieces), block(256);
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = pen ? sizeof(double) * (size_t)pen->res * 4 * 2 * s : 0;
-  if (lds > 60 * 1024) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_penalty.res too large for the basis table");
-  if (s == 2) hipLaunchKernelGGL(anet::k_piece_grad<2>, grid, block, lds, st, a);
-  else if (s == 3) hipLaunchKernelGGL(anet::k_piece_grad<3>, grid, block, lds, st, a);
-  else hipLaunchKernelGGL(anet::k_piece_grad<4>, grid, block, lds, st, a);
+  if (pen && pen->res > 4096) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_penalty.res too large for the basis table");
+  if (pen && (ctx->tab_s != s || ctx->tab_res != pen->res)) {  // (re)build the basis table: rare, so simply serialised
+    const int need = pen->res * 4 * 2 * s;
+    ANET_HIP(ctx, hipDeviceSynchronize());  // no launch still reading the old table
+    if (need > ctx->tab_cap) {
+      if (ctx->d_tab) ANET_HIP(ctx, hipFree(ctx->d_tab));
+      ctx->d_tab = nullptr;
+      ANET_HIP(ctx, hipMalloc((void **)&ctx->d_tab, sizeof(double) * need));
+      ctx->tab_cap = need;
+    }
+    hipLaunchKernelGGL(anet::k_build_basis_table, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, ctx->d_tab, pen->res, 2 * s);
+    ANET_HIP(ctx, hipGetLastError());
+    ANET_HIP(ctx, hipStreamSynchronize(st));
+    ctx->tab_s = s;
+    ctx->tab_res = pen->res;
+  }
+  const double *tab = ctx->d_tab;
+  if (s == 2) hipLaunchKernelGGL(anet::k_piece_grad<2>, grid, block, 0, st, a, tab);
+  else if (s == 3) hipLaunchKernelGGL(anet::k_piece_grad<3>, grid, block, 0, st, a, tab);
+  else hipLaunchKernelGGL(anet::k_piece_grad<4>, grid, block, 0, st, a, tab);
   ANET_HIP(ctx, hipGetLastError());
   return ANET_OK;
 }

@@ -164,24 +164,27 @@ struct PieceGradArgs {
 // coefficients and duration.  J_pen = (T/res) sum_{j<res} [wc sum_rows phi(a.p-b) + wv sum phi(+-v-vmax)
 // + wa sum phi(+-a-amax)] sampled at t = j T/res: the rows of the reference's inequality block
 // (qp_solver.hpp:244-296 / min_traj_opt.py:535-613) turned into a smoothed-L1 penalty.
-template <int S>
-__global__ void __launch_bounds__(256) k_piece_grad(PieceGradArgs a) {
-  constexpr int D = 2 * S;
-  extern __shared__ double tab[];  // [res][4][D] basis rows in normalised time
-  if (a.with_penalty) {
-    for (int e = threadIdx.x; e < a.pp.res * 4 * D; e += 256) {
-      const int j = e / (4 * D), d = (e / D) % 4, col = e % D, k = D - 1 - col;
-      const double tau = (double)j / (double)a.pp.res;
-      double v = 0.0;
-      if (k >= d) {
-        v = 1.0;
-        for (int q = 0; q < d; ++q) v *= (double)(k - q);
-        for (int q = 0; q < k - d; ++q) v *= tau;
-      }
-      tab[e] = v;
-    }
-    __syncthreads();
+// Basis rows in normalised time, tab[j][d][col] = k!/(k-d)! tau_j^(k-d) (k = D-1-col, tau_j = j/res): built once per
+// (order, res) into a small device buffer.  k_piece_grad reads it through a `const __restrict__` kernel argument with a
+// wave-uniform index, i.e. as SCALAR loads: the values arrive in SGPRs and feed the FMAs directly, no LDS traffic and
+// no vector registers for the table.
+__global__ void __launch_bounds__(256) k_build_basis_table(double *tab, int res, int D) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= res * 4 * D) return;
+  const int j = e / (4 * D), d = (e / D) % 4, col = e % D, k = D - 1 - col;
+  const double tau = (double)j / (double)res;
+  double v = 0.0;
+  if (k >= d) {
+    v = 1.0;
+    for (int q = 0; q < d; ++q) v *= (double)(k - q);
+    for (int q = 0; q < k - d; ++q) v *= tau;
   }
+  tab[e] = v;
+}
+
+template <int S>
+__global__ void __launch_bounds__(256, 2) k_piece_grad(PieceGradArgs a, const double *__restrict__ tab) {
+  constexpr int D = 2 * S;
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b >= a.B) return;
   const int i = blockIdx.y;
