@@ -668,9 +668,14 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
     ctx->tab_res = pen->res;
   }
   const double *tab = ctx->d_tab;
-  if (s == 2) hipLaunchKernelGGL(anet::k_piece_grad<2>, grid, block, 0, st, a, tab);
-  else if (s == 3) hipLaunchKernelGGL(anet::k_piece_grad<3>, grid, block, 0, st, a, tab);
-  else hipLaunchKernelGGL(anet::k_piece_grad<4>, grid, block, 0, st, a, tab);
+  if (pen && batch <= axis_variant_max_batch()) {  // small batches: two lanes per (trajectory, piece)
+    const dim3 g2((unsigned)((2 * batch + 255) / 256), (unsigned)n_pieces);
+    if (s == 2) hipLaunchKernelGGL((anet::k_piece_grad<2, true>), g2, block, 0, st, a, tab);
+    else if (s == 3) hipLaunchKernelGGL((anet::k_piece_grad<3, true>), g2, block, 0, st, a, tab);
+    else hipLaunchKernelGGL((anet::k_piece_grad<4, true>), g2, block, 0, st, a, tab);
+  } else if (s == 2) hipLaunchKernelGGL((anet::k_piece_grad<2, false>), grid, block, 0, st, a, tab);
+  else if (s == 3) hipLaunchKernelGGL((anet::k_piece_grad<3, false>), grid, block, 0, st, a, tab);
+  else hipLaunchKernelGGL((anet::k_piece_grad<4, false>), grid, block, 0, st, a, tab);
   ANET_HIP(ctx, hipGetLastError());
   return ANET_OK;
 }

@@ -182,11 +182,26 @@ __global__ void __launch_bounds__(256) k_build_basis_table(double *tab, int res,
   tab[e] = v;
 }
 
-template <int S>
+// SPLIT (small batches): TWO adjacent lanes per (trajectory, piece).  Lane 0 of the pair takes the energy part and
+// the even row chunks, lane 1 the box rows and the odd chunks; the partial gradients are summed across the pair
+// with a DPP swap.  Same work, half the dependent chain per lane and twice the waves -- what counts when the
+// batch leaves one wave per SIMD.
+__device__ __forceinline__ double pair_sum(double v) {  // v + the value of the other lane of the pair (lanes 2k, 2k+1)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, true);
+  return v + __hiloint2double(hi, lo);
+}
+
+template <int S, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 2) k_piece_grad(PieceGradArgs a, const double *__restrict__ tab) {
   constexpr int D = 2 * S;
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B) return;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int half = SPLIT ? (int)(gid & 1) : 0;
+  const int64_t bq = SPLIT ? (gid >> 1) : gid;
+  const bool live = bq < a.B;
+  if (!SPLIT && !live) return;
+  const int64_t b = live ? bq : 0;  // (SPLIT: idle pairs compute on trajectory 0 and store nothing: the DPP sum needs both lanes)
   const int i = blockIdx.y;
   const int64_t ld = a.ld;
   const double Ti = a.T[(int64_t)i * ld + b];
@@ -199,7 +214,7 @@ __global__ void __launch_bounds__(256, 2) k_piece_grad(PieceGradArgs a, const do
       gC[ax][col] = 0.0;
     }
   double gT = 0.0, pc = 0.0;
-  if (a.with_energy) {
+  if (a.with_energy && half == 0) {
     // d/dc of sum_{j,k>=S} c_j c_k f_j f_k T^(j+k-2S+1)/(j+k-2S+1) ;  d/dT = (p^(S)(T))^2
     double tp[D];
     tp[0] = 1.0;
@@ -255,7 +270,13 @@ __global__ void __launch_bounds__(256, 2) k_piece_grad(PieceGradArgs a, const do
     // them from L2 for every sample (res x M x 32 B per lane) was the bottleneck of this kernel.
     constexpr int RC = 8;
     const int nchunk = a.hpolys ? (pp.M + RC - 1) / RC : 0;
-    for (int ch = 0; ch < (nchunk > 0 ? nchunk : 1); ++ch) {
+    // chunks of this lane: all of them, or (SPLIT) every second one starting at `half`; at least one pass so
+    // that the box rows are visited
+    const int cstep = SPLIT ? 2 : 1;
+    int npass = SPLIT ? (nchunk - half + 1) / 2 : nchunk;
+    if (npass < 1) npass = 1;
+    for (int pass = 0; pass < npass; ++pass) {
+      const int ch = half + cstep * pass;
       double hr[RC][4];
 #pragma unroll
       for (int r = 0; r < RC; ++r) {
@@ -265,7 +286,7 @@ __global__ void __launch_bounds__(256, 2) k_piece_grad(PieceGradArgs a, const do
         for (int q = 0; q < 4; ++q)
           hr[r][q] = ok ? a.hpolys[(int64_t)((i * pp.M + rr) * 4 + q) * ld + b] : 0.0;
       }
-      const bool first = (ch == 0);  // box rows are evaluated with the first chunk
+      const bool first = SPLIT ? (half == 1 && pass == 0) : (ch == 0);  // the pass that also evaluates the box rows
       for (int j = 0; j < pp.res; ++j) {
         const double *tb = tab + (size_t)j * 4 * D;
         double st[4][3];
@@ -346,6 +367,15 @@ __global__ void __launch_bounds__(256, 2) k_piece_grad(PieceGradArgs a, const do
         tk *= Ti;
       }
     }
+  }
+  if (SPLIT) {
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+      for (int col = 0; col < D; ++col) gC[ax][col] = pair_sum(gC[ax][col]);
+    gT = pair_sum(gT);
+    pc = pair_sum(pc);
+    if (!live || half != 0) return;
   }
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax)

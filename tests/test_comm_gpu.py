@@ -28,8 +28,8 @@ def test_config5_sharded_cost_grad_full_size(anet_ctx):
     """SURVEY 8(d) config 5 at its full size: B = 32768 8-segment snap problems with corridor and
     dynamic-limit penalties, seed 3, split into the 8 contiguous shards 8 ranks would own; each
     shard's costs go through the native all-gather.  Size-independent properties: the gathered costs
-    and the waypoint gradients are bit-identical to the unsharded evaluation (no cross-trajectory
-    coupling, padding rows inert), ragged shard sizes included; a sample is checked against the numpy
+    and the gradients equal the unsharded evaluation to rounding (no cross-trajectory coupling, padding
+    rows inert; the shards run the small-batch kernel shapes), ragged shard sizes included; a sample is checked against the numpy
     oracle."""
     import torch
     import allocnet_amd as aa
@@ -56,11 +56,12 @@ def test_config5_sharded_cost_grad_full_size(anet_ctx):
             comm.allgather_costs(send, recv, hi - lo)
             torch.cuda.synchronize()
             gathered[lo:hi] = recv.cpu().numpy()
-            assert np.array_equal(gP_r, gP[lo:hi])
-            # a 4096-trajectory shard runs the axis-parallel propagate kernel, the full batch the lane-per-
-            # trajectory one: dJ/dT is summed over the axes in a different order
+            # a 4096-trajectory shard runs the small-batch kernels (two lanes per piece in the penalty kernel, one
+            # lane per axis in the propagate kernel), the full batch the lane-per-trajectory ones: sums are
+            # taken in a different order
+            assert np.abs(gP_r - gP[lo:hi]).max() <= 1e-11 * np.abs(gP).max()
             assert np.abs(gT_r - gT[lo:hi]).max() <= 1e-11 * np.abs(gT).max()
-        assert np.array_equal(gathered[:total], cost[:total])
+        assert np.abs(gathered[:total] - cost[:total]).max() <= 1e-12 * np.abs(cost).max()
     comm.close()
     ctx.close()
     for b in (0, 4097, 20000, B - 1):
