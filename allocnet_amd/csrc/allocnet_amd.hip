@@ -256,15 +256,19 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
         bl = dim3(64u * waves);
       };
       dim3 gw, bw;
+      const bool one = L.n <= 64;  // one variable per lane: half the registers
       if (a.p.mem_size <= 8) {
         shape(anet::LbfgsWaveShape<8>::kWaves, gw, bw);
-        hipLaunchKernelGGL(anet::k_lbfgs_update_wave<8>, gw, bw, 0, st, a);
+        if (one) hipLaunchKernelGGL((anet::k_lbfgs_update_wave<8, 1>), gw, bw, 0, st, a);
+        else hipLaunchKernelGGL((anet::k_lbfgs_update_wave<8, 2>), gw, bw, 0, st, a);
       } else if (a.p.mem_size <= 20) {
         shape(anet::LbfgsWaveShape<20>::kWaves, gw, bw);
-        hipLaunchKernelGGL(anet::k_lbfgs_update_wave<20>, gw, bw, 0, st, a);
+        if (one) hipLaunchKernelGGL((anet::k_lbfgs_update_wave<20, 1>), gw, bw, 0, st, a);
+        else hipLaunchKernelGGL((anet::k_lbfgs_update_wave<20, 2>), gw, bw, 0, st, a);
       } else {
         shape(anet::LbfgsWaveShape<0>::kWaves, gw, bw);
-        hipLaunchKernelGGL(anet::k_lbfgs_update_wave<0>, gw, bw, 0, st, a);
+        if (one) hipLaunchKernelGGL((anet::k_lbfgs_update_wave<0, 1>), gw, bw, 0, st, a);
+        else hipLaunchKernelGGL((anet::k_lbfgs_update_wave<0, 2>), gw, bw, 0, st, a);
       }
     } else {
       hipLaunchKernelGGL(anet::k_lbfgs_update, grid, block, 0, st, a);

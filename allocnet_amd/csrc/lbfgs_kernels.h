@@ -313,7 +313,8 @@ template <int LBFGS_WAVE_MREG>
 struct LbfgsWaveShape {
   static constexpr int kWaves = (LBFGS_WAVE_MREG > 8) ? 4 : (LBFGS_WAVE_MREG > 0) ? 8 : 16;  // register budget
 };
-template <int LBFGS_WAVE_MREG>
+// NV: variables per lane (1 for n <= 64, 2 for n <= 128)
+template <int LBFGS_WAVE_MREG, int NV = 2>
 __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const int64_t b, const int lane) {
   constexpr int MR = LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1;
   const int64_t ld = a.ld;
@@ -324,8 +325,13 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
   const int64_t vs = a.vs, ps = a.ps;
   double *x = a.x + b, *g = a.g + b;                       // batch-minor (shared with the objective)
   double *xp = a.xp + b * ps, *gp = a.gp + b * ps, *d = a.d + b * ps;
-  const bool h[2] = {lane < n, lane + 64 < n};
-  const int64_t iv[2] = {lane, lane + 64};                  // this lane's variable indices
+  bool h[NV];
+  int64_t iv[NV];  // this lane's variable indices
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    iv[q] = lane + 64 * q;
+    h[q] = iv[q] < n;
+  }
 
   // ---- round trip 1
   const int done = is[IS_DONE * ld];
@@ -338,9 +344,9 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
   int count = is[IS_COUNT * ld], brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
   double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
   double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
-  double xr[2], gr[2], dr[2], xpr[2], gpr[2];
+  double xr[NV], gr[NV], dr[NV], xpr[NV], gpr[NV];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < NV; ++q) {
     xr[q] = h[q] ? x[iv[q] * ld] : 0.0;
     gr[q] = h[q] ? g[iv[q] * ld] : 0.0;
     dr[q] = h[q] ? d[iv[q] * vs] : 0.0;
@@ -358,7 +364,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
   double *lms = a.lm_s + b * ps * m, *lmy = a.lm_y + b * ps * m;  // [j][i] at (j*js + i*vs)
   const int64_t js = (vs == 1) ? ps : (int64_t)n * vs;             // stride between history slots
   const bool hist_in_regs = LBFGS_WAVE_MREG > 0 && m <= LBFGS_WAVE_MREG;
-  double hs[MR][2], hy[MR][2], hys[MR];
+  double hs[MR][NV], hy[MR][NV], hys[MR];
   double pf_old = 0.0;
   if (phase != 0) {
     if (0 < P.past && P.past <= k) pf_old = a.pf[(int64_t)(k % P.past) * ld + b];
@@ -366,13 +372,14 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
       const int nb = (bound + 1 < m) ? bound + 1 : m;  // bound after an accepted step
 #pragma unroll
       for (int it = 1; it < MR; ++it) {
-        hs[it][0] = hs[it][1] = hy[it][0] = hy[it][1] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) hs[it][q] = hy[it][q] = 0.0;
         hys[it] = 1.0;
         if (it < nb) {
           const int jj = (end - it + m) % m;  // it-th slot behind the new one
           const double *sj = lms + (int64_t)jj * js, *yj = lmy + (int64_t)jj * js;
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
+          for (int q = 0; q < NV; ++q)
             if (h[q]) {
               hs[it][q] = sj[iv[q] * vs];
               hy[it][q] = yj[iv[q] * vs];
@@ -385,20 +392,27 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
 
   bool start_ls = false;
   int finish = 0x7fffffff;
-  auto dot = [&](const double (&u)[2], const double (&v)[2]) {
-    return wave_sum(__builtin_fma(u[1], v[1], __builtin_fma(u[0], v[0], 0.0)));
+  auto dot = [&](const double (&u)[NV], const double (&v)[NV]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc = __builtin_fma(u[q], v[q], acc);
+    return wave_sum(acc);
   };
   auto conv_test = [&]() {
-    const double gn = wave_max_nonneg(fmax(fabs(gr[0]), fabs(gr[1])));
-    const double xn = wave_max_nonneg(fmax(fabs(xr[0]), fabs(xr[1])));
-    return gn / fmax(1.0, xn) < P.g_epsilon;
+    double gm = 0.0, xm = 0.0;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      gm = fmax(gm, fabs(gr[q]));
+      xm = fmax(xm, fabs(xr[q]));
+    }
+    return wave_max_nonneg(gm) / fmax(1.0, wave_max_nonneg(xm)) < P.g_epsilon;
   };
 
   if (phase == 0) {
     fx = f;
     if (lane == 0) a.pf[b] = fx;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NV; ++q) {
       dr[q] = -gr[q];
       if (h[q]) d[iv[q] * vs] = dr[q];
     }
@@ -452,7 +466,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
     }
     if (err) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < NV; ++q)
         if (h[q]) {
           store_x(a, b, (int)iv[q], xpr[q]);
           g[iv[q] * ld] = gpr[q];
@@ -461,7 +475,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
       finish = err;
     } else if (!success) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < NV; ++q)
         if (h[q]) store_x(a, b, (int)iv[q], __builtin_fma(step, dr[q], xpr[q]));
     } else {
       fx = f;
@@ -479,9 +493,9 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
         if (finish == 0x7fffffff) {
           ++k;
           double *se = lms + (int64_t)end * js, *ye = lmy + (int64_t)end * js;
-          double sreg[2], yreg[2], dv[2];
+          double sreg[NV], yreg[NV], dv[NV];
 #pragma unroll
-          for (int q = 0; q < 2; ++q) {
+          for (int q = 0; q < NV; ++q) {
             sreg[q] = xr[q] - xpr[q];
             yreg[q] = gr[q] - gpr[q];
             dv[q] = -gr[q];
@@ -499,8 +513,11 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
             const int newest = end;
             end = (end + 1) % m;
             if (hist_in_regs) {
-              hs[0][0] = sreg[0]; hs[0][1] = sreg[1];
-              hy[0][0] = yreg[0]; hy[0][1] = yreg[1];
+#pragma unroll
+              for (int q = 0; q < NV; ++q) {
+                hs[0][q] = sreg[q];
+                hy[0][q] = yreg[q];
+              }
               hys[0] = ys;
               double alpha[MR];
 #pragma unroll
@@ -508,19 +525,19 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
                 alpha[it] = 0.0;
                 if (it < bound) {
                   alpha[it] = dot(hs[it], dv) / hys[it];
-                  dv[0] = __builtin_fma(-alpha[it], hy[it][0], dv[0]);
-                  dv[1] = __builtin_fma(-alpha[it], hy[it][1], dv[1]);
+#pragma unroll
+                  for (int q = 0; q < NV; ++q) dv[q] = __builtin_fma(-alpha[it], hy[it][q], dv[q]);
                 }
               }
               const double sc = ys / yy;
-              dv[0] *= sc;
-              dv[1] *= sc;
+#pragma unroll
+              for (int q = 0; q < NV; ++q) dv[q] *= sc;
 #pragma unroll
               for (int it = MR - 1; it >= 0; --it) {
                 if (it < bound) {
                   const double cf = alpha[it] - dot(hy[it], dv) / hys[it];
-                  dv[0] = __builtin_fma(cf, hs[it][0], dv[0]);
-                  dv[1] = __builtin_fma(cf, hs[it][1], dv[1]);
+#pragma unroll
+                  for (int q = 0; q < NV; ++q) dv[q] = __builtin_fma(cf, hs[it][q], dv[q]);
                 }
               }
             } else {
@@ -529,9 +546,11 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
               for (int it = 0; it < bound; ++it) {
                 j = (j + m - 1) % m;
                 const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
-                double sv[2] = {0.0, 0.0}, yv[2] = {0.0, 0.0};
+                double sv[NV], yv[NV];
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                for (int q = 0; q < NV; ++q) sv[q] = yv[q] = 0.0;
+#pragma unroll
+                for (int q = 0; q < NV; ++q)
                   if (h[q]) {
                     sv[q] = sj[iv[q] * vs];
                     yv[q] = yj[iv[q] * vs];
@@ -539,31 +558,33 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
                 const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
                 const double al = dot(sv, dv) / ysj;
                 alpha = (lane == it) ? al : alpha;
-                dv[0] = __builtin_fma(-al, yv[0], dv[0]);
-                dv[1] = __builtin_fma(-al, yv[1], dv[1]);
+#pragma unroll
+                for (int q = 0; q < NV; ++q) dv[q] = __builtin_fma(-al, yv[q], dv[q]);
               }
               const double sc = ys / yy;
-              dv[0] *= sc;
-              dv[1] *= sc;
+#pragma unroll
+              for (int q = 0; q < NV; ++q) dv[q] *= sc;
               for (int it = 0; it < bound; ++it) {
                 const double *sj = lms + (int64_t)j * js, *yj = lmy + (int64_t)j * js;
-                double sv[2] = {0.0, 0.0}, yv[2] = {0.0, 0.0};
+                double sv[NV], yv[NV];
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                for (int q = 0; q < NV; ++q) sv[q] = yv[q] = 0.0;
+#pragma unroll
+                for (int q = 0; q < NV; ++q)
                   if (h[q]) {
                     sv[q] = sj[iv[q] * vs];
                     yv[q] = yj[iv[q] * vs];
                   }
                 const double ysj = (j == newest) ? ys : a.lm_ys[(int64_t)j * ld + b];
                 const double cf = __shfl(alpha, bound - 1 - it) - dot(yv, dv) / ysj;
-                dv[0] = __builtin_fma(cf, sv[0], dv[0]);
-                dv[1] = __builtin_fma(cf, sv[1], dv[1]);
+#pragma unroll
+                for (int q = 0; q < NV; ++q) dv[q] = __builtin_fma(cf, sv[q], dv[q]);
                 j = (j + 1) % m;
               }
             }
           }
 #pragma unroll
-          for (int q = 0; q < 2; ++q) {
+          for (int q = 0; q < NV; ++q) {
             dr[q] = dv[q];
             if (h[q]) d[iv[q] * vs] = dv[q];
           }
@@ -575,7 +596,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
   }
   if (start_ls) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < NV; ++q)
       if (h[q]) {
         xp[iv[q] * vs] = xr[q];
         gp[iv[q] * vs] = gr[q];
@@ -595,7 +616,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
       brackt = 0;
       touched = 0;
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < NV; ++q)
         if (h[q]) store_x(a, b, (int)iv[q], __builtin_fma(step, dr[q], xr[q]));
     }
   }
@@ -614,12 +635,12 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
   }
 }
 
-template <int LBFGS_WAVE_MREG>
+template <int LBFGS_WAVE_MREG, int NV>
 __global__ void __launch_bounds__(64 * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves)
 k_lbfgs_update_wave(LbfgsArgs a) {
   const int64_t b = (int64_t)blockIdx.x * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves + (threadIdx.x >> 6);
   if (b >= a.B) return;  // whole waves only: the reductions need all 64 lanes
-  lbfgs_update_wave_body<LBFGS_WAVE_MREG>(a, b, threadIdx.x & 63);
+  lbfgs_update_wave_body<LBFGS_WAVE_MREG, NV>(a, b, threadIdx.x & 63);
 }
 
 // firi::costMVIE (gcopter/firi.hpp:86-157): x = [p, rtd, cde], A is M x 3 column-major per problem
@@ -760,7 +781,7 @@ k_lbfgs_mvie_persistent(LbfgsArgs la, MvieArgs ma, int max_evals) {
     if (__builtin_amdgcn_readfirstlane(*(volatile const int *)done)) break;
     mvie_eval_wave(ma, b, lane);
     __threadfence_block();
-    lbfgs_update_wave_body<LBFGS_WAVE_MREG>(la, b, lane);
+    lbfgs_update_wave_body<LBFGS_WAVE_MREG, 1>(la, b, lane);  // nine variables: one per lane
     __threadfence_block();
   }
 }
