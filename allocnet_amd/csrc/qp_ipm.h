@@ -298,8 +298,14 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
         double dinv[BK];  // 1 / L[c][c], wave-uniform
 #pragma unroll
         for (int c = 0; c < BK; ++c) {
-          const double piv = sqrt(fmax(rl(Dr[c], c), 1e-300));
-          dinv[c] = 1.0 / piv;
+          // pivot and its reciprocal from v_rsq_f64 + two Newton steps (a sqrt and a division cost ~70 instructions
+          // on this sequential path, twelve times per block)
+          const double dcc = fmax(rl(Dr[c], c), 1e-300);
+          double rs = __builtin_amdgcn_rsq(dcc);
+          rs = rs * __builtin_fma(-0.5 * dcc * rs, rs, 1.5);
+          rs = rs * __builtin_fma(-0.5 * dcc * rs, rs, 1.5);
+          dinv[c] = rs;
+          const double piv = dcc * rs;
           Dr[c] = (lane == c) ? piv : Dr[c] * dinv[c];  // column c of L (rows > c); upper part is never read
 #pragma unroll
           for (int c2 = c + 1; c2 < BK; ++c2) Dr[c2] -= Dr[c] * rl(Dr[c], c2);
