@@ -907,22 +907,36 @@ void anet_firi_default_params(anet_firi_params *p) {
   p->mvie_max_evals = 2000;
 }
 
-int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
-              const double *pc, const int32_t *n_points, const double *a, const double *b,
-              const anet_firi_params *params, double *hpoly, int32_t *n_rows, int32_t *ok, double *ellipsoid) {
+static int firi_check(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const anet_firi_params &P) {
+  if (batch < 0 || n_bd < 1 || n_bd > 64 || max_points < 0 || max_rows < 4 || P.iterations < 1 || !(P.epsilon >= 0.0) ||
+      !(P.smooth_eps > 0.0) || P.mvie_max_evals < 1)
+    return fail(ctx, ANET_ERR_INVALID, "anet_firi: bad argument (1 <= n_bd <= 64, max_rows >= 4, iterations >= 1)");
+  if ((size_t)max_rows * 4 * sizeof(double) > 60 * 1024) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_firi: max_rows too large");
+  return ANET_OK;
+}
+
+// doubles of device workspace of anet_firi_dev: ellipsoid state, forward points, MVIE rows, L-BFGS state, flags
+int64_t anet_firi_workspace(int64_t batch, int max_points, int max_rows) {
+  if (batch < 0 || max_points < 0 || max_rows < 4) return -1;
+  const int64_t Np = max_points > 0 ? max_points : 1, ld = anet_recommended_ld(batch);
+  return batch * anet::kFiriEll + batch * Np * 4 + 3 * (int64_t)max_rows * ld + LbfgsLayout::doubles(9, 18, 3, ld) +
+         (batch * (2 + Np)) / 2 + 16;
+}
+
+int anet_firi_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
+                  const double *pc, const int32_t *n_points, const double *a, const double *b,
+                  const anet_firi_params *params, double *work, double *hpoly, int32_t *n_rows, int32_t *ok,
+                  double *ellipsoid, void *stream) {
   if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
   anet_firi_params P;
   anet_firi_default_params(&P);
   if (params) P = *params;
-  if (batch < 0 || n_bd < 1 || n_bd > 64 || max_points < 0 || max_rows < 4 || P.iterations < 1 || !(P.epsilon >= 0.0) ||
-      !(P.smooth_eps > 0.0) || P.mvie_max_evals < 1)
-    return fail(ctx, ANET_ERR_INVALID, "anet_firi: bad argument (1 <= n_bd <= 64, max_rows >= 4, iterations >= 1)");
+  int rc = firi_check(ctx, batch, n_bd, max_points, max_rows, P);
+  if (rc) return rc;
   if (batch == 0) return ANET_OK;
-  if (!bd || (max_points > 0 && (!pc || !n_points)) || !a || !b || !hpoly || !n_rows)
-    return fail(ctx, ANET_ERR_INVALID, "anet_firi: NULL pointer");
-  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  if (!bd || (max_points > 0 && (!pc || !n_points)) || !a || !b || !work || !hpoly || !n_rows || !ok)
+    return fail(ctx, ANET_ERR_INVALID, "anet_firi_dev: NULL pointer");
   const int H = max_rows, Np = max_points > 0 ? max_points : 1;
-  if ((size_t)H * 4 * sizeof(double) > 60 * 1024) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_firi: max_rows too large");
   // firi.hpp:212-217
   anet_lbfgs_params lp;
   anet_lbfgs_default_params(&lp);
@@ -930,35 +944,24 @@ int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_ro
   const int n = 9, m = lp.mem_size, npf = lp.past;
   const int64_t ld = anet_recommended_ld(batch);
   const int64_t w_l = LbfgsLayout::doubles(n, m, npf, ld);
-  // device scratch (doubles): bd, pc, a, b, ell, fpc, hpoly, A, lbfgs | ints: npts, flag, nh, ok, mvie_ok
-  const size_t n_bdv = (size_t)batch * n_bd * 4, n_pc = (size_t)batch * Np * 3, n_ab = (size_t)batch * 3;
   const size_t n_ell = (size_t)batch * anet::kFiriEll, n_fpc = (size_t)batch * Np * 4, n_hp = (size_t)batch * H * 4;
   const size_t n_A = (size_t)3 * H * ld;
-  const size_t n_int = (size_t)batch * (4 + (size_t)Np);
-  int rc = ensure_scratch(ctx, sizeof(double) * (n_bdv + n_pc + 2 * n_ab + n_ell + n_fpc + n_hp + n_A + (size_t)w_l + n_int / 2 + 16));
-  if (rc) return rc;
-  double *d_bd = (double *)ctx->scratch, *d_pc = d_bd + n_bdv, *d_a = d_pc + n_pc, *d_b = d_a + n_ab, *d_ell = d_b + n_ab;
-  double *d_fpc = d_ell + n_ell, *d_hp = d_fpc + n_fpc, *d_A = d_hp + n_hp, *d_l = d_A + n_A;
-  int *d_np = (int *)(d_l + w_l), *d_flag = d_np + batch, *d_nh = d_flag + (size_t)batch * Np, *d_ok = d_nh + batch,
-      *d_mok = d_ok + batch;
-  hipStream_t st = ctx->stream;
-  ANET_HIP(ctx, hipMemcpyAsync(d_bd, bd, sizeof(double) * n_bdv, hipMemcpyHostToDevice, st));
-  if (max_points > 0) {
-    ANET_HIP(ctx, hipMemcpyAsync(d_pc, pc, sizeof(double) * n_pc, hipMemcpyHostToDevice, st));
-    ANET_HIP(ctx, hipMemcpyAsync(d_np, n_points, sizeof(int) * batch, hipMemcpyHostToDevice, st));
-  } else {
-    ANET_HIP(ctx, hipMemsetAsync(d_np, 0, sizeof(int) * batch, st));
+  double *d_ell = work, *d_fpc = d_ell + n_ell, *d_A = d_fpc + n_fpc, *d_l = d_A + n_A;
+  int *d_flag = (int *)(d_l + w_l), *d_mok = d_flag + (size_t)batch * Np, *d_np0 = d_mok + batch;
+  hipStream_t st = (hipStream_t)stream;
+  const int *d_np = n_points;
+  if (max_points == 0) {  // no obstacle points at all: a zero count per corridor
+    ANET_HIP(ctx, hipMemsetAsync(d_np0, 0, sizeof(int) * batch, st));
+    d_np = d_np0;
   }
-  ANET_HIP(ctx, hipMemcpyAsync(d_a, a, sizeof(double) * n_ab, hipMemcpyHostToDevice, st));
-  ANET_HIP(ctx, hipMemcpyAsync(d_b, b, sizeof(double) * n_ab, hipMemcpyHostToDevice, st));
-  ANET_HIP(ctx, hipMemsetAsync(d_hp, 0, sizeof(double) * n_hp, st));
-  anet::FiriArgs fa{d_bd, d_pc, d_np, d_a, d_b, d_ell, d_fpc, d_flag, d_hp, d_nh, d_ok, batch, n_bd, Np, H, P.epsilon};
+  ANET_HIP(ctx, hipMemsetAsync(hpoly, 0, sizeof(double) * n_hp, st));
+  anet::FiriArgs fa{bd, pc, d_np, a, b, d_ell, d_fpc, d_flag, hpoly, n_rows, ok, batch, n_bd, Np, H, P.epsilon};
   const dim3 g64((unsigned)((batch + 63) / 64)), b64(64), gB((unsigned)batch), b256(256);
   hipLaunchKernelGGL(anet::k_firi_init, g64, b64, 0, st, fa);
   ANET_HIP(ctx, hipGetLastError());
   LbfgsLayout L{n, m, npf, ld};
   L.carve(d_l);
-  anet::FiriMvieArgs ma{d_hp, d_nh, d_ok, d_ell, d_A, L.x, L.is + (int64_t)anet::IS_DONE * ld, L.is + (int64_t)anet::IS_RET * ld,
+  anet::FiriMvieArgs ma{hpoly, n_rows, ok, d_ell, d_A, L.x, L.is + (int64_t)anet::IS_DONE * ld, L.is + (int64_t)anet::IS_RET * ld,
                         d_mok, batch, ld, H};
   anet::MvieArgs ev{d_A, L.x, L.feval, L.g, L.is, batch, ld, H, P.smooth_eps, P.penalty_wt};
   // wave-per-problem layout of the internal vectors (element i of problem b at [i + b*n]), no "still running" counter
@@ -981,11 +984,49 @@ int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_ro
     hipLaunchKernelGGL(anet::k_firi_mvie_finish, g64, b64, 0, st, ma);
     ANET_HIP(ctx, hipGetLastError());
   }
+  if (ellipsoid)
+    ANET_HIP(ctx, hipMemcpy2DAsync(ellipsoid, sizeof(double) * 15, d_ell, sizeof(double) * anet::kFiriEll, sizeof(double) * 15, batch,
+                                   hipMemcpyDeviceToDevice, st));
+  return ANET_OK;
+}
+
+int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
+              const double *pc, const int32_t *n_points, const double *a, const double *b,
+              const anet_firi_params *params, double *hpoly, int32_t *n_rows, int32_t *ok, double *ellipsoid) {
+  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  anet_firi_params P;
+  anet_firi_default_params(&P);
+  if (params) P = *params;
+  int rc = firi_check(ctx, batch, n_bd, max_points, max_rows, P);
+  if (rc) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!bd || (max_points > 0 && (!pc || !n_points)) || !a || !b || !hpoly || !n_rows)
+    return fail(ctx, ANET_ERR_INVALID, "anet_firi: NULL pointer");
+  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  const int H = max_rows, Np = max_points > 0 ? max_points : 1;
+  const size_t n_bdv = (size_t)batch * n_bd * 4, n_pc = (size_t)batch * Np * 3, n_ab = (size_t)batch * 3;
+  const size_t n_hp = (size_t)batch * H * 4, n_ell = (size_t)batch * 15;
+  const size_t n_work = (size_t)anet_firi_workspace(batch, max_points, max_rows);
+  rc = ensure_scratch(ctx, sizeof(double) * (n_bdv + n_pc + 2 * n_ab + n_hp + n_ell + n_work + (size_t)(3 * batch) / 2 + 16));
+  if (rc) return rc;
+  double *d_bd = (double *)ctx->scratch, *d_pc = d_bd + n_bdv, *d_a = d_pc + n_pc, *d_b = d_a + n_ab, *d_hp = d_b + n_ab;
+  double *d_el = d_hp + n_hp, *d_work = d_el + n_ell;
+  int *d_np = (int *)(d_work + n_work), *d_nh = d_np + batch, *d_ok = d_nh + batch;
+  hipStream_t st = ctx->stream;
+  ANET_HIP(ctx, hipMemcpyAsync(d_bd, bd, sizeof(double) * n_bdv, hipMemcpyHostToDevice, st));
+  if (max_points > 0) {
+    ANET_HIP(ctx, hipMemcpyAsync(d_pc, pc, sizeof(double) * n_pc, hipMemcpyHostToDevice, st));
+    ANET_HIP(ctx, hipMemcpyAsync(d_np, n_points, sizeof(int) * batch, hipMemcpyHostToDevice, st));
+  }
+  ANET_HIP(ctx, hipMemcpyAsync(d_a, a, sizeof(double) * n_ab, hipMemcpyHostToDevice, st));
+  ANET_HIP(ctx, hipMemcpyAsync(d_b, b, sizeof(double) * n_ab, hipMemcpyHostToDevice, st));
+  rc = anet_firi_dev(ctx, batch, n_bd, max_points, max_rows, d_bd, d_pc, d_np, d_a, d_b, &P, d_work, d_hp, d_nh, d_ok,
+                     ellipsoid ? d_el : nullptr, st);
+  if (rc) return rc;
   ANET_HIP(ctx, hipMemcpyAsync(hpoly, d_hp, sizeof(double) * n_hp, hipMemcpyDeviceToHost, st));
   ANET_HIP(ctx, hipMemcpyAsync(n_rows, d_nh, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
   if (ok) ANET_HIP(ctx, hipMemcpyAsync(ok, d_ok, sizeof(int) * batch, hipMemcpyDeviceToHost, st));
-  if (ellipsoid) ANET_HIP(ctx, hipMemcpy2DAsync(ellipsoid, sizeof(double) * 15, d_ell, sizeof(double) * anet::kFiriEll,
-                                                sizeof(double) * 15, batch, hipMemcpyDeviceToHost, st));
+  if (ellipsoid) ANET_HIP(ctx, hipMemcpyAsync(ellipsoid, d_el, sizeof(double) * n_ell, hipMemcpyDeviceToHost, st));
   ANET_HIP(ctx, hipStreamSynchronize(st));
   return ANET_OK;
 }

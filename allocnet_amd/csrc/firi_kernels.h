@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(256) k_firi_planes(FiriArgs g) {
     else completed = false;
     ++nH;
   }
+  for (int e = nH * 4 + tid; e < g.H * 4; e += 256) hp[e] = 0.0;  // rows of an earlier, larger pass
   if (tid == 0) {
     g.nh[b] = nH;
     if (overflow) g.ok[b] = -1;

@@ -44,6 +44,35 @@ def firi(bd, pc, a, b, n_points=None, max_rows=64, params=None, ctx=None):
     return dict(hpoly=hp, n_rows=nh, ok=ok, ellipsoid=ell)
 
 
+def firi_dev(bd, pc, n_points, a, b, max_rows=64, params=None, stream=None, ctx=None):
+    """anet_firi_dev: the same with torch CUDA tensors in and out (float64 bd (B,Mb,4), pc (B,Np,3), a, b (B,3);
+    int32 n_points (B,)).  Nothing leaves the device; asynchronous on `stream` (default: torch's current stream).
+    Returns dict(hpoly (B,max_rows,4), n_rows, ok, ellipsoid) of device tensors."""
+    import torch
+    ctx = ctx or default_context()
+    B, Mb, _ = bd.shape
+    Np = pc.shape[1]
+    for t in (bd, pc, a, b):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise ValueError("float64 contiguous CUDA tensors expected")
+    if not (n_points.is_cuda and n_points.dtype == torch.int32 and n_points.is_contiguous() and n_points.shape == (B,)):
+        raise ValueError("n_points: int32 contiguous CUDA tensor of shape (B,)")
+    dev = bd.device
+    hp = torch.empty((B, max_rows, 4), device=dev, dtype=torch.float64)
+    nh = torch.empty(B, device=dev, dtype=torch.int32); ok = torch.empty(B, device=dev, dtype=torch.int32)
+    ell = torch.empty((B, 15), device=dev, dtype=torch.float64)
+    work = torch.empty(int(ctx.lib.anet_firi_workspace(B, Np, int(max_rows))), device=dev, dtype=torch.float64)
+    st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+    pp = ctypes.cast(ctypes.pointer(params), ctypes.c_void_p) if params is not None else None
+    ctx.check(ctx.lib.anet_firi_dev(ctx.handle, B, Mb, Np, int(max_rows), ctypes.c_void_p(bd.data_ptr()),
+                                    ctypes.c_void_p(pc.data_ptr()) if Np else None,
+                                    ctypes.c_void_p(n_points.data_ptr()) if Np else None, ctypes.c_void_p(a.data_ptr()),
+                                    ctypes.c_void_p(b.data_ptr()), pp, ctypes.c_void_p(work.data_ptr()),
+                                    ctypes.c_void_p(hp.data_ptr()), ctypes.c_void_p(nh.data_ptr()),
+                                    ctypes.c_void_p(ok.data_ptr()), ctypes.c_void_p(ell.data_ptr()), ctypes.c_void_p(st)))
+    return dict(hpoly=hp, n_rows=nh, ok=ok, ellipsoid=ell, _work=work)
+
+
 def to_planner_form(hpoly, n_rows):
     """learning_planner.hpp:293-299: rows divided by the norm of their normal, offset negated: a.x <= b."""
     out = np.zeros_like(hpoly)

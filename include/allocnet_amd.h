@@ -406,6 +406,14 @@ void anet_firi_default_params(anet_firi_params *p);
 int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
               const double *pc, const int32_t *n_points, const double *a, const double *b,
               const anet_firi_params *params, double *hpoly, int32_t *n_rows, int32_t *ok, double *ellipsoid);
+/* The same with DEVICE pointers (same layouts; ok is required) and a device workspace of
+ * anet_firi_workspace() doubles: corridor generation, the QP / MINCO solve and the evaluation chain on the
+ * device without a PCIe round trip.  Asynchronous on `stream`.                                        */
+int64_t anet_firi_workspace(int64_t batch, int max_points, int max_rows);
+int anet_firi_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
+                  const double *pc, const int32_t *n_points, const double *a, const double *b,
+                  const anet_firi_params *params, double *work, double *hpoly, int32_t *n_rows, int32_t *ok,
+                  double *ellipsoid, void *stream);
 
 /* ---- multi-GPU: all-gather of the per-trajectory costs over RCCL / xGMI --------------------------- */
 /* Trajectories are independent, so a batch shards contiguously across GPUs (one process and one
