@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import scipy.linalg as sla
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import minco_np as onp  # noqa: E402  (prototype / analysis script, not product code)
 

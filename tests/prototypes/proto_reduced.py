@@ -4,7 +4,7 @@ import numpy as np
 from math import factorial
 from fractions import Fraction
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools"))
 from minco_tables import tables
 
 

@@ -4,35 +4,9 @@ import numpy as np
 import pytest
 
 from oracle import firi_np as F
+from tests.util import firi_scene as make_case, firi_pack as pack
 
 pytestmark = pytest.mark.gpu
-
-
-def make_case(rng, n_pts, clearance=0.5, box=3.0):
-    a = rng.uniform(-2, 2, size=3)
-    d = rng.normal(size=3); d /= np.linalg.norm(d)
-    b = a + d * rng.uniform(0.5, 2.5)
-    lo = np.minimum(a, b) - box; hi = np.maximum(a, b) + box
-    bd = np.zeros((6, 4))
-    for ax in range(3):
-        bd[2 * ax, ax] = 1.0; bd[2 * ax, 3] = -hi[ax]
-        bd[2 * ax + 1, ax] = -1.0; bd[2 * ax + 1, 3] = lo[ax]
-    pts = rng.uniform(lo + 1e-3, hi - 1e-3, size=(4 * n_pts, 3))
-    dd = b - a
-    t = np.clip(((pts - a) @ dd) / (dd @ dd), 0, 1)
-    dist = np.linalg.norm(pts - (a + t[:, None] * dd), axis=1)
-    pts = pts[dist > clearance][:n_pts]
-    return bd, pts, a, b
-
-
-def pack(cases):
-    B = len(cases)
-    Np = max(1, max(len(c[1]) for c in cases))
-    bd = np.array([c[0] for c in cases]); a = np.array([c[2] for c in cases]); b = np.array([c[3] for c in cases])
-    pc = np.zeros((B, Np, 3)); npts = np.zeros(B, dtype=np.int32)
-    for i, c in enumerate(cases):
-        pc[i, :len(c[1])] = c[1]; npts[i] = len(c[1])
-    return bd, pc, npts, a, b
 
 
 def check_properties(hp, bd, pts, a, b, eps=1e-6):

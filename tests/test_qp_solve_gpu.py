@@ -5,28 +5,9 @@ import pytest
 
 from oracle import minco_np as onp
 from oracle import qp_np
-from tests.util import golden_files
+from tests.util import golden_files, qp_corridor_problem as _corridor_problem
 
 pytestmark = pytest.mark.gpu
-
-
-def _corridor_problem(rng, N, M, margin=1.0):
-    pts = np.cumsum(np.vstack([np.zeros(3), rng.normal(size=(N, 3)) * 1.5]), axis=0)
-    hp = np.zeros((N, M, 4))
-    for i in range(N):
-        lo = np.minimum(pts[i], pts[i + 1]) - margin
-        hi = np.maximum(pts[i], pts[i + 1]) + margin
-        for ax in range(3):
-            hp[i, 2 * ax, ax] = 1.0; hp[i, 2 * ax, 3] = hi[ax]
-            hp[i, 2 * ax + 1, ax] = -1.0; hp[i, 2 * ax + 1, 3] = -lo[ax]
-        mid = 0.5 * (pts[i] + pts[i + 1])
-        for r in range(6, M - 1):
-            a = rng.normal(size=3); a /= np.linalg.norm(a)
-            hp[i, r, :3] = a; hp[i, r, 3] = max(a @ pts[i], a @ pts[i + 1]) + rng.uniform(0.3, 1.5)
-    ini = np.zeros((3, 3)); fin = np.zeros((3, 3))
-    ini[:, 0] = pts[0]; fin[:, 0] = pts[-1]
-    T = rng.uniform(1.5, 2.5, size=N)
-    return ini, fin, hp, T
 
 
 def _dense(s, ini, fin, hp, T, res, vmax, amax, keep=None, want_keep=False):
