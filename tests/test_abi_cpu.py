@@ -54,6 +54,12 @@ def test_oracle_is_not_imported_by_the_product():
     for dp, _, files in os.walk(os.path.join(ROOT, "include")):
         for f in files:
             assert "oracle" not in open(os.path.join(dp, f)).read()
+    # the measurement scripts under tools/ do not import it either (bench.py's cpu_baseline leg is the one exception)
+    import re
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            txt = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f"tools/{f} imports the oracle"
 
 
 def test_cpp_facade_compiles_as_cxx14():
