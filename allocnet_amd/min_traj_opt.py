@@ -121,6 +121,44 @@ class OsqpLayer:
         self.implicit_time_grad[:segments] = out["grad_T"][0] / qp_traj.path_length
         return z, curr_obj1_val, None, curr_objc_val, curr_padding_loss
 
+    def forward_batch(self, qp_trajs):
+        """Extension: the minibatch of the training loop in ONE solve per (order, segment count, res, limits) group
+        instead of one `forward` call per sample (minsnap_network_conv_lstm.py:340-352 loops in Python).
+        Returns a list with the 5-tuple `forward` returns for each sample, and lists `time_grads`,
+        `implicit_time_grads` (None where the QP was not solved)."""
+        n = len(qp_trajs)
+        results, tg, itg = [None] * n, [None] * n, [None] * n
+        groups = {}
+        for idx, q in enumerate(qp_trajs):
+            groups.setdefault((q.order, q.seg, q.res, q._limits[0], q._limits[1]), []).append(idx)
+        for (order, seg, res, vmax, amax), ids in groups.items():
+            M = max(max(p.shape[0] for p in qp_trajs[i].hpolys) for i in ids)
+            B = len(ids)
+            hp = np.zeros((B, seg, M, 4)); ini = np.zeros((B, 3, 3)); fin = np.zeros((B, 3, 3)); T = np.zeros((B, seg))
+            for r, i in enumerate(ids):
+                q = qp_trajs[i]
+                for k, pl in enumerate(q.hpolys):
+                    hp[r, k, :pl.shape[0]] = pl
+                ini[r] = q.start_state.reshape(3, 3); fin[r] = q.end_state.reshape(3, 3); T[r] = q.Times[:seg]
+            out = _qp.qp_solve(order, ini, fin, hp, T, res=res, max_vel=vmax, max_acc=amax, settings=self._settings,
+                               time_grad=True, ctx=self._ctx)
+            eff = traj_cost_grad_T(out["coeffs"], T, m34=1400.0, ctx=self._ctx)
+            for r, i in enumerate(ids):
+                q = qp_trajs[i]
+                Times = q.Times
+                obj1 = float(np.sum(Times[:seg]) / (1.0 * seg))
+                pad = float(np.mean(Times[seg:] ** 2)) if 5 - seg != 0 else 0.0
+                if out["status"][r] != 1:
+                    objt = None
+                    if hasattr(q, "ref_time_factor"):
+                        objt = float(np.mean((Times[:seg] - q.ref_time_factor[:seg]) ** 2) / seg + pad)
+                    results[i] = (None, obj1, objt, None, pad)
+                    continue
+                results[i] = (out["coeffs"][r].reshape(-1), obj1, None, float(out["obj"][r] / q.path_length), pad)
+                tg[i] = np.zeros_like(Times); tg[i][:seg] = eff[r] / q.path_length
+                itg[i] = np.zeros_like(Times); itg[i][:seg] = out["grad_T"][r] / q.path_length
+        return results, tg, itg
+
     def forward4lstm(self, qp_traj, pred_stop_tokens, seq_len=5):
         segments = qp_traj.seg
         Times = qp_traj.Times

@@ -76,3 +76,34 @@ def test_osqp_layer_forward(anet_ctx):
     assert np.abs(lay2.implicit_time_grad[:3] - imp[:3]).max() <= 0.1 * np.abs(imp[:3]).max() + 1e-3
     z2, o1, ot, oc, stl = layer.forward4lstm(opt, np.array([0.1, 0.2, 0.9, 0.95, 0.99]), seq_len=5)
     assert z2 is not None and stl > 0 and abs(oc - objc) <= 1e-2 * max(1.0, objc)
+
+
+def test_osqp_layer_forward_batch(anet_ctx):
+    """forward_batch == forward sample by sample (mixed segment counts are grouped, order preserved)."""
+    import allocnet_amd as aa
+    from tests.util import qp_corridor_problem
+    rng = np.random.default_rng(33)
+    opts = []
+    for seg in (3, 2, 3, 4, 2):
+        ini, fin, hp, T = qp_corridor_problem(rng, seg, 8)
+        state = np.zeros((9, 2)); state[:, 0] = ini.reshape(-1); state[:, 1] = fin.reshape(-1)
+        hp50 = np.zeros((50, 4, 5))
+        for i in range(seg):
+            rows = hp[i][np.abs(hp[i]).sum(axis=1) > 0]
+            hp50[:rows.shape[0], :, i] = rows
+        times = np.r_[T, np.zeros(5 - seg)]
+        o = aa.MinTrajOpt(make_params(4, 10, vmax=3.0, amax=4.0), ctx=anet_ctx)
+        o.update(state, hp50, times, phase=2, seq_len=5)
+        opts.append(o)
+    layer = aa.OsqpLayer(ctx=anet_ctx, method=aa.qp.QP_METHOD_INTERIOR_POINT)
+    res, tg, itg = layer.forward_batch(opts)
+    assert len(res) == len(opts)
+    for i, o in enumerate(opts):
+        one = aa.OsqpLayer(ctx=anet_ctx, method=aa.qp.QP_METHOD_INTERIOR_POINT)
+        z, o1, ot, oc, pad = one.forward(o)
+        zb, o1b, otb, ocb, padb = res[i]
+        assert (z is None) == (zb is None) and o1 == o1b and pad == padb
+        if z is not None:
+            assert np.abs(z - zb).max() <= 1e-7 * max(1.0, np.abs(z).max()) and abs(oc - ocb) <= 1e-9 * max(1.0, abs(oc))
+            assert np.abs(one.time_grad - tg[i]).max() <= 1e-7 * max(1.0, np.abs(tg[i]).max())
+            assert np.abs(one.implicit_time_grad - itg[i]).max() <= 1e-6 * max(1.0, np.abs(itg[i]).max())
