@@ -636,7 +636,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
 }
 
 template <int LBFGS_WAVE_MREG, int NV>
-__global__ void __launch_bounds__(64 * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves)
+__global__ void __launch_bounds__(64 * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves, (LBFGS_WAVE_MREG == 8 && NV == 1) ? 4 : 1)
 k_lbfgs_update_wave(LbfgsArgs a) {
   const int64_t b = (int64_t)blockIdx.x * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves + (threadIdx.x >> 6);
   if (b >= a.B) return;  // whole waves only: the reductions need all 64 lanes
