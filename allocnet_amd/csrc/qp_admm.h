@@ -5,7 +5,8 @@
 // defaults -- rho 0.1, 1e3*rho on equality rows, sigma 1e-6, alpha 1.6, eps_abs = eps_rel = 1e-3,
 // max_iter 4000, termination check every 25 iterations, rho adaptation by the residual-ratio rule.
 //
-// MI355X-specific restatement (one 256-thread workgroup per trajectory, everything except z, y in LDS):
+// MI355X-specific restatement (one 256-thread workgroup per trajectory; everything in LDS, the per-row state too
+// when it fits -- one number per row instead of OSQP's z and y, see `wg` below):
 //  * the QP is posed in NORMALISED time (variables a~_k = c_k T^k, derivative rows scaled by T^d), which
 //    is an analytic equilibration: every basis row depends only on tau_j = j/res, identical for all
 //    pieces and trajectories (tables + their Gram matrices built once per workgroup), and the cost
@@ -708,7 +709,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   }
 }
 
-// LDS bytes without / with z, y resident; the launcher keeps z, y in LDS when the larger figure fits.
+// LDS bytes without / with the per-row state resident; the launcher keeps it in LDS when the larger figure fits.
 template <int S>
 inline size_t qp_admm_lds_bytes(int N, int R, int M, bool zy_in_lds) {
   constexpr int D = 2 * S, NB = 3 * D;
