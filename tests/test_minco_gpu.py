@@ -3,6 +3,7 @@ KKT solutions computed from the reference-assembled QP matrices."""
 import numpy as np
 import pytest
 
+from oracle import cbind
 from oracle import minco_np as onp
 from tests.util import golden_files, random_problem, rel_err
 
@@ -105,3 +106,22 @@ def test_large_batch_properties(anet_ctx):
         z = coeffs[:, i, :, :4]                                               # (B,3,4)
         e2 += np.einsum("bak,klb,bal->b", z, Q, z)
     assert np.abs(e2 - energy).max() / energy.max() < 1e-9
+
+
+@pytest.mark.parametrize("s,c,N", [(4, 3, 8), (3, 3, 16), (4, 4, 8)])
+def test_duration_spread_accuracy_envelope(anet_ctx, s, c, N):
+    """Durations spread over a factor 25 and 100 INSIDE one trajectory (the planner's network outputs stay within
+    ~20).  The Hermite / block-LDL' form has no pivoting, so its error grows with the spread faster than the
+    oracle's pivoted banded LU; this pins the envelope: well inside the north star's 1e-6 on coefficients and
+    energy up to a spread of 100 (beyond ~10^3 the snap coefficients drift to 1e-4..1e-3)."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(100 + s + N)
+    B = 300
+    head, tail, wps, T = random_problem(rng, B, N, c)
+    for half_decades, tol in ((0.7, 1e-8), (1.0, 1e-6)):
+        Tm = 10.0 ** rng.uniform(-half_decades, half_decades, size=T.shape)
+        co, en = aa.minco_solve(head, tail, wps, Tm, s, ctx=anet_ctx)
+        cc, ec = cbind.minco_solve_batch(s, head, tail, wps, Tm)
+        err = np.array([np.abs(co[b] - cc[b]).max() / np.abs(cc[b]).max() for b in range(B)])
+        assert err.max() <= tol, (half_decades, err.max())
+        assert np.abs(en - ec).max() <= 1e-9 * np.abs(ec).max()
