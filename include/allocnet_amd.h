@@ -306,8 +306,8 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
  * with respect to the segment durations -- the "time-allocation gradient" the reference's training loop
  * is after (network/layers.py:120-147 installs a -J^-1 grad KKT hook for it, a dense (n+m)^2 solve per
  * sample).  Because the loss IS the QP objective, no KKT solve is needed: by the
- * envelope theorem the derivative is dL/dT at the optimum, assembled inside the ADMM kernel from the
- * solution and its multipliers (allocnet_amd/csrc/qp_admm.h).  Exact at the optimum of a problem with a
+ * envelope theorem the derivative is dL/dT at the optimum, assembled inside the solve kernel (either method)
+ * from the solution and its multipliers (allocnet_amd/csrc/qp_admm.h, qp_ipm.h).  Exact at the optimum of a problem with a
  * stable active set; its accuracy follows the solve tolerance.  Not what the reference's autograd
  * delivers today (its z is a detached leaf: that quantity is anet_traj_cost_grad_T) -- see DESIGN.md 8b. */
 int anet_qp_solve_time_grad(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
