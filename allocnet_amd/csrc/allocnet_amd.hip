@@ -158,8 +158,22 @@ int launch_prop(anet_ctx *ctx, const anet::PropArgs &a, hipStream_t st) {
   const dim3 grid((unsigned)((a.B + anet::kSolveBlock - 1) / anet::kSolveBlock));
   const dim3 block(anet::kSolveBlock);
   if (a.B <= axis_variant_max_batch()) {  // same small-batch split as launch_solve
-    // (generic instantiations only: the fully specialised ones spill here -- tools/kernel_resources.sh)
     const dim3 g3((unsigned)((a.B + 20) / 21));
+    bool done = true;
+    if constexpr (S == 4) {
+      if (a.N == 8 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate_axis<4, 8, true, 2>), g3, block, 0, st, a);
+      else if (a.N == 8 && a.c == 4) hipLaunchKernelGGL((anet::k_minco_propagate_axis<4, 8, true, 3>), g3, block, 0, st, a);
+      else done = false;
+    } else if constexpr (S == 3) {
+      if (a.N == 16 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate_axis<3, 16, true, 2>), g3, block, 0, st, a);
+      else done = false;
+    } else {
+      done = false;
+    }
+    if (done) {
+      ANET_HIP(ctx, hipGetLastError());
+      return ANET_OK;
+    }
     if (a.N <= 4) hipLaunchKernelGGL((anet::k_minco_propagate_axis<S, 4>), g3, block, 0, st, a);
     else if (a.N <= 8) hipLaunchKernelGGL((anet::k_minco_propagate_axis<S, 8>), g3, block, 0, st, a);
     else hipLaunchKernelGGL((anet::k_minco_propagate_axis<S, 16>), g3, block, 0, st, a);

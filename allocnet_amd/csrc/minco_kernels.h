@@ -399,7 +399,11 @@ struct PropArgs {
 };
 
 // One axis of the adjoint: accumulates this axis' share of dJ/dT into gT and stores its gradP rows.
-template <int S, int NB>
+// CHAIN (fully specialised small-batch instantiations): 1/T of a piece is made to depend, through an empty asm, on
+// the previous step of the sweep it is used in.  Without the masks of the generic code the body is one straight-line
+// block and the scheduler computes every piece's powers of 1/T up front for all three sweeps, which spills
+// (~1 KB/lane); the false dependency keeps each piece's powers next to their use.
+template <int S, int NB, bool CHAIN = false>
 __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int N, const int np, const PropArgs &a,
                                                const int64_t b, const int ax, const double Tlast,
                                                double (&gT)[NB], const bool store) {
@@ -452,17 +456,49 @@ __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int
     for (int l = 0; l < m; ++l) XA[k][l] = 0.0;
   }
   // ---- g_x = Phi' gdC and the direct dPhi/dT term
+  // CHAIN: the loads of piece i+1 (its gdC, the state of node i+2) are issued before piece i is computed, so each
+  // piece no longer starts with a full L2 round trip; the state of the last node is computed once.
+  double xN[S], xc[S], xn1[S], xn2[S] = {}, gnext[D];
+  if constexpr (CHAIN) {
+    node_state(ca, N, xN);
+    node_state(ca, 0, xc);
+    if (N > 1) node_state(ca, 1, xn1);
+#pragma unroll
+    for (int col = 0; col < D; ++col) gnext[col] = ga[(int64_t)col * ld];
+  }
 #pragma unroll
   for (int i = 0; i < NB; ++i)
     if (i < N) {
+      if constexpr (CHAIN)
+        if (i > 0) asm volatile("" : "+v"(rr[i]) : "v"(gT[i - 1]));
       Pw<S> p(rr[i]);
       double gc[D];
-#pragma unroll
-      for (int col = 0; col < D; ++col) gc[col] = ga[(int64_t)(i * 3 * D + col) * ld];
       // low powers k < S: c_k = x_i[k]/k!
       double x0[S], x1[S];
-      node_state(ca, i, x0);
-      node_state(ca, i + 1, x1);
+      if constexpr (CHAIN) {
+#pragma unroll
+        for (int col = 0; col < D; ++col) gc[col] = gnext[col];
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          x0[j] = xc[j];
+          x1[j] = (i + 1 < N) ? xn1[j] : xN[j];
+        }
+        if (i + 1 < N) {
+#pragma unroll
+          for (int col = 0; col < D; ++col) gnext[col] = ga[(int64_t)((i + 1) * 3 * D + col) * ld];
+        }
+        if (i + 2 < N) node_state(ca, i + 2, xn2);
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          xc[j] = x1[j];
+          xn1[j] = xn2[j];
+        }
+      } else {
+#pragma unroll
+        for (int col = 0; col < D; ++col) gc[col] = ga[(int64_t)(i * 3 * D + col) * ld];
+        node_state(ca, i, x0);
+        node_state(ca, i + 1, x1);
+      }
       auto addg = [&](int node, int dg, double v) {  // node-state adjoint: slot 0 = position
         if (dg == 0) GP[node] += v;
         else XA[node][dg - 1] += v;
@@ -495,6 +531,8 @@ __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int
     }
   // ---- adjoint solve K lam = g_x|free (pinned rows 0)
   sweep_forward<S, NB>(F, N, np, rr, XA, [&](int k, double (&y)[m]) {
+    if constexpr (CHAIN)
+      if (k > 0) asm volatile("" : "+v"(rr[k - 1]) : "v"(XA[k - 1][0]));
 #pragma unroll
     for (int l = 0; l < m; ++l) y[l] = ((k == 0 || k == N) && l < np) ? 0.0 : XA[k][l];
   });
@@ -502,6 +540,14 @@ __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int
   for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
   const double *cb2 = ca;
   asm volatile("" : "+v"(cb2));
+  // CHAIN: piece k needs the states of nodes k and k+1; node k+1 is kept from the previous step and node k-1 is
+  // requested while piece k is computed
+  double ya[S], yb[S], yp[S] = {};
+  if constexpr (CHAIN) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) yb[j] = xN[j];
+    node_state(cb2, N - 1, ya);
+  }
   sweep_backward<S, NB>(F, N, np, rr, XA, [&](int k, const Pw<S> &p) {
     // (W_k lam^)[position row of node k]; the row of node k+1 is its negative
     double wl = 0.0;
@@ -514,8 +560,19 @@ __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int
     GP[k + 1] += wl;
     // - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b
     double x0[S], x1[S], xs[2 * S];
-    node_state(cb2, k, x0);
-    node_state(cb2, k + 1, x1);
+    if constexpr (CHAIN) {
+      if (k > 0) node_state(cb2, k - 1, yp);
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        x0[j] = ya[j];
+        x1[j] = yb[j];
+        yb[j] = ya[j];
+        ya[j] = yp[j];
+      }
+    } else {
+      node_state(cb2, k, x0);
+      node_state(cb2, k + 1, x1);
+    }
 #pragma unroll
     for (int bb = 0; bb < 2 * S; ++bb) xs[bb] = ((bb < S) ? x0[bb % S] : x1[bb % S]) * p[S - bb % S];
     double acc = 0.0;
@@ -531,6 +588,8 @@ __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int
       acc = __builtin_fma(ls, row, acc);
     }
     gT[k] += acc;
+    if constexpr (CHAIN)
+      if (k > 0) asm volatile("" : "+v"(rr[k - 1]) : "v"(gT[k]));
   });
 #pragma unroll
   for (int k = 1; k < NB; ++k)
@@ -593,30 +652,41 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate_axis(PropArgs a
   const int64_t bb = live ? b : 0;
 
   Factor<S, NB> F;
-  double gT[NB];
+  double gT[NB], tt[NB];
   double tsum = 0.0, Tlast = 0.0;
+  // (all loads of a group first, then their uses: interleaved, every load is followed by a full wait)
+#pragma unroll
+  for (int i = 0; i < NB; ++i) tt[i] = a.T[(i < N ? i : 0) * ld + bb];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     gT[i] = 0.0;
     if (i < N) {
-      const double t = a.T[i * ld + bb];
+      const double t = tt[i];
       F.r[i] = fast_rcp(t);
       tsum += t;
       if (i == N - 1) Tlast = t;
     }
   }
   F.factorize(N, np);
-  propagate_axis<S, NB>(F, N, np, a, bb, ax, Tlast, gT, live);
+  propagate_axis<S, NB, NEXACT>(F, N, np, a, bb, ax, Tlast, gT, live);
 
+  double gd[NB], tu[NB], pc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int64_t o = (i < N ? i : 0) * ld + bb;
+    gd[i] = a.gdT[o];
+    tu[i] = a.tau ? a.tau[o] : 0.0;
+    pc[i] = a.pcost ? a.pcost[o] : 0.0;
+  }
   double csum = 0.0;
 #pragma unroll
   for (int i = 0; i < NB; ++i)
     if (i < N) {
       const double tot = gT[i] + __shfl_down(gT[i], 1) + __shfl_down(gT[i], 2);
       if (live && ax == 0) {
-        const double gt = a.gdT[i * ld + bb] + tot + a.rho;
-        a.gradT[i * ld + bb] = a.tau ? gt * dforward_T(a.tau[i * ld + bb]) : gt;
-        if (a.pcost) csum += a.pcost[i * ld + bb];
+        const double gt = gd[i] + tot + a.rho;
+        a.gradT[i * ld + bb] = a.tau ? gt * dforward_T(tu[i]) : gt;
+        csum += pc[i];
       }
     }
   if (a.cost && live && ax == 0) a.cost[bb] = (a.energy_in ? a.energy_in[bb] : 0.0) + a.rho * tsum + csum;
