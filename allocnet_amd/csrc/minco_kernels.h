@@ -403,7 +403,7 @@ struct PropArgs {
 // the previous step of the sweep it is used in.  Without the masks of the generic code the body is one straight-line
 // block and the scheduler computes every piece's powers of 1/T up front for all three sweeps, which spills
 // (~1 KB/lane); the false dependency keeps each piece's powers next to their use.
-template <int S, int NB, bool CHAIN = false>
+template <int S, int NB, bool CHAIN = false, bool PIPE = CHAIN>
 __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int N, const int np, const PropArgs &a,
                                                const int64_t b, const int ax, const double Tlast,
                                                double (&gT)[NB], const bool store) {
@@ -459,7 +459,7 @@ __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int
   // CHAIN: the loads of piece i+1 (its gdC, the state of node i+2) are issued before piece i is computed, so each
   // piece no longer starts with a full L2 round trip; the state of the last node is computed once.
   double xN[S], xc[S], xn1[S], xn2[S] = {}, gnext[D];
-  if constexpr (CHAIN) {
+  if constexpr (PIPE) {
     node_state(ca, N, xN);
     node_state(ca, 0, xc);
     if (N > 1) node_state(ca, 1, xn1);
@@ -475,7 +475,7 @@ __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int
       double gc[D];
       // low powers k < S: c_k = x_i[k]/k!
       double x0[S], x1[S];
-      if constexpr (CHAIN) {
+      if constexpr (PIPE) {
 #pragma unroll
         for (int col = 0; col < D; ++col) gc[col] = gnext[col];
 #pragma unroll
@@ -543,7 +543,7 @@ __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int
   // CHAIN: piece k needs the states of nodes k and k+1; node k+1 is kept from the previous step and node k-1 is
   // requested while piece k is computed
   double ya[S], yb[S], yp[S] = {};
-  if constexpr (CHAIN) {
+  if constexpr (PIPE) {
 #pragma unroll
     for (int j = 0; j < S; ++j) yb[j] = xN[j];
     node_state(cb2, N - 1, ya);
@@ -560,7 +560,7 @@ __device__ __forceinline__ void propagate_axis(const Factor<S, NB> &F, const int
     GP[k + 1] += wl;
     // - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b
     double x0[S], x1[S], xs[2 * S];
-    if constexpr (CHAIN) {
+    if constexpr (PIPE) {
       if (k > 0) node_state(cb2, k - 1, yp);
 #pragma unroll
       for (int j = 0; j < S; ++j) {
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate_axis(PropArgs a
     }
   }
   F.factorize(N, np);
-  propagate_axis<S, NB, NEXACT>(F, N, np, a, bb, ax, Tlast, gT, live);
+  propagate_axis<S, NB, NEXACT, true>(F, N, np, a, bb, ax, Tlast, gT, live);
 
   double gd[NB], tu[NB], pc[NB];
 #pragma unroll
