@@ -88,6 +88,7 @@ inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 // Up to this batch the axis-parallel kernel is used (3*B/63 waves still fit the chip's 1024 SIMDs about
 // once); measured crossover on MI355X in DESIGN.md section 4.
+constexpr int64_t kPieceSampleSplitMaxPairs = 16384;  // (trajectory, piece) pairs up to which k_piece_grad splits the samples over waves
 constexpr int64_t kAxisVariantMaxBatchDefault = 16384;
 inline int64_t axis_variant_max_batch() {  // ANET_AXIS_MAX_BATCH overrides (tuning / A-B runs)
   static const int64_t v = [] {
@@ -686,7 +687,15 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
     ctx->tab_res = pen->res;
   }
   const double *tab = ctx->d_tab;
-  if (pen && batch <= axis_variant_max_batch()) {  // small batches: two lanes per (trajectory, piece)
+  // ANET_PIECE_SW_MAX_PAIRS overrides (tuning / A-B runs)
+  static const int64_t sw_max_pairs = [] { const char *e = getenv("ANET_PIECE_SW_MAX_PAIRS"); return e ? (int64_t)atoll(e) : kPieceSampleSplitMaxPairs; }();
+  if (pen && batch <= axis_variant_max_batch() && batch * n_pieces <= sw_max_pairs) {
+    // fewest waves: two lanes per (trajectory, piece) AND the samples spread over the four waves of a workgroup
+    const dim3 g4((unsigned)((2 * batch + 63) / 64), (unsigned)n_pieces);
+    if (s == 2) hipLaunchKernelGGL((anet::k_piece_grad<2, true, 4>), g4, block, 0, st, a, tab);
+    else if (s == 3) hipLaunchKernelGGL((anet::k_piece_grad<3, true, 4>), g4, block, 0, st, a, tab);
+    else hipLaunchKernelGGL((anet::k_piece_grad<4, true, 4>), g4, block, 0, st, a, tab);
+  } else if (pen && batch <= axis_variant_max_batch()) {  // small batches: two lanes per (trajectory, piece)
     const dim3 g2((unsigned)((2 * batch + 255) / 256), (unsigned)n_pieces);
     if (s == 2) hipLaunchKernelGGL((anet::k_piece_grad<2, true>), g2, block, 0, st, a, tab);
     else if (s == 3) hipLaunchKernelGGL((anet::k_piece_grad<3, true>), g2, block, 0, st, a, tab);

@@ -193,10 +193,16 @@ __device__ __forceinline__ double pair_sum(double v) {  // v + the value of the 
   return v + __hiloint2double(hi, lo);
 }
 
-template <int S, bool SPLIT = false>
-__global__ void __launch_bounds__(256, 2) k_piece_grad(PieceGradArgs a, const double *__restrict__ tab) {
+// SW = 4 (smaller batches still, with SPLIT): the four WAVES of a workgroup take every fourth sample of the SAME 32
+// (trajectory, piece) pairs -- the sample index stays wave-uniform, so the basis table is still read with scalar
+// loads -- and their partial gradients are summed through LDS by wave 0.  A quarter of the dependent chain per lane
+// and four times the waves: at 4096 x 8 pieces the two-lane variant leaves one wave per SIMD.
+template <int S, bool SPLIT = false, int SW = 1>
+__global__ void __launch_bounds__(256, SW > 1 ? 1 : 2) k_piece_grad(PieceGradArgs a, const double *__restrict__ tab) {
   constexpr int D = 2 * S;
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  static_assert(SW == 1 || SPLIT, "the sample split builds on the two-lane variant");
+  const int wv = SW > 1 ? (int)(threadIdx.x >> 6) : 0;  // which samples: j = wv, wv + SW, ...
+  const int64_t gid = SW > 1 ? (int64_t)blockIdx.x * 64 + (threadIdx.x & 63) : (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int half = SPLIT ? (int)(gid & 1) : 0;
   const int64_t bq = SPLIT ? (gid >> 1) : gid;
   const bool live = bq < a.B;
@@ -214,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) k_piece_grad(PieceGradArgs a, const do
       gC[ax][col] = 0.0;
     }
   double gT = 0.0, pc = 0.0;
-  if (a.with_energy && half == 0) {
+  if (a.with_energy && half == 0 && wv == 0) {
     // d/dc of sum_{j,k>=S} c_j c_k f_j f_k T^(j+k-2S+1)/(j+k-2S+1) ;  d/dT = (p^(S)(T))^2
     double tp[D];
     tp[0] = 1.0;
@@ -287,7 +293,7 @@ __global__ void __launch_bounds__(256, 2) k_piece_grad(PieceGradArgs a, const do
           hr[r][q] = ok ? a.hpolys[(int64_t)((i * pp.M + rr) * 4 + q) * ld + b] : 0.0;
       }
       const bool first = SPLIT ? (half == 1 && pass == 0) : (ch == 0);  // the pass that also evaluates the box rows
-      for (int j = 0; j < pp.res; ++j) {
+      for (int j = wv; j < pp.res; j += SW) {
         const double *tb = tab + (size_t)j * 4 * D;
         double st[4][3];
 #pragma unroll
@@ -375,6 +381,29 @@ __global__ void __launch_bounds__(256, 2) k_piece_grad(PieceGradArgs a, const do
       for (int col = 0; col < D; ++col) gC[ax][col] = pair_sum(gC[ax][col]);
     gT = pair_sum(gT);
     pc = pair_sum(pc);
+    if constexpr (SW > 1) {  // sum over the waves of the workgroup (fixed order: deterministic)
+      __shared__ double red[SW - 1][3 * D + 2][32];
+      const int pl = (int)(threadIdx.x & 63) >> 1;
+      if (wv > 0 && half == 0) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+          for (int col = 0; col < D; ++col) red[wv - 1][ax * D + col][pl] = gC[ax][col];
+        red[wv - 1][3 * D][pl] = gT;
+        red[wv - 1][3 * D + 1][pl] = pc;
+      }
+      __syncthreads();
+      if (wv != 0) return;
+#pragma unroll
+      for (int q = 0; q < SW - 1; ++q) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+          for (int col = 0; col < D; ++col) gC[ax][col] += red[q][ax * D + col][pl];
+        gT += red[q][3 * D][pl];
+        pc += red[q][3 * D + 1][pl];
+      }
+    }
     if (!live || half != 0) return;
   }
 #pragma unroll

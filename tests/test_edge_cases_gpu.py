@@ -133,3 +133,27 @@ def test_gradient_propagation_lane_and_axis_kernels_agree(anet_ctx, s, c, N):
     c3, gP3, gT3 = aa.minco_cost_grad(head[:odd], tail[:odd], wps[:odd], T[:odd], s, penalty=pen, ctx=anet_ctx)
     assert np.abs(gT3 - gT[:odd]).max() <= 1e-10 * max(1.0, np.abs(gT).max())
     assert np.abs(gP3 - gP[:odd]).max() <= 1e-10 * max(1.0, np.abs(gP).max())
+
+
+@pytest.mark.parametrize("s,c,N,M", [(4, 3, 8, 16), (3, 3, 5, 10), (3, 3, 16, 9)])
+def test_penalty_kernel_launch_shapes_agree(anet_ctx, s, c, N, M):
+    """k_piece_grad has three launch shapes: one lane per (trajectory, piece) above 16384 trajectories, two lanes
+    per pair below, and -- up to 16384 pairs -- the samples spread over the four waves of a workgroup as well.
+    Corridor rows, box rows and the energy part are split differently in each; the sums must agree."""
+    import allocnet_amd as aa
+    from tests.util import corridor_problem
+    rng = np.random.default_rng(5 * N + s + M)
+    B = 16384 + 200
+    head, tail, wps, T, hp = corridor_problem(rng, B, N, c, M)
+    hp[:, :, :, 3] -= 0.8          # tighten the corridors so that rows are active
+    pen = aa.make_penalty(rho=2.0, w_corridor=300.0, w_vel=20.0, w_acc=8.0, smooth_mu=0.05, max_vel=1.5, max_acc=2.0,
+                          res=7, poly_rows=M)
+    full = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, ctx=anet_ctx)            # lane per pair
+    n2 = 16384 // N + 40                                                                              # two lanes
+    n4 = 16384 // N - 40                                                                              # + sample split
+    assert (full[0] > 0).all()
+    for n in (n2, n4, 1, 33):
+        part = aa.minco_cost_grad(head[:n], tail[:n], wps[:n], T[:n], s, hpolys=hp[:n], penalty=pen, ctx=anet_ctx)
+        assert rel_err(part[0], full[0][:n]) < 1e-12
+        for g, gf in zip(part[1:], full[1:]):
+            assert np.abs(g - gf[:n]).max() <= 1e-10 * max(1.0, np.abs(gf).max())
