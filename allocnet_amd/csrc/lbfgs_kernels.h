@@ -384,9 +384,13 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
               hs[it][q] = sj[iv[q] * vs];
               hy[it][q] = yj[iv[q] * vs];
             }
-          hys[it] = uniform_f64(a.lm_ys[(int64_t)jj * ld + b]);
+          hys[it] = a.lm_ys[(int64_t)jj * ld + b];
         }
       }
+      // (made wave-uniform only after every slot's loads are out: a readfirstlane right behind its load would put
+      //  one full wait per slot into the loop above)
+#pragma unroll
+      for (int it = 1; it < MR; ++it) hys[it] = uniform_f64(hys[it]);
     }
   }
 
