@@ -78,3 +78,41 @@ def test_energy_only_gradient_finite_difference(anet_ctx):
         fd = (aa.minco_cost_grad(head, tail, wps, tp, s, penalty=pen, ctx=anet_ctx)[0]
               - aa.minco_cost_grad(head, tail, wps, tm, s, penalty=pen, ctx=anet_ctx)[0]) / (2 * h)
         assert np.abs(fd - gT[:, i]).max() <= 2e-5 * max(1.0, np.abs(gT[:, i]).max())
+
+
+def test_random_shapes_against_both_oracles(anet_ctx):
+    """Every (order, boundary count, piece count) combination the kernels are instantiated for is reachable
+    here: 30 random shapes with random batch sizes, coefficients and energy against the C restatement for the whole
+    batch, cost and gradients against the numpy adjoint on two members of each."""
+    import allocnet_amd as aa
+    from oracle import cbind
+    rng = np.random.default_rng(4242)
+    seen = set()
+    for trial in range(30):
+        s = int(rng.integers(3, 5))
+        c = int(rng.integers(1, s + 1))
+        N = int(rng.integers(1, 17))
+        M = int(rng.choice([0, 3, 8, 11, 16]))
+        B = int(rng.choice([1, 2, 20, 21, 22, 63, 64, 65, 130]))
+        seen.add((s, c, N))
+        head, tail, wps, T = random_problem(rng, B, N, c)
+        hp = make_corridors(rng, head, tail, wps, M) if M else None
+        kw = dict(res=int(rng.integers(2, 9)), vmax=1.5, amax=2.5, wc=60.0, wv=25.0, wa=9.0, mu=0.05)
+        pen = aa.make_penalty(rho=0.8, w_corridor=kw["wc"], w_vel=kw["wv"], w_acc=kw["wa"], smooth_mu=kw["mu"],
+                              max_vel=kw["vmax"], max_acc=kw["amax"], res=kw["res"], poly_rows=M)
+        cost, gP, gT, co = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, want_coeffs=True,
+                                              ctx=anet_ctx)
+        cc, ec = cbind.minco_solve_batch(s, head, tail, wps, T)
+        assert rel_err(co, cc) < 1e-8, (s, c, N, B)
+        for b in {0, B - 1}:
+            hpb = np.transpose(hp[b], (1, 2, 0)) if M else np.zeros((1, 4, N))
+            co0, e0, *_ = onp.minco_dense_solve(s, head[b], tail[b], wps[b].T, T[b])
+            jp, gC, gTp, pc = onp.penalty_partials(s, co0, T[b], hpb, **kw)
+            eC, eT = onp.energy_partials(s, co0, T[b])
+            gP0, gT0 = onp.minco_dense_propagate(s, head[b], tail[b], wps[b].T, T[b], gC + eC, gTp + eT + 0.8)
+            c0 = e0 + 0.8 * T[b].sum() + jp
+            assert abs(cost[b] - c0) <= 1e-8 * abs(c0), (s, c, N, B)
+            if N > 1:
+                assert np.abs(gP[b].T - gP0).max() <= 1e-6 * max(1.0, np.abs(gP0).max()), (s, c, N, B)
+            assert np.abs(gT[b] - gT0).max() <= 1e-6 * max(1.0, np.abs(gT0).max()), (s, c, N, B)
+    assert len(seen) >= 20
