@@ -90,31 +90,32 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_solve_axis(SolveArgs a) {
   const int64_t ld = a.ld;
   const int64_t bb = live ? b : 0;  // idle lanes compute on trajectory 0 and store nothing
 
+  // Every load is issued before the first use and none sits behind a branch on the (runtime) piece count: with one
+  // wave per SIMD each load-then-use pair is a full L2 round trip of dead time, and the generic instantiations had
+  // fifteen of them here.
   Factor<S, NB> F;
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-    if (i < N) F.r[i] = fast_rcp(a.T[i * ld + bb]);
-  F.factorize(N, np);
-
-  double P[NB + 1], hv[m], tv[m], X[NB + 1][m];
+  double P[NB + 1], hv[m], tv[m], X[NB + 1][m], tt[NB];
   const double *hp = a.head + (int64_t)(ax * c) * ld + bb;
   const double *tp = a.tail + (int64_t)(ax * c) * ld + bb;
 #pragma unroll
+  for (int i = 0; i < NB; ++i) tt[i] = a.T[(int64_t)(i < N ? i : 0) * ld + bb];
+#pragma unroll
   for (int k = 0; k <= NB; ++k) {
-    if (k == 0)
-      P[k] = hp[0];
-    else if (k < N)
-      P[k] = a.wps[(int64_t)((k - 1) * 3 + ax) * ld + bb];
-    else if (k == N)
-      P[k] = tp[0];
-    else
-      P[k] = 0.0;
+    const double *src = (k == 0) ? hp : (k < N) ? a.wps + (int64_t)((k - 1) * 3 + ax) * ld + bb : tp;
+    const double v = *src;
+    P[k] = (k <= N) ? v : 0.0;
   }
 #pragma unroll
   for (int j = 0; j < m; ++j) {
-    hv[j] = (j < np) ? hp[(int64_t)(1 + j) * ld] : 0.0;
-    tv[j] = (j < np) ? tp[(int64_t)(1 + j) * ld] : 0.0;
+    const int64_t row = (j < np) ? 1 + j : 0;  // (rows past c-1 belong to the next axis: read row 0 instead)
+    const double h = hp[row * ld], t = tp[row * ld];
+    hv[j] = (j < np) ? h : 0.0;
+    tv[j] = (j < np) ? t : 0.0;
   }
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i < N) F.r[i] = fast_rcp(tt[i]);
+  F.factorize(N, np);
   double *cp = (a.coeffs && live) ? a.coeffs + (int64_t)(ax * D) * ld + bb : nullptr;
   double e = solve_axis<S, NB>(F, N, np, P, hv, tv, X, [&](int piece, int col, double v) {
     if (cp) cp[(int64_t)(piece * 3 * D + col) * ld] = v;
