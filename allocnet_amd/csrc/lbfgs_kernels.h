@@ -313,10 +313,27 @@ template <int LBFGS_WAVE_MREG>
 struct LbfgsWaveShape {
   static constexpr int kWaves = (LBFGS_WAVE_MREG > 8) ? 4 : (LBFGS_WAVE_MREG > 0) ? 8 : 16;  // register budget
 };
+// The register copy of the (s, y) history: slot `it` = the it-th pair behind the one an accepted step is about to
+// add (slot 0 = that new pair).  The per-launch kernel fills it from memory every tick; the one-launch kernel
+// (CARRY) keeps it across its iterations and only shifts it by one slot when a pair is stored.
+template <int MR, int NV>
+struct WaveHistory {
+  double s[MR][NV], y[MR][NV], ys[MR];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int it = 0; it < MR; ++it) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) s[it][q] = y[it][q] = 0.0;
+      ys[it] = 1.0;
+    }
+  }
+};
 // NV: variables per lane (1 for n <= 64, 2 for n <= 128)
-template <int LBFGS_WAVE_MREG, int NV = 2>
-__device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const int64_t b, const int lane) {
+template <int LBFGS_WAVE_MREG, int NV = 2, bool CARRY = false>
+__device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const int64_t b, const int lane,
+                                                       WaveHistory<(LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1), NV> &H) {
   constexpr int MR = LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1;
+  double (&hs)[MR][NV] = H.s, (&hy)[MR][NV] = H.y, (&hys)[MR] = H.ys;
   const int64_t ld = a.ld;
   int *is = a.is + b;
   double *ds = a.ds + b;
@@ -364,11 +381,10 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
   double *lms = a.lm_s + b * ps * m, *lmy = a.lm_y + b * ps * m;  // [j][i] at (j*js + i*vs)
   const int64_t js = (vs == 1) ? ps : (int64_t)n * vs;             // stride between history slots
   const bool hist_in_regs = LBFGS_WAVE_MREG > 0 && m <= LBFGS_WAVE_MREG;
-  double hs[MR][NV], hy[MR][NV], hys[MR];
   double pf_old = 0.0;
   if (phase != 0) {
     if (0 < P.past && P.past <= k) pf_old = a.pf[(int64_t)(k % P.past) * ld + b];
-    if (hist_in_regs) {
+    if (hist_in_regs && !CARRY) {
       const int nb = (bound + 1 < m) ? bound + 1 : m;  // bound after an accepted step
 #pragma unroll
       for (int it = 1; it < MR; ++it) {
@@ -544,6 +560,17 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
                   for (int q = 0; q < NV; ++q) dv[q] = __builtin_fma(cf, hs[it][q], dv[q]);
                 }
               }
+              {  // the pair was stored: it is one slot behind the next new pair (dead code unless H is carried)
+#pragma unroll
+                for (int it = MR - 1; it > 0; --it) {
+#pragma unroll
+                  for (int q = 0; q < NV; ++q) {
+                    hs[it][q] = hs[it - 1][q];
+                    hy[it][q] = hy[it - 1][q];
+                  }
+                  hys[it] = hys[it - 1];
+                }
+              }
             } else {
               int j = end;
               double alpha = 0.0;  // lane `it` keeps alpha of the it-th visited slot (mem_size <= 64, host-checked)
@@ -644,7 +671,8 @@ __global__ void __launch_bounds__(64 * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves, 
 k_lbfgs_update_wave(LbfgsArgs a) {
   const int64_t b = (int64_t)blockIdx.x * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves + (threadIdx.x >> 6);
   if (b >= a.B) return;  // whole waves only: the reductions need all 64 lanes
-  lbfgs_update_wave_body<LBFGS_WAVE_MREG, NV>(a, b, threadIdx.x & 63);
+  WaveHistory<(LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1), NV> H;
+  lbfgs_update_wave_body<LBFGS_WAVE_MREG, NV>(a, b, threadIdx.x & 63, H);
 }
 
 // firi::costMVIE (gcopter/firi.hpp:86-157): x = [p, rtd, cde], A is M x 3 column-major per problem
@@ -781,11 +809,18 @@ k_lbfgs_mvie_persistent(LbfgsArgs la, MvieArgs ma, int max_evals) {
   if (b >= la.B) return;
   const int lane = threadIdx.x & 63;
   const int *done = la.is + (int64_t)IS_DONE * la.ld + b;
+  // When mem_size fits, the history stays in registers across the iterations: the first one fills it from memory
+  // as the per-launch kernel does (nothing to read in a fresh run), the later ones carry it.
+  WaveHistory<(LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1), 1> H;
+  H.clear();
+  const bool carry = LBFGS_WAVE_MREG > 0 && la.p.mem_size <= LBFGS_WAVE_MREG;
   for (int e = 0; e < max_evals; ++e) {
     if (__builtin_amdgcn_readfirstlane(*(volatile const int *)done)) break;
     mvie_eval_wave(ma, b, lane);
     __threadfence_block();
-    lbfgs_update_wave_body<LBFGS_WAVE_MREG, 1>(la, b, lane);  // nine variables: one per lane
+    // nine variables: one per lane
+    if (carry && e > 0) lbfgs_update_wave_body<LBFGS_WAVE_MREG, 1, true>(la, b, lane, H);
+    else lbfgs_update_wave_body<LBFGS_WAVE_MREG, 1>(la, b, lane, H);
     __threadfence_block();
   }
 }
