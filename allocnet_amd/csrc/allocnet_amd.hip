@@ -243,7 +243,7 @@ static int ensure_counter(anet_ctx *ctx) {
 }
 
 // eval(): enqueue the objective at L.x -> L.feval, L.g (for all problems).  The loop advances every
-// problem by one evaluation per pass and polls the number of unfinished problems every `poll` passes.
+// problem by one evaluation per pass and polls an "any problem still running" flag every `poll` passes.
 template <class Eval>
 static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfgs_params &prm, int max_evals,
                        hipStream_t st, Eval &&eval, double *map_T = nullptr, int map_nw = 0, bool reset = true) {

@@ -34,7 +34,7 @@ struct LbfgsArgs {
   const double *feval;
   int *is;
   LbfgsP p;
-  int *n_active;
+  int *n_active;  // optional: set to 1 by every problem that is still running after this tick
   int64_t vs, ps;  // internal vectors (xp, gp, d, lm_s, lm_y): element i of problem b at [i*vs + b*ps]
   // MINCO objective: variables [map_nw, n) are tau of the durations; wherever x is written the mapped
   // duration T = forward_T(tau) is written too (saves a launch per evaluation).  nullptr: no mapping.
@@ -247,7 +247,7 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
     is[IS_DONE * ld] = 1;
     is[IS_RET * ld] = finish;
   } else if (a.n_active) {
-    atomicAdd(a.n_active, 1);
+    *a.n_active = 1;  // a flag, not a count: 10^5 atomics on one address cost more than the rest of the tick
   }
 }
 
@@ -386,13 +386,14 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
     if (0 < P.past && P.past <= k) pf_old = a.pf[(int64_t)(k % P.past) * ld + b];
     if (hist_in_regs && !CARRY) {
       const int nb = (bound + 1 < m) ? bound + 1 : m;  // bound after an accepted step
+      int jj = end;                                     // walks backwards through the ring (no division per slot)
 #pragma unroll
       for (int it = 1; it < MR; ++it) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) hs[it][q] = hy[it][q] = 0.0;
         hys[it] = 1.0;
+        jj = (jj == 0 ? m : jj) - 1;                    // it-th slot behind the new one
         if (it < nb) {
-          const int jj = (end - it + m) % m;  // it-th slot behind the new one
           const double *sj = lms + (int64_t)jj * js, *yj = lmy + (int64_t)jj * js;
 #pragma unroll
           for (int q = 0; q < NV; ++q)
@@ -661,7 +662,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
       is[IS_DONE * ld] = 1;
       is[IS_RET * ld] = finish;
     } else if (a.n_active) {
-      atomicAdd(a.n_active, 1);
+      *a.n_active = 1;  // (flag: see k_lbfgs_update)
     }
   }
 }
