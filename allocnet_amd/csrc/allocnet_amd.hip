@@ -37,7 +37,8 @@ struct anet_ctx {
   size_t scratch_bytes = 0;
   // L-BFGS completion polling: device counter + pinned host mirror
   int *d_counter = nullptr;
-  int *h_counter = nullptr;
+  int *h_counter = nullptr;          // two pinned ints (polls alternate)
+  hipEvent_t poll_ev[2] = {nullptr, nullptr};
   // pinned host staging for single-trajectory calls (inputs are packed and sent with ONE copy)
   double *h_pack = nullptr;
   size_t h_pack_doubles = 0;
@@ -238,12 +239,17 @@ static anet::LbfgsP to_kernel_params(const anet_lbfgs_params &p) {
 
 static int ensure_counter(anet_ctx *ctx) {
   if (!ctx->d_counter) ANET_HIP(ctx, hipMalloc((void **)&ctx->d_counter, sizeof(int)));
-  if (!ctx->h_counter) ANET_HIP(ctx, hipHostMalloc((void **)&ctx->h_counter, sizeof(int), hipHostMallocDefault));
+  if (!ctx->h_counter) ANET_HIP(ctx, hipHostMalloc((void **)&ctx->h_counter, 2 * sizeof(int), hipHostMallocDefault));
+  for (int i = 0; i < 2; ++i)
+    if (!ctx->poll_ev[i]) ANET_HIP(ctx, hipEventCreateWithFlags(&ctx->poll_ev[i], hipEventDisableTiming));
   return ANET_OK;
 }
 
 // eval(): enqueue the objective at L.x -> L.feval, L.g (for all problems).  The loop advances every
 // problem by one evaluation per pass and polls an "any problem still running" flag every `poll` passes.
+// The poll is one group behind the enqueue: the flag of group g is read only after group g+1 is in the
+// stream, so the device never idles while the host looks.  The price is up to `poll` extra passes after the
+// last problem stopped; they change nothing (finished problems ignore evaluations).
 template <class Eval>
 static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfgs_params &prm, int max_evals,
                        hipStream_t st, Eval &&eval, double *map_T = nullptr, int map_nw = 0, bool reset = true) {
@@ -260,6 +266,7 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
                     L.feval, L.is, to_kernel_params(prm), nullptr, wave ? 1 : L.ld, wave ? L.n : 1, map_T, map_nw};
   const dim3 grid(wave ? (unsigned)B : (unsigned)((B + 63) / 64)), block(64);
   const int poll = 8;
+  int group = 0;
   for (int it = 0; it < max_evals; ++it) {
     if ((rc = eval())) return rc;
     const bool check = ((it + 1) % poll == 0) || it + 1 == max_evals;
@@ -290,11 +297,17 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
     }
     ANET_HIP(ctx, hipGetLastError());
     if (check) {
-      ANET_HIP(ctx, hipMemcpyAsync(ctx->h_counter, ctx->d_counter, sizeof(int), hipMemcpyDeviceToHost, st));
-      ANET_HIP(ctx, hipStreamSynchronize(st));
-      if (*ctx->h_counter == 0) break;
+      const int slot = group & 1;
+      ANET_HIP(ctx, hipMemcpyAsync(ctx->h_counter + slot, ctx->d_counter, sizeof(int), hipMemcpyDeviceToHost, st));
+      ANET_HIP(ctx, hipEventRecord(ctx->poll_ev[slot], st));
+      if (group > 0) {
+        ANET_HIP(ctx, hipEventSynchronize(ctx->poll_ev[slot ^ 1]));
+        if (ctx->h_counter[slot ^ 1] == 0) break;
+      }
+      ++group;
     }
   }
+  ANET_HIP(ctx, hipStreamSynchronize(st));
   return ANET_OK;
 }
 
@@ -351,6 +364,8 @@ void anet_destroy(anet_ctx *ctx) {
   if (ctx->d_counter) (void)hipFree(ctx->d_counter);
   if (ctx->d_tab) (void)hipFree(ctx->d_tab);
   if (ctx->h_counter) (void)hipHostFree(ctx->h_counter);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->poll_ev[i]) (void)hipEventDestroy(ctx->poll_ev[i]);
   if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
