@@ -237,6 +237,18 @@ static anet::LbfgsP to_kernel_params(const anet_lbfgs_params &p) {
                       p.min_step, p.max_step, p.f_dec_coeff, p.s_curv_coeff, p.cautious_factor, p.machine_prec};
 }
 
+// One wave per problem at every batch size: at 131072 x 29 variables the lane-per-problem update kernel took 1.67 ms
+// per tick (three times the objective evaluation), the wave kernel 0.4 ms.  The lane kernel remains for n > 128 or
+// mem_size > 64.
+constexpr int64_t kLbfgsWaveMaxBatchDefault = INT64_MAX;
+inline int64_t lbfgs_wave_max_batch() {  // ANET_LBFGS_WAVE_MAX_BATCH overrides (tuning / A-B runs)
+  static const int64_t v = [] {
+    const char *e = getenv("ANET_LBFGS_WAVE_MAX_BATCH");
+    return e ? (int64_t)atoll(e) : kLbfgsWaveMaxBatchDefault;
+  }();
+  return v;
+}
+
 static int ensure_counter(anet_ctx *ctx) {
   if (!ctx->d_counter) ANET_HIP(ctx, hipMalloc((void **)&ctx->d_counter, sizeof(int)));
   if (!ctx->h_counter) ANET_HIP(ctx, hipHostMalloc((void **)&ctx->h_counter, 2 * sizeof(int), hipHostMallocDefault));
@@ -259,9 +271,9 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
     ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * L.ld, st));
     ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_ * L.ld, st));
   }
-  // small batches: one wave per problem (shuffle reductions, internal vectors problem-major);
-  // large batches: one lane per problem (internal vectors batch-minor)
-  const bool wave = B <= 32768 && L.n <= 128 && prm.mem_size <= 64;
+  // one wave per problem (DPP reductions, internal vectors problem-major) whenever the problem fits a wave's
+  // registers; otherwise one lane per problem (internal vectors batch-minor)
+  const bool wave = B <= lbfgs_wave_max_batch() && L.n <= 128 && prm.mem_size <= 64;
   anet::LbfgsArgs a{L.n, B, L.ld, L.x, L.g, L.xp, L.gp, L.d, L.lm_s, L.lm_y, L.lm_ys, L.lm_alpha, L.pf, L.ds,
                     L.feval, L.is, to_kernel_params(prm), nullptr, wave ? 1 : L.ld, wave ? L.n : 1, map_T, map_nw};
   const dim3 grid(wave ? (unsigned)B : (unsigned)((B + 63) / 64)), block(64);
@@ -904,8 +916,8 @@ int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A, double
   ANET_HIP(ctx, hipMemcpyAsync(L.x, d_x0, sizeof(double) * n * st.ld, hipMemcpyDeviceToDevice, s0));
   anet::MvieArgs ma{d_A, L.x, L.feval, L.g, L.is, batch, st.ld, M, smooth_eps, penalty_wt};
   const dim3 grid((unsigned)((batch + 63) / 64)), block(64);
-  if (batch <= 32768 && params->mem_size <= 64) {
-    // small batches: one wave per problem, the whole optimisation in one launch (k_lbfgs_mvie_persistent)
+  if (batch <= lbfgs_wave_max_batch() && params->mem_size <= 64) {
+    // one wave per problem, the whole optimisation in one launch (k_lbfgs_mvie_persistent)
     ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * L.ld, s0));
     ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_ * L.ld, s0));
     anet::LbfgsArgs la{L.n, batch, L.ld, L.x, L.g, L.xp, L.gp, L.d, L.lm_s, L.lm_y, L.lm_ys, L.lm_alpha, L.pf, L.ds,
