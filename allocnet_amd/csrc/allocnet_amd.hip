@@ -110,9 +110,11 @@ int launch_solve(anet_ctx *ctx, const anet::SolveArgs &a, hipStream_t st) {
     if constexpr (S == 4) {
       if (a.N == 8 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_solve_axis<4, 8, true, 2>), g3, block, 0, st, a);
       else if (a.N == 8 && a.c == 4) hipLaunchKernelGGL((anet::k_minco_solve_axis<4, 8, true, 3>), g3, block, 0, st, a);
+      else if (a.N == 5 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_solve_axis<4, 5, true, 2>), g3, block, 0, st, a);
       else done = false;
     } else if constexpr (S == 3) {
       if (a.N == 16 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_solve_axis<3, 16, true, 2>), g3, block, 0, st, a);
+      else if (a.N == 5 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_solve_axis<3, 5, true, 2>), g3, block, 0, st, a);
       else done = false;
     } else {
       done = false;
@@ -137,10 +139,20 @@ int launch_solve(anet_ctx *ctx, const anet::SolveArgs &a, hipStream_t st) {
       ANET_HIP(ctx, hipGetLastError());
       return ANET_OK;
     }
+    if (a.N == 5 && a.c == 3) {  // the planner's own shape: five pieces (learning_planner.hpp:179), PVA ends
+      hipLaunchKernelGGL((anet::k_minco_solve<4, 5, true, 2>), grid, block, 0, st, a);
+      ANET_HIP(ctx, hipGetLastError());
+      return ANET_OK;
+    }
   }
   if constexpr (S == 3) {
     if (a.N == 16 && a.c == 3) {
       hipLaunchKernelGGL((anet::k_minco_solve<3, 16, true, 2>), grid, block, 0, st, a);
+      ANET_HIP(ctx, hipGetLastError());
+      return ANET_OK;
+    }
+    if (a.N == 5 && a.c == 3) {
+      hipLaunchKernelGGL((anet::k_minco_solve<3, 5, true, 2>), grid, block, 0, st, a);
       ANET_HIP(ctx, hipGetLastError());
       return ANET_OK;
     }
@@ -165,9 +177,11 @@ int launch_prop(anet_ctx *ctx, const anet::PropArgs &a, hipStream_t st) {
     if constexpr (S == 4) {
       if (a.N == 8 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate_axis<4, 8, true, 2>), g3, block, 0, st, a);
       else if (a.N == 8 && a.c == 4) hipLaunchKernelGGL((anet::k_minco_propagate_axis<4, 8, true, 3>), g3, block, 0, st, a);
+      else if (a.N == 5 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate_axis<4, 5, true, 2>), g3, block, 0, st, a);
       else done = false;
     } else if constexpr (S == 3) {
       if (a.N == 16 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate_axis<3, 16, true, 2>), g3, block, 0, st, a);
+      else if (a.N == 5 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate_axis<3, 5, true, 2>), g3, block, 0, st, a);
       else done = false;
     } else {
       done = false;
@@ -196,6 +210,12 @@ int launch_prop(anet_ctx *ctx, const anet::PropArgs &a, hipStream_t st) {
       ANET_HIP(ctx, hipGetLastError());
       return ANET_OK;
     }
+  }
+  if (a.N == 5 && a.c == 3 && S >= 3) {  // the planner's shape
+    if constexpr (S == 4) hipLaunchKernelGGL((anet::k_minco_propagate<4, 5, true, 2>), grid, block, 0, st, a);
+    else if constexpr (S == 3) hipLaunchKernelGGL((anet::k_minco_propagate<3, 5, true, 2>), grid, block, 0, st, a);
+    ANET_HIP(ctx, hipGetLastError());
+    return ANET_OK;
   }
   if (a.N <= 4)
     hipLaunchKernelGGL((anet::k_minco_propagate<S, 4>), grid, block, 0, st, a);

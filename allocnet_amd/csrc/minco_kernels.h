@@ -36,9 +36,18 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_solve(SolveArgs a) {
   const int64_t ld = a.ld;
 
   Factor<S, NB> F;
+  if constexpr (NEXACT) {
 #pragma unroll
-  for (int i = 0; i < NB; ++i)
-    if (i < N) F.r[i] = fast_rcp(a.T[i * ld + b]);
+    for (int i = 0; i < NB; ++i)
+      if (i < N) F.r[i] = fast_rcp(a.T[i * ld + b]);
+  } else {  // runtime piece count: all loads first, none behind a branch (as in k_minco_solve_axis)
+    double tt[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) tt[i] = a.T[(int64_t)(i < N ? i : 0) * ld + b];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (i < N) F.r[i] = fast_rcp(tt[i]);
+  }
   F.factorize(N, np);
 
   double etot = 0.0;
@@ -47,21 +56,37 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_solve(SolveArgs a) {
     double P[NB + 1], hv[m], tv[m], X[NB + 1][m];
     const double *hp = a.head + (int64_t)(ax * c) * ld + b;
     const double *tp = a.tail + (int64_t)(ax * c) * ld + b;
+    if constexpr (NEXACT) {
 #pragma unroll
-    for (int k = 0; k <= NB; ++k) {
-      if (k == 0)
-        P[k] = hp[0];
-      else if (k < N)
-        P[k] = a.wps[(int64_t)((k - 1) * 3 + ax) * ld + b];
-      else if (k == N)
-        P[k] = tp[0];
-      else
-        P[k] = 0.0;
-    }
+      for (int k = 0; k <= NB; ++k) {
+        if (k == 0)
+          P[k] = hp[0];
+        else if (k < N)
+          P[k] = a.wps[(int64_t)((k - 1) * 3 + ax) * ld + b];
+        else if (k == N)
+          P[k] = tp[0];
+        else
+          P[k] = 0.0;
+      }
 #pragma unroll
-    for (int j = 0; j < m; ++j) {
-      hv[j] = (j < np) ? hp[(int64_t)(1 + j) * ld] : 0.0;
-      tv[j] = (j < np) ? tp[(int64_t)(1 + j) * ld] : 0.0;
+      for (int j = 0; j < m; ++j) {
+        hv[j] = (j < np) ? hp[(int64_t)(1 + j) * ld] : 0.0;
+        tv[j] = (j < np) ? tp[(int64_t)(1 + j) * ld] : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k <= NB; ++k) {
+        const double *src = (k == 0) ? hp : (k < N) ? a.wps + (int64_t)((k - 1) * 3 + ax) * ld + b : tp;
+        const double v = *src;
+        P[k] = (k <= N) ? v : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < m; ++j) {
+        const int64_t row = (j < np) ? 1 + j : 0;
+        const double h = hp[row * ld], t = tp[row * ld];
+        hv[j] = (j < np) ? h : 0.0;
+        tv[j] = (j < np) ? t : 0.0;
+      }
     }
     double *cp = a.coeffs ? a.coeffs + (int64_t)(ax * D) * ld + b : nullptr;
     etot += solve_axis<S, NB>(F, N, np, P, hv, tv, X, [&](int piece, int col, double v) {
