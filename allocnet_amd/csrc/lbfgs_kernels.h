@@ -263,9 +263,10 @@ __device__ __forceinline__ double dpp_f64(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+template <int LANE = 63>
 __device__ __forceinline__ double last_lane(double v) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
-                          __builtin_amdgcn_readlane(__double2loint(v), 63));
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), LANE),
+                          __builtin_amdgcn_readlane(__double2loint(v), LANE));
 }
 __global__ void __launch_bounds__(64) k_lbfgs_update(LbfgsArgs a) {
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -277,24 +278,28 @@ __device__ __forceinline__ double uniform_f64(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
                           __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+// LAST = 15 / 31: the caller guarantees zeros in the lanes above it, so the steps that chain the upper rows would only
+// add zeros and are left out (the value is the same; a problem of nine variables saves a third of every reduction).
+template <int LAST = 63>
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_f64<0x111>(v);
   v += dpp_f64<0x112>(v);
   v += dpp_f64<0x114>(v);
   v += dpp_f64<0x118>(v);
-  v += dpp_f64<0x142, 0xa>(v);
-  v += dpp_f64<0x143, 0xc>(v);
-  return last_lane(v);
+  if constexpr (LAST >= 31) v += dpp_f64<0x142, 0xa>(v);
+  if constexpr (LAST >= 63) v += dpp_f64<0x143, 0xc>(v);
+  return last_lane<LAST>(v);
 }
 // maximum of NON-NEGATIVE values (0 is the fill of masked / missing lanes)
+template <int LAST = 63>
 __device__ __forceinline__ double wave_max_nonneg(double v) {
   v = fmax(v, dpp_f64<0x111>(v));
   v = fmax(v, dpp_f64<0x112>(v));
   v = fmax(v, dpp_f64<0x114>(v));
   v = fmax(v, dpp_f64<0x118>(v));
-  v = fmax(v, dpp_f64<0x142, 0xa>(v));
-  v = fmax(v, dpp_f64<0x143, 0xc>(v));
-  return last_lane(v);
+  if constexpr (LAST >= 31) v = fmax(v, dpp_f64<0x142, 0xa>(v));
+  if constexpr (LAST >= 63) v = fmax(v, dpp_f64<0x143, 0xc>(v));
+  return last_lane<LAST>(v);
 }
 
 // Same state machine, ONE WAVE per problem: the n <= 128 variables are spread over the 64 lanes (two
@@ -329,7 +334,8 @@ struct WaveHistory {
   }
 };
 // NV: variables per lane (1 for n <= 64, 2 for n <= 128)
-template <int LBFGS_WAVE_MREG, int NV = 2, bool CARRY = false>
+// RL: highest lane that can hold a variable (63 in general; 15 when the caller knows n <= 16)
+template <int LBFGS_WAVE_MREG, int NV = 2, bool CARRY = false, int RL = 63>
 __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const int64_t b, const int lane,
                                                        WaveHistory<(LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1), NV> &H) {
   constexpr int MR = LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1;
@@ -417,7 +423,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < NV; ++q) acc = __builtin_fma(u[q], v[q], acc);
-    return wave_sum(acc);
+    return wave_sum<RL>(acc);
   };
   auto conv_test = [&]() {
     double gm = 0.0, xm = 0.0;
@@ -426,7 +432,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
       gm = fmax(gm, fabs(gr[q]));
       xm = fmax(xm, fabs(xr[q]));
     }
-    return wave_max_nonneg(gm) / fmax(1.0, wave_max_nonneg(xm)) < P.g_epsilon;
+    return wave_max_nonneg<RL>(gm) / fmax(1.0, wave_max_nonneg<RL>(xm)) < P.g_epsilon;
   };
 
   if (phase == 0) {
@@ -820,8 +826,8 @@ k_lbfgs_mvie_persistent(LbfgsArgs la, MvieArgs ma, int max_evals) {
     mvie_eval_wave(ma, b, lane);
     __threadfence_block();
     // nine variables: one per lane
-    if (carry && e > 0) lbfgs_update_wave_body<LBFGS_WAVE_MREG, 1, true>(la, b, lane, H);
-    else lbfgs_update_wave_body<LBFGS_WAVE_MREG, 1>(la, b, lane, H);
+    if (carry && e > 0) lbfgs_update_wave_body<LBFGS_WAVE_MREG, 1, true, 15>(la, b, lane, H);
+    else lbfgs_update_wave_body<LBFGS_WAVE_MREG, 1, false, 15>(la, b, lane, H);
     __threadfence_block();
   }
 }
