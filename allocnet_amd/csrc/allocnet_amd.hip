@@ -311,7 +311,13 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
       };
       dim3 gw, bw;
       const bool one = L.n <= 64;  // one variable per lane: half the registers
-      if (a.p.mem_size <= 8) {
+      static const int half_ok = [] { const char *e = getenv("ANET_LBFGS_HALF_WAVE"); return e ? atoi(e) : 1; }();
+      if (a.p.mem_size <= 8 && L.n <= 32 && half_ok) {  // two problems per wave
+        const int waves = anet::LbfgsWaveShape<8>::kWaves;
+        gw = dim3((unsigned)((B + 2 * waves - 1) / (2 * waves)));
+        bw = dim3(64u * waves);
+        hipLaunchKernelGGL((anet::k_lbfgs_update_wave<8, 1, true>), gw, bw, 0, st, a);
+      } else if (a.p.mem_size <= 8) {
         shape(anet::LbfgsWaveShape<8>::kWaves, gw, bw);
         if (one) hipLaunchKernelGGL((anet::k_lbfgs_update_wave<8, 1>), gw, bw, 0, st, a);
         else hipLaunchKernelGGL((anet::k_lbfgs_update_wave<8, 2>), gw, bw, 0, st, a);

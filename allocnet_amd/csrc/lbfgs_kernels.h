@@ -302,6 +302,29 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
   return last_lane<LAST>(v);
 }
 
+// Two problems per wave (32 lanes each): the same scans, chained over the two rows of a half only; each half then
+// reads its total from its own last lane.  Needs the lanes of a HALF to be active together, not the whole wave.
+__device__ __forceinline__ double half_pick(double v) {
+  const double lo = last_lane<31>(v), hi = last_lane<63>(v);
+  return (threadIdx.x & 32) ? hi : lo;
+}
+__device__ __forceinline__ double half_sum(double v) {
+  v += dpp_f64<0x111>(v);
+  v += dpp_f64<0x112>(v);
+  v += dpp_f64<0x114>(v);
+  v += dpp_f64<0x118>(v);
+  v += dpp_f64<0x142, 0xa>(v);
+  return half_pick(v);
+}
+__device__ __forceinline__ double half_max_nonneg(double v) {
+  v = fmax(v, dpp_f64<0x111>(v));
+  v = fmax(v, dpp_f64<0x112>(v));
+  v = fmax(v, dpp_f64<0x114>(v));
+  v = fmax(v, dpp_f64<0x118>(v));
+  v = fmax(v, dpp_f64<0x142, 0xa>(v));
+  return half_pick(v);
+}
+
 // Same state machine, ONE WAVE per problem: the n <= 128 variables are spread over the 64 lanes (two
 // per lane, held in registers for the whole tick), every dot product / norm is a wave reduction,
 // scalars are wave-uniform.  Used for small batches, where one lane per problem leaves the chip idle
@@ -335,7 +358,10 @@ struct WaveHistory {
 };
 // NV: variables per lane (1 for n <= 64, 2 for n <= 128)
 // RL: highest lane that can hold a variable (63 in general; 15 when the caller knows n <= 16)
-template <int LBFGS_WAVE_MREG, int NV = 2, bool CARRY = false, int RL = 63>
+// HALF: the wave carries TWO problems of at most 32 variables, `lane` is the lane within the half (0..31) and `b`
+// differs between the halves: nothing is wave-uniform any more (state in vector registers, branches by exec mask),
+// every reduction runs in both halves at once.  Half the instruction issue per problem -- what bounds the kernel.
+template <int LBFGS_WAVE_MREG, int NV = 2, bool CARRY = false, int RL = 63, bool HALF = false>
 __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const int64_t b, const int lane,
                                                        WaveHistory<(LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1), NV> &H) {
   constexpr int MR = LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1;
@@ -377,11 +403,13 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
     gpr[q] = h[q] ? gp[iv[q] * vs] : 0.0;
   }
   if (done) return;
-  // the scalars are the same in every lane: make that visible (scalar branches, SGPR operands)
-  k = __builtin_amdgcn_readfirstlane(k);
-  end = __builtin_amdgcn_readfirstlane(end);
-  bound = __builtin_amdgcn_readfirstlane(bound);
-  phase = __builtin_amdgcn_readfirstlane(phase);
+  if constexpr (!HALF) {
+    // the scalars are the same in every lane: make that visible (scalar branches, SGPR operands)
+    k = __builtin_amdgcn_readfirstlane(k);
+    end = __builtin_amdgcn_readfirstlane(end);
+    bound = __builtin_amdgcn_readfirstlane(bound);
+    phase = __builtin_amdgcn_readfirstlane(phase);
+  }
 
   // ---- round trip 2 (speculative): history slots other than the one this tick writes, past-f entry
   double *lms = a.lm_s + b * ps * m, *lmy = a.lm_y + b * ps * m;  // [j][i] at (j*js + i*vs)
@@ -412,8 +440,10 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
       }
       // (made wave-uniform only after every slot's loads are out: a readfirstlane right behind its load would put
       //  one full wait per slot into the loop above)
+      if constexpr (!HALF) {
 #pragma unroll
-      for (int it = 1; it < MR; ++it) hys[it] = uniform_f64(hys[it]);
+        for (int it = 1; it < MR; ++it) hys[it] = uniform_f64(hys[it]);
+      }
     }
   }
 
@@ -423,7 +453,8 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < NV; ++q) acc = __builtin_fma(u[q], v[q], acc);
-    return wave_sum<RL>(acc);
+    if constexpr (HALF) return half_sum(acc);
+    else return wave_sum<RL>(acc);
   };
   auto conv_test = [&]() {
     double gm = 0.0, xm = 0.0;
@@ -432,7 +463,8 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
       gm = fmax(gm, fabs(gr[q]));
       xm = fmax(xm, fabs(xr[q]));
     }
-    return wave_max_nonneg<RL>(gm) / fmax(1.0, wave_max_nonneg<RL>(xm)) < P.g_epsilon;
+    if constexpr (HALF) return half_max_nonneg(gm) / fmax(1.0, half_max_nonneg(xm)) < P.g_epsilon;
+    else return wave_max_nonneg<RL>(gm) / fmax(1.0, wave_max_nonneg<RL>(xm)) < P.g_epsilon;
   };
 
   if (phase == 0) {
@@ -673,13 +705,15 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
   }
 }
 
-template <int LBFGS_WAVE_MREG, int NV>
-__global__ void __launch_bounds__(64 * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves, (LBFGS_WAVE_MREG == 8 && NV == 1) ? 4 : 1)
+template <int LBFGS_WAVE_MREG, int NV, bool HALF = false>
+__global__ void __launch_bounds__(64 * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves, (LBFGS_WAVE_MREG == 8 && NV == 1 && !HALF) ? 4 : 1)
 k_lbfgs_update_wave(LbfgsArgs a) {
-  const int64_t b = (int64_t)blockIdx.x * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves + (threadIdx.x >> 6);
-  if (b >= a.B) return;  // whole waves only: the reductions need all 64 lanes
+  static_assert(!HALF || (NV == 1 && LBFGS_WAVE_MREG > 0), "two problems per wave: one variable per lane, history in registers");
+  const int64_t w = (int64_t)blockIdx.x * LbfgsWaveShape<LBFGS_WAVE_MREG>::kWaves + (threadIdx.x >> 6);
+  const int64_t b = HALF ? 2 * w + ((threadIdx.x >> 5) & 1) : w;
+  if (b >= a.B) return;  // whole waves (halves) only: the reductions need all their lanes
   WaveHistory<(LBFGS_WAVE_MREG > 0 ? LBFGS_WAVE_MREG : 1), NV> H;
-  lbfgs_update_wave_body<LBFGS_WAVE_MREG, NV>(a, b, threadIdx.x & 63, H);
+  lbfgs_update_wave_body<LBFGS_WAVE_MREG, NV, false, 63, HALF>(a, b, HALF ? (threadIdx.x & 31) : (threadIdx.x & 63), H);
 }
 
 // firi::costMVIE (gcopter/firi.hpp:86-157): x = [p, rtd, cde], A is M x 3 column-major per problem
