@@ -215,7 +215,7 @@ def main():
                                 "note": "launch-latency bound: 2 MB per launch"}
         # PCIe-inclusive host API
         import numpy as np
-        from tests.util import random_problem
+        from allocnet_amd.synth import random_problem
         rng = np.random.default_rng(0)
         bh = 1 << 16
         h_head, h_tail, h_wps, h_T = random_problem(rng, bh, N, c, rest=True)

@@ -1,0 +1,128 @@
+"""BASELINE.json configs[2] and configs[3] at their full sizes, with the generators and seeds of SURVEY.md 8(d):
+
+  configs[2]  Batch=4096 x 8-segment min-snap, SFC corridor penalties + time-allocation gradients   (seed 1)
+  configs[3]  Batch=4096 x 16-segment min-jerk, full L-BFGS to convergence, lbfgs_parameter_t defaults (seed 2)
+
+The whole batch runs on the GPU; a strided sample is compared with the oracles (the numpy dense adjoint for cost and
+gradients, the C restatement of lbfgs.hpp:434-717 driving that numpy objective for the L-BFGS counters)."""
+import numpy as np
+import pytest
+
+from oracle import cbind
+from oracle import minco_np as onp
+from tests.util import corridor_problem
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(res=20, vmax=4.0, amax=6.0, wc=1e4, wv=1e3, wa=1e3, mu=1e-2)      # planner.yaml:17-21 limits, res
+RHO = 50.0
+
+
+def _penalty(aa, M):
+    return aa.make_penalty(rho=RHO, w_corridor=KW["wc"], w_vel=KW["wv"], w_acc=KW["wa"], smooth_mu=KW["mu"],
+                           max_vel=KW["vmax"], max_acc=KW["amax"], res=KW["res"], poly_rows=M)
+
+
+def _fwd(tau):
+    return np.where(tau > 0, (0.5 * tau + 1) * tau + 1, 1.0 / ((0.5 * tau - 1) * tau + 1))
+
+
+def _dfwd(tau):
+    den = (0.5 * tau - 1) * tau + 1
+    return np.where(tau > 0, tau + 1, (1 - tau) / den ** 2)
+
+
+def _bwd(T):
+    with np.errstate(invalid="ignore"):          # (np.where evaluates both branches)
+        return np.where(T > 1, np.sqrt(2 * T - 1) - 1, 1 - np.sqrt(2 / T - 1))
+
+
+def _oracle_cost_grad(s, head, tail, wps, T, hp):
+    """cost, dJ/dwaypoints (3, N-1), dJ/dT (N,) of one trajectory by the numpy oracle (classic dense adjoint)."""
+    hpb = np.transpose(hp, (1, 2, 0))
+    co, e, *_ = onp.minco_dense_solve(s, head, tail, wps.T, T)
+    jp, gC, gTp, _ = onp.penalty_partials(s, co, T, hpb, **KW)
+    eC, eT = onp.energy_partials(s, co, T)
+    gP, gT = onp.minco_dense_propagate(s, head, tail, wps.T, T, gC + eC, gTp + eT + RHO)
+    return e + RHO * T.sum() + jp, gP, gT, co
+
+
+def test_config2_corridor_cost_and_time_gradients_full_batch(anet_ctx):
+    """configs[2]: 4096 x 8-segment min-snap, corridor + limit penalties, gradients w.r.t. waypoints and durations."""
+    import allocnet_amd as aa
+    B, s, c, N, M = 4096, 4, 3, 8, 16
+    rng = np.random.default_rng(1)
+    head, tail, wps, T, hp = corridor_problem(rng, B, N, c, M)
+    pen = _penalty(aa, M)
+    cost, gP, gT, co = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, want_coeffs=True, ctx=anet_ctx)
+    assert np.isfinite(cost).all() and np.isfinite(gP).all() and np.isfinite(gT).all()
+    active = 0
+    for b in range(0, B, 512):
+        c0, gP0, gT0, co0 = _oracle_cost_grad(s, head[b], tail[b], wps[b], T[b], hp[b])
+        e0 = onp.minco_dense_solve(s, head[b], tail[b], wps[b].T, T[b])[1]
+        active += c0 - e0 - RHO * T[b].sum() > 1e-9 * c0
+        assert np.abs(co[b] - co0).max() <= 1e-9 * np.abs(co0).max(), b
+        assert abs(cost[b] - c0) <= 1e-9 * abs(c0), b
+        assert np.abs(gP[b].T - gP0).max() <= 1e-7 * max(1.0, np.abs(gP0).max()), b
+        assert np.abs(gT[b] - gT0).max() <= 1e-7 * max(1.0, np.abs(gT0).max()), b
+    assert active >= 4          # the penalty rows really are violated in the compared sample
+    # size-independent property over the whole batch: the directional derivative along a random direction of the
+    # durations agrees with a central difference of the cost (one extra pair of evaluations for all 4096)
+    dT = rng.normal(size=T.shape) * 1e-6
+    cp = aa.minco_cost_grad(head, tail, wps, T + dT, s, hpolys=hp, penalty=pen, ctx=anet_ctx)[0]
+    cm = aa.minco_cost_grad(head, tail, wps, T - dT, s, hpolys=hp, penalty=pen, ctx=anet_ctx)[0]
+    dd = (gT * dT).sum(axis=1)
+    assert np.abs((cp - cm) / 2 - dd).max() <= 1e-5 * np.abs(dd).max()
+
+
+def test_config3_lbfgs_to_convergence_full_batch(anet_ctx):
+    """configs[3]: 4096 x 16-segment min-jerk, L-BFGS with lbfgs_parameter_t defaults until every problem stops on
+    its own (lbfgs.hpp:434-717); the evaluation budget is only a cap."""
+    import allocnet_amd as aa
+    B, s, c, N, M = 4096, 3, 3, 16, 16
+    rng = np.random.default_rng(2)
+    head, tail, wps, T, hp = corridor_problem(rng, B, N, c, M)
+    pen = _penalty(aa, M)
+    c0 = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, ctx=anet_ctx)[0]
+    out = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=aa.lbfgs_parameter_t(), max_evals=40000,
+                         ctx=anet_ctx)
+    st = out["status"]
+    assert np.isin(st, (aa.lbfgs.LBFGS_STOP, aa.lbfgs.LBFGS_CONVERGENCE)).all(), np.unique(st, return_counts=True)
+    assert (out["cost"] < c0).all()
+    assert (out["T"] > 0).all() and np.isfinite(out["wps"]).all()
+    assert (out["evals"] >= out["iters"]).all() and out["evals"].max() < 40000
+    # the returned parameters reproduce the returned cost, and the returned coefficients are their MINCO solution
+    c1, _, _, co1 = aa.minco_cost_grad(head, tail, out["wps"], out["T"], s, hpolys=hp, penalty=pen, want_coeffs=True,
+                                       ctx=anet_ctx)
+    assert np.abs(c1 - out["cost"]).max() <= 1e-9 * np.abs(c1).max()
+    assert np.abs(co1 - out["coeffs"]).max() <= 1e-9 * np.abs(co1).max()
+    for b in range(0, B, 1024):          # ... also according to the oracle
+        cb, *_ = _oracle_cost_grad(s, head[b], tail[b], out["wps"][b], out["T"][b], hp[b])
+        assert abs(cb - out["cost"][b]) <= 1e-8 * abs(cb), b
+
+
+@pytest.mark.parametrize("max_iterations", [2, 6])
+def test_config3_lbfgs_counters_match_the_restatement(anet_ctx, max_iterations):
+    """Same batch, fixed iteration budgets: (status, iterations, evaluations) of a strided sample equal the C
+    restatement of lbfgs_optimize driving the numpy objective, iterates to rounding."""
+    import allocnet_amd as aa
+    B, s, c, N, M = 4096, 3, 3, 16, 16
+    rng = np.random.default_rng(2)
+    head, tail, wps, T, hp = corridor_problem(rng, B, N, c, M)
+    pen = _penalty(aa, M)
+    nw = 3 * (N - 1)
+    out = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen,
+                         param=aa.lbfgs_parameter_t(max_iterations=max_iterations), max_evals=400, ctx=anet_ctx)
+    tol = 1e-9 if max_iterations <= 2 else 1e-7
+    for b in range(0, B, 512):
+        def fun(x, b=b):
+            w = x[:nw].reshape(N - 1, 3)
+            tau = x[nw:]
+            f, gP, gT, _ = _oracle_cost_grad(s, head[b], tail[b], w, _fwd(tau), hp[b])
+            return f, np.r_[gP.T.reshape(-1), gT * _dfwd(tau)]
+        x0 = np.r_[wps[b].reshape(-1), _bwd(T[b])]
+        ret, xo, fo, it, ev = cbind.lbfgs_optimize(x0, fun, cbind.lbfgs_default_param(max_iterations=max_iterations))
+        assert (out["status"][b], out["iters"][b], out["evals"][b]) == (ret, it, ev), (b, ret, it, ev)
+        assert abs(out["cost"][b] - fo) <= tol * abs(fo), b
+        xg = np.r_[out["wps"][b].reshape(-1), _bwd(out["T"][b])]
+        assert np.abs(xg - xo).max() <= tol * max(1.0, np.abs(xo).max()), b

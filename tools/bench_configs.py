@@ -22,7 +22,7 @@ def to_bm(torch, a, B, ld, device):
     return t
 
 
-from tests.util import corridor_problem as synth  # noqa: E402  (SURVEY 8(d) config 3/5 generator)
+from allocnet_amd.synth import corridor_problem as synth  # noqa: E402  (SURVEY 8(d) config 3/5 generator)
 
 
 def main():

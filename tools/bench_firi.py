@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     import allocnet_amd as aa
-    from tests.util import firi_scene as make_case, firi_pack as pack
+    from allocnet_amd.synth import firi_scene as make_case, firi_pack as pack
     ctx = aa.Context(0)
     out = {}
     for B, Np in ((5, 1000), (256, 1000), (2048, 500)):

@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import allocnet_amd as aa  # noqa: E402
-from tests.util import corridor_problem  # noqa: E402
+from allocnet_amd.synth import corridor_problem  # noqa: E402
 
 ctx = aa.Context(0)
 out = {}

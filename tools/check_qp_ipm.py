@@ -12,8 +12,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     import allocnet_amd as aa
-    from tests.util import qp_corridor_problem as _corridor_problem
-    from tests.util import corridor_problem
+    from allocnet_amd.synth import qp_corridor_problem as _corridor_problem
+    from allocnet_amd.synth import corridor_problem
     ctx = aa.Context(0)
     for (s, N, M, res) in [(4, 3, 9, 6), (3, 4, 8, 5), (4, 5, 12, 10), (4, 1, 7, 8)]:
         rng = np.random.default_rng(10 * s + N)

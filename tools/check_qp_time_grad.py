@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     import allocnet_amd as aa
-    from tests.util import qp_corridor_problem as _corridor_problem
+    from allocnet_amd.synth import qp_corridor_problem as _corridor_problem
     ctx = aa.Context(0)
     for (s, N, M, res, vmax, amax) in [(4, 3, 9, 6, 3.0, 4.0), (3, 4, 8, 5, 3.0, 4.0), (3, 2, 7, 10, 1.0, 1.5), (4, 5, 12, 10, 2.0, 2.5)]:
         rng = np.random.default_rng(10 * s + N)

@@ -5,7 +5,7 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import allocnet_amd as aa
-from tests.util import random_problem
+from allocnet_amd.synth import random_problem
 ctx = aa.Context(0)
 rng = np.random.default_rng(0)
 head, tail, wps, T = random_problem(rng, 1, 5, 3)

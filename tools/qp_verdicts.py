@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     import allocnet_amd as aa
-    from tests.util import corridor_problem
+    from allocnet_amd.synth import corridor_problem
     ctx = aa.Context(0)
     for (s, N, M, sc) in [(4, 8, 16, 0.7), (4, 8, 16, 1.5), (4, 8, 16, 4.0), (3, 5, 16, 0.5), (3, 5, 16, 10.0), (4, 5, 16, 0.2)]:
         B = 512

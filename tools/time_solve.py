@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
     import allocnet_amd as aa
-    from tests.util import random_problem
+    from allocnet_amd.synth import random_problem
     from tools.bench_configs import to_bm
     dev = torch.device("cuda", 0)
     ctx = aa.Context(0)
