@@ -19,6 +19,7 @@
 #include "traj_kernels.h"
 #include "rate_kernels.h"
 #include "lbfgs_kernels.h"
+#include "lbfgs_minco_persistent.h"
 #include "firi_kernels.h"
 #include "qp_assemble.h"
 #include "qp_admm.h"
@@ -1151,6 +1152,53 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
   const double *wps_eval = nw ? L.x : wps;
   double *gP_out = nw ? L.g : w_gP, *gT_out = nt ? L.g + (int64_t)nw * ld : w_gT;
   const double *tau = nt ? L.x + (int64_t)nw * ld : nullptr;
+  // One launch, one wave per problem (lbfgs_minco_persistent.h) whenever the problem fits a wave: every problem runs
+  // until ITS OWN stop instead of the batch advancing in lockstep, four launches per evaluation.  Above
+  // ANET_LBFGS_PERSISTENT_MAX_BATCH problems the launch-per-evaluation kernels (all 64 lanes busy in the chains) have
+  // the higher throughput per evaluation step.
+  static const int64_t persist_max_batch = [] {
+    const char *e = getenv("ANET_LBFGS_PERSISTENT_MAX_BATCH");
+    return e ? (int64_t)atoll(e) : (int64_t)65536;
+  }();
+  const int Mrows = (pen && hpolys) ? pen->poly_rows : 0;
+  const size_t row_bytes = sizeof(double) * anet::persist_lds_row_doubles(N, Mrows);
+  if (batch <= persist_max_batch && (s == 3 || s == 4) && n <= 64 && params->mem_size <= 8 && params->past <= 64) {
+    anet::PersistArgs pa{};
+    pa.head = head; pa.tail = tail; pa.wps = wps; pa.T = T; pa.hpolys = Mrows ? hpolys : nullptr;
+    pa.x = L.x; pa.is = L.is; pa.ds = L.ds; pa.B = batch; pa.ld = ld;
+    pa.N = N; pa.c = c; pa.nw = nw; pa.nt = nt; pa.M = Mrows; pa.max_evals = max_evals; pa.with_penalty = pen ? 1 : 0;
+    if (pen) pa.pp = anet::Penalty{pen->rho, pen->w_corridor, pen->w_vel, pen->w_acc, pen->smooth_mu, pen->max_vel,
+                                   pen->max_acc, pen->res, Mrows};
+    else pa.pp = anet::Penalty{0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1, 0};
+    pa.p = to_kernel_params(*params);
+    size_t fixed = 0;
+    auto launch = [&](auto kernel, size_t fixed_bytes) {
+      fixed = fixed_bytes;
+      hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
+    };
+    const size_t lds_cap = 64 * 1024;
+    bool launched = true;
+    if (s == 3 && N <= 8 && anet::persist_lds_fixed_bytes<3, 8>() + row_bytes <= lds_cap)
+      launch(anet::k_lbfgs_minco_persistent<3, 8, 8>, anet::persist_lds_fixed_bytes<3, 8>());
+    else if (s == 3 && anet::persist_lds_fixed_bytes<3, 16>() + row_bytes <= lds_cap)
+      launch(anet::k_lbfgs_minco_persistent<3, 16, 8>, anet::persist_lds_fixed_bytes<3, 16>());
+    else if (s == 4 && N <= 8 && anet::persist_lds_fixed_bytes<4, 8>() + row_bytes <= lds_cap)
+      launch(anet::k_lbfgs_minco_persistent<4, 8, 8>, anet::persist_lds_fixed_bytes<4, 8>());
+    else if (s == 4 && anet::persist_lds_fixed_bytes<4, 16>() + row_bytes <= lds_cap)
+      launch(anet::k_lbfgs_minco_persistent<4, 16, 8>, anet::persist_lds_fixed_bytes<4, 16>());
+    else
+      launched = false;
+    if (launched) {
+      ANET_HIP(ctx, hipGetLastError());
+      mp.mode = 1;
+      hipLaunchKernelGGL(anet::k_minco_map, gmap, b256, 0, st, mp);
+      ANET_HIP(ctx, hipGetLastError());
+      hipLaunchKernelGGL(k_lbfgs_results, g256, b256, 0, st, L.is, L.ds, batch, ld, status, iters, evals, cost);
+      ANET_HIP(ctx, hipGetLastError());
+      if (coeffs_out) return anet_minco_solve_dev(ctx, s, c, N, batch, ld, head, tail, wps, T, coeffs_out, nullptr, st);
+      return ANET_OK;
+    }
+  }
   rc = lbfgs_drive(ctx, L, batch, *params, max_evals, st, [&]() -> int {
     return cost_grad_dev_impl(ctx, s, c, N, batch, ld, head, tail, wps_eval, T, hpolys, pen, w_cg, L.feval, gP_out,
                               gT_out, nullptr, st, tau);
