@@ -39,7 +39,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + [os.path.join(SRC_DIR, s) for s in SOURCES] + ["-o", LIB_PATH]
+    extra = os.environ.get("ANET_BUILD_FLAGS", "").split()      # e.g. -DANET_PERSIST_PROF (tools/ only)
+    cmd = [HIPCC] + FLAGS + extra + [os.path.join(SRC_DIR, s) for s in SOURCES] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -1162,7 +1162,8 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
   }();
   const int Mrows = (pen && hpolys) ? pen->poly_rows : 0;
   const size_t row_bytes = sizeof(double) * anet::persist_lds_row_doubles(N, Mrows);
-  if (batch <= persist_max_batch && (s == 3 || s == 4) && n <= 64 && params->mem_size <= 8 && params->past <= 64) {
+  if (!(opt_flags & ANET_OPT_LOCKSTEP) && batch <= persist_max_batch && (s == 3 || s == 4) && n <= 64 &&
+      params->mem_size <= 8 && params->past <= 64) {
     anet::PersistArgs pa{};
     pa.head = head; pa.tail = tail; pa.wps = wps; pa.T = T; pa.hpolys = Mrows ? hpolys : nullptr;
     pa.x = L.x; pa.is = L.is; pa.ds = L.ds; pa.B = batch; pa.ld = ld;
@@ -1171,9 +1172,13 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                                    pen->max_acc, pen->res, Mrows};
     else pa.pp = anet::Penalty{0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1, 0};
     pa.p = to_kernel_params(*params);
-    size_t fixed = 0;
+#ifdef ANET_PERSIST_PROF
+    static long long *d_prof = nullptr;
+    if (!d_prof) ANET_HIP(ctx, hipMalloc((void **)&d_prof, 16 * sizeof(long long)));
+    ANET_HIP(ctx, hipMemsetAsync(d_prof, 0, 16 * sizeof(long long), st));
+    pa.prof = d_prof;
+#endif
     auto launch = [&](auto kernel, size_t fixed_bytes) {
-      fixed = fixed_bytes;
       hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
     };
     const size_t lds_cap = 64 * 1024;
@@ -1190,6 +1195,15 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
       launched = false;
     if (launched) {
       ANET_HIP(ctx, hipGetLastError());
+#ifdef ANET_PERSIST_PROF
+      {
+        long long h[16];
+        ANET_HIP(ctx, hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, st));
+        ANET_HIP(ctx, hipStreamSynchronize(st));
+        fprintf(stderr, "persist_prof cycles (problem 0): E1 %lld E2 %lld E3 %lld E4 %lld E5 %lld E6 %lld E7 %lld E8 %lld update %lld\n",
+                h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+      }
+#endif
       mp.mode = 1;
       hipLaunchKernelGGL(anet::k_minco_map, gmap, b256, 0, st, mp);
       ANET_HIP(ctx, hipGetLastError());

@@ -28,7 +28,24 @@ struct PersistArgs {
   int N, c, nw, nt, M, max_evals, with_penalty;
   Penalty pp;
   LbfgsP p;
+#ifdef ANET_PERSIST_PROF
+  long long *prof;  // [16] cycle counters of problem 0 (tools/persist_prof.py)
+#endif
 };
+#ifdef ANET_PERSIST_PROF
+#define PERSIST_TICK(slot)                                              \
+  do {                                                                  \
+    if (a.prof && blockIdx.x == 0) {                                    \
+      const long long now_ = __builtin_readcyclecounter();              \
+      if (threadIdx.x == 0) a.prof[slot] += now_ - prof_t_;             \
+      prof_t_ = now_;                                                   \
+    }                                                                   \
+  } while (0)
+#define PERSIST_TICK_DECL long long prof_t_ = __builtin_readcyclecounter()
+#else
+#define PERSIST_TICK(slot) do {} while (0)
+#define PERSIST_TICK_DECL do {} while (0)
+#endif
 
 template <int S, int NB>
 struct PersistLds {
@@ -36,20 +53,23 @@ struct PersistLds {
   double P[3][NB + 2];       // node positions per axis
   double T[NB], r[NB];       // durations, 1/T
   double hv[3][m], tv[3][m];  // pinned end derivatives
-  double FL[NB + 1][nl > 0 ? nl : 1], Fd[NB + 1][m];  // block LDL^T factor
-  double X[3][NB + 1][m];    // primal: right-hand side -> node derivatives
-  double A[3][NB + 1][m];    // adjoint: right-hand side -> multipliers
-  double co[NB][3][D];       // coefficients, highest power first
+  double Ad[NB + 1][m][m];   // diagonal block of node k before elimination (lower triangle, end nodes pinned)
+  double Kp[NB][m][m];       // coupling block Ko_k of piece k
+  double Si[NB + 1][m][m];   // inverse Schur complements S_k^-1
+  double H[NB][m][m];        // H_k = S_k^-1 Ko_k: y_k+1 = rhs_k+1 - H_k' y_k ;  x_k = z_k - H_k x_k+1
+  double X[3][NB + 1][m];    // primal: right-hand side -> node derivatives; then adjoint: right-hand side -> multipliers
+  double co[NB][3][D];       // coefficients, highest power first; then the node-state adjoint contributions of a piece
+                             // to its start node (first S entries) and its end node (last S), written by their reader
   double gc[NB][3][D];       // penalty part of dJ/dc
   double gdT[NB], pc[NB];    // penalty part of dJ/dT, penalty cost per piece
-  double cA[NB][3][S], cB[NB][3][S];  // node-state adjoint contributions of a piece to its start / end node
   double wl[NB + 1][3], gTp[NB][3], ep[NB][3];
 };
 
 template <int S, int NB>
 constexpr size_t persist_lds_fixed_bytes() { return (sizeof(PersistLds<S, NB>) + 15) / 16 * 16; }
-// corridor rows of piece i start at i * (4 M + 4) doubles: the pad spreads the pieces over the LDS banks
-inline size_t persist_lds_row_doubles(int N, int M) { return (size_t)N * (4 * (size_t)M + 4); }
+// corridor rows of piece i start at i * (4 M4 + 4) doubles, M4 = M rounded up to a multiple of four with zero rows
+// (a zero row is never violated); the pad of four doubles spreads the pieces over the LDS banks
+inline size_t persist_lds_row_doubles(int N, int M) { return (size_t)N * (4 * (size_t)((M + 3) & ~3) + 4); }
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v) { return v + dpp_f64<CTRL>(v); }
@@ -144,7 +164,7 @@ __device__ __forceinline__ void rhs_primal_node_rt(int k, int N, int np, double 
 template <int MR>
 struct LbfgsResident {
   double x, g, d, xp, gp;
-  double hs[MR], hy[MR], hys[MR];
+  double hs[MR], hy[MR], hys[MR];  // hys: 1 / (y.s) of the slot
   double fx, step, finit, dgtest, dstest, mu, nu, pf;
   int k, bound, count, brackt, touched, evals, phase;
 
@@ -160,8 +180,9 @@ struct LbfgsResident {
     k = bound = count = brackt = touched = evals = phase = 0;
   }
   __device__ __forceinline__ static double dot(double u, double v) { return wave_sum<63>(u * v); }
+  // |g|_inf / max(1, |x|_inf) < g_epsilon (lbfgs.hpp:520-524, 592-596), the quotient cleared
   __device__ __forceinline__ bool conv_test(const LbfgsP &P) const {
-    return wave_max_nonneg<63>(fabs(g)) / fmax(1.0, wave_max_nonneg<63>(fabs(x))) < P.g_epsilon;
+    return wave_max_nonneg<63>(fabs(g)) < P.g_epsilon * fmax(1.0, wave_max_nonneg<63>(fabs(x)));
   }
   // consumes f = objective at x (gradient already in g); leaves the next point in x.  Returns the lbfgs.hpp
   // return code when the problem stops, 0x7fffffff while it runs.
@@ -253,13 +274,13 @@ struct LbfgsResident {
               bound = m < bound ? m : bound;
               hs[0] = sreg;
               hy[0] = yreg;
-              hys[0] = ys;
+              hys[0] = 1.0 / ys;  // one division per stored pair instead of two per slot and iteration
               double alpha[MR];
 #pragma unroll
               for (int it = 0; it < MR; ++it) {
                 alpha[it] = 0.0;
                 if (it < bound) {
-                  alpha[it] = dot(hs[it], dv) / hys[it];
+                  alpha[it] = dot(hs[it], dv) * hys[it];
                   dv = __builtin_fma(-alpha[it], hy[it], dv);
                 }
               }
@@ -267,7 +288,7 @@ struct LbfgsResident {
 #pragma unroll
               for (int it = MR - 1; it >= 0; --it) {
                 if (it < bound) {
-                  const double cf = alpha[it] - dot(hy[it], dv) / hys[it];
+                  const double cf = alpha[it] - dot(hy[it], dv) * hys[it];
                   dv = __builtin_fma(cf, hs[it], dv);
                 }
               }
@@ -309,6 +330,120 @@ struct LbfgsResident {
   }
 };
 
+// K v = rhs for the three axes at once, in place, given S_k^-1 and H_k (E2):
+//   forward   y_k = rhs_k - H_{k-1}' y_{k-1}     lanes 0..2 = axes: an m x m product per node; operands of the next
+//   scaling   z_k = S_k^-1 y_k                    lanes = (node, axis)          nodes arrive in alternating buffers
+//   backward  x_k = z_k - H_k x_{k+1}             lanes 0..2
+template <int S, int NB>
+__device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3][NB + 1][S - 1], const int N,
+                                            const int lane, const int na, const int ax) {
+  constexpr int m = S - 1;
+  constexpr int CH = (m <= 2) ? 4 : 2;
+  if (lane < 3 && N >= 1) {
+    double yp[m];
+#pragma unroll
+    for (int l = 0; l < m; ++l) yp[l] = V[lane][0][l];
+    // node k (1..N) needs rhs_k and H_{k-1}
+    auto load = [&](int k0, double (&BH)[CH][m][m], double (&BR)[CH][m]) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int kk = (k0 + u <= N) ? k0 + u : N;
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+          BR[u][j] = V[lane][kk][j];
+#pragma unroll
+          for (int l = 0; l < m; ++l) BH[u][j][l] = Lm.H[kk - 1][j][l];
+        }
+      }
+    };
+    auto step = [&](const int k, const double (&Hk)[m][m], const double (&rk)[m]) {
+      double y[m];
+#pragma unroll
+      for (int l = 0; l < m; ++l) {
+        y[l] = rk[l];
+#pragma unroll
+        for (int j = 0; j < m; ++j) y[l] = __builtin_fma(-Hk[j][l], yp[j], y[l]);
+        V[lane][k][l] = y[l];
+      }
+#pragma unroll
+      for (int l = 0; l < m; ++l) yp[l] = y[l];
+    };
+    double H1[CH][m][m], R1[CH][m], H2[CH][m][m], R2[CH][m];
+    load(1, H1, R1);
+#pragma unroll 1
+    for (int k0 = 1; k0 <= N; k0 += 2 * CH) {
+      load(k0 + CH, H2, R2);
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (k0 + u <= N) step(k0 + u, H1[u], R1[u]);
+      load(k0 + 2 * CH, H1, R1);
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (k0 + CH + u <= N) step(k0 + CH + u, H2[u], R2[u]);
+    }
+  }
+  __syncthreads();
+  if (na <= N) {
+    double y[m], z[m];
+#pragma unroll
+    for (int l = 0; l < m; ++l) y[l] = V[ax][na][l];
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < m; ++l) acc = __builtin_fma(Lm.Si[na][j][l], y[l], acc);
+      z[j] = acc;
+    }
+#pragma unroll
+    for (int l = 0; l < m; ++l) V[ax][na][l] = z[l];
+  }
+  __syncthreads();
+  if (lane < 3 && N >= 1) {
+    double xn[m];
+#pragma unroll
+    for (int l = 0; l < m; ++l) xn[l] = V[lane][N][l];
+    // node k (N-1..0) needs z_k and H_k; chunk q covers the nodes N-1-q*CH-u
+    auto load = [&](int d0, double (&BH)[CH][m][m], double (&BR)[CH][m]) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int kk = (N - 1 - d0 - u >= 0) ? N - 1 - d0 - u : 0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+          BR[u][j] = V[lane][kk][j];
+#pragma unroll
+          for (int l = 0; l < m; ++l) BH[u][j][l] = Lm.H[kk][j][l];
+        }
+      }
+    };
+    auto step = [&](const int k, const double (&Hk)[m][m], const double (&zk)[m]) {
+      double x[m];
+#pragma unroll
+      for (int j = 0; j < m; ++j) {
+        x[j] = zk[j];
+#pragma unroll
+        for (int l = 0; l < m; ++l) x[j] = __builtin_fma(-Hk[j][l], xn[l], x[j]);
+        V[lane][k][j] = x[j];
+      }
+#pragma unroll
+      for (int l = 0; l < m; ++l) xn[l] = x[l];
+    };
+    double H1[CH][m][m], R1[CH][m], H2[CH][m][m], R2[CH][m];
+    load(0, H1, R1);
+#pragma unroll 1
+    for (int d0 = 0; d0 < N; d0 += 2 * CH) {
+      load(d0 + CH, H2, R2);
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (N - 1 - d0 - u >= 0) step(N - 1 - d0 - u, H1[u], R1[u]);
+      load(d0 + 2 * CH, H1, R1);
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (N - 1 - d0 - CH - u >= 0) step(N - 1 - d0 - CH - u, H2[u], R2[u]);
+    }
+  }
+  __syncthreads();
+}
+
 // ---- one objective evaluation of one problem by one wave ---------------------------------------------------------
 // in: Lm.P (node positions), Lm.T (durations), Lm.hv / tv, rows; out: f (wave-uniform) and this lane's gradient
 // component (lane < nw: waypoint coordinate lane = 3 (k-1) + axis; lane in [nw, nw+nt): dJ/dT of piece lane - nw,
@@ -321,6 +456,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   using F = Factor<S, NB>;
   const int N = a.N, np = a.c - 1;
   const int na = lane / 3, ax = lane - 3 * na;  // (node | piece, axis) mapping of the per-node / per-piece phases
+  PERSIST_TICK_DECL;
 
   // ---- E1: 1/T and the primal right-hand sides, lanes = (node, axis)
   if (na <= N) {
@@ -338,25 +474,22 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
     rhs_primal_node_rt<S>(k, N, np, rk, rkm, Pm, P0, Pp, hv, tv, y);
 #pragma unroll
     for (int l = 0; l < m; ++l) Lm.X[ax][k][l] = y[l];
-  }
-  __syncthreads();
-
-  // ---- E2: block LDL^T factor fused with the primal forward sweep, then the backward sweep; lanes 0..2 = axes
-  if (lane < 3) {
-    double Dk[m][m], Lp[NLA] = {}, dip[m] = {}, wp[m] = {};
+    if (ax == 0) {  // the blocks of the system (minco_core.h Factor::factorize, assembly part)
+      double Ak[m][m];
 #pragma unroll
-    for (int j = 0; j < m; ++j)
+      for (int j = 0; j < m; ++j)
 #pragma unroll
-      for (int l = 0; l < m; ++l) Dk[j][l] = 0.0;
-#pragma unroll 1
-    for (int k = 0; k <= N; ++k) {
-      const double rk = Lm.r[k < N ? k : 0], rkm = Lm.r[k > 0 ? k - 1 : 0];
+        for (int l = 0; l < m; ++l) Ak[j][l] = 0.0;
       if (k < N) {
         Pw<S> p(rk);
 #pragma unroll
         for (int j = 0; j < m; ++j)
 #pragma unroll
-          for (int l = 0; l <= j; ++l) Dk[j][l] = __builtin_fma(Tab<S>::M[1 + j][1 + l], p[2 * S - 3 - j - l], Dk[j][l]);
+          for (int l = 0; l <= j; ++l) Ak[j][l] = __builtin_fma(Tab<S>::M[1 + j][1 + l], p[2 * S - 3 - j - l], Ak[j][l]);
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+          for (int l = 0; l < m; ++l) Lm.Kp[k][j][l] = F::ko_const(k, N, np, j, l) * p[2 * S - 3 - j - l];
       }
       if (k > 0) {
         Pw<S> p(rkm);
@@ -364,15 +497,54 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
         for (int j = 0; j < m; ++j)
 #pragma unroll
           for (int l = 0; l <= j; ++l)
-            Dk[j][l] = __builtin_fma(Tab<S>::M[S + 1 + j][S + 1 + l], p[2 * S - 3 - j - l], Dk[j][l]);
+            Ak[j][l] = __builtin_fma(Tab<S>::M[S + 1 + j][S + 1 + l], p[2 * S - 3 - j - l], Ak[j][l]);
       }
       if (k == 0 || k == N) {
 #pragma unroll
         for (int j = 0; j < m; ++j)
 #pragma unroll
           for (int l = 0; l <= j; ++l)
-            if (j < np || l < np) Dk[j][l] = (j == l) ? 1.0 : 0.0;
+            if (j < np || l < np) Ak[j][l] = (j == l) ? 1.0 : 0.0;
       }
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+#pragma unroll
+        for (int l = 0; l <= j; ++l) Lm.Ad[k][j][l] = Ak[j][l];
+    }
+  }
+  __syncthreads();
+
+  PERSIST_TICK(1);
+  // ---- E2: block LDL^T factorisation of the Schur complements S_k = A_k - Ko_{k-1}' S_{k-1}^-1 Ko_{k-1}, one lane.
+  //      This is the only part that is sequential in earnest: per node two (three) reciprocals in a row.  Its inputs
+  //      come from LDS a few nodes at a time into alternating register buffers (a load-then-use per node is an LDS
+  //      round trip of dead time per node); what the sweeps need of it leaves as S_k^-1 and H_k = S_k^-1 Ko_k, so
+  //      the sweeps are bare m x m recurrences (chain_solve) and the products with S_k^-1 run on lanes = (node, axis).
+  if (lane == 0) {
+    constexpr int CH = (m <= 2) ? 4 : 2;
+    double Dk[m][m];
+#pragma unroll
+    for (int j = 0; j < m; ++j)
+#pragma unroll
+      for (int l = 0; l < m; ++l) Dk[j][l] = 0.0;
+    auto load = [&](int k0, double (&BA)[CH][m][m], double (&BK)[CH][m][m]) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int kk = (k0 + u <= N) ? k0 + u : N, kp = (kk < N) ? kk : (N > 0 ? N - 1 : 0);
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+          for (int l = 0; l < m; ++l) {
+            if (l <= j) BA[u][j][l] = Lm.Ad[kk][j][l];
+            BK[u][j][l] = Lm.Kp[kp][j][l];
+          }
+      }
+    };
+    auto step = [&](const int k, const double (&Ak)[m][m], const double (&Kk)[m][m]) {
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+#pragma unroll
+        for (int l = 0; l <= j; ++l) Dk[j][l] += Ak[j][l];
       double Lk[NLA] = {}, dd[m], dik[m];
 #pragma unroll
       for (int j = 0; j < m; ++j) {
@@ -393,36 +565,13 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
           Lk[BlkOps<S>::li(i, j)] = v * dik[j];
         }
       }
-      if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < BlkOps<S>::nl; ++q) Lm.FL[k][q] = Lk[q];
-#pragma unroll
-        for (int j = 0; j < m; ++j) Lm.Fd[k][j] = dik[j];
-      }
-      // forward step of this axis
-      double y[m];
-#pragma unroll
-      for (int l = 0; l < m; ++l) y[l] = Lm.X[lane][k][l];
-      if (k > 0) {
-        Pw<S> p(rkm);
-        double v[m];
-#pragma unroll
-        for (int j = 0; j < m; ++j) v[j] = wp[j] * dip[j];
-        BlkOps<S>::solve_LT(Lp, v);
-        F::sub_KoT(k - 1, N, np, p, v, y);
-      }
-      BlkOps<S>::solve_L(Lk, y);
-#pragma unroll
-      for (int l = 0; l < m; ++l) Lm.X[lane][k][l] = y[l];
-      // Schur complement seed for node k+1
-      if (k < N) {
-        Pw<S> p(rk);
+      if (k < N) {  // Schur complement seed for node k+1 (the chain continues with it) and H_k
         double Y[m][m], Z[m][m];
 #pragma unroll
         for (int l = 0; l < m; ++l) {
           double col[m];
 #pragma unroll
-          for (int j = 0; j < m; ++j) col[j] = F::ko_const(k, N, np, j, l) * p[2 * S - 3 - j - l];
+          for (int j = 0; j < m; ++j) col[j] = Kk[j][l];
           BlkOps<S>::solve_L(Lk, col);
 #pragma unroll
           for (int j = 0; j < m; ++j) {
@@ -439,47 +588,47 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
             for (int j = 0; j < m; ++j) acc = __builtin_fma(-Y[j][aa], Z[j][bb], acc);
             Dk[aa][bb] = acc;
           }
+#pragma unroll
+        for (int l = 0; l < m; ++l) {  // H_k(:, l) = L^-T Z(:, l)
+          double col[m];
+#pragma unroll
+          for (int j = 0; j < m; ++j) col[j] = Z[j][l];
+          BlkOps<S>::solve_LT(Lk, col);
+#pragma unroll
+          for (int j = 0; j < m; ++j) Lm.H[k][j][l] = col[j];
+        }
       }
 #pragma unroll
-      for (int q = 0; q < NLA; ++q) Lp[q] = Lk[q];
+      for (int cc = 0; cc < m; ++cc) {  // S_k^-1(:, cc) = L^-T D^-1 L^-1 e_cc
+        double col[m];
 #pragma unroll
-      for (int j = 0; j < m; ++j) {
-        dip[j] = dik[j];
-        wp[j] = y[j];
+        for (int j = 0; j < m; ++j) col[j] = (j == cc) ? 1.0 : 0.0;
+        BlkOps<S>::solve_L(Lk, col);
+#pragma unroll
+        for (int j = 0; j < m; ++j) col[j] *= dik[j];
+        BlkOps<S>::solve_LT(Lk, col);
+#pragma unroll
+        for (int j = 0; j < m; ++j) Lm.Si[k][j][cc] = col[j];
       }
-    }
-    // backward sweep (the factor of the last node is still in registers; the others come back from LDS)
-    double xn[m] = {};
+    };
+    double A1[CH][m][m], K1[CH][m][m], A2[CH][m][m], K2[CH][m][m];
+    load(0, A1, K1);
 #pragma unroll 1
-    for (int k = N; k >= 0; --k) {
-      double Lk[NLA] = {}, dik[m], x[m];
+    for (int k0 = 0; k0 <= N; k0 += 2 * CH) {
+      load(k0 + CH, A2, K2);
 #pragma unroll
-      for (int q = 0; q < BlkOps<S>::nl; ++q) Lk[q] = Lm.FL[k][q];
+      for (int u = 0; u < CH; ++u)
+        if (k0 + u <= N) step(k0 + u, A1[u], K1[u]);
+      load(k0 + 2 * CH, A1, K1);
 #pragma unroll
-      for (int j = 0; j < m; ++j) {
-        dik[j] = Lm.Fd[k][j];
-        x[j] = Lm.X[lane][k][j];
-      }
-      if (k < N) {
-        Pw<S> p(Lm.r[k]);
-        double t[m];
-        F::mul_Ko(k, N, np, p, xn, t);
-        BlkOps<S>::solve_L(Lk, t);
-#pragma unroll
-        for (int l = 0; l < m; ++l) x[l] -= t[l];
-      }
-#pragma unroll
-      for (int l = 0; l < m; ++l) x[l] *= dik[l];
-      BlkOps<S>::solve_LT(Lk, x);
-#pragma unroll
-      for (int l = 0; l < m; ++l) {
-        Lm.X[lane][k][l] = x[l];
-        xn[l] = x[l];
-      }
+      for (int u = 0; u < CH; ++u)
+        if (k0 + CH + u <= N) step(k0 + CH + u, A2[u], K2[u]);
     }
   }
   __syncthreads();
+  chain_solve<S, NB>(Lm, Lm.X, N, lane, na, ax);
 
+  PERSIST_TICK(2);
   // ---- E3: coefficients and energy share of every (piece, axis)
   if (na < N) {
     const int i = na;
@@ -496,9 +645,13 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   }
   __syncthreads();
 
-  // ---- E4: penalty functional, lanes = (piece, sample group)
+  PERSIST_TICK(3);
+  // ---- E4: penalty functional, lanes = (piece, sample group).  A lane holds NS samples of its piece at a time: their
+  //      positions first, then the corridor rows are walked ONCE for all of them (four rows per LDS round trip, one
+  //      wave-uniform test per row), then velocity / acceleration / jerk, the box rows and the gradient per sample.
   {
     const int i = lane / G, grp = lane - G * i;
+    constexpr int NS = (G == 4) ? 5 : 3;  // G * NS >= 20 samples (planner.yaml:21) in one pass
     double gC[3][D], gT = 0.0, pc = 0.0;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
@@ -521,89 +674,148 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
             tk *= Ti;
           }
         }
-        const double *rp = rows + (size_t)i * (4 * (size_t)a.M + 4);
-        const int M = a.hpolys ? a.M : 0;
-        for (int j = grp; j < pp.res; j += G) {
-          const double tau = (double)j * inv_res;
-          // basis rows of the sample: tb[d][col] = k!/(k-d)! tau^(k-d), k = D-1-col
-          double pw[D];
-          pw[0] = 1.0;
+        const int M4 = a.hpolys ? (a.M + 3) & ~3 : 0;  // rows per piece in LDS, zero rows up to a multiple of four
+        const double *rp = rows + (size_t)i * (4 * (size_t)M4 + 4);
+        const bool all_ok = pp.res % (G * NS) == 0;  // every lane has a full set of samples in every pass
+        for (int base = 0; base < pp.res; base += G * NS) {
+          double tau[NS], pos[NS][3], gp[NS][3], cs[NS];
+          bool ok[NS];
 #pragma unroll
-          for (int e = 1; e < D; ++e) pw[e] = pw[e - 1] * tau;
-          double tb[4][D];
+          for (int sI = 0; sI < NS; ++sI) {
+            const int j = base + grp + sI * G;
+            ok[sI] = j < pp.res;
+            tau[sI] = (double)j * inv_res;
+            cs[sI] = 0.0;
 #pragma unroll
-          for (int col = 0; col < D; ++col) {
-            const int k = D - 1 - col;
+            for (int q = 0; q < 3; ++q) {
+              double acc = ct[q][0];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
+              for (int col = 1; col < D; ++col) acc = __builtin_fma(acc, tau[sI], ct[q][col]);
+              pos[sI][q] = acc;
+              gp[sI][q] = 0.0;
+            }
+          }
+          for (int r0 = 0; r0 < M4; r0 += 4) {
+            double h[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) h[u][q] = rp[4 * (r0 + u) + q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              double viol[NS], worst = 0.0;
+#pragma unroll
+              for (int sI = 0; sI < NS; ++sI)
+                viol[sI] = __builtin_fma(h[u][0], pos[sI][0], __builtin_fma(h[u][1], pos[sI][1], h[u][2] * pos[sI][2])) - h[u][3];
+              if (!all_ok) {
+#pragma unroll
+                for (int sI = 0; sI < NS; ++sI) viol[sI] = ok[sI] ? viol[sI] : -1.0;
+              }
+#pragma unroll
+              for (int sI = 0; sI < NS; ++sI) worst = fmax(worst, viol[sI]);
+              if (__any(worst > 0.0)) {
+#pragma unroll
+                for (int sI = 0; sI < NS; ++sI) {
+                  double f, df;
+                  smoothed_l1_clamped(pp.mu, inv_mu, viol[sI], f, df);
+                  cs[sI] += f;
+                  gp[sI][0] = __builtin_fma(df, h[u][0], gp[sI][0]);
+                  gp[sI][1] = __builtin_fma(df, h[u][1], gp[sI][1]);
+                  gp[sI][2] = __builtin_fma(df, h[u][2], gp[sI][2]);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int sI = 0; sI < NS; ++sI) {
+            // basis rows of the sample: tb[d][col] = k!/(k-d)! tau^(k-d), k = D-1-col (tb[0][col] = pw[k])
+            double pw[D];
+            pw[0] = 1.0;
+#pragma unroll
+            for (int e = 1; e < D; ++e) pw[e] = pw[e - 1] * tau[sI];
+            auto basis = [&](const int d, const int col) {
+              const int k = D - 1 - col;
               double fct = 1.0;
 #pragma unroll
               for (int q = 0; q < d; ++q) fct *= (double)(k - q);
-              tb[d][col] = (k >= d) ? fct * pw[k >= d ? k - d : 0] : 0.0;
-            }
-          }
-          double st[4][3];
+              return (k >= d) ? fct * pw[k >= d ? k - d : 0] : 0.0;
+            };
+            double tb1[D], tb2[D], vel[3], acc_[3];
 #pragma unroll
-          for (int d = 0; d < 4; ++d)
+            for (int col = 0; col < D; ++col) {
+              tb1[col] = basis(1, col);
+              tb2[col] = basis(2, col);
+            }
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-              double acc = 0.0;
-#pragma unroll
-              for (int col = 0; col < D; ++col) acc = __builtin_fma(ct[q][col], tb[d][col], acc);
-              st[d][q] = acc * (d == 0 ? 1.0 : d == 1 ? rT : d == 2 ? rT2 : rT3);
-            }
-          double cost = 0.0, g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-          bool active = false;
-          for (int r = 0; r < M; ++r) {
-            const double h0 = rp[4 * r], h1 = rp[4 * r + 1], h2 = rp[4 * r + 2], h3 = rp[4 * r + 3];
-            const double viol = __builtin_fma(h0, st[0][0], __builtin_fma(h1, st[0][1], h2 * st[0][2])) - h3;
-            if (__any(viol > 0.0)) {
-              double f, df;
-              smoothed_l1_clamped(pp.mu, inv_mu, viol, f, df);
-              cost = __builtin_fma(pp.wc, f, cost);
-              df *= pp.wc;
-              g[0][0] = __builtin_fma(df, h0, g[0][0]);
-              g[0][1] = __builtin_fma(df, h1, g[0][1]);
-              g[0][2] = __builtin_fma(df, h2, g[0][2]);
-              active = true;
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            const double av = fabs(st[1][q]) - pp.vmax, aa_ = fabs(st[2][q]) - pp.amax;
-            if (__any(av > 0.0)) {
-              double f, df;
-              smoothed_l1_clamped(pp.mu, inv_mu, av, f, df);
-              cost = __builtin_fma(pp.wv, f, cost);
-              g[1][q] = __builtin_fma(pp.wv * (st[1][q] < 0.0 ? -1.0 : 1.0), df, g[1][q]);
-              active = true;
-            }
-            if (__any(aa_ > 0.0)) {
-              double f, df;
-              smoothed_l1_clamped(pp.mu, inv_mu, aa_, f, df);
-              cost = __builtin_fma(pp.wa, f, cost);
-              g[2][q] = __builtin_fma(pp.wa * (st[2][q] < 0.0 ? -1.0 : 1.0), df, g[2][q]);
-              active = true;
-            }
-          }
-          if (__any(active)) {
-            pc = __builtin_fma(step, cost, pc);
-            double dt = 0.0;
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-#pragma unroll
-              for (int q = 0; q < 3; ++q) dt = __builtin_fma(g[d][q], st[d + 1][q], dt);
-            gT += cost * inv_res + step * dt * ((double)j * inv_res);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              const double g0 = step * g[0][q], g1 = step * g[1][q] * rT, g2 = step * g[2][q] * rT2;
+              double a1 = 0.0, a2 = 0.0;
 #pragma unroll
               for (int col = 0; col < D; ++col) {
-                double acc = g0 * tb[0][col];
-                acc = __builtin_fma(g1, tb[1][col], acc);
-                acc = __builtin_fma(g2, tb[2][col], acc);
-                gC[q][col] += acc;
+                a1 = __builtin_fma(ct[q][col], tb1[col], a1);
+                a2 = __builtin_fma(ct[q][col], tb2[col], a2);
               }
+              vel[q] = a1 * rT;
+              acc_[q] = a2 * rT2;
+            }
+            double ex[2][3], worst = 0.0;  // excess over the velocity / acceleration box (only one of +-v can be violated)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              ex[0][q] = fabs(vel[q]) - pp.vmax;
+              ex[1][q] = fabs(acc_[q]) - pp.amax;
+            }
+            if (!all_ok) {
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                ex[0][q] = ok[sI] ? ex[0][q] : -1.0;
+                ex[1][q] = ok[sI] ? ex[1][q] : -1.0;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) worst = fmax(worst, fmax(ex[0][q], ex[1][q]));
+            const bool box = __any(worst > 0.0);
+            const bool cor = __any(cs[sI] > 0.0);
+            if (box || cor) {
+              double cost = pp.wc * cs[sI];
+              double g0[3], dt = 0.0;  // d cost / d t = g_p.v + g_v.a + g_a.j
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                g0[q] = pp.wc * gp[sI][q];
+                dt = __builtin_fma(g0[q], vel[q], dt);
+              }
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                const double s0 = step * g0[q];
+#pragma unroll
+                for (int col = 0; col < D; ++col) gC[q][col] = __builtin_fma(s0, pw[D - 1 - col], gC[q][col]);
+              }
+              if (box) {  // (rare once the limits hold: the jerk is only needed for the time derivative of the acceleration rows)
+                double jer[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                  double a3 = 0.0;
+#pragma unroll
+                  for (int col = 0; col < D; ++col) a3 = __builtin_fma(ct[q][col], basis(3, col), a3);
+                  jer[q] = a3 * rT3;
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                  double f, df;
+                  smoothed_l1_clamped(pp.mu, inv_mu, ex[0][q], f, df);
+                  cost = __builtin_fma(pp.wv, f, cost);
+                  const double g1 = pp.wv * (vel[q] < 0.0 ? -1.0 : 1.0) * df;
+                  smoothed_l1_clamped(pp.mu, inv_mu, ex[1][q], f, df);
+                  cost = __builtin_fma(pp.wa, f, cost);
+                  const double g2 = pp.wa * (acc_[q] < 0.0 ? -1.0 : 1.0) * df;
+                  dt = __builtin_fma(g1, acc_[q], dt);
+                  dt = __builtin_fma(g2, jer[q], dt);
+                  const double s1 = step * g1 * rT, s2 = step * g2 * rT2;
+#pragma unroll
+                  for (int col = 0; col < D; ++col)
+                    gC[q][col] = __builtin_fma(s2, tb2[col], __builtin_fma(s1, tb1[col], gC[q][col]));
+                }
+              }
+              pc = __builtin_fma(step, cost, pc);
+              gT += cost * inv_res + step * dt * tau[sI];
             }
           }
         }
@@ -636,6 +848,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   }
   __syncthreads();
 
+  PERSIST_TICK(4);
   // ---- E5: energy part of dJ/dc, node-state adjoint contributions and the direct dPhi/dT term; lanes = (piece, axis)
   double x0s[S], x1s[S];  // node states of this lane's piece (position, derivatives), reused by E7
 #pragma unroll
@@ -712,80 +925,29 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
     gTl = __builtin_fma(-p[1], dsum, gTl);
 #pragma unroll
     for (int k = 0; k < S; ++k) {
-      Lm.cA[i][ax][k] = cA[k];
-      Lm.cB[i][ax][k] = cB[k];
+      Lm.co[i][ax][k] = cA[k];
+      Lm.co[i][ax][S + k] = cB[k];
     }
     Lm.gTp[i][ax] = gTl;
   }
   __syncthreads();
 
-  // ---- E6: adjoint solve K lam = g_x|free with the factor of E2; lanes 0..2 = axes
-  if (lane < 3) {
-    double Lp[NLA] = {}, dip[m] = {}, wp[m] = {};
-#pragma unroll 1
-    for (int k = 0; k <= N; ++k) {
-      double Lk[NLA] = {}, dik[m], y[m];
+  PERSIST_TICK(5);
+  // ---- E6: adjoint solve K lam = g_x|free (pinned rows 0): right-hand sides on lanes = (node, axis), then the sweeps
+  if (na <= N) {
+    const int k = na;
 #pragma unroll
-      for (int q = 0; q < BlkOps<S>::nl; ++q) Lk[q] = Lm.FL[k][q];
-#pragma unroll
-      for (int j = 0; j < m; ++j) dik[j] = Lm.Fd[k][j];
-#pragma unroll
-      for (int l = 0; l < m; ++l) {
-        double v = 0.0;
-        if (k > 0) v += Lm.cB[k - 1][lane][l + 1];
-        if (k < N) v += Lm.cA[k < N ? k : 0][lane][l + 1];
-        y[l] = ((k == 0 || k == N) && l < np) ? 0.0 : v;
-      }
-      if (k > 0) {
-        Pw<S> p(Lm.r[k - 1]);
-        double v[m];
-#pragma unroll
-        for (int j = 0; j < m; ++j) v[j] = wp[j] * dip[j];
-        BlkOps<S>::solve_LT(Lp, v);
-        F::sub_KoT(k - 1, N, np, p, v, y);
-      }
-      BlkOps<S>::solve_L(Lk, y);
-#pragma unroll
-      for (int l = 0; l < m; ++l) Lm.A[lane][k][l] = y[l];
-#pragma unroll
-      for (int q = 0; q < NLA; ++q) Lp[q] = Lk[q];
-#pragma unroll
-      for (int j = 0; j < m; ++j) {
-        dip[j] = dik[j];
-        wp[j] = y[j];
-      }
-    }
-    double xn[m] = {};
-#pragma unroll 1
-    for (int k = N; k >= 0; --k) {
-      double Lk[NLA] = {}, dik[m], x[m];
-#pragma unroll
-      for (int q = 0; q < BlkOps<S>::nl; ++q) Lk[q] = Lm.FL[k][q];
-#pragma unroll
-      for (int j = 0; j < m; ++j) {
-        dik[j] = Lm.Fd[k][j];
-        x[j] = Lm.A[lane][k][j];
-      }
-      if (k < N) {
-        Pw<S> p(Lm.r[k]);
-        double t[m];
-        F::mul_Ko(k, N, np, p, xn, t);
-        BlkOps<S>::solve_L(Lk, t);
-#pragma unroll
-        for (int l = 0; l < m; ++l) x[l] -= t[l];
-      }
-#pragma unroll
-      for (int l = 0; l < m; ++l) x[l] *= dik[l];
-      BlkOps<S>::solve_LT(Lk, x);
-#pragma unroll
-      for (int l = 0; l < m; ++l) {
-        Lm.A[lane][k][l] = x[l];
-        xn[l] = x[l];
-      }
+    for (int l = 0; l < m; ++l) {
+      double v = 0.0;
+      if (k > 0) v += Lm.co[k - 1][ax][S + l + 1];
+      if (k < N) v += Lm.co[k < N ? k : 0][ax][l + 1];
+      Lm.X[ax][k][l] = ((k == 0 || k == N) && l < np) ? 0.0 : v;
     }
   }
   __syncthreads();
+  chain_solve<S, NB>(Lm, Lm.X, N, lane, na, ax);
 
+  PERSIST_TICK(6);
   // ---- E7: position-row term and -lam' (dW/dT) x of every (piece, axis)
   if (na < N) {
     const int k = na;
@@ -793,8 +955,8 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
     double la[m], lb[m];
 #pragma unroll
     for (int l = 0; l < m; ++l) {
-      la[l] = Lm.A[ax][k][l];
-      lb[l] = Lm.A[ax][k + 1][l];
+      la[l] = Lm.X[ax][k][l];
+      lb[l] = Lm.X[ax][k + 1][l];
     }
     double wl = 0.0;
 #pragma unroll
@@ -822,11 +984,12 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   }
   __syncthreads();
 
+  PERSIST_TICK(7);
   // ---- E8: total gradient component of this lane and the cost
   double g = 0.0;
   if (lane < a.nw) {
     const int k = na + 1;  // waypoint node 1 .. N-1
-    g = Lm.cA[k][ax][0] + Lm.cB[k - 1][ax][0] - Lm.wl[k][ax] + Lm.wl[k - 1][ax];
+    g = Lm.co[k][ax][0] + Lm.co[k - 1][ax][S] - Lm.wl[k][ax] + Lm.wl[k - 1][ax];
   } else if (lane < a.nw + a.nt) {
     const int i = lane - a.nw;
     g = Lm.gdT[i] + ((Lm.gTp[i][0] + Lm.gTp[i][1]) + Lm.gTp[i][2]) + a.pp.rho;
@@ -836,6 +999,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   f_out = wave_sum<63>(fp);
   g_out = g;
   __syncthreads();  // (the next evaluation overwrites P / T)
+  PERSIST_TICK(8);
 }
 
 // MR: history slots in registers (mem_size <= MR).
@@ -865,10 +1029,10 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
     Lm.tv[q][j] = (j < np) ? a.tail[(int64_t)(q * a.c + 1 + j) * ld + b] : 0.0;
   }
   if (a.with_penalty && a.hpolys) {
-    const int per = 4 * a.M;
-    for (int e = lane; e < N * per; e += 64) {
-      const int i = e / per, w = e - per * i;
-      rows[(size_t)i * (per + 4) + w] = a.hpolys[(int64_t)e * ld + b];
+    const int per = 4 * a.M, per4 = 4 * ((a.M + 3) & ~3);
+    for (int e = lane; e < N * per4; e += 64) {
+      const int i = e / per4, w = e - per4 * i;
+      rows[(size_t)i * (per4 + 4) + w] = (w < per) ? a.hpolys[(int64_t)(i * per + w) * ld + b] : 0.0;
     }
   }
   LbfgsResident<MR> st;
@@ -884,10 +1048,12 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
     __syncthreads();
     double f, g;
     persist_eval<S, NB>(Lm, rows, a, lane, f, g);
+    PERSIST_TICK_DECL;
     if (lane >= a.nw && lane < n) g *= dforward_T(st.x);
     st.g = (lane < n) ? g : 0.0;
     finish = st.update(a.p, lane, f);
     finish = __builtin_amdgcn_readfirstlane(finish);
+    PERSIST_TICK(9);
     if (finish != 0x7fffffff) break;
   }
   if (lane < n) a.x[(int64_t)lane * ld + b] = st.x;

@@ -37,6 +37,7 @@ LBFGS_RUNNING = 2147483647
 
 OPT_WAYPOINTS = 1
 OPT_TIMES = 2
+OPT_LOCKSTEP = 4      # force the launch-per-evaluation kernels (default: one launch, one wave per problem, when it fits)
 
 
 def lbfgs_parameter_t(**over):
