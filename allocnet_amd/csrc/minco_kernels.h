@@ -177,6 +177,13 @@ __device__ __forceinline__ void smoothed_l1_clamped(double mu, double inv_mu, do
   df = sq * __builtin_fma(-0.5, xd, (3.0 * inv_mu) * mm);
 }
 
+// F and F' of the note in k_piece_grad: smoothed L1 of x = mu u is mu F(u), its slope F'(u)
+__device__ __forceinline__ void smoothed_l1_unit(double u, double &F, double &dF) {
+  const double w = fmax(u, 0.0), uc = fmin(w, 1.0), sq = uc * uc;
+  F = __builtin_fma(sq * uc, __builtin_fma(-0.5, uc, 1.0), w - uc);
+  dF = sq * __builtin_fma(-2.0, uc, 3.0);
+}
+
 struct PieceGradArgs {
   const double *coeffs, *T, *hpolys;
   double *gdC, *gdT, *pcost;
@@ -246,43 +253,26 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : 2) k_piece_grad(PieceGradArg
       gC[ax][col] = 0.0;
     }
   double gT = 0.0, pc = 0.0;
-  if (a.with_energy && half == 0 && wv == 0) {
-    // d/dc of sum_{j,k>=S} c_j c_k f_j f_k T^(j+k-2S+1)/(j+k-2S+1) ;  d/dT = (p^(S)(T))^2
-    double tp[D];
-    tp[0] = 1.0;
-#pragma unroll
-    for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-      double ps = 0.0;
-#pragma unroll
-      for (int j = S; j < D; ++j) {
-        double fj = 1.0;
-#pragma unroll
-        for (int e = 0; e < S; ++e) fj *= (double)(j - e);
-        ps = __builtin_fma(fj * tp[j - S], c[ax][D - 1 - j], ps);
-        double acc = 0.0;
-#pragma unroll
-        for (int k = S; k < D; ++k) {
-          double fk = 1.0;
-#pragma unroll
-          for (int e = 0; e < S; ++e) fk *= (double)(k - e);
-          acc = __builtin_fma(2.0 * fj * fk / (double)(j + k - 2 * S + 1) * tp[j + k - 2 * S + 1],
-                              c[ax][D - 1 - k], acc);
-        }
-        gC[ax][D - 1 - j] = acc;
-      }
-      gT = __builtin_fma(ps, ps, gT);
-    }
-  }
   if (a.with_penalty) {
     // Normalised time: with c~_k = c_k T^k the state rows at sample j depend on tau_j = j/res only,
     //   d^d p/dt^d (t_j) = T^-d sum_col c~[col] tab[j][d][col],  tab[j][d][col] = k!/(k-d)! tau_j^(k-d)
-    // the table is built once per block in LDS and read with a wave-uniform index (broadcast).
+    // (table read with a wave-uniform index: scalar loads).
+    //
+    // Instruction diet (the kernel is bound by FP64 issue, tools/micro/fp64_peak.hip):
+    //  * smoothed L1 in normalised form: with u = x/mu, F(u) = uc^3 (1 - uc/2) + max(u-1, 0), F'(u) = uc^2 (3 - 2 uc),
+    //    uc = clamp(u, 0, 1), the penalty is mu F(u) and its slope F'(u); the polytope rows are divided by mu when
+    //    they are loaded, the weights are applied once per sample;
+    //  * only the pass that holds the box rows evaluates velocity and acceleration; the other passes need the
+    //    position alone;
+    //  * no jerk and no per-sample d/dt: the sample times t_j = tau_j T move with T, and since
+    //    tau tab[j][d+1][col] = (k-d) tab[j][d][col] the sum over the samples of step tau_j (g_p.v + g_v.a + g_a.j)
+    //    is  (1/T) sum_col c~[col] k gN[col] - Rs,  gN the gradient w.r.t. c~ that is accumulated anyway and Rs the
+    //    scalar sum_j (s1.v + 2 T s2.a) over the samples with a violated box row (s1, s2: their weights in gN).
     const Penalty pp = a.pp;
     const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
     const double step = Ti * inv_res;
-    const double rT = 1.0 / Ti, rT2 = rT * rT, rT3 = rT2 * rT;
+    const double rT = 1.0 / Ti, rT2 = rT * rT;
+    const double wcm = pp.wc * pp.mu, wvm = pp.wv * pp.mu, wam = pp.wa * pp.mu;
     double ct[3][D];  // c~
     {
       double tk = 1.0;
@@ -298,6 +288,7 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : 2) k_piece_grad(PieceGradArg
     for (int ax = 0; ax < 3; ++ax)
 #pragma unroll
       for (int col = 0; col < D; ++col) gN[ax][col] = 0.0;
+    double csum = 0.0, Rs = 0.0;  // sum of the sample costs; see above
     // Polytope rows are held in registers, RC at a time, and the sample loop runs inside: re-reading
     // them from L2 for every sample (res x M x 32 B per lane) was the bottleneck of this kernel.
     constexpr int RC = 8;
@@ -318,77 +309,95 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : 2) k_piece_grad(PieceGradArg
         for (int q = 0; q < 4; ++q)
           hr[r][q] = ok ? a.hpolys[(int64_t)((i * pp.M + rr) * 4 + q) * ld + b] : 0.0;
       }
+#pragma unroll
+      for (int r = 0; r < RC; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hr[r][q] *= inv_mu;
       const bool first = SPLIT ? (half == 1 && pass == 0) : (ch == 0);  // the pass that also evaluates the box rows
       for (int j = wv; j < pp.res; j += SW) {
         const double *tb = tab + (size_t)j * 4 * D;
-        double st[4][3];
+        double pos[3];
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int ax = 0; ax < 3; ++ax) {
+          double acc = 0.0;
 #pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            double acc = 0.0;
-#pragma unroll
-            for (int col = 0; col < D; ++col) acc = __builtin_fma(ct[ax][col], tb[d * D + col], acc);
-            st[d][ax] = acc * (d == 0 ? 1.0 : d == 1 ? rT : d == 2 ? rT2 : rT3);
-          }
-        double cost = 0.0, g[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // d cost / d (p,v,a)
-        bool active = false;
+          for (int col = 0; col < D; ++col) acc = __builtin_fma(ct[ax][col], tb[col], acc);
+          pos[ax] = acc;
+        }
+        double Fs = 0.0, G[3] = {0.0, 0.0, 0.0};  // sum of F(u) and of F'(u) a/mu over the rows
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
-          const double viol =
-              __builtin_fma(hr[r][0], st[0][0], __builtin_fma(hr[r][1], st[0][1], hr[r][2] * st[0][2])) - hr[r][3];
-          if (__any(viol > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
-            double f, df;
-            smoothed_l1_clamped(pp.mu, inv_mu, viol, f, df);
-            cost = __builtin_fma(pp.wc, f, cost);
-            df *= pp.wc;
-            g[0][0] = __builtin_fma(df, hr[r][0], g[0][0]);
-            g[0][1] = __builtin_fma(df, hr[r][1], g[0][1]);
-            g[0][2] = __builtin_fma(df, hr[r][2], g[0][2]);
-            active = true;
+          const double u = __builtin_fma(hr[r][0], pos[0], __builtin_fma(hr[r][1], pos[1], __builtin_fma(hr[r][2], pos[2], -hr[r][3])));
+          if (__any(u > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
+            const double w = fmax(u, 0.0), uc = fmin(w, 1.0), sq = uc * uc;
+            Fs += w - uc;
+            Fs = __builtin_fma(sq * uc, __builtin_fma(-0.5, uc, 1.0), Fs);
+            const double df = sq * __builtin_fma(-2.0, uc, 3.0);
+            G[0] = __builtin_fma(df, hr[r][0], G[0]);
+            G[1] = __builtin_fma(df, hr[r][1], G[1]);
+            G[2] = __builtin_fma(df, hr[r][2], G[2]);
           }
         }
+        double cost = wcm * Fs;
+        bool box = false;
+        double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
         if (first) {
+          double vel[3], acc_[3], worst = 0.0;
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
-            const double av = fabs(st[1][ax]) - pp.vmax, aa_ = fabs(st[2][ax]) - pp.amax;
-            if (__any(av > 0.0)) {  // only one of +v, -v can be violated
-              double f, df;
-              smoothed_l1_clamped(pp.mu, inv_mu, av, f, df);
-              cost = __builtin_fma(pp.wv, f, cost);
-              g[1][ax] = __builtin_fma(pp.wv * (st[1][ax] < 0.0 ? -1.0 : 1.0), df, g[1][ax]);
-              active = true;
-            }
-            if (__any(aa_ > 0.0)) {
-              double f, df;
-              smoothed_l1_clamped(pp.mu, inv_mu, aa_, f, df);
-              cost = __builtin_fma(pp.wa, f, cost);
-              g[2][ax] = __builtin_fma(pp.wa * (st[2][ax] < 0.0 ? -1.0 : 1.0), df, g[2][ax]);
-              active = true;
-            }
-          }
-        }
-        if (__any(active)) {
-          pc = __builtin_fma(step, cost, pc);
-          double dt = 0.0;  // d cost / d t = g_p.v + g_v.a + g_a.j
-#pragma unroll
-          for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) dt = __builtin_fma(g[d][ax], st[d + 1][ax], dt);
-          gT += cost * inv_res + step * dt * ((double)j * inv_res);
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            const double g0 = step * g[0][ax], g1 = step * g[1][ax] * rT, g2 = step * g[2][ax] * rT2;
+            double a1 = 0.0, a2 = 0.0;
 #pragma unroll
             for (int col = 0; col < D; ++col) {
-              double acc = g0 * tb[col];
-              acc = __builtin_fma(g1, tb[D + col], acc);
-              acc = __builtin_fma(g2, tb[2 * D + col], acc);
-              gN[ax][col] += acc;
+              a1 = __builtin_fma(ct[ax][col], tb[D + col], a1);
+              a2 = __builtin_fma(ct[ax][col], tb[2 * D + col], a2);
             }
+            vel[ax] = a1 * rT;
+            acc_[ax] = a2 * rT2;
+            worst = fmax(worst, fmax(fabs(vel[ax]) - pp.vmax, fabs(acc_[ax]) - pp.amax));
+          }
+          box = __any(worst > 0.0);
+          if (box) {  // only one of +v, -v (+a, -a) can be violated
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+              double f, df;
+              smoothed_l1_unit((fabs(vel[ax]) - pp.vmax) * inv_mu, f, df);
+              cost = __builtin_fma(wvm, f, cost);
+              s1[ax] = step * rT * pp.wv * (vel[ax] < 0.0 ? -df : df);
+              smoothed_l1_unit((fabs(acc_[ax]) - pp.amax) * inv_mu, f, df);
+              cost = __builtin_fma(wam, f, cost);
+              s2[ax] = step * rT2 * pp.wa * (acc_[ax] < 0.0 ? -df : df);
+              Rs = __builtin_fma(s1[ax], vel[ax], Rs);
+              Rs = __builtin_fma(2.0 * Ti * s2[ax], acc_[ax], Rs);
+            }
+          }
+        }
+        if (__any(cost > 0.0)) {
+          csum += cost;
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            const double s0 = step * wcm * G[ax];
+#pragma unroll
+            for (int col = 0; col < D; ++col) gN[ax][col] = __builtin_fma(s0, tb[col], gN[ax][col]);
+          }
+          if (box) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+              for (int col = 0; col < D; ++col)
+                gN[ax][col] = __builtin_fma(s2[ax], tb[2 * D + col], __builtin_fma(s1[ax], tb[D + col], gN[ax][col]));
           }
         }
       }
+    }
+    pc = step * csum;
+    {  // d/dT at fixed c: the quadrature weight T/res and the sample times tau_j T
+      double acc = 0.0;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+        for (int col = 0; col < D; ++col)
+          acc = __builtin_fma(ct[ax][col] * (double)(D - 1 - col), gN[ax][col], acc);
+      gT += csum * inv_res + rT * acc - Rs;
     }
     {  // d/dc = T^k d/dc~
       double tk = 1.0;
@@ -398,6 +407,41 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : 2) k_piece_grad(PieceGradArg
         for (int ax = 0; ax < 3; ++ax) gC[ax][col] = __builtin_fma(gN[ax][col], tk, gC[ax][col]);
         tk *= Ti;
       }
+    }
+  }
+  if (a.with_energy && half == 0 && wv == 0) {
+    // d/dc of sum_{j,k>=S} c_j c_k f_j f_k T^(j+k-2S+1)/(j+k-2S+1) ;  d/dT = (p^(S)(T))^2
+    // (the S highest-power coefficients are read again here: the penalty part above has the registers for itself)
+    double ch[3][S];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+      for (int col = 0; col < S; ++col) ch[ax][col] = a.coeffs[(int64_t)((i * 3 + ax) * D + col) * ld + b];
+    double tp[D];
+    tp[0] = 1.0;
+#pragma unroll
+    for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      double ps = 0.0;
+#pragma unroll
+      for (int j = S; j < D; ++j) {
+        double fj = 1.0;
+#pragma unroll
+        for (int e = 0; e < S; ++e) fj *= (double)(j - e);
+        ps = __builtin_fma(fj * tp[j - S], ch[ax][D - 1 - j], ps);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = S; k < D; ++k) {
+          double fk = 1.0;
+#pragma unroll
+          for (int e = 0; e < S; ++e) fk *= (double)(k - e);
+          acc = __builtin_fma(2.0 * fj * fk / (double)(j + k - 2 * S + 1) * tp[j + k - 2 * S + 1],
+                              ch[ax][D - 1 - k], acc);
+        }
+        gC[ax][D - 1 - j] += acc;
+      }
+      gT = __builtin_fma(ps, ps, gT);
     }
   }
   if (SPLIT) {
