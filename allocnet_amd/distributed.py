@@ -37,6 +37,9 @@ def allgather_costs(local_costs, total, group=None, out=None):
     gathered = torch.empty(world * m, dtype=local_costs.dtype, device=local_costs.device)
     dist.all_gather_into_tensor(gathered, send.contiguous(), group=group)
     if total == world * m:
+        if out is not None:
+            out.copy_(gathered)
+            return out
         return gathered
     res = out if out is not None else torch.empty(total, dtype=local_costs.dtype, device=local_costs.device)
     for r in range(world):

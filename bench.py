@@ -15,6 +15,12 @@ Prints ONE JSON line (rank 0).  `value` is whole-job trajectories/s.  Extra obje
   cpu_baseline  the C oracle (classic banded-LU MINCO, oracle/minco_oracle.c) on the host cores
   config1_b1024 the literal configs[1] batch (B=1024), which is launch-latency bound
   host_api      PCIe-inclusive rate through the host-pointer entry point (never `value`)
+  config5       BASELINE.json configs[4] (SURVEY 8(d) "config 5"): 32768 x 8-segment min-snap with corridor and
+                dynamic-limit penalties, sharded over the ranks, one cost + gradient evaluation per step, costs
+                all-gathered; every rank takes part, so an N-GPU run measures the configuration BASELINE names for 8 GPUs
+
+`--workload config5` makes that evaluation the timed main workload instead (same JSON contract; strong scaling:
+the 32768 trajectories are a fixed total).
 """
 import argparse
 import json
@@ -51,6 +57,86 @@ def pmc_traffic_bytes(B, N, s):
     return best
 
 
+def config5_bytes(s, c, N, M):
+    """compulsory bytes of one cost + gradient evaluation per trajectory: the energy-only figure plus
+    the corridor rows 8*4*sum(M_i) and the gradient outputs 8*(N + 3(N-1)) (6248 B at N = 8, s = 4, M = 16)."""
+    return algorithmic_bytes(s, c, N) + 8 * 4 * N * M + 8 * (N + 3 * (N - 1))
+
+
+FP64_PEAK_TFLOPS = 74.5        # measured FMA peak, tools/micro/fp64_peak.hip (profiles/r02_fp64_peak.txt); nominal 78.6
+
+
+def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warmup, total=32768):
+    """BASELINE configs[4]: `total` x 8-segment min-snap, corridor + velocity / acceleration limit penalties (seed 3),
+    contiguous shards over the ranks (remainder to the low ranks), one cost + gradient evaluation of the shard per step
+    (k_minco_solve -> k_piece_grad -> k_minco_propagate) and the all-gather of the costs."""
+    import numpy as np
+    from allocnet_amd.synth import corridor_problem
+    from allocnet_amd.distributed import shard_bounds
+    s, c, N, M = 4, 3, 8, 16
+    lo, hi = shard_bounds(total, world, rank)
+    B = hi - lo
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(3), total, N, c, M)
+    ld = aa.recommended_ld(max(B, 1))
+
+    def to_bm(a):
+        f = np.ascontiguousarray(a[lo:hi].reshape(B, -1).T)
+        t = torch.zeros(f.shape[0], ld, device=device, dtype=torch.float64)
+        t[:, :B] = torch.from_numpy(f).to(device)
+        return t
+    th, tt, tw, tT, thp = (to_bm(x) for x in (head, tail, wps, T, hp))
+    pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0,
+                          res=20, poly_rows=M)
+    cost, gP, gT, work = aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, ctx=ctx)
+    m = -(-total // world)                      # padded shard length of the gather (ragged shards)
+    send = torch.zeros(m, device=device, dtype=torch.float64)
+    gathered = torch.empty(world * m, device=device, dtype=torch.float64) if use_dist else None
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, work=work, cost=cost, gradP=gP,
+                               gradT=gT, ctx=ctx)
+        if ev is not None:
+            ev[1].record()
+        if use_dist:
+            send[:B].copy_(cost[:B])
+            dist.all_gather_into_tensor(gathered, send)
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(ev[i])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        if not torch.equal(gathered[rank * m:rank * m + B], cost[:B]):
+            raise SystemExit("config5: all-gather of costs returned wrong data")
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    ab = config5_bytes(s, c, N, M)
+    achieved = B * ab / (kernel_ms * 1e-3) / 1e9
+    return {"value": total * steps / elapsed, "unit": "trajectory cost+gradient evaluations/s", "total_batch": total,
+            "batch_this_rank": B, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kernel_ms, "steps": steps,
+            "scaling": "strong", "pieces": N, "order": s, "poly_rows": M, "res": 20,
+            "penalty_active_frac": float((cost[:B] > 0).double().mean().item()),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "kernel": "k_piece_grad (+ k_minco_solve, k_minco_propagate)",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_trajectory": ab,
+                         "note": "the evaluation is bound by FP64 issue, not by HBM: k_piece_grad runs at 63 % of the "
+                                 "measured FP64 FMA peak (profiles/r02_cost_grad_counters.txt)",
+                         "fp64_peak_tflops_measured": FP64_PEAK_TFLOPS}}
+
+
 def synth_batch_minor(torch, B, ld, N, c, seed, device):
     """SURVEY.md 8(d) config 2 generator, produced directly on the device in batch-minor layout:
     random walk, step ~U(1,3) m in a random direction, z clamped to [0,5]; T ~U(0.5,2); rest-to-rest."""
@@ -84,6 +170,8 @@ def main():
     ap.add_argument("--main-only", action="store_true",
                     help="only the timed main workload (used under rocprofv3 so kernel stats are not mixed)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--workload", choices=("solve", "config5"), default="solve",
+                    help="solve: the headline (configs[1] problem at a saturating batch); config5: BASELINE configs[4]")
     args = ap.parse_args()
 
     import torch
@@ -114,6 +202,28 @@ def main():
     D = 2 * s
     ld = aa.recommended_ld(B)      # non-power-of-two row stride (HBM channel/bank spread)
     ctx = aa.Context(local_rank)
+    if args.workload == "config5":
+        c5 = run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, args.steps, args.warmup)
+        if use_dist:
+            dist.destroy_process_group()
+        if rank != 0:
+            return
+        out = {"metric": "MINCO trajectories solved/sec (8-seg min-snap)", "value": c5["value"],
+               "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": c5["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "configs[4]: 32768 x 8-segment min-snap, corridor + dynamic-limit penalties, one "
+                                      "cost + gradient evaluation per trajectory per step, sharded, costs all-gathered",
+                          "global_batch": c5["total_batch"], "batch_this_rank": c5["batch_this_rank"],
+                          "parallelism": f"dp{world}" + ("+allgather(costs)" if use_dist else "")},
+               "roofline": dict(c5["roofline"], traffic=None), "config5": c5}
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+        return
     head, tail, wps, T = synth_batch_minor(torch, B, ld, N, c, seed=rank, device=device)
     coeffs = torch.empty(N * 3 * D, ld, device=device, dtype=torch.float64)
     # two cost buffers: the all-gather of step k (RCCL stream) overlaps the solve of step k+1
@@ -167,6 +277,12 @@ def main():
             raise SystemExit("all-gather of costs returned wrong data")
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
+    # every rank takes part in the sharded cost + gradient evaluation (BASELINE configs[4])
+    c5 = None
+    if not args.main_only:
+        del coeffs
+        c5 = run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps=50, warmup=5)
+        coeffs = torch.empty(N * 3 * D, ld, device=device, dtype=torch.float64)
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -194,6 +310,8 @@ def main():
     }
 
     out["roofline"]["traffic"] = pmc_traffic_bytes(B, N, s)
+    if c5 is not None:
+        out["config5"] = c5
     if world == 1 and not args.main_only:
         # literal configs[1]: B = 1024 (launch-latency bound; reported, not the headline)
         b2 = 1024

@@ -14,6 +14,18 @@ def test_algorithmic_bytes_match_survey():
     assert bench.algorithmic_bytes(3, 3, 16) == 2944     # 16-seg jerk
 
 
+def test_config5_workload_bookkeeping():
+    """`--workload config5` / the config5 sub-object: SURVEY 8(d) bytes of one cost + gradient evaluation, the CLI
+    switch, and the shard arithmetic it relies on."""
+    import bench
+    from allocnet_amd.distributed import shard_bounds
+    assert bench.config5_bytes(4, 3, 8, 16) == 1920 + 4096 + 232 == 6248
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"--workload"' in src and '"config5"' in src and "scaling\": \"strong" in src.replace("'", '"')
+    assert sum(shard_bounds(32768, 8, r)[1] - shard_bounds(32768, 8, r)[0] for r in range(8)) == 32768
+    assert shard_bounds(32768, 3, 0) == (0, 10923) and shard_bounds(32768, 3, 2) == (21846, 32768)
+
+
 def test_pmc_traffic_lookup_uses_committed_profile():
     import bench
     t = bench.pmc_traffic_bytes(1 << 20, 8, 4)
