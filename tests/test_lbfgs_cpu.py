@@ -76,3 +76,68 @@ def test_lbfgs_mvie_reference_call_site_parameters():
         viol = np.linalg.norm(A @ L, axis=1) + A @ x[:3] - 1.0
         assert viol.max() < 2e-2             # smoothed penalty: inside up to ~eps
         assert f < cbind.cost_mvie(A, 1e-2, 1e3, x0)[0]
+
+
+# ---- second, independent restatement (tests/golden/make_lbfgs_traces.py) --------------------------------------------
+def _trace_objective(t):
+    """The objectives of the committed traces, written once more for the C oracle (numpy)."""
+    name = t["problem"]
+    if name.startswith("quadratic_n6"):
+        w = np.array([1.0, 4.0, 25.0, 100.0, 400.0, 2500.0]); sh = np.array([1.0, -2.0, 0.5, 3.0, -1.0, 0.25])
+        return lambda x: (float(0.5 * (w * (x - sh) ** 2).sum()), w * (x - sh))
+    if name.startswith("rosenbrock"):
+        def ros(x):
+            a = x[1:] - x[:-1] ** 2; b = 1.0 - x[:-1]
+            g = np.zeros_like(x); g[:-1] += -400.0 * a * x[:-1] - 2.0 * b; g[1:] += 200.0 * a
+            return float((100.0 * a * a + b * b).sum()), g
+        return ros
+    if name.startswith("nonsmooth"):
+        def ns(x):
+            g = x - 0.3
+            g[0] += 1.0 if x[0] > 0 else -1.0
+            g[1] += 3.0 if x[1] > 1.0 else -3.0
+            return float(abs(x[0]) + 3.0 * abs(x[1] - 1.0) + 0.5 * ((x - 0.3) ** 2).sum()), g
+        return ns
+    if name == "already_stationary":
+        w = np.array([1.0, 2.0]); sh = np.array([0.5, -0.5])
+        return lambda x: (float(0.5 * (w * (x - sh) ** 2).sum()), w * (x - sh))
+    if name == "uphill_direction":
+        return lambda x: (float(-(x[0] ** 2)), np.array([2.0 * x[0]]))
+    return None
+
+
+def test_oracle_reproduces_the_independent_python_traces():
+    """`lbfgs_oracle.c` against the traces of a pure-Python restatement of lbfgs.hpp / costMVIE that shares no code with
+    it (different data structures, written from the header's statements): return code, iteration and evaluation counters
+    exact, x and f to 1e-9 -- except where the generator itself found the counters to depend on the summation order of
+    the dot products (long runs on non-smooth objectives), where the outcome is compared."""
+    import json
+    import os
+    traces = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lbfgs_traces.json")))
+    assert len(traces) >= 40
+    exact = 0
+    for t in traces:
+        over = dict(t["params"], max_iterations=t["max_iterations"])
+        prm = cbind.lbfgs_default_param(**over)
+        x0 = np.array(t["x0"], dtype=float)
+        if "mvie" in t:
+            A = np.array(t["mvie"]["A"], dtype=float)
+            ret, x, f, it, ev = cbind.lbfgs_mvie(A, t["mvie"]["eps"], t["mvie"]["wt"], x0, prm)
+        else:
+            fun = _trace_objective(t)
+            if fun is None:              # quadratic_n12_mem3: its coefficients come out of the generator's own LCG
+                continue
+            ret, x, f, it, ev = cbind.lbfgs_optimize(x0, fun, prm)
+        key = (t["problem"], t["max_iterations"])
+        assert ret == t["status"], key
+        if t["order_sensitive"]:
+            assert abs(f - t["f"]) <= 2e-3 * max(1.0, abs(t["f"])), key
+            continue
+        if t["status"] != 0 or t["k"] > 0:          # (an already stationary start leaves k unset in lbfgs.hpp)
+            assert it == t["k"], key
+        assert ev == t["evals"], key
+        tol = 1e-9 * max(1, t["k"])
+        assert np.abs(x - np.array(t["x"])).max() <= tol * max(1.0, np.abs(t["x"]).max()), key
+        assert abs(f - t["f"]) <= tol * max(1.0, abs(t["f"])), key
+        exact += 1
+    assert exact >= 30
