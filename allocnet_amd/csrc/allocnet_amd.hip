@@ -46,9 +46,15 @@ struct anet_ctx {
   // RCCL communicator for the all-gather of costs
   ncclComm_t comm = nullptr;
   int comm_ranks = 0;
-  // basis table of k_piece_grad for the last (order, res) used
-  double *d_tab = nullptr;
-  int tab_s = 0, tab_res = 0, tab_cap = 0;
+  // basis tables of k_piece_grad, one per (order, res) ever used: never rebuilt, never freed before anet_destroy
+  // (a launch on another stream may still be reading one), built on the caller's stream
+  struct BasisTable {
+    int s, res;
+    double *d;
+    hipStream_t built_on;
+    hipEvent_t ready;
+  };
+  std::vector<BasisTable> tabs;
 };
 
 namespace {
@@ -67,6 +73,14 @@ int hip_fail(anet_ctx *ctx, hipError_t e, const char *what) {
   do {                                                        \
     hipError_t e_ = (call);                                   \
     if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);    \
+  } while (0)
+
+// Every entry point makes the context's device current first: allocations made inside *_dev calls (counters, basis
+// tables) and the launches must land on the context's GPU, not on whatever device the calling thread used last.
+#define ANET_ON_DEVICE(ctx)                                                   \
+  do {                                                                        \
+    if (!(ctx)) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");        \
+    ANET_HIP(ctx, hipSetDevice((ctx)->device));                               \
   } while (0)
 
 int ensure_scratch(anet_ctx *ctx, size_t bytes) {
@@ -401,7 +415,10 @@ void anet_destroy(anet_ctx *ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->comm) (void)anet_comm_destroy(ctx);
   if (ctx->d_counter) (void)hipFree(ctx->d_counter);
-  if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+  for (auto &t : ctx->tabs) {
+    if (t.d) (void)hipFree(t.d);
+    if (t.ready) (void)hipEventDestroy(t.ready);
+  }
   if (ctx->h_counter) (void)hipHostFree(ctx->h_counter);
   for (int i = 0; i < 2; ++i)
     if (ctx->poll_ev[i]) (void)hipEventDestroy(ctx->poll_ev[i]);
@@ -452,6 +469,7 @@ int anet_dev_download(anet_ctx *ctx, double *dst_host, const double *src_dev, si
 
 int anet_to_batch_minor_dev(anet_ctx *ctx, int64_t batch, int64_t nfield, int64_t ld,
                             const double *src, double *dst, void *stream) {
+  ANET_ON_DEVICE(ctx);
   if (!ctx || !src || !dst || batch < 0 || nfield < 0 || ld < batch)
     return fail(ctx, ANET_ERR_INVALID, "anet_to_batch_minor_dev: bad argument");
   if (batch == 0 || nfield == 0) return ANET_OK;
@@ -465,6 +483,7 @@ int anet_to_batch_minor_dev(anet_ctx *ctx, int64_t batch, int64_t nfield, int64_
 
 int anet_to_traj_major_dev(anet_ctx *ctx, int64_t batch, int64_t nfield, int64_t ld,
                            const double *src, double *dst, void *stream) {
+  ANET_ON_DEVICE(ctx);
   if (!ctx || !src || !dst || batch < 0 || nfield < 0 || ld < batch)
     return fail(ctx, ANET_ERR_INVALID, "anet_to_traj_major_dev: bad argument");
   if (batch == 0 || nfield == 0) return ANET_OK;
@@ -477,7 +496,7 @@ int anet_to_traj_major_dev(anet_ctx *ctx, int64_t batch, int64_t nfield, int64_t
 }
 
 static int check_solve_args(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch) {
-  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  ANET_ON_DEVICE(ctx);
   if (s < 2 || s > 4) return fail(ctx, ANET_ERR_INVALID, "order s must be 2, 3 or 4");
   if (c < 1 || c > s) return fail(ctx, ANET_ERR_INVALID, "boundary derivative count c must be in [1, s]");
   if (n_pieces < 1 || n_pieces > ANET_MAX_PIECES)
@@ -725,22 +744,26 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
   const dim3 grid((unsigned)((batch + 255) / 256), (unsigned)n_pieces), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (pen && pen->res > 4096) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_penalty.res too large for the basis table");
-  if (pen && (ctx->tab_s != s || ctx->tab_res != pen->res)) {  // (re)build the basis table: rare, so simply serialised
-    const int need = pen->res * 4 * 2 * s;
-    ANET_HIP(ctx, hipDeviceSynchronize());  // no launch still reading the old table
-    if (need > ctx->tab_cap) {
-      if (ctx->d_tab) ANET_HIP(ctx, hipFree(ctx->d_tab));
-      ctx->d_tab = nullptr;
-      ANET_HIP(ctx, hipMalloc((void **)&ctx->d_tab, sizeof(double) * need));
-      ctx->tab_cap = need;
+  const double *tab = nullptr;
+  if (pen) {
+    for (auto &t : ctx->tabs)
+      if (t.s == s && t.res == pen->res) {
+        // built on another stream: order this stream behind the build (no host or device-wide synchronisation)
+        if (t.built_on != st) ANET_HIP(ctx, hipStreamWaitEvent(st, t.ready, 0));
+        tab = t.d;
+      }
+    if (!tab) {
+      anet_ctx::BasisTable t{s, pen->res, nullptr, st, nullptr};
+      const int need = pen->res * 4 * 2 * s;
+      ANET_HIP(ctx, hipMalloc((void **)&t.d, sizeof(double) * need));
+      ANET_HIP(ctx, hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+      hipLaunchKernelGGL(anet::k_build_basis_table, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, t.d, pen->res, 2 * s);
+      ANET_HIP(ctx, hipGetLastError());
+      ANET_HIP(ctx, hipEventRecord(t.ready, st));
+      ctx->tabs.push_back(t);
+      tab = t.d;
     }
-    hipLaunchKernelGGL(anet::k_build_basis_table, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, ctx->d_tab, pen->res, 2 * s);
-    ANET_HIP(ctx, hipGetLastError());
-    ANET_HIP(ctx, hipStreamSynchronize(st));
-    ctx->tab_s = s;
-    ctx->tab_res = pen->res;
   }
-  const double *tab = ctx->d_tab;
   // ANET_PIECE_SW_MAX_PAIRS overrides (tuning / A-B runs)
   static const int64_t sw_max_pairs = [] { const char *e = getenv("ANET_PIECE_SW_MAX_PAIRS"); return e ? (int64_t)atoll(e) : kPieceSampleSplitMaxPairs; }();
   if (pen && batch <= axis_variant_max_batch() && batch * n_pieces <= sw_max_pairs) {
@@ -921,7 +944,7 @@ static int check_lbfgs(anet_ctx *ctx, int n, const anet_lbfgs_params *params, in
 int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A, double smooth_eps,
                     double penalty_wt, double *x, double *f, const anet_lbfgs_params *params,
                     int max_evals, int32_t *status, int32_t *iters, int32_t *evals) {
-  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  ANET_ON_DEVICE(ctx);
   int rc = check_lbfgs(ctx, 9, params, max_evals);
   if (rc) return rc;
   if (batch < 0 || M < 1 || !(smooth_eps > 0.0)) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_mvie: bad batch, M or smooth_eps");
@@ -981,7 +1004,7 @@ void anet_firi_default_params(anet_firi_params *p) {
   p->epsilon = 1.0e-6;     // firi.hpp:274
   p->smooth_eps = 1.0e-2;  // firi.hpp:218
   p->penalty_wt = 1.0e+3;  // firi.hpp:219
-  p->mvie_max_evals = 2000;
+  p->mvie_max_evals = 20000;  // a cap, not a tolerance: the reference has none; corridors cut off by it report ok = 2
 }
 
 static int firi_check(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const anet_firi_params &P) {
@@ -1004,7 +1027,7 @@ int anet_firi_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int ma
                   const double *pc, const int32_t *n_points, const double *a, const double *b,
                   const anet_firi_params *params, double *work, double *hpoly, int32_t *n_rows, int32_t *ok,
                   double *ellipsoid, void *stream) {
-  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  ANET_ON_DEVICE(ctx);
   anet_firi_params P;
   anet_firi_default_params(&P);
   if (params) P = *params;
@@ -1292,7 +1315,7 @@ int anet_qp_assemble_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int 
                          double max_vel, double max_acc, double m34, int float_time, int row_order,
                          const double *state, const double *T, const double *hpolys, const int32_t *rows,
                          double *Q, double *A, double *b, double *G, double *h, void *stream) {
-  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  ANET_ON_DEVICE(ctx);
   if (s != 3 && s != 4) return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: order must be 3 (jerk) or 4 (snap), qp_solver.hpp:61-83");
   if (n_pieces < 1 || batch < 0 || res < 1 || M < 0 || (row_order != 0 && row_order != 1))
     return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: bad argument");
@@ -1386,7 +1409,7 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
                              const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
                              double *obj, int32_t *status, int32_t *iters, double *residuals, double *grad_T,
                              void *stream) {
-  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  ANET_ON_DEVICE(ctx);
   if (s != 3 && s != 4) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: order must be 3 (jerk) or 4 (snap)");
   if (n_pieces < 1 || batch < 0 || res < 1 || M < 0) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad argument");
   if (batch == 0) return ANET_OK;
@@ -1625,6 +1648,7 @@ int anet_comm_init(anet_ctx *ctx, int nranks, int rank, const unsigned char id[A
 }
 
 int anet_comm_allgather_costs_dev(anet_ctx *ctx, const double *send, double *recv, int64_t count, void *stream) {
+  ANET_ON_DEVICE(ctx);
   if (!ctx || !ctx->comm) return fail(ctx, ANET_ERR_INVALID, "anet_comm_allgather_costs_dev: call anet_comm_init first");
   if (!send || !recv || count < 0) return fail(ctx, ANET_ERR_INVALID, "anet_comm_allgather_costs_dev: bad argument");
   if (count == 0) return ANET_OK;

@@ -31,7 +31,7 @@ struct FiriArgs {
   double *fpc;         // [B][Np][4] scratch: forward-transformed points + their tangent distance
   int *flag;           // [B][Np] scratch
   double *hpoly;       // [B][H][4]
-  int *nh, *ok;        // [B]  ok: 1 running / done, 0 a or b outside bd, -1 more than H rows needed
+  int *nh, *ok;        // [B]  ok: 1 running / done (2: an MVIE optimisation hit its budget), 0 a or b outside bd, -1 more than H rows needed
   int64_t B;
   int Mb, Np, H;
   double eps;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_firi_planes(FiriArgs g) {
   const int tid = threadIdx.x;
   __shared__ double s_row[4], s_red_d[4], s_fw[9], s_p[3], s_fa[3], s_fb[3];
   __shared__ int s_red_j[4], s_state[4];  // [0] completed, [1] nH, [2] overflow
-  if (g.ok[b] != 1) return;
+  if (g.ok[b] < 1) return;
   const int N = min(max(g.npts[b], 0), g.Np), M = g.Mb;  // counts beyond the padded capacity are clamped
   const double *E = g.ell + b * kFiriEll;
   const double eps = g.eps;
@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(256) k_firi_planes(FiriArgs g) {
 
 struct FiriMvieArgs {
   const double *hpoly;  // [B][H][4]
-  const int *nh, *ok;
+  const int *nh;
+  int *ok;              // set to 2 where an MVIE optimisation was cut off by its evaluation budget
   double *ell;          // [B][kFiriEll]
   double *A;            // [3*H][ld] batch-minor rows for k_mvie_eval (zero rows = inactive)
   double *x;            // [9][ld]   L-BFGS variables
@@ -240,7 +241,7 @@ __global__ void __launch_bounds__(256) k_firi_mvie_setup(FiriMvieArgs g) {
   extern __shared__ double sm[];  // [H][4]: unit normals + offsets
   __shared__ double s_best[4][5];
   const int H = g.H, nH = g.nh[b];
-  const bool live = g.ok[b] == 1 && nH >= 4;
+  const bool live = g.ok[b] >= 1 && nH >= 4;
   for (int r = tid; r < nH; r += 256) {
     const double *h = g.hpoly + (b * H + r) * 4;
     const double nrm = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
@@ -352,6 +353,10 @@ __global__ void __launch_bounds__(64) k_firi_mvie_finish(FiriMvieArgs g) {
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= g.B || !g.mvie_ok[b]) return;
   const int64_t ld = g.ld;
+  // The reference optimises without an evaluation budget (max_iterations = 0, firi.hpp:212-227).  A corridor whose
+  // optimisation was still running at the budget continues from the unfinished iterate, like the reference continues
+  // after a negative return code (firi.hpp:229-232), and says so in its ok flag.
+  if (!g.is_done[b]) g.ok[b] = 2;
   double x[9];
   for (int i = 0; i < 9; ++i) x[i] = g.x[(int64_t)i * ld + b];
   double *E = g.ell + b * kFiriEll;

@@ -611,6 +611,9 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
                 }
               }
             } else {
+              // (history re-read from memory: wave-wide lane indexing below, so never with two problems per wave --
+              //  the host only dispatches HALF for mem_size <= LBFGS_WAVE_MREG)
+              if constexpr (HALF) __builtin_trap();
               int j = end;
               double alpha = 0.0;  // lane `it` keeps alpha of the it-th visited slot (mem_size <= 64, host-checked)
               for (int it = 0; it < bound; ++it) {

@@ -169,8 +169,8 @@ class OsqpLayer:
         end_penalty, thresh = 5.0, 0.42                                     # layers.py:190-191
         premature = float(np.sum((pred > thresh) & (gt < thresh)) * end_penalty)
         late = float(np.sum((pred < thresh) & (gt > thresh)) * end_penalty)
-        eps = 1e-12
-        bce = float(-np.mean(gt * np.log(np.clip(pred, eps, 1)) + (1 - gt) * np.log(np.clip(1 - pred, eps, 1))))
+        with np.errstate(divide="ignore"):               # nn.BCELoss: mean reduction, each log clamped at -100
+            bce = float(-np.mean(gt * np.maximum(np.log(pred), -100.0) + (1 - gt) * np.maximum(np.log(1 - pred), -100.0)))
         stop_token_loss = bce + premature + late
         if out["status"][0] != 1:
             curr_objt_val = None

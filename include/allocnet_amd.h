@@ -32,7 +32,8 @@
  *           exactly the reference's flattening).  Synchronous.
  *
  * All functions return ANET_OK (0) or a negative error code; anet_last_error() gives text.
- * One context per host thread per device; a context is not re-entrant (same as the
+ * One context per host thread per device; a context is not re-entrant: in particular ONE L-BFGS call in flight per
+ * context (its completion flag lives in the context), whatever the streams (same as the
  * reference's QPSolver, qp_solver.hpp:43-45).
  */
 #ifndef ALLOCNET_AMD_H
@@ -395,7 +396,9 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
  * form; LearningPlanner normalises and negates it into a.x <= b, learning_planner.hpp:293-299);
  * pc [batch][max_points][3] with n_points[batch] valid points each; a, b [batch][3].
  * n_rows [batch] rows written per corridor (the rest of hpoly is zero);
- * ok [batch]: 1 = done, 0 = a or b violates bd (firi returns false, firi.hpp:282-286),
+ * ok [batch]: 1 = done, 2 = done, but an inner MVIE optimisation was cut off by mvie_max_evals (the corridor is still
+ *            valid: every pass only shrinks towards the obstacles; the reference continues after a failed optimisation
+ *            too, firi.hpp:229-232), 0 = a or b violates bd (firi returns false, firi.hpp:282-286),
  *            -1 = the polytope needs more than max_rows rows;   ellipsoid [batch][15] (optional) =
  * R row-major, p, r of the last inscribed ellipsoid.  All HOST pointers.
  * sdlp::linprog<4> and Eigen::JacobiSVD, third-party pieces of the reference, are replaced by exact
@@ -405,7 +408,7 @@ typedef struct anet_firi_params {
   double epsilon;         /* 1e-6  firi.hpp:274 */
   double smooth_eps;      /* 1e-2  firi.hpp:218 */
   double penalty_wt;      /* 1e3   firi.hpp:219 */
-  int32_t mvie_max_evals; /* 2000  evaluation budget of one MVIE optimisation (the reference has none) */
+  int32_t mvie_max_evals; /* 20000 evaluation budget of one MVIE optimisation (the reference has none) */
 } anet_firi_params;
 void anet_firi_default_params(anet_firi_params *p);
 int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,

@@ -6,6 +6,7 @@
 // here; anet_firi itself is batched -- convexCover's segments are independent, see allocnet_amd/firi.py).
 // Matrix arguments are duck-typed ((r,c) access, rows(), cols(), resize(r,c)): Eigen types work unchanged.
 #pragma once
+#include <stdio.h>
 #include <vector>
 
 #include "core.hpp"
@@ -40,7 +41,8 @@ inline bool firi(const Bd &bd, const Pc &pc, const VA &a, const VB &b, Poly &hPo
     if (ok != -1 || cap >= M + N) break;
     cap = cap * 4 < M + N ? cap * 4 : M + N;
   }
-  if (ok != 1) return false;
+  if (ok < 1) return false;
+  if (ok == 2) printf("FIRI WARNING: an MVIE optimisation stopped at its evaluation budget\n");  // cf. firi.hpp:229-232
   hPoly.resize(nh, 4);
   for (int r = 0; r < nh; ++r)
     for (int c = 0; c < 4; ++c) hPoly(r, c) = hp[(size_t)r * 4 + c];

@@ -5,11 +5,33 @@
 // problems with the objective evaluated on the device: lbfgs_optimize_mvie (that call site) and
 // lbfgs_optimize_minco (the trajectory cost of the north star).
 #pragma once
+#include <stdexcept>
+#include <string.h>
 #include <vector>
 
 #include "core.hpp"
 
+namespace firi {
+// firi::costMVIE (gcopter/firi.hpp:86-157).  In this build the objective is evaluated on the device inside
+// lbfgs::lbfgs_optimize (k_mvie_eval / k_lbfgs_mvie_persistent); the function exists so that the reference's call
+// expression `lbfgs_optimize(x, minCost, &costMVIE, nullptr, nullptr, optData, paramsMVIE)` (firi.hpp:221-227) keeps
+// compiling -- its address is the tag the overload below dispatches on.  There is no CPU evaluation to fall back to.
+template <class V>
+inline double costMVIE(void *, const V &, V &) {
+  throw std::logic_error("firi::costMVIE is evaluated on the device: pass it to lbfgs::lbfgs_optimize");
+}
+}  // namespace firi
+
 namespace lbfgs {
+
+namespace detail {
+template <class T> struct same { typedef T type; };
+}
+// The callback types of lbfgs.hpp:200-259, on any VectorXd-like V ((i) access, size()).
+template <class V> using lbfgs_evaluate_t = double (*)(void *instance, const typename detail::same<V>::type &x, typename detail::same<V>::type &g);
+template <class V> using lbfgs_stepbound_t = double (*)(void *instance, const typename detail::same<V>::type &xp, const typename detail::same<V>::type &d);
+template <class V> using lbfgs_progress_t = int (*)(void *instance, const typename detail::same<V>::type &x, const typename detail::same<V>::type &g,
+                                                    const double fx, const double step, const int k, const int ls);
 
 struct lbfgs_parameter_t {
   int mem_size = 8;
@@ -76,6 +98,34 @@ inline std::vector<int> lbfgs_optimize_mvie(int batch, int M, const std::vector<
   ctx.check(anet_lbfgs_mvie(ctx.get(), batch, M, A.data(), smoothEps, penaltyWt, x.data(), minCost.data(), &q,
                             max_evals, status.data(), iters.data(), evals.data()));
   return status;
+}
+
+// lbfgs::lbfgs_optimize (lbfgs.hpp:434-440) for the reference's own call (firi.hpp:221-227): objective
+// &firi::costMVIE, no step bound, no progress monitor, `instance` = firi's optData blob {int M; double smoothEps,
+// penaltyWt; double A[3 M] column-major} (firi.hpp:186-200).  Runs anet_lbfgs_mvie with a batch of one; x and f are
+// updated like the reference's, the return value is its return code.  Any other host callback is refused: there is no
+// CPU L-BFGS in this library (batched device objectives: lbfgs_optimize_mvie above, anet_lbfgs_minco).
+template <class V>
+inline int lbfgs_optimize(V &x, double &f, lbfgs_evaluate_t<V> proc_evaluate, lbfgs_stepbound_t<V> proc_stepbound,
+                          lbfgs_progress_t<V> proc_progress, void *instance, const lbfgs_parameter_t &param) {
+  if (proc_evaluate != static_cast<lbfgs_evaluate_t<V>>(&firi::costMVIE<V>))
+    throw std::invalid_argument("lbfgs_optimize: only firi::costMVIE is available as a host-named objective (device evaluation)");
+  if (proc_stepbound || proc_progress)
+    throw std::invalid_argument("lbfgs_optimize: step-bound / progress callbacks are not supported (the optimisation runs on the device)");
+  if ((int)x.size() != 9) return LBFGSERR_INVALID_N;
+  int M = 0;
+  double eps = 0.0, wt = 0.0;
+  const unsigned char *blob = static_cast<const unsigned char *>(instance);
+  memcpy(&M, blob, sizeof(int));                       // (the doubles follow the int unaligned, as firi packs them)
+  memcpy(&eps, blob + sizeof(int), sizeof(double));
+  memcpy(&wt, blob + sizeof(int) + sizeof(double), sizeof(double));
+  std::vector<double> A((size_t)3 * M), xs(9), cost;
+  memcpy(A.data(), blob + sizeof(int) + 2 * sizeof(double), sizeof(double) * 3 * M);
+  for (int i = 0; i < 9; ++i) xs[i] = x(i);
+  const std::vector<int> ret = lbfgs_optimize_mvie(1, M, A, eps, wt, xs, cost, param);
+  for (int i = 0; i < 9; ++i) x(i) = xs[i];
+  f = cost[0];
+  return ret[0];
 }
 
 }  // namespace lbfgs

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 
+#include <stdint.h>
 #include "allocnet_amd/firi.hpp"
 #include "allocnet_amd/lbfgs.hpp"
 #include "allocnet_amd/minco.hpp"
@@ -196,6 +197,40 @@ int main() {
       fa(0) = 100.0;
       DynMat h2;
       printf("\"firi_outside\": %d,\n", firi::firi(bd, pc, fa, fb, h2) ? 1 : 0);
+    }
+    {
+      // the reference's only lbfgs_optimize call, statement for statement (firi.hpp:186-227): optData blob, call-site
+      // parameters, `&costMVIE, nullptr, nullptr`; the unit cube |x_i| <= 1 as A x <= 1, start = small sphere
+      using namespace firi;
+      const int M = 6;
+      uint8_t *optData = new uint8_t[sizeof(int) + (2 + 3 * M) * sizeof(double)];
+      int *pM = (int *)optData;
+      double *pSmoothEps = (double *)(pM + 1);
+      double *pPenaltyWt = pSmoothEps + 1;
+      double *pA = pPenaltyWt + 1;
+      *pM = M;
+      const double rows[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+      for (int r = 0; r < M; ++r)
+        for (int c = 0; c < 3; ++c) pA[c * M + r] = rows[r][c];  // column-major M x 3, as Eigen::Map<MatrixX3d>
+      struct VX9 {
+        double a[9];
+        long size() const { return 9; }
+        double &operator()(long i) { return a[i]; }
+        double operator()(long i) const { return a[i]; }
+      } x = {{0.05, -0.02, 0.01, 0.5, 0.5, 0.5, 0.0, 0.0, 0.0}};
+      double minCost;
+      lbfgs::lbfgs_parameter_t paramsMVIE;
+      paramsMVIE.mem_size = 18;
+      paramsMVIE.g_epsilon = 0.0;
+      paramsMVIE.min_step = 1.0e-32;
+      paramsMVIE.past = 3;
+      paramsMVIE.delta = 1.0e-7;
+      *pSmoothEps = 1.0e-2;
+      *pPenaltyWt = 1.0e+3;
+      int ret = lbfgs::lbfgs_optimize(x, minCost, &costMVIE, nullptr, nullptr, optData, paramsMVIE);
+      printf("\"mvie_ret\": %d, \"mvie_cost\": %.17g,\n", ret, minCost);
+      print_vec("mvie_x", std::vector<double>(x.a, x.a + 9));
+      delete[] optData;
     }
     lbfgs::lbfgs_parameter_t prm;
     printf("\"lbfgs_default_mem\": %d, \"strerror\": \"%s\"\n", prm.mem_size, lbfgs::lbfgs_strerror(lbfgs::LBFGSERR_MAXIMUMLINESEARCH));

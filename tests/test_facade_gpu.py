@@ -45,6 +45,17 @@ def test_cpp_facade_program():
     assert abs(out["max_acc"] - max(onp.piece_max_rate(co[i], 1.0, 2) for i in range(N))) <= 1e-9 * out["max_acc"]
     assert out["check_vel"] == 1
     assert out["lbfgs_default_mem"] == 8 and out["strerror"].startswith("Line search reaches")
+    # lbfgs::lbfgs_optimize(x, minCost, &costMVIE, nullptr, nullptr, optData, paramsMVIE) as firi.hpp:221-227 writes it:
+    # largest ellipsoid in the unit cube = the unit ball at the origin; same outcome as the C restatement
+    from oracle import cbind
+    cube = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=float)
+    x0 = np.array([0.05, -0.02, 0.01, 0.5, 0.5, 0.5, 0.0, 0.0, 0.0])
+    ret, xo, fo, it, ev = cbind.lbfgs_mvie(cube, 1e-2, 1e3, x0, cbind.lbfgs_default_param(
+        mem_size=18, g_epsilon=0.0, min_step=1e-32, past=3, delta=1e-7))
+    assert out["mvie_ret"] >= 0 and ret >= 0
+    assert abs(out["mvie_cost"] - fo) <= 2e-3 * max(1.0, abs(fo))
+    xm = np.array(out["mvie_x"])
+    assert np.abs(xm[:3]).max() < 2e-2 and np.abs(xm[3:6] ** 2 - 1.0).max() < 3e-2 and np.abs(xm[6:]).max() < 3e-2
 
     # QPSolver facade: solved, ends where asked, inside the velocity box, objective == 1/2 z'Qz of its coefficients
     assert out["qp_ok"] == 1 and out["qp_iters"] > 0

@@ -75,7 +75,18 @@ def test_osqp_layer_forward(anet_ctx):
     assert zi is not None and abs(objc_i - objc) <= 2e-2 * max(1.0, objc)
     assert np.abs(lay2.implicit_time_grad[:3] - imp[:3]).max() <= 0.1 * np.abs(imp[:3]).max() + 1e-3
     z2, o1, ot, oc, stl = layer.forward4lstm(opt, np.array([0.1, 0.2, 0.9, 0.95, 0.99]), seq_len=5)
-    assert z2 is not None and stl > 0 and abs(oc - objc) <= 1e-2 * max(1.0, objc)
+    assert z2 is not None and abs(oc - objc) <= 1e-2 * max(1.0, objc)
+    # stop-token loss (layers.py:186-204): BCE against [0]*(seg-1) + [1]*(seq_len-seg+1) plus 5.0 per premature / late
+    # token at threshold 0.42 -- three segments here, so the ground truth is [0, 0, 1, 1, 1]
+    import torch
+    gt = torch.tensor([0.0, 0.0, 1.0, 1.0, 1.0], dtype=torch.float64)
+    hand = -(np.log(0.9) + np.log(0.8) + np.log(0.9) + np.log(0.95) + np.log(0.99)) / 5.0
+    assert abs(stl - hand) <= 1e-14
+    for pred, extra in (([0.1, 0.2, 0.9, 0.95, 0.99], 0.0), ([0.5, 0.2, 0.9, 0.3, 0.99], 10.0),     # one premature, one late
+                        ([0.43, 0.9, 0.41, 0.1, 0.2], 25.0), ([0.0, 0.42, 0.42, 1.0, 1.0], 0.0)):    # at the threshold: neither
+        want = float(torch.nn.BCELoss()(torch.tensor(pred, dtype=torch.float64), gt)) + extra
+        got = layer.forward4lstm(opt, np.array(pred), seq_len=5)[4]
+        assert abs(got - want) <= 1e-12 * max(1.0, want), (pred, got, want)
 
 
 def test_osqp_layer_forward_batch(anet_ctx):
