@@ -1396,7 +1396,7 @@ void anet_qp_default_settings(anet_qp_settings *s) {
   if (!s) return;
   s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
   s->max_iter = 4000; s->check_termination = 25; s->adaptive_rho_interval = 100; s->scaled_termination = 0;
-  s->method = ANET_QP_METHOD_ADMM;
+  s->method = ANET_QP_METHOD_INTERIOR_POINT;
 }
 
 int64_t anet_qp_solve_workspace(int s, int n_pieces, int64_t batch, int res, int M) {

@@ -34,7 +34,7 @@ struct AdmmArgs {
   double *z, *y;         // z: [B][m] workspace, ONE value per constraint row (see `wg` in the kernel), m = me + N*R*(M+12); y: unused
   double *coeffs;        // [B][n]  (piece, axis, highest power first) -- the reference's flatten order
   double *obj;           // [B]  1/2 z'Qz in original units (QPSolver::getObjCost)
-  int *status, *iters;   // [B]  1 = solved, 0 = max_iter reached, -3 = primal infeasible (OSQP codes)
+  int *status, *iters;   // [B]  OSQP's status values: 1 = solved, -2 = max_iter reached, -3 = primal infeasible
   double *res;           // [B][2] primal / dual residual at exit (scaled problem)
   int64_t B;
   int N, R, M;
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) k_qp_admm(AdmmArgs a) {
   factorize();
   __syncthreads();
 
-  int it = 0, status = 0;
+  int it = 0, status = -2;  // OSQP_MAX_ITER_REACHED unless decided below
   double rp = 0.0, rd = 0.0;
   for (it = 1; it <= a.p.max_iter; ++it) {
     const bool check = (it % a.p.check_every) == 0;

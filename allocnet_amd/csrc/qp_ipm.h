@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     }
   };
 
-  int it = 0, status = 0;
+  int it = 0, status = -2;  // OSQP_MAX_ITER_REACHED unless decided below
   double pres = 0.0, dres = 0.0, mu = 0.0, mu0 = 0.0;
   for (it = 0; it < a.max_iter; ++it) {
     // ---- pass A: residuals, weights, right-hand-side pieces per sample ---------------------------

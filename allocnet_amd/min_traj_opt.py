@@ -77,11 +77,11 @@ class MinTrajOpt:
 class OsqpLayer:
     """Solve + loss terms of layers.py:51-151 (forward) and :153-247 (forward4lstm)."""
 
-    def __init__(self, ctx=None, method=_qp.QP_METHOD_ADMM):
-        """method: QP_METHOD_ADMM (default: OSQP's algorithm and tolerances, as layers.py:77-81 runs them) or
-        QP_METHOD_INTERIOR_POINT (same optimum to 1e-6, an order of magnitude faster)."""
+    def __init__(self, ctx=None, method=_qp.QP_METHOD_INTERIOR_POINT):
+        """method: QP_METHOD_INTERIOR_POINT (default: the optimum to 1e-6, an order of magnitude faster, solves every
+        problem either method can) or QP_METHOD_ADMM (OSQP's algorithm and tolerances, as layers.py:77-81 runs them)."""
         self._ctx = ctx
-        self._settings = _qp.qp_settings(method=method) if method != _qp.QP_METHOD_ADMM else None
+        self._settings = _qp.qp_settings(method=method)
         self.time_grad = None             # what the reference's autograd delivers (z detached): 1/2 z'(dQ/dT)z
         self.implicit_time_grad = None    # d(optimal objc)/dTimes through the QP (anet_qp_solve_time_grad)
 

@@ -73,13 +73,14 @@ def qp_assemble(order, iniPVA, finPVA, hPolys, times, res=20, max_vel=4.0, max_a
 # -------------------------------------------------------------------------------------------------
 # the solve: QPSolver (planner/qp_solver.hpp:28-366)
 # -------------------------------------------------------------------------------------------------
-QP_METHOD_ADMM = 0             # OSQP's algorithm (default)
-QP_METHOD_INTERIOR_POINT = 1   # primal-dual interior point in Hermite node coordinates (csrc/qp_ipm.h)
+QP_METHOD_ADMM = 0             # OSQP's algorithm and settings (opt-in)
+QP_METHOD_INTERIOR_POINT = 1   # primal-dual interior point in Hermite node coordinates (csrc/qp_ipm.h): the default
 
 
 def qp_settings(**over):
-    """OSQP's default settings as the reference uses them (it never overrides any:
-    qp_solver.hpp:299-302, layers.py:79)."""
+    """anet_qp_default_settings: OSQP's default tolerances and iteration parameters as the reference uses them (it never
+    overrides any: qp_solver.hpp:299-302, layers.py:79), method = QP_METHOD_INTERIOR_POINT; method=QP_METHOD_ADMM
+    selects OSQP's own iteration."""
     from ._lib import QpSettings, load
     s = QpSettings()
     load().anet_qp_default_settings(ctypes.byref(s))
@@ -136,7 +137,7 @@ class QPSolver:
         self.order_ = None
         self.obj_cost_ = -1.0
         self._ctx = ctx
-        self._method = QP_METHOD_ADMM
+        self._method = QP_METHOD_INTERIOR_POINT
 
     def setMethod(self, method):
         """Extension: QP_METHOD_ADMM (default, OSQP's algorithm and tolerances) or QP_METHOD_INTERIOR_POINT."""
@@ -163,7 +164,7 @@ class QPSolver:
         t = np.asarray(times, dtype=np.float64)[:seg]
         out = qp_solve(self.order_, np.asarray(iniPVA)[None], np.asarray(finPVA)[None], hp, t[None],
                        res=self.config.ConstRes, max_vel=self.config.MaxVelBox, max_acc=self.config.MaxAccBox,
-                       settings=qp_settings(method=self._method) if self._method != QP_METHOD_ADMM else None,
+                       settings=qp_settings(method=self._method),
                        ctx=self._ctx)
         result = float(np.float32(out["obj"][0]))          # the reference reads the objective into a float
         if result > 5000 or result < -0.01 or out["status"][0] != 1:

@@ -259,10 +259,14 @@ int anet_qp_assemble(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res,
  * initSolver, solveProblem, getObjValue, getStatus, getSolution) and OsqpLayer's forward solve
  * (network/utils/learning/layers.py:66-81,167-181), batched: the SAME QP the reference assembles
  *      min 1/2 z'Qz   s.t.  A z = b,   G z <= h                      (anet_qp_assemble gives it densely)
- * solved with OSQP's ADMM iteration and OSQP's default settings (below).  OSQP itself is a third-party
- * dependency absent from the reference tree: iterates are not comparable, the solution is (same convex
- * problem, same stopping rule and tolerances) -- parity is checked through the KKT conditions.
- * The solve never forms Q, A, G: see allocnet_amd/csrc/qp_admm.h.                                    */
+ * OSQP itself is a third-party dependency absent from the reference tree: its iterates are not comparable, the
+ * solution is (same convex problem) -- parity is checked through the KKT conditions.  Two methods:
+ *   INTERIOR_POINT (default): the optimum to 1e-6 in 10-20 Newton steps.  On random corridor problems it returns
+ *       `Solved` for every problem either method can solve (profiles/r02_qp_unsolved.json);
+ *   ADMM: OSQP's own iteration with OSQP's default settings (below) and stopping rule.  Without OSQP's Ruiz
+ *       equilibration it leaves 4-6 % of feasible 8-piece snap problems at max_iter, which QPSolver::solve's
+ *       caller treats as a failed plan (qp_solver.hpp:334-352) -- hence not the default.
+ * The solve never forms Q, A, G: see allocnet_amd/csrc/qp_ipm.h, qp_admm.h.                          */
 typedef struct anet_qp_settings {
   double rho;        /* 0.1   OSQP default; equality rows use 1e3*rho like OSQP                 */
   double sigma;      /* 1e-6                                                                    */
@@ -275,8 +279,8 @@ typedef struct anet_qp_settings {
   int32_t scaled_termination;    /* 0: OSQP's rule -- residuals of the reference's own (unscaled) QP;
                                     1: residuals of the internally normalised QP (like OSQP's
                                     scaled_termination): ~2-3x fewer iterations, looser on stiff problems */
-  int32_t method;                /* ANET_QP_METHOD_ADMM (default): OSQP's algorithm, settings above.
-                                    ANET_QP_METHOD_INTERIOR_POINT: primal-dual interior point on the same QP in
+  int32_t method;                /* ANET_QP_METHOD_ADMM: OSQP's algorithm, settings above.
+                                    ANET_QP_METHOD_INTERIOR_POINT (default): primal-dual interior point on the same QP in
                                     Hermite node coordinates (allocnet_amd/csrc/qp_ipm.h) -- the optimum to
                                     min(eps, 1e-6) in 10-20 Newton steps; uses only eps_abs/eps_rel and max_iter
                                     (capped at 200) of the fields above; infeasible problems are reported
@@ -286,7 +290,7 @@ typedef struct anet_qp_settings {
 #define ANET_QP_METHOD_INTERIOR_POINT 1
 void anet_qp_default_settings(anet_qp_settings *s);
 #define ANET_QP_SOLVED 1          /* OSQP_SOLVED                 */
-#define ANET_QP_MAX_ITER_REACHED 0 /* the reference treats anything but Solved as failure (qp_solver.hpp:346-350) */
+#define ANET_QP_MAX_ITER_REACHED (-2) /* OSQP_MAX_ITER_REACHED; the reference treats anything but Solved as failure (qp_solver.hpp:346-350) */
 #define ANET_QP_PRIMAL_INFEASIBLE (-3) /* OSQP_PRIMAL_INFEASIBLE: OSQP's certificate test on y(k+1)-y(k), eps_prim_inf 1e-4 */
 /* hpolys [batch][N][M][4] rows a.x <= b with all-zero rows as inert padding.
  * coeffs [batch][N][3][2s] (the flatten order callModel unpacks, learning_planner.hpp:212,227),

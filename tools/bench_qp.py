@@ -19,7 +19,7 @@ out = {}
 for (s, N, M, B) in [(4, 8, 16, 4096), (3, 5, 16, 4096), (3, 16, 16, 1024), (4, 5, 16, 1)]:
     head, tail, wps, T, hp = corridor_problem(np.random.default_rng(1), B, N, 3, M)
     T = T * 1.5
-    for name, st in (("admm", None), ("ipm", aa.qp_settings(method=aa.qp.QP_METHOD_INTERIOR_POINT))):
+    for name, st in (("admm", aa.qp_settings(method=aa.qp.QP_METHOD_ADMM)), ("ipm", aa.qp_settings(method=aa.qp.QP_METHOD_INTERIOR_POINT))):
         if name == "admm" and N == 16:
             continue                      # the 16-piece jerk factor of the ADMM kernel needs more LDS than it has at M = 16
         kw = dict(res=20, max_vel=4.0, max_acc=6.0, settings=st, ctx=ctx)

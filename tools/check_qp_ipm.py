@@ -21,7 +21,7 @@ def main():
         ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
         hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs])
         kw = dict(res=res, max_vel=3.0, max_acc=4.0, ctx=ctx)
-        ref = aa.qp_solve(s, ini, fin, hp, T, settings=aa.qp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000), **kw)
+        ref = aa.qp_solve(s, ini, fin, hp, T, settings=aa.qp_settings(method=aa.qp.QP_METHOD_ADMM, eps_abs=1e-10, eps_rel=1e-10, max_iter=200000), **kw)
         ipm = aa.qp_solve(s, ini, fin, hp, T, settings=aa.qp_settings(method=1), **kw)
         print(s, N, "admm status", ref["status"], "ipm status", ipm["status"], "iters", ipm["iters"])
         print("   obj admm", np.round(ref["obj"], 6), "\n   obj ipm ", np.round(ipm["obj"], 6), "res", ipm["residuals"].max(axis=0))

@@ -20,7 +20,7 @@ def main():
         probs = [_corridor_problem(rng, N, M, margin=0.6) for _ in range(B)]
         ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
         hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs])
-        st = aa.qp_settings(eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
+        st = aa.qp_settings(method=aa.qp.QP_METHOD_ADMM, eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
         out = aa.qp_solve(s, ini, fin, hp, T, res=res, max_vel=vmax, max_acc=amax, settings=st, time_grad=True, ctx=ctx)
         g = out["grad_T"]
         fd = np.zeros_like(g)

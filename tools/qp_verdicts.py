@@ -19,7 +19,7 @@ def main():
         head, tail, wps, T, hp = corridor_problem(np.random.default_rng(11), B, N, 3, M)
         kw = dict(res=20, max_vel=4.0, max_acc=6.0, ctx=ctx)
         ipm = aa.qp_solve(s, head, tail, hp, T * sc, settings=aa.qp_settings(method=1), **kw)
-        adm = aa.qp_solve(s, head, tail, hp, T * sc, settings=aa.qp_settings(eps_abs=1e-7, eps_rel=1e-7, max_iter=100000), **kw)
+        adm = aa.qp_solve(s, head, tail, hp, T * sc, settings=aa.qp_settings(method=aa.qp.QP_METHOD_ADMM, eps_abs=1e-7, eps_rel=1e-7, max_iter=100000), **kw)
         si, sa = ipm["status"] == 1, adm["status"] == 1
         both = si & sa
         rel = np.abs(ipm["obj"][both] - adm["obj"][both]) / np.maximum(1e-3, np.abs(adm["obj"][both]))
