@@ -11,7 +11,7 @@ from .trajectory import Piece, Trajectory, traj_eval, traj_cost, traj_cost_grad_
 from . import lbfgs  # noqa: F401
 from .lbfgs import lbfgs_parameter_t, lbfgs_strerror, lbfgs_mvie, lbfgs_minco, lbfgs_minco_dev  # noqa: F401
 from . import qp  # noqa: F401
-from .qp import qp_assemble, qp_dims, qp_solve, qp_settings, QPSolver, QPConfig  # noqa: F401
+from .qp import qp_assemble, qp_dims, qp_solve, qp_solve_vjp, qp_settings, QPSolver, QPConfig  # noqa: F401
 from .min_traj_opt import MinTrajOpt, OsqpLayer  # noqa: F401
 from . import firi as _firi_mod  # noqa: F401
 from .firi import firi, firi_dev, firi_params, convex_cover  # noqa: F401

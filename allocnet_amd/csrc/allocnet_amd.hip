@@ -1408,7 +1408,7 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
                              double max_acc, double m34, const double *state, const double *T,
                              const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
                              double *obj, int32_t *status, int32_t *iters, double *residuals, double *grad_T,
-                             void *stream) {
+                             void *stream, const double *grad_z = nullptr, double *vjp_T = nullptr) {
   ANET_ON_DEVICE(ctx);
   if (s != 3 && s != 4) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: order must be 3 (jerk) or 4 (snap)");
   if (n_pieces < 1 || batch < 0 || res < 1 || M < 0) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad argument");
@@ -1430,9 +1430,13 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     const int64_t mi = (int64_t)n_pieces * res * (M + 12);
     double tol = st_.eps_rel < st_.eps_abs ? st_.eps_rel : st_.eps_abs;
     if (!(tol > 0.0) || tol > 1e-6) tol = 1e-6;   // Newton's method: the last digits cost one or two steps
+    if (tol < 1e-10) tol = 1e-10;                 // (below that the slacks of the touched rows underflow the factorisation)
+    // the backward pass differentiates the central path at the barrier parameter the solve stopped at: its error is
+    // of that order, so it asks for three more digits (one or two Newton steps)
+    if (grad_z && tol > 1e-9) tol = 1e-9;
     anet::IpmArgs ia{state, T, hpolys, work, work + mi * batch, coeffs, obj, status, iters,
-                     residuals ? residuals : work + 2 * mi * batch, grad_T, batch, n_pieces, res, M, max_vel, max_acc, m34,
-                     tol, st_.max_iter < 200 ? st_.max_iter : 200};
+                     residuals ? residuals : work + 2 * mi * batch, grad_T, grad_z, vjp_T, batch, n_pieces, res, M, max_vel,
+                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200};
     hipStream_t sti = (hipStream_t)stream;
     if (s == 4) {
       ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_ipm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
@@ -1444,6 +1448,7 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     ANET_HIP(ctx, hipGetLastError());
     return ANET_OK;
   }
+  if (grad_z) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_qp_solve_vjp: the backward pass needs the interior-point method");
   size_t lds = (s == 4) ? anet::qp_admm_lds_bytes<4>(n_pieces, res, M, true) : anet::qp_admm_lds_bytes<3>(n_pieces, res, M, true);
   int zy_in_lds = 1;
   if (lds > 160 * 1024) {
@@ -1490,10 +1495,21 @@ int anet_qp_solve_time_grad_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batc
                            coeffs, obj, status, iters, residuals, grad_T, stream);
 }
 
+int anet_qp_solve_vjp_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                          double max_acc, double m34, const double *state, const double *T, const double *hpolys,
+                          const anet_qp_settings *settings, const double *grad_z, double *work, double *coeffs,
+                          double *obj, int32_t *status, int32_t *iters, double *residuals, double *grad_T,
+                          void *stream) {
+  if (ctx && batch > 0 && (!grad_z || !grad_T)) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve_vjp: grad_z / grad_T is NULL");
+  return qp_solve_dev_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, state, T, hpolys, settings, work,
+                           coeffs, obj, status, iters, residuals, nullptr, stream, grad_z, grad_T);
+}
+
 static int qp_solve_host_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
                               double max_acc, double m34, const double *state, const double *T,
                               const double *hpolys, const anet_qp_settings *settings, double *coeffs, double *obj,
-                              int32_t *status, int32_t *iters, double *residuals, double *grad_T) {
+                              int32_t *status, int32_t *iters, double *residuals, double *grad_T,
+                              const double *grad_z = nullptr) {
   if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
   if ((s != 3 && s != 4) || n_pieces < 1 || batch < 0 || res < 1 || M < 0)
     return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad argument");
@@ -1504,18 +1520,21 @@ static int qp_solve_host_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch,
   const size_t n_state = 18 * (size_t)batch, n_T = (size_t)n_pieces * batch, n_hp = (size_t)batch * n_pieces * M * 4;
   const size_t n_work = (size_t)anet_qp_solve_workspace(s, n_pieces, batch, res, M);
   const size_t n_int = (size_t)batch;  // 2 int32 arrays fit in `batch` doubles
-  int rc = ensure_scratch(ctx, sizeof(double) * (n_state + n_T + n_hp + n_work + n * batch + 3 * batch + n_int + n_T + 8));
+  int rc = ensure_scratch(ctx, sizeof(double) * (n_state + n_T + n_hp + n_work + 2 * n * batch + 3 * batch + n_int + n_T + 8));
   if (rc) return rc;
   double *d_state = (double *)ctx->scratch, *d_T = d_state + n_state, *d_hp = d_T + n_T, *d_work = d_hp + n_hp;
   double *d_co = d_work + n_work, *d_obj = d_co + n * batch, *d_res = d_obj + batch;
   int32_t *d_status = (int32_t *)(d_res + 2 * batch), *d_iters = d_status + batch;
   double *d_gT = d_res + 2 * batch + n_int;
+  double *d_gz = d_gT + n_T;
   hipStream_t st = ctx->stream;
   ANET_HIP(ctx, hipMemcpyAsync(d_state, state, sizeof(double) * n_state, hipMemcpyHostToDevice, st));
   ANET_HIP(ctx, hipMemcpyAsync(d_T, T, sizeof(double) * n_T, hipMemcpyHostToDevice, st));
   if (n_hp) ANET_HIP(ctx, hipMemcpyAsync(d_hp, hpolys, sizeof(double) * n_hp, hipMemcpyHostToDevice, st));
+  if (grad_z) ANET_HIP(ctx, hipMemcpyAsync(d_gz, grad_z, sizeof(double) * n * batch, hipMemcpyHostToDevice, st));
   rc = qp_solve_dev_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, d_state, d_T, d_hp, settings, d_work,
-                         d_co, d_obj, d_status, d_iters, d_res, grad_T ? d_gT : nullptr, st);
+                         d_co, d_obj, d_status, d_iters, d_res, (grad_T && !grad_z) ? d_gT : nullptr, st,
+                         grad_z ? d_gz : nullptr, grad_z ? d_gT : nullptr);
   if (rc) return rc;
   if (grad_T) ANET_HIP(ctx, hipMemcpyAsync(grad_T, d_gT, sizeof(double) * n_T, hipMemcpyDeviceToHost, st));
   ANET_HIP(ctx, hipMemcpyAsync(coeffs, d_co, sizeof(double) * n * batch, hipMemcpyDeviceToHost, st));
@@ -1542,6 +1561,15 @@ int anet_qp_solve_time_grad(anet_ctx *ctx, int s, int n_pieces, int64_t batch, i
   if (ctx && batch > 0 && !grad_T) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve_time_grad: grad_T is NULL");
   return qp_solve_host_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, state, T, hpolys, settings, coeffs,
                             obj, status, iters, residuals, grad_T);
+}
+
+int anet_qp_solve_vjp(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                      double max_acc, double m34, const double *state, const double *T, const double *hpolys,
+                      const anet_qp_settings *settings, const double *grad_z, double *coeffs, double *obj,
+                      int32_t *status, int32_t *iters, double *residuals, double *grad_T) {
+  if (ctx && batch > 0 && (!grad_z || !grad_T)) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve_vjp: grad_z / grad_T is NULL");
+  return qp_solve_host_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, state, T, hpolys, settings, coeffs,
+                            obj, status, iters, residuals, grad_T, grad_z);
 }
 
 int anet_traj_cost_grad_T_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,

@@ -32,6 +32,8 @@ struct IpmArgs {
   int *status, *iters;   // [B]
   double *res;           // [B][2] primal / dual residual at exit (relative)
   double *gradT;         // optional [B][N]
+  const double *grad_z;  // optional [B][n]: d loss / d coefficients (the layout of `coeffs`) ...
+  double *vjpT;          // ... -> [B][N] d loss / d T through the optimum (the KKT backward pass, layers.py:129-141)
   int64_t B;
   int N, R, M;
   double vmax, amax, m34, tol;
@@ -390,6 +392,52 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     }
   };
 
+  // Newton matrix of the current iterate into (Dg, Of) from the per-sample weights acc[0..11] of pass A
+  auto assemble_newton = [&]() {
+    // Newton matrix: per piece and pair (m, m') of Hermite basis functions the twelve weighted sums over the
+    // samples (six corridor 3x3 entries, three velocity, three acceleration weights) are formed once and
+    // scattered to the nine axis pairs of the node blocks -- 18 LDS reads per 12 results, where one thread per
+    // matrix entry needed 9 per result.
+    for (int e = tid; e < (2 * N + 1) * BK * BK; e += nt) Dg[e] = 0.0;  // Of follows Dg
+    __syncthreads();
+    for (int w = tid; w < N * D * D; w += nt) {
+      const int i = w / (D * D), m = (w / D) % D, m2 = w % D;
+      if (m < S && m2 >= S) continue;  // upper off-diagonal block: the transpose of the stored one
+      double Sa[6] = {0, 0, 0, 0, 0, 0}, Sd[3] = {0, 0, 0};
+      for (int j = 0; j < R; ++j) {
+        const double *as = acc + (size_t)(i * R + j) * 30;
+        const double *hj = ht + (size_t)j * 3 * D;
+        const double p0 = hj[m] * hj[m2], p1 = hj[D + m] * hj[D + m2], p2 = hj[2 * D + m] * hj[2 * D + m2];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Sa[q] += as[q] * p0;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) Sd[ax] += as[6 + ax] * p1 + as[9 + ax] * p2;
+      }
+      const double scale = sc[i * D + m] * sc[i * D + m2], ob = qsv[i] * Hobj[m * D + m2];
+#pragma unroll
+      for (int axr = 0; axr < 3; ++axr)
+#pragma unroll
+        for (int axc = 0; axc < 3; ++axc) {
+          const int wa = axr <= axc ? (axr == 0 ? axc : (axr == 1 ? 2 + axc : 5)) : (axc == 0 ? axr : (axc == 1 ? 2 + axr : 5));
+          const double v = scale * (Sa[wa] + (axr == axc ? Sd[axr] + ob : 0.0));
+          if (m < S) atomicAdd(&Dg[(size_t)i * BK * BK + (axr * S + m) * BK + axc * S + m2], v);
+          else if (m2 >= S) atomicAdd(&Dg[(size_t)(i + 1) * BK * BK + (axr * S + m - S) * BK + axc * S + (m2 - S)], v);
+          else Of[(size_t)i * BK * BK + (axr * S + m - S) * BK + axc * S + m2] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < (2 * N + 1) * BK * BK; e += nt) {  // pinned components, diagonal regularisation
+      const int blk = e / (BK * BK), r = (e % (BK * BK)) / BK, c = e % BK;
+      const bool diag = blk <= N;
+      const int k = diag ? blk : blk - (N + 1);
+      const int kr = diag ? k : k + 1, kc = k;
+      double v = Dg[e];
+      if (pinned(kr, r % S) || pinned(kc, c % S)) v = (diag && r == c) ? 1.0 : 0.0;
+      if (diag && r == c) v += 1e-13 * fabs(v) + 1e-300;
+      Dg[e] = v;
+    }
+  };
+
   int it = 0, status = -2;  // OSQP_MAX_ITER_REACHED unless decided below
   double pres = 0.0, dres = 0.0, mu = 0.0, mu0 = 0.0;
   for (it = 0; it < a.max_iter; ++it) {
@@ -478,48 +526,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     if (pres < a.tol && dres < a.tol && mu * mrows < a.tol * fmax(1.0, 0.5 * fabs(objn))) { status = 1; break; }
     if (!(mu == mu) || mu > 1e12 * fmax(mu0, 1.0)) { status = -3; break; }  // diverging: no strictly feasible point
     __syncthreads();
-    // Newton matrix: per piece and pair (m, m') of Hermite basis functions the twelve weighted sums over the
-    // samples (six corridor 3x3 entries, three velocity, three acceleration weights) are formed once and
-    // scattered to the nine axis pairs of the node blocks -- 18 LDS reads per 12 results, where one thread per
-    // matrix entry needed 9 per result.
-    for (int e = tid; e < (2 * N + 1) * BK * BK; e += nt) Dg[e] = 0.0;  // Of follows Dg
-    __syncthreads();
-    for (int w = tid; w < N * D * D; w += nt) {
-      const int i = w / (D * D), m = (w / D) % D, m2 = w % D;
-      if (m < S && m2 >= S) continue;  // upper off-diagonal block: the transpose of the stored one
-      double Sa[6] = {0, 0, 0, 0, 0, 0}, Sd[3] = {0, 0, 0};
-      for (int j = 0; j < R; ++j) {
-        const double *as = acc + (size_t)(i * R + j) * 30;
-        const double *hj = ht + (size_t)j * 3 * D;
-        const double p0 = hj[m] * hj[m2], p1 = hj[D + m] * hj[D + m2], p2 = hj[2 * D + m] * hj[2 * D + m2];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) Sa[q] += as[q] * p0;
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) Sd[ax] += as[6 + ax] * p1 + as[9 + ax] * p2;
-      }
-      const double scale = sc[i * D + m] * sc[i * D + m2], ob = qsv[i] * Hobj[m * D + m2];
-#pragma unroll
-      for (int axr = 0; axr < 3; ++axr)
-#pragma unroll
-        for (int axc = 0; axc < 3; ++axc) {
-          const int wa = axr <= axc ? (axr == 0 ? axc : (axr == 1 ? 2 + axc : 5)) : (axc == 0 ? axr : (axc == 1 ? 2 + axr : 5));
-          const double v = scale * (Sa[wa] + (axr == axc ? Sd[axr] + ob : 0.0));
-          if (m < S) atomicAdd(&Dg[(size_t)i * BK * BK + (axr * S + m) * BK + axc * S + m2], v);
-          else if (m2 >= S) atomicAdd(&Dg[(size_t)(i + 1) * BK * BK + (axr * S + m - S) * BK + axc * S + (m2 - S)], v);
-          else Of[(size_t)i * BK * BK + (axr * S + m - S) * BK + axc * S + m2] = v;
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < (2 * N + 1) * BK * BK; e += nt) {  // pinned components, diagonal regularisation
-      const int blk = e / (BK * BK), r = (e % (BK * BK)) / BK, c = e % BK;
-      const bool diag = blk <= N;
-      const int k = diag ? blk : blk - (N + 1);
-      const int kr = diag ? k : k + 1, kc = k;
-      double v = Dg[e];
-      if (pinned(kr, r % S) || pinned(kc, c % S)) v = (diag && r == c) ? 1.0 : 0.0;
-      if (diag && r == c) v += 1e-13 * fabs(v) + 1e-300;
-      Dg[e] = v;
-    }
+    assemble_newton();
     // affine right-hand side: -(P y + q) - G'(lambda + w (Gy - h))
     node_vector(dya, 12, true, uu);
     __syncthreads();
@@ -647,6 +654,159 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     __syncthreads();
   }
   __syncthreads();
+  // ---- backward pass through the optimum (anet_qp_solve_vjp) ---------------------------------------------------
+  // The reference's hook solves the dense KKT system  J [d_z; d_lambda; d_nu] = -grad  (layers.py:129-141) and stops
+  // there: its z is a detached leaf.  Here the same adjoint is taken in Hermite coordinates and carried through to the
+  // durations.  On the central path y(T) solves F(y, T) = grad_y L(y, lambda(y, T); T) = 0 with lambda_r = mu / s_r, so
+  //   dy/dT = -K^-1 dF/dT,  K = dF/dy = P + G' diag(lambda / s) G   -- the Newton matrix of the method, at the optimum;
+  // with d_y = -K^-1 g_y and d_lambda_r = w_r g_r.d_y (w = lambda / s) the chain rule collapses to the DIRECTIONAL
+  // DERIVATIVE of the time gradient of the Lagrangian (the closed form below) along (d_y, d_lambda), plus the explicit
+  // dependence of the coefficients on T at fixed node states (c = Hm u T^-k, the (T_i/T_i+1)^d halves, the pinned ends).
+  if (a.grad_z && a.vjpT) {
+    const double *gz = a.grad_z + b * (int64_t)N * NB;
+    // At a finite barrier parameter lambda / s is a SOFT weight: a row with a small multiplier is only enforced with
+    // stiffness lambda^2 / mu, and the adjoint comes out wrong by the inverse of that (1e-3 relative on rows with
+    // multipliers of 1e-3 at the tolerance the solve stops at).  The optimum itself tells which rows it touches:
+    // s lambda = mu on the central path, so a touched row has lambda ~ lambda* and s = mu / lambda*, an untouched one
+    // s ~ s* and lambda = mu / s* -- at mu ~ 1e-10 the two kinds are ten orders of magnitude apart in lambda / s, and
+    // lambda > s separates them (a row is misjudged only if its multiplier AND its slack are below 1e-5: degenerate,
+    // where the derivative does not exist either).  The adjoint system of the QP proper has the touched rows as
+    // equalities g_r.d_y = 0 and ignores the others (the J of layers.py:129-141 with its diag(lambda), diag(Gz-h)
+    // blocks): they get a penalty weight (made exact by the multiplier passes below), the others none.
+    double pmax = 0.0;
+    for (int i = 0; i < N; ++i)
+      for (int m = 0; m < D; ++m) pmax = fmax(pmax, qsv[i] * Hobj[m * D + m] * sc[i * D + m] * sc[i * D + m]);
+    const double w_act = 1.0e4 * pmax;
+    for (int smp = tid; smp < NS; smp += nt) {
+      const int i = smp / R;
+      double A_[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) A_[q] = 0.0;
+      for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double) {
+        const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
+        const double w = (lm > sl) ? w_act : 0.0;
+        if (dsel == 0) {
+          A_[0] += w * c0 * c0; A_[1] += w * c0 * c1; A_[2] += w * c0 * c2;
+          A_[3] += w * c1 * c1; A_[4] += w * c1 * c2; A_[5] += w * c2 * c2;
+        } else {
+          A_[3 + dsel * 3 + 0] += w * c0 * c0;
+          A_[3 + dsel * 3 + 1] += w * c1 * c1;
+          A_[3 + dsel * 3 + 2] += w * c2 * c2;
+        }
+      });
+      double *as = acc + (size_t)smp * 30;
+#pragma unroll
+      for (int q = 0; q < 12; ++q) as[q] = A_[q];
+    }
+    __syncthreads();
+    assemble_newton();
+    __syncthreads();
+    wave0_factor();
+    // g_u = d loss / d u_i (duc), g_y (dyc)
+    for (int e = tid; e < N * NB; e += nt) {
+      const int i = e / NB, ax = (e % NB) / D, m = e % D;
+      double v = 0.0, tk = 1.0;
+      const double rT = 1.0 / Tn[i];
+      for (int col = D - 1; col >= 0; --col) {  // k = D-1-col = 0, 1, ..: T^-k
+        v += gz[(size_t)i * NB + ax * D + col] * tk * Hm[col * D + m];
+        tk *= rT;
+      }
+      duc[e] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < NY; e += nt) {
+      const int k = e / BK, ax = (e / S) % 3, d = e % S;
+      double v = 0.0;
+      if (!pinned(k, d)) {
+        if (k < N) v += sc[k * D + d] * duc[(size_t)k * NB + ax * D + d];
+        if (k > 0) v += sc[(k - 1) * D + S + d] * duc[(size_t)(k - 1) * NB + ax * D + S + d];
+      }
+      dyc[e] = v;
+    }
+    for (int i = tid; i < 3 * N; i += nt) rhs[i] = 0.0;
+    for (int smp = tid; smp < NS; smp += nt) {
+      double *as = acc + (size_t)smp * 30 + 12;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) as[q] = 0.0;
+    }
+    __syncthreads();
+    // Method of multipliers on  min 1/2 d'P d + g_y.d  s.t.  g_r.d = 0 (touched rows):  (P + w Ga'Ga) d_k = -g_y - Ga'nu_k,
+    // nu_k+1 = nu_k + w Ga d_k.  The penalty alone would need w so large that the factorisation loses the small
+    // curvatures of the cost (they span five orders of magnitude: 1e-4 .. 1e-3 relative error at w = 1e8 pmax); with
+    // the multiplier update a moderate w does, the constraint residual falling by ~1e-4 per pass.  Only Ga'nu per
+    // sample (acc[12..20]) and the per-piece sums of nu over the box rows are carried -- what the time gradient needs
+    // of d_lambda = nu.
+    for (int pass = 0; pass < 4; ++pass) {
+      node_vector(dya, 12, false, uu);
+      __syncthreads();
+      for (int e = tid; e < NY; e += nt) dya[e] = -dyc[e] - dya[e];
+      __syncthreads();
+      wave0_solve(dya);
+      __syncthreads();
+      to_u(dya, dua);
+      __syncthreads();
+      for (int smp = tid; smp < NS; smp += nt) {
+        const int i = smp / R, j = smp % R;
+        double d3[3][3], G_[9], bsv = 0.0, bsa = 0.0;
+        state_of(dua, i, j, d3);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) G_[q] = 0.0;
+        for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double) {
+          const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
+          const double dl = ((lm > sl) ? w_act : 0.0) * (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
+          G_[dsel * 3 + 0] += dl * c0; G_[dsel * 3 + 1] += dl * c1; G_[dsel * 3 + 2] += dl * c2;
+          if (dsel == 1) bsv += dl;
+          if (dsel == 2) bsa += dl;
+        });
+        double *as = acc + (size_t)smp * 30 + 12;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) as[q] += G_[q];
+        atomicAdd(&rhs[N + i], bsv);
+        atomicAdd(&rhs[2 * N + i], bsa);
+      }
+      __syncthreads();
+    }
+    for (int e = tid; e < N * NB; e += nt) {
+      const int i = e / NB, ax = (e % NB) / D, m = e % D, d = m % S;
+      const double *ui = uu + (size_t)i * NB + ax * D, *vi = dua + (size_t)i * NB + ax * D;
+      double hu = 0.0, hv = 0.0;
+      for (int m2 = 0; m2 < D; ++m2) {
+        hu += Hobj[m * D + m2] * ui[m2];
+        hv += Hobj[m * D + m2] * vi[m2];
+      }
+      double t = (double)(1 - 2 * S) * qsv[i] * ui[m] * hv / Tn[i];   // along d_y of (1-2s) J_i / T_i
+      {  // explicit T^-k of the coefficients: - k c_col g_z / T_i  (col = m as a running index over the D columns)
+        const int col = m, k = D - 1 - col;
+        double cc = 0.0;
+        for (int m2 = 0; m2 < D; ++m2) cc += Hm[col * D + m2] * ui[m2];
+        t -= (double)k * cc * pow(Tn[i], (double)(-k)) * gz[(size_t)i * NB + ax * D + col] / Tn[i];
+      }
+      atomicAdd(&rhs[i], t);
+      if (d == 0) continue;
+      double g = qsv[i] * hu, dg = qsv[i] * hv;
+      for (int j = 0; j < R; ++j) {
+        const double *ga = acc + (size_t)(i * R + j) * 30;
+        const double *hj = ht + (size_t)j * 3 * D;
+        g += ga[21 + ax] * hj[m] + ga[24 + ax] * hj[D + m] + ga[27 + ax] * hj[2 * D + m];
+        dg += ga[12 + ax] * hj[m] + ga[15 + ax] * hj[D + m] + ga[18 + ax] * hj[2 * D + m];
+      }
+      const double c = (dg * ui[m] + g * vi[m] + duc[e] * ui[m]) * (double)d;
+      if (m >= S) {
+        if (i < N - 1) {
+          atomicAdd(&rhs[i], c / Tn[i]);
+          atomicAdd(&rhs[i + 1], -c / Tn[i + 1]);
+        } else if (d < 3) {
+          atomicAdd(&rhs[i], c / Tn[i]);
+        }
+      } else if (i == 0 && d < 3) {
+        atomicAdd(&rhs[0], c / Tn[0]);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += nt)
+      a.vjpT[b * N + i] = rhs[i] - (a.vmax * rhs[N + i] + 2.0 * a.amax * Tn[i] * rhs[2 * N + i]);
+    __syncthreads();
+  }
   // ---- time gradient of the optimal cost (anet_qp_solve_time_grad): envelope theorem in these coordinates ----
   // L = sum_i q_i 1/2 u_i'H_obj u_i + lambda'(G u - h) at fixed (y, lambda) depends on T through q_i = T_i^(1-2s),
   // the end halves u_i[S+d] = (T_i/T_i+1)^d y_i+1[d], the pinned boundary values y_0[d] = ini_d T_0^d,

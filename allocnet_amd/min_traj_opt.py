@@ -121,6 +121,27 @@ class OsqpLayer:
         self.implicit_time_grad[:segments] = out["grad_T"][0] / qp_traj.path_length
         return z, curr_obj1_val, None, curr_objc_val, curr_padding_loss
 
+    def backward(self, qp_traj, grad_z):
+        """The backward pass the reference's KKT hook is after (layers.py:129-141, 230-243), carried through to the
+        durations: grad_z = d loss / d z (the flat solution `forward` returns, or (N,3,2s)) -> d loss / d Times (zeros
+        beyond the used segments).  None if the QP is not solved.  Any loss of the optimal coefficients can be
+        differentiated; for the reference's own objc loss use `implicit_time_grad`, which needs no extra solve."""
+        seg = qp_traj.seg
+        M = max(p.shape[0] for p in qp_traj.hpolys)
+        hp = np.zeros((1, seg, M, 4))
+        for i, p in enumerate(qp_traj.hpolys):
+            hp[0, i, :p.shape[0]] = p
+        ini = qp_traj.start_state.reshape(1, 3, 3); fin = qp_traj.end_state.reshape(1, 3, 3)
+        T = np.asarray(qp_traj.Times[:seg], dtype=np.float64)[None]
+        out = _qp.qp_solve_vjp(qp_traj.order, ini, fin, hp, T, np.asarray(grad_z, dtype=np.float64).reshape(1, seg, 3, -1),
+                               res=qp_traj.res, max_vel=qp_traj._limits[0], max_acc=qp_traj._limits[1],
+                               settings=_qp.qp_settings(method=_qp.QP_METHOD_INTERIOR_POINT), ctx=self._ctx)
+        if out["status"][0] != 1:
+            return None
+        g = np.zeros_like(np.asarray(qp_traj.Times, dtype=np.float64))
+        g[:seg] = out["grad_T"][0]
+        return g
+
     def forward_batch(self, qp_trajs):
         """Extension: the minibatch of the training loop in ONE solve per (order, segment count, res, limits) group
         instead of one `forward` call per sample (minsnap_network_conv_lstm.py:340-352 loops in Python).

@@ -121,6 +121,30 @@ def qp_solve(order, iniPVA, finPVA, hPolys, times, res=20, max_vel=4.0, max_acc=
     return out
 
 
+def qp_solve_vjp(order, iniPVA, finPVA, hPolys, times, grad_z, res=20, max_vel=4.0, max_acc=6.0, m34=1400.0,
+                 settings=None, ctx=None):
+    """Backward pass through the QP (anet_qp_solve_vjp; the KKT hook of layers.py:129-141 carried through to the
+    durations): grad_z (B,N,3,2s) = d loss / d optimal coefficients -> grad_T (B,N) = d loss / d times.  Returns the
+    dict of qp_solve with grad_T added.  Interior-point method only."""
+    ctx = ctx or default_context()
+    hp = np.ascontiguousarray(hPolys, dtype=np.float64)
+    B, N, M, _ = hp.shape
+    state = np.ascontiguousarray(np.stack([np.asarray(iniPVA, dtype=np.float64),
+                                           np.asarray(finPVA, dtype=np.float64)], axis=1))
+    T = np.ascontiguousarray(times, dtype=np.float64)
+    D = 2 * order
+    gz = np.ascontiguousarray(grad_z, dtype=np.float64).reshape(B, N, 3, D)
+    if state.shape != (B, 2, 3, 3) or T.shape != (B, N):
+        raise ValueError("shape mismatch")
+    coeffs = np.empty((B, N, 3, D)); obj = np.empty(B); gT = np.empty((B, N))
+    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); resid = np.empty((B, 2))
+    sp = ctypes.cast(ctypes.pointer(settings), ctypes.c_void_p) if settings is not None else None
+    ctx.check(ctx.lib.anet_qp_solve_vjp(ctx.handle, int(order), N, B, int(res), M, float(max_vel), float(max_acc), float(m34),
+                                        _p(state), _p(T), _p(hp), sp, _p(gz), _p(coeffs), _p(obj), _p(status), _p(iters),
+                                        _p(resid), _p(gT)))
+    return dict(coeffs=coeffs, obj=obj, status=status, iters=iters, residuals=resid, grad_T=gT)
+
+
 class QPConfig:
     """struct QPConfig (qp_solver.hpp:14-26) without the ros::NodeHandle: the three parameters it reads."""
 

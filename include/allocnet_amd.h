@@ -325,6 +325,26 @@ int anet_qp_solve_time_grad_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batc
                                 double *coeffs, double *obj, int32_t *status, int32_t *iters, double *residuals,
                                 double *grad_T, void *stream);
 
+/* Backward pass through the QP (replaces the KKT hook of network/utils/learning/layers.py:129-141,
+ * 230-243: grad <- -J^-1 grad with J = [[Q, G'diag(lambda), A'], [G, diag(Gz-h), 0], [A, 0, 0]], a dense (n+m)^2 solve
+ * per sample whose result stops at the detached leaf z).  Solves the QP (interior-point method only) and returns,
+ * for a caller-supplied gradient grad_z = d loss / d z* (layout of `coeffs`), grad_T [batch][N] = d loss / d T:
+ * the adjoint is taken at the optimum with the method's own block-tridiagonal Newton matrix (Hermite coordinates:
+ * the equality block is built in, the inequality rows enter through lambda / s) and contracted in closed form with
+ * the dependence of the cost blocks, the continuity scalings, the pinned end states, the box bounds and the
+ * coefficient scaling on the durations.  Any smooth loss of the optimal coefficients can be differentiated this way;
+ * for loss = the QP objective it reproduces anet_qp_solve_time_grad (minus the explicit 1/2 z'(dQ/dT)z part, which
+ * anet_traj_cost_grad_T gives).  settings as in anet_qp_solve (the tolerance is tightened to 1e-9).            */
+int anet_qp_solve_vjp(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                      double max_acc, double m34, const double *state, const double *T, const double *hpolys,
+                      const anet_qp_settings *settings, const double *grad_z /* [batch][N][3][2s] */, double *coeffs,
+                      double *obj, int32_t *status, int32_t *iters, double *residuals, double *grad_T /* [batch][N] */);
+int anet_qp_solve_vjp_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                          double max_acc, double m34, const double *state, const double *T, const double *hpolys,
+                          const anet_qp_settings *settings, const double *grad_z, double *work, double *coeffs,
+                          double *obj, int32_t *status, int32_t *iters, double *residuals, double *grad_T,
+                          void *stream);
+
 /* ---- batched L-BFGS ------------------------------------------------------------------------ */
 /* lbfgs::lbfgs_parameter_t, same fields and defaults (gcopter/lbfgs.hpp:15-129). */
 typedef struct anet_lbfgs_params {

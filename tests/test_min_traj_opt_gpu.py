@@ -69,6 +69,24 @@ def test_osqp_layer_forward(anet_ctx):
             vals.append(aa.OsqpLayer(ctx=anet_ctx).forward(o)[3])
         fd = (vals[0] - vals[1]) / (2 * h)
         assert abs(fd - imp[i]) <= 0.1 * np.abs(imp[:3]).max() + 1e-3, (i, fd, imp)
+    # OsqpLayer.backward: the pass the KKT hook of layers.py:129-141 is after, carried to the durations.  With
+    # grad_z = Q z / path_length (the gradient of objc w.r.t. the solution) plus the explicit part (time_grad) it is
+    # the implicit gradient of objc; and the position of the middle knot, a loss that is NOT the objective, moves
+    # with the durations as central differences of re-solved QPs say
+    gz = (Q @ z) / opt.path_length
+    total = layer.backward(opt, gz) + layer.time_grad
+    assert np.abs(total[:3] - imp[:3]).max() <= 1e-3 * np.abs(imp[:3]).max() + 1e-6 and (total[3:] == 0).all()
+    wsel = np.zeros(3 * 3 * 8); wsel[(1 * 3 + 0) * 8 + 7] = 1.0          # x-position at the start of piece 1 (constant term)
+    gb = layer.backward(opt, wsel)
+    for i in range(3):
+        vals = []
+        for sg in (+1, -1):
+            tt = times.copy(); tt[i] += sg * 1e-4
+            o = aa.MinTrajOpt(make_params(4, 10, vmax=3.0, amax=4.0), ctx=anet_ctx); o.update(state, hp50, tt, phase=2, seq_len=5)
+            lay = aa.OsqpLayer(ctx=anet_ctx); lay._settings = aa.qp_settings(eps_abs=1e-10, eps_rel=1e-10)
+            vals.append(lay.forward(o)[0] @ wsel)
+        fd = (vals[0] - vals[1]) / 2e-4
+        assert abs(fd - gb[i]) <= 1e-4 * np.abs(gb[:3]).max() + 1e-7, (i, fd, gb)
     # the interior-point method behind the same layer: same objective (to OSQP's tolerance), sharper gradient
     lay2 = aa.OsqpLayer(ctx=anet_ctx, method=aa.qp.QP_METHOD_INTERIOR_POINT)
     zi, _, _, objc_i, _ = lay2.forward(opt)

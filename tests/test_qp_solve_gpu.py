@@ -360,3 +360,55 @@ def test_default_method_solves_what_is_feasible(anet_ctx):
     osqp_like = aa.qp_solve(s, head, tail, hp, T, settings=aa.qp_settings(method=ADMM), **kw)
     print("feasible", int(feas.sum()), "default unsolved", int((feas & ~solved).sum()),
           "ADMM@OSQP-defaults unsolved", int((feas & (osqp_like["status"] != 1)).sum()))
+
+
+@pytest.mark.parametrize("s,N,M,res", [(4, 3, 9, 8), (3, 4, 8, 6), (4, 5, 12, 20), (3, 5, 16, 20)])
+def test_backward_pass_through_the_qp(anet_ctx, s, N, M, res):
+    """anet_qp_solve_vjp: d loss / d T through the optimum for a caller-supplied d loss / d z (the KKT hook of
+    layers.py:129-141 carried through to the durations).
+    (1) an arbitrary smooth loss of the optimal coefficients -- NOT the QP objective -- against central differences of
+        the loss over re-solved QPs;
+    (2) with grad_z = Q z the pass plus the explicit 1/2 z'(dQ/dT)z reproduces anet_qp_solve_time_grad."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(70 + 10 * s + N)
+    B = 8
+    probs = [_corridor_problem(rng, N, M, margin=1.2) for _ in range(B)]
+    ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
+    hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs])
+    kw = dict(res=res, max_vel=3.0, max_acc=4.0, ctx=anet_ctx)
+    tight = aa.qp_settings(method=aa.qp.QP_METHOD_INTERIOR_POINT, eps_abs=1e-10, eps_rel=1e-10)
+    D = 2 * s
+    w1 = rng.normal(size=(N, 3, D)); w2 = rng.uniform(0.0, 1.0, size=(N, 3, D))
+
+    def loss(z):                        # z (B,N,3,D): linear + diagonal quadratic, different weights per coefficient
+        return (w1 * z).sum(axis=(1, 2, 3)) + 0.5 * (w2 * z * z).sum(axis=(1, 2, 3))
+    base = aa.qp_solve(s, ini, fin, hp, T, settings=tight, **kw)
+    ok = base["status"] == 1
+    assert ok.sum() >= 5
+    gz = w1[None] + w2[None] * base["coeffs"]
+    out = aa.qp_solve_vjp(s, ini, fin, hp, T, gz, **kw)
+    assert (out["status"][ok] == 1).all()
+    assert np.abs(out["coeffs"] - base["coeffs"])[ok].max() <= 1e-6 * np.abs(base["coeffs"])[ok].max()
+    h = 1e-5
+    fd = np.zeros((B, N))
+    for i in range(N):
+        Tp = T.copy(); Tp[:, i] += h
+        Tm = T.copy(); Tm[:, i] -= h
+        fd[:, i] = (loss(aa.qp_solve(s, ini, fin, hp, Tp, settings=tight, **kw)["coeffs"])
+                    - loss(aa.qp_solve(s, ini, fin, hp, Tm, settings=tight, **kw)["coeffs"])) / (2 * h)
+    scale = np.abs(fd).max(axis=1, keepdims=True)
+    err = np.abs(out["grad_T"] - fd) / scale
+    assert (err[ok] <= 1e-4).all(), err[ok].max(axis=1)
+    # (2) the QP objective as the loss
+    Qz = np.zeros_like(base["coeffs"])
+    for bb in range(B):
+        Q = _dense(s, ini[bb], fin[bb], hp[bb], T[bb], res, 3.0, 4.0)[0]
+        Qz[bb] = (Q @ base["coeffs"][bb].reshape(-1)).reshape(N, 3, D)
+    vj = aa.qp_solve_vjp(s, ini, fin, hp, T, Qz, **kw)["grad_T"]
+    tg = aa.qp_solve(s, ini, fin, hp, T, settings=tight, time_grad=True, **kw)["grad_T"]
+    explicit = aa.traj_cost_grad_T(base["coeffs"], T, m34=1400.0, ctx=anet_ctx)
+    sc2 = np.abs(tg).max(axis=1, keepdims=True)
+    assert (np.abs(vj + explicit - tg)[ok] <= 1e-4 * sc2[ok]).all(), (np.abs(vj + explicit - tg) / sc2)[ok].max(axis=1)
+    # the ADMM method has no factored Newton matrix to reuse: refused, not approximated
+    with pytest.raises(aa.AnetError):
+        aa.qp_solve_vjp(s, ini, fin, hp, T, gz, settings=aa.qp_settings(method=ADMM), **kw)
