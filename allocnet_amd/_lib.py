@@ -34,6 +34,8 @@ PROTOTYPES = {
     "anet_to_traj_major_dev": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "anet_minco_solve_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anet_minco_solve_wide_spread_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p]),
     "anet_minco_solve": (c_int, [c_void_p, c_int, c_int, c_int, c_int64,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "anet_traj_eval_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,

@@ -16,6 +16,7 @@
 #include "../../include/allocnet_amd.h"
 #include "minco_core.h"
 #include "minco_kernels.h"
+#include "minco_dense_kernels.h"
 #include "traj_kernels.h"
 #include "rate_kernels.h"
 #include "lbfgs_kernels.h"
@@ -101,6 +102,10 @@ int ensure_scratch(anet_ctx *ctx, size_t bytes) {
 }
 
 inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// max T / min T inside one trajectory above which the host entry point of the coefficient solve switches to the pivoted
+// collocation solve (minco_dense_kernels.h)
+constexpr double kWideSpread = 50.0;
 
 // Up to this batch the axis-parallel kernel is used (3*B/63 waves still fit the chip's 1024 SIMDs about
 // once); measured crossover on MI355X in DESIGN.md section 4.
@@ -522,6 +527,29 @@ int anet_minco_solve_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
   }
 }
 
+int anet_minco_solve_wide_spread_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                                     const double *head, const double *tail, const double *wps, const double *T,
+                                     double min_spread, double *coeffs, double *energy, void *stream) {
+  int rc = check_solve_args(ctx, s, c, n_pieces, batch);
+  if (rc) return rc;
+  if (batch == 0) return ANET_OK;
+  if (!head || !tail || !T || (n_pieces > 1 && !wps) || ld < batch)
+    return fail(ctx, ANET_ERR_INVALID, "anet_minco_solve_wide_spread_dev: NULL input or ld < batch");
+  if (!coeffs && !energy) return fail(ctx, ANET_ERR_INVALID, "anet_minco_solve_wide_spread_dev: no output requested");
+  anet::DenseSolveArgs a{head, tail, wps, T, coeffs, energy, batch, ld, n_pieces, c, min_spread};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)batch), block(64);
+  auto launch = [&](auto kernel, size_t lds) -> int {
+    if (lds > 64 * 1024) ANET_HIP(ctx, hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, a);
+    ANET_HIP(ctx, hipGetLastError());
+    return ANET_OK;
+  };
+  if (s == 2) return launch(anet::k_minco_solve_dense<2>, anet::minco_dense_lds_bytes<2>(n_pieces));
+  if (s == 3) return launch(anet::k_minco_solve_dense<3>, anet::minco_dense_lds_bytes<3>(n_pieces));
+  return launch(anet::k_minco_solve_dense<4>, anet::minco_dense_lds_bytes<4>(n_pieces));
+}
+
 int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
                      const double *tail, const double *wps, const double *T, double *coeffs,
                      double *energy);
@@ -667,6 +695,26 @@ int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
   rc = anet_minco_solve_dev(ctx, s, c, N, batch, st.ld, d_head, d_tail, d_wps, d_T, coeffs ? d_co : nullptr, d_en,
                             ctx->stream);
   if (rc) return rc;
+  {
+    // The durations are in host memory here, so the check is free: trajectories whose durations spread over more
+    // than kWideSpread are redone by the pivoted collocation solve (the reduced form of the fast kernel loses the
+    // north star's 1e-6 on the coefficients beyond a spread of ~100).  Device callers decide for
+    // themselves (anet_minco_solve_wide_spread_dev): the fast path never pays for the check.
+    bool wide = false;
+    for (int64_t b = 0; b < batch && !wide; ++b) {
+      double lo = T[b * N], hi = lo;
+      for (int i = 1; i < N; ++i) {
+        lo = T[b * N + i] < lo ? T[b * N + i] : lo;
+        hi = T[b * N + i] > hi ? T[b * N + i] : hi;
+      }
+      wide = hi > kWideSpread * lo;
+    }
+    if (wide) {
+      rc = anet_minco_solve_wide_spread_dev(ctx, s, c, N, batch, st.ld, d_head, d_tail, d_wps, d_T, kWideSpread,
+                                            coeffs ? d_co : nullptr, d_en, ctx->stream);
+      if (rc) return rc;
+    }
+  }
   if (energy) ANET_HIP(ctx, hipMemcpyAsync(energy, d_en, sizeof(double) * batch, hipMemcpyDeviceToHost, ctx->stream));
   if (coeffs) return st.download(d_co, n_co, coeffs);
   ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));

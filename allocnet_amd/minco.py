@@ -72,6 +72,21 @@ def minco_solve_dev(head, tail, wps, T, s, c, N, B, coeffs=None, energy=None, st
     return coeffs, energy
 
 
+def minco_solve_wide_spread_dev(head, tail, wps, T, s, c, N, B, coeffs=None, energy=None, min_spread=50.0, stream=None,
+                                ctx=None):
+    """anet_minco_solve_wide_spread_dev: trajectories whose durations spread over more than `min_spread` are solved
+    again by the pivoted collocation solve, their coeffs / energy overwritten (same tensors as minco_solve_dev)."""
+    import torch
+    ctx = ctx or default_context(T.device.index or 0)
+    ld = T.stride(0) if T.dim() == 2 else T.shape[-1]
+    if stream is None:
+        stream = torch.cuda.current_stream(T.device).cuda_stream
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    ctx.check(ctx.lib.anet_minco_solve_wide_spread_dev(ctx.handle, s, c, N, B, ld, p(head), p(tail), p(wps) if N > 1 else None,
+                                                       p(T), float(min_spread), p(coeffs), p(energy), ctypes.c_void_p(stream)))
+    return coeffs, energy
+
+
 class MINCO:
     """Batched MINCO_S{s}NU mirror: setConditions -> setParameters -> getCoeffs/getEnergy."""
 

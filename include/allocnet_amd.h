@@ -104,6 +104,15 @@ int anet_minco_solve_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                          double *coeffs,      /* [N*3*2s][ld]     */
                          double *energy,      /* [batch]          */
                          void *stream);
+/* Trajectories whose durations spread widely (max T / min T > min_spread; <= 1 selects all) solved again by the classic
+ * formulation -- one 2sN x 2sN banded collocation system, LU with partial pivoting -- and their coeffs / energy
+ * overwritten; the others are left as they are.  The fast kernel solves a reduced system whose conditioning is the
+ * square of this one's: accurate to 1e-8 up to a spread of 100, 5e-4 at 10^3 (snap).  The host entry point
+ * anet_minco_solve applies this by itself above a spread of 50; device callers call it when their durations can spread
+ * (about 10^3 times slower per trajectory that is redone).                                                    */
+int anet_minco_solve_wide_spread_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                                     const double *head, const double *tail, const double *wps, const double *T,
+                                     double min_spread, double *coeffs, double *energy, void *stream);
 int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch,
                      const double *head,  /* [batch][3][c]     */
                      const double *tail,  /* [batch][3][c]     */

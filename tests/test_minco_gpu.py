@@ -125,3 +125,50 @@ def test_duration_spread_accuracy_envelope(anet_ctx, s, c, N):
         err = np.array([np.abs(co[b] - cc[b]).max() / np.abs(cc[b]).max() for b in range(B)])
         assert err.max() <= tol, (half_decades, err.max())
         assert np.abs(en - ec).max() <= 1e-9 * np.abs(ec).max()
+    # beyond a spread of 50 the host entry point redoes the trajectory with the pivoted collocation solve
+    # (anet_minco_solve_wide_spread_dev): 1e-6 on the coefficients holds at spreads of 10^3 and 10^4 as well
+    for half_decades in (1.5, 2.0):
+        Tm = 10.0 ** rng.uniform(-half_decades, half_decades, size=T.shape)
+        co, en = aa.minco_solve(head, tail, wps, Tm, s, ctx=anet_ctx)
+        cc, ec = cbind.minco_solve_batch(s, head, tail, wps, Tm)
+        err = np.array([np.abs(co[b] - cc[b]).max() / np.abs(cc[b]).max() for b in range(B)])
+        assert err.max() <= 1e-6, (half_decades, err.max())
+        assert np.abs(en - ec).max() <= 1e-6 * np.abs(ec).max()
+
+
+def test_wide_spread_solve_touches_only_wide_trajectories(anet_ctx):
+    """Device entry point: trajectories below the spread threshold keep the fast kernel's output bit for bit, the
+    others are overwritten with the collocation solve (checked against the oracle); min_spread <= 1 redoes all and
+    agrees with the fast kernel where that one is accurate."""
+    import torch
+    import allocnet_amd as aa
+    rng = np.random.default_rng(77)
+    s, c, N, B = 4, 3, 8, 130
+    head, tail, wps, T = random_problem(rng, B, N, c)
+    wide = np.arange(B) % 3 == 0
+    T[wide] = 10.0 ** rng.uniform(-1.5, 1.5, size=(int(wide.sum()), N))
+    ld = aa.recommended_ld(B)
+    dev = torch.device("cuda", 0)
+
+    def bm(x):
+        f = np.ascontiguousarray(x.reshape(B, -1).T)
+        t = torch.zeros(f.shape[0], ld, device=dev, dtype=torch.float64)
+        t[:, :B] = torch.from_numpy(f).to(dev)
+        return t
+    th, tt, tw, tT = bm(head), bm(tail), bm(wps), bm(T)
+    co = torch.empty(N * 3 * 2 * s, ld, device=dev, dtype=torch.float64); en = torch.empty(ld, device=dev, dtype=torch.float64)
+    aa.minco_solve_dev(th, tt, tw, tT, s, c, N, B, coeffs=co, energy=en, ctx=anet_ctx)
+    fast = co[:, :B].T.cpu().numpy().reshape(B, N, 3, 2 * s).copy(); efast = en[:B].cpu().numpy().copy()
+    aa.minco.minco_solve_wide_spread_dev(th, tt, tw, tT, s, c, N, B, coeffs=co, energy=en, min_spread=50.0, ctx=anet_ctx)
+    after = co[:, :B].T.cpu().numpy().reshape(B, N, 3, 2 * s); eafter = en[:B].cpu().numpy()
+    spread = T.max(axis=1) / T.min(axis=1)
+    keep = spread <= 50.0
+    assert keep.sum() > 40 and (~keep).sum() > 20
+    assert np.array_equal(after[keep], fast[keep]) and np.array_equal(eafter[keep], efast[keep])
+    cc, ec = cbind.minco_solve_batch(s, head, tail, wps, T)
+    err = np.array([np.abs(after[b] - cc[b]).max() / np.abs(cc[b]).max() for b in range(B)])
+    assert err[~keep].max() <= 1e-7 and not np.array_equal(after[~keep], fast[~keep])
+    assert np.abs(eafter - ec)[~keep].max() <= 1e-7 * np.abs(ec).max()
+    aa.minco.minco_solve_wide_spread_dev(th, tt, tw, tT, s, c, N, B, coeffs=co, energy=en, min_spread=0.0, ctx=anet_ctx)
+    allc = co[:, :B].T.cpu().numpy().reshape(B, N, 3, 2 * s)
+    assert np.abs(allc[keep] - fast[keep]).max() <= 1e-8 * np.abs(fast[keep]).max()
