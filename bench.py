@@ -331,6 +331,55 @@ def main():
                                 "stream_ms_per_step": e0.elapsed_time(e1) / K2,
                                 "hbm_frac": b2 * abytes / (e0.elapsed_time(e1) / K2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "note": "launch-latency bound: 2 MB per launch"}
+        # The same 1024-trajectory launches from EIGHT streams (a sampler of time allocations issues many independent
+        # batches): a launch is 49 waves on 1024 SIMDs, so independent batches overlap until the chip fills.
+        ns = 8
+        streams = [torch.cuda.Stream(device=device) for _ in range(ns)]
+        ld2 = aa.recommended_ld(b2)
+        outs = [(torch.empty(N * 3 * D, ld2, device=device, dtype=torch.float64), torch.empty(ld2, device=device, dtype=torch.float64))
+                for _ in range(ns)]
+        ins = [x[:, :ld2].contiguous() for x in (head, tail, wps, T)]
+        torch.cuda.synchronize()
+        for rep in range(2):                      # first pass = warm-up
+            t0 = time.perf_counter()
+            for k in range(K2 * ns if rep else ns * 4):
+                j = k % ns
+                aa.minco_solve_dev(ins[0], ins[1], ins[2], ins[3], s, c, N, b2, coeffs=outs[j][0], energy=outs[j][1],
+                                   stream=streams[j].cuda_stream, ctx=ctx)
+            torch.cuda.synchronize()
+            dt8 = time.perf_counter() - t0
+        # ... and as ONE hipGraph of 64 such launches on 8 parallel chains, replayed: what is left of the launch side
+        try:
+            cap = torch.cuda.Stream(device=device)
+            graph = torch.cuda.CUDAGraph()
+            NG = 64
+            with torch.cuda.graph(graph, stream=cap):
+                cur = torch.cuda.current_stream(device)
+                for st in streams:
+                    st.wait_stream(cur)
+                for k in range(NG):
+                    j = k % ns
+                    aa.minco_solve_dev(ins[0], ins[1], ins[2], ins[3], s, c, N, b2, coeffs=outs[j][0], energy=outs[j][1],
+                                       stream=streams[j].cuda_stream, ctx=ctx)
+                for st in streams:
+                    cur.wait_stream(st)
+            for _ in range(5):
+                graph.replay()
+            torch.cuda.synchronize()
+            reps = 50
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                graph.replay()
+            torch.cuda.synchronize()
+            dtg = time.perf_counter() - t0
+            out["config1_b1024"]["graph64x8"] = {"value": b2 * NG * reps / dtg, "ms_per_launch": dtg / (NG * reps) * 1e3,
+                                                 "hbm_frac": b2 * abytes / (dtg / (NG * reps)) / 1e9 / HBM_PEAK_GBS,
+                                                 "note": "64 launches of 1024 trajectories on 8 parallel chains captured in one hipGraph"}
+        except Exception as exc:      # (graph capture is an extra, never the headline)
+            out["config1_b1024"]["graph64x8"] = {"error": str(exc)[:200]}
+        out["config1_b1024"]["streams8"] = {"value": b2 * K2 * ns / dt8, "ms_per_launch": dt8 / (K2 * ns) * 1e3,
+                                            "hbm_frac": b2 * abytes / (dt8 / (K2 * ns)) / 1e9 / HBM_PEAK_GBS,
+                                            "note": "1024-trajectory launches round-robin on 8 streams"}
         # PCIe-inclusive host API
         import numpy as np
         from allocnet_amd.synth import random_problem

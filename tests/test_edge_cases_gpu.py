@@ -157,3 +157,49 @@ def test_penalty_kernel_launch_shapes_agree(anet_ctx, s, c, N, M):
         assert rel_err(part[0], full[0][:n]) < 1e-12
         for g, gf in zip(part[1:], full[1:]):
             assert np.abs(g - gf[:n]).max() <= 1e-10 * max(1.0, np.abs(gf).max())
+
+
+def test_device_entry_points_capture_into_a_hip_graph(anet_ctx):
+    """The *_dev entry points only enqueue work on the caller's stream (no allocation, no synchronisation once the
+    basis table of an (order, res) exists), so a caller can capture them into a hipGraph -- what bench.py does for
+    the literal BASELINE configs[1] batch of 1024 trajectories, where launches, not bytes, are the cost.  Replays
+    reproduce the eager results bit for bit: coefficient solve and cost + gradient evaluation on parallel chains."""
+    import torch
+    import allocnet_amd as aa
+    from tests.util import corridor_problem
+    dev = torch.device("cuda", 0)
+    s, c, N, M, B = 4, 3, 8, 16, 1024
+    ld = aa.recommended_ld(B)
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(9), B, N, c, M)
+
+    def bm(x):
+        f = np.ascontiguousarray(x.reshape(B, -1).T)
+        t = torch.zeros(f.shape[0], ld, device=dev, dtype=torch.float64)
+        t[:, :B] = torch.from_numpy(f).to(dev)
+        return t
+    th, tt, tw, tT, thp = (bm(x) for x in (head, tail, wps, T, hp))
+    pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0,
+                          res=20, poly_rows=M)
+    co = torch.zeros(N * 3 * 2 * s, ld, device=dev, dtype=torch.float64); en = torch.zeros(ld, device=dev, dtype=torch.float64)
+    cost, gP, gT, work = aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, ctx=anet_ctx)   # eager: builds the table
+    aa.minco_solve_dev(th, tt, tw, tT, s, c, N, B, coeffs=co, energy=en, ctx=anet_ctx)
+    torch.cuda.synchronize()
+    ref = (co.clone(), en.clone(), cost.clone(), gP.clone(), gT.clone())
+    for t in (co, en, cost, gP, gT):
+        t.zero_()
+    side = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=torch.cuda.Stream(device=dev)):
+        cur = torch.cuda.current_stream(dev)
+        for st in side:
+            st.wait_stream(cur)
+        aa.minco_solve_dev(th, tt, tw, tT, s, c, N, B, coeffs=co, energy=en, stream=side[0].cuda_stream, ctx=anet_ctx)
+        aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, work=work, cost=cost, gradP=gP, gradT=gT,
+                               stream=side[1].cuda_stream, ctx=anet_ctx)
+        for st in side:
+            cur.wait_stream(st)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    for got, want in zip((co, en, cost, gP, gT), ref):
+        assert torch.equal(got[..., :B], want[..., :B])
