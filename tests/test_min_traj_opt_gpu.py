@@ -68,7 +68,7 @@ def test_osqp_layer_forward(anet_ctx):
             o = aa.MinTrajOpt(make_params(4, 10, vmax=3.0, amax=4.0), ctx=anet_ctx); o.update(state, hp50, tt, phase=2, seq_len=5)
             vals.append(aa.OsqpLayer(ctx=anet_ctx).forward(o)[3])
         fd = (vals[0] - vals[1]) / (2 * h)
-        assert abs(fd - imp[i]) <= 0.1 * np.abs(imp[:3]).max() + 1e-3, (i, fd, imp)
+        assert abs(fd - imp[i]) <= 2e-3 * np.abs(imp[:3]).max() + 1e-6, (i, fd, imp)      # (10 % with the ADMM default of round 1)
     # OsqpLayer.backward: the pass the KKT hook of layers.py:129-141 is after, carried to the durations.  With
     # grad_z = Q z / path_length (the gradient of objc w.r.t. the solution) plus the explicit part (time_grad) it is
     # the implicit gradient of objc; and the position of the middle knot, a loss that is NOT the objective, moves
