@@ -142,6 +142,36 @@ class OsqpLayer:
         g[:seg] = out["grad_T"][0]
         return g
 
+    def backward_batch(self, qp_trajs, grad_zs):
+        """`backward` for a minibatch: one anet_qp_solve_vjp per (order, segment count, res, limits) group, as
+        forward_batch groups its solves.  grad_zs[i] may be None (sample skipped).  Returns a list of d loss / d Times
+        arrays (None where skipped or unsolved)."""
+        n = len(qp_trajs)
+        out = [None] * n
+        groups = {}
+        for idx, q in enumerate(qp_trajs):
+            if grad_zs[idx] is not None:
+                groups.setdefault((q.order, q.seg, q.res, q._limits[0], q._limits[1]), []).append(idx)
+        st = _qp.qp_settings(method=_qp.QP_METHOD_INTERIOR_POINT)
+        for (order, seg, res, vmax, amax), ids in groups.items():
+            M = max(max(p.shape[0] for p in qp_trajs[i].hpolys) for i in ids)
+            B = len(ids)
+            hp = np.zeros((B, seg, M, 4)); ini = np.zeros((B, 3, 3)); fin = np.zeros((B, 3, 3)); T = np.zeros((B, seg))
+            gz = np.zeros((B, seg, 3, 2 * order))
+            for r, i in enumerate(ids):
+                q = qp_trajs[i]
+                for k, pl in enumerate(q.hpolys):
+                    hp[r, k, :pl.shape[0]] = pl
+                ini[r] = q.start_state.reshape(3, 3); fin[r] = q.end_state.reshape(3, 3); T[r] = q.Times[:seg]
+                gz[r] = np.asarray(grad_zs[i], dtype=np.float64).reshape(seg, 3, 2 * order)
+            res_ = _qp.qp_solve_vjp(order, ini, fin, hp, T, gz, res=res, max_vel=vmax, max_acc=amax, settings=st, ctx=self._ctx)
+            for r, i in enumerate(ids):
+                if res_["status"][r] == 1:
+                    g = np.zeros_like(np.asarray(qp_trajs[i].Times, dtype=np.float64))
+                    g[:seg] = res_["grad_T"][r]
+                    out[i] = g
+        return out
+
     def forward_batch(self, qp_trajs):
         """Extension: the minibatch of the training loop in ONE solve per (order, segment count, res, limits) group
         instead of one `forward` call per sample (minsnap_network_conv_lstm.py:340-352 loops in Python).

@@ -136,3 +136,12 @@ def test_osqp_layer_forward_batch(anet_ctx):
             assert np.abs(z - zb).max() <= 1e-7 * max(1.0, np.abs(z).max()) and abs(oc - ocb) <= 1e-9 * max(1.0, abs(oc))
             assert np.abs(one.time_grad - tg[i]).max() <= 1e-7 * max(1.0, np.abs(tg[i]).max())
             assert np.abs(one.implicit_time_grad - itg[i]).max() <= 1e-6 * max(1.0, np.abs(itg[i]).max())
+    # backward_batch == backward sample by sample (a skipped sample stays None)
+    gzs = [None if (r[0] is None or i == 1) else np.cos(np.arange(r[0].size) * 0.37) for i, r in enumerate(res)]
+    gb = layer.backward_batch(opts, gzs)
+    for i, o in enumerate(opts):
+        if gzs[i] is None:
+            assert gb[i] is None
+        else:
+            one = layer.backward(o, gzs[i])
+            assert np.abs(one - gb[i]).max() <= 1e-7 * max(1.0, np.abs(one).max())
