@@ -7,14 +7,40 @@ from ctypes import c_int, c_int64, c_double, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.path.join(_HERE, "liboracle.so")
+_CPU_PATH = os.path.join(_HERE, "libcpu_reduced.so")
 _lib = None
+_cpu_lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("minco_oracle.c", "lbfgs_oracle.c")]
-    if force or not os.path.exists(_PATH) or any(os.path.getmtime(_PATH) < os.path.getmtime(s) for s in srcs):
-        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    srcs = [os.path.join(_HERE, f) for f in ("minco_oracle.c", "lbfgs_oracle.c", "minco_cpu_reduced.cpp")]
+    srcs += [os.path.join(os.path.dirname(_HERE), "allocnet_amd", "csrc", f) for f in ("minco_core.h", "minco_tables.h")]
+    outs = (_PATH, _CPU_PATH)
+    if force or not all(os.path.exists(o) for o in outs) or any(os.path.getmtime(o) < os.path.getmtime(s) for o in outs for s in srcs):
+        subprocess.run(["make", "-C", _HERE, "-B", "all"], check=True, capture_output=True)
     return _PATH
+
+
+def cpu_reduced_solve_batch(s, head, tail, wps, T, nthreads=1, want_coeffs=True, out=None):
+    """CPU BASELINE of bench.py (not an oracle): the kernels' own reduced algorithm compiled for the host
+    (oracle/minco_cpu_reduced.cpp).  Same arguments and returns as minco_solve_batch."""
+    global _cpu_lib
+    if _cpu_lib is None:
+        build()
+        _cpu_lib = ctypes.CDLL(_CPU_PATH)
+        _cpu_lib.cpu_reduced_minco_solve_batch.restype = c_int
+        _cpu_lib.cpu_reduced_minco_solve_batch.argtypes = [c_int, c_int, c_int, c_int64] + [c_void_p] * 6 + [c_int]
+    head = np.ascontiguousarray(head, dtype=np.float64)
+    tail = np.ascontiguousarray(tail, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    B, _, c = head.shape
+    N = T.shape[1]
+    wps = np.ascontiguousarray(wps if N > 1 else np.zeros((B, 0, 3)), dtype=np.float64)
+    coeffs, energy = out if out is not None else ((np.empty((B, N, 3, 2 * s)) if want_coeffs else None), np.empty(B))
+    rc = _cpu_lib.cpu_reduced_minco_solve_batch(s, c, N, B, _p(head), _p(tail), _p(wps), _p(T), _p(coeffs), _p(energy), nthreads)
+    if rc:
+        raise RuntimeError(f"cpu_reduced_minco_solve_batch failed: {rc}")
+    return coeffs, energy
 
 
 def lib():
@@ -104,15 +130,14 @@ def _p(a):
     return a.ctypes.data_as(c_void_p) if a is not None else None
 
 
-def minco_solve_batch(s, head, tail, wps, T, nthreads=1, want_coeffs=True):
+def minco_solve_batch(s, head, tail, wps, T, nthreads=1, want_coeffs=True, out=None):
     head = np.ascontiguousarray(head, dtype=np.float64)
     tail = np.ascontiguousarray(tail, dtype=np.float64)
     T = np.ascontiguousarray(T, dtype=np.float64)
     B, _, c = head.shape
     N = T.shape[1]
     wps = np.ascontiguousarray(wps if N > 1 else np.zeros((B, 0, 3)), dtype=np.float64)
-    coeffs = np.empty((B, N, 3, 2 * s)) if want_coeffs else None
-    energy = np.empty(B)
+    coeffs, energy = out if out is not None else ((np.empty((B, N, 3, 2 * s)) if want_coeffs else None), np.empty(B))
     rc = lib().oracle_minco_solve_batch(s, c, N, B, _p(head), _p(tail), _p(wps), _p(T), _p(coeffs),
                                         _p(energy), nthreads)
     if rc:
