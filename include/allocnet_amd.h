@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define ANET_ABI_VERSION 1
+#define ANET_ABI_VERSION 2 /* 2: QP default method = interior point, QP max-iter status -2 (OSQP), FIRI ok = 2, new entry points */
 
 enum {
   ANET_OK = 0,

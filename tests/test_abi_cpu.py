@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
     assert set(names) == set(_lib.PROTOTYPES), set(names) ^ set(_lib.PROTOTYPES)
-    assert _lib.load().anet_abi_version() == 1
+    assert _lib.load().anet_abi_version() == 2
 
 
 def test_no_cpu_fallback():
