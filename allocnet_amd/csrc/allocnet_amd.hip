@@ -1486,6 +1486,21 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
                      residuals ? residuals : work + 2 * mi * batch, grad_T, grad_z, vjp_T, batch, n_pieces, res, M, max_vel,
                      max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200};
     hipStream_t sti = (hipStream_t)stream;
+#ifdef ANET_IPM_PROF
+    static long long *d_iprof = nullptr;
+    if (!d_iprof) ANET_HIP(ctx, hipMalloc((void **)&d_iprof, 16 * sizeof(long long)));
+    ANET_HIP(ctx, hipMemsetAsync(d_iprof, 0, 16 * sizeof(long long), sti));
+    ia.prof = d_iprof;
+    struct ProfDump {
+      anet_ctx *c; long long *d; hipStream_t st;
+      ~ProfDump() {
+        long long h[16];
+        if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
+        fprintf(stderr, "ipm_prof cycles (problem 0): setup %lld | passA %lld resid %lld assemble %lld rhs %lld factor %lld solve1 %lld passB %lld passC %lld rhs2 %lld solve2 %lld passD %lld passE %lld\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12]);
+      }
+    } prof_dump{ctx, d_iprof, sti};
+#endif
     if (s == 4) {
       ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_ipm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
       hipLaunchKernelGGL((anet::k_qp_ipm<4>), dim3((unsigned)batch), dim3(256), ldsb, sti, ia);

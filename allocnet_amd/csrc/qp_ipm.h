@@ -38,7 +38,23 @@ struct IpmArgs {
   int N, R, M;
   double vmax, amax, m34, tol;
   int max_iter;
+#ifdef ANET_IPM_PROF
+  long long *prof;  // [16] cycle counters of problem 0 (tools: ANET_BUILD_FLAGS=-DANET_IPM_PROF)
+#endif
 };
+#ifdef ANET_IPM_PROF
+#define IPM_TICK(slot)                                                          \
+  do {                                                                          \
+    __syncthreads();                                                            \
+    if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {                        \
+      const long long now_ = __builtin_readcyclecounter();                      \
+      a.prof[slot] += now_ - prof_t_;                                           \
+      prof_t_ = now_;                                                           \
+    }                                                                           \
+  } while (0)
+#else
+#define IPM_TICK(slot) do {} while (0)
+#endif
 
 template <int S>
 inline size_t qp_ipm_lds_bytes(int N, int R, int M) {
@@ -440,6 +456,10 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
 
   int it = 0, status = -2;  // OSQP_MAX_ITER_REACHED unless decided below
   double pres = 0.0, dres = 0.0, mu = 0.0, mu0 = 0.0;
+#ifdef ANET_IPM_PROF
+  long long prof_t_ = __builtin_readcyclecounter();
+#endif
+  IPM_TICK(0);
   for (it = 0; it < a.max_iter; ++it) {
     // ---- pass A: residuals, weights, right-hand-side pieces per sample ---------------------------
     if (tid < 32) red[tid] = 0.0;
@@ -478,6 +498,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     block_reduce(1.0 / fmax(l_pres, 1e-300), 1, true);  // max via min of reciprocals -> stored as max
     block_reduce(1.0 / fmax(l_h, 1e-300), 2, true);
     __syncthreads();
+    IPM_TICK(1);
     mu = red[0] / mrows;
     if (it == 0) mu0 = mu;
     pres = red[1] / fmax(1.0, red[2]);
@@ -521,21 +542,24 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
       __syncthreads();
       dres = red[8] / fmax(1.0, red[9]);
     }
+    IPM_TICK(2);
     const double objn = red[10];
     // (the duality gap is mu * rows: that, not mu, is what bounds the distance of the objective from the optimum)
     if (pres < a.tol && dres < a.tol && mu * mrows < a.tol * fmax(1.0, 0.5 * fabs(objn))) { status = 1; break; }
     if (!(mu == mu) || mu > 1e12 * fmax(mu0, 1.0)) { status = -3; break; }  // diverging: no strictly feasible point
     __syncthreads();
     assemble_newton();
+    IPM_TICK(3);
     // affine right-hand side: -(P y + q) - G'(lambda + w (Gy - h))
     node_vector(dya, 12, true, uu);
     __syncthreads();
     for (int e = tid; e < NY; e += nt) dya[e] = -dya[e];
     __syncthreads();
+    IPM_TICK(4);
     wave0_factor();
-    __syncthreads();
+    IPM_TICK(5);
     wave0_solve(dya);
-    __syncthreads();
+    IPM_TICK(6);
     to_u(dya, dua);
     if (tid < 32) red[tid] = 0.0;
     __syncthreads();
@@ -563,6 +587,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
       block_reduce(l_s2, 5, false);
     }
     __syncthreads();
+    IPM_TICK(7);
     const double a_aff = fmin(1.0, red[3] > 0.0 ? 1.0 / red[3] : 1.0);
     const double mu_aff = (mu * mrows + a_aff * red[4] + a_aff * a_aff * red[5]) / mrows;
     double sigma = mu_aff / mu;
@@ -591,12 +616,13 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
       for (int q = 0; q < 9; ++q) as[q] = G_[q];
     }
     __syncthreads();
+    IPM_TICK(8);
     node_vector(dyc, 12, true, uu);
     __syncthreads();
     for (int e = tid; e < NY; e += nt) dyc[e] = -dyc[e];
-    __syncthreads();
+    IPM_TICK(9);
     wave0_solve(dyc);
-    __syncthreads();
+    IPM_TICK(10);
     to_u(dyc, duc);
     if (tid < 32) red[tid] = 0.0;
     __syncthreads();
@@ -630,6 +656,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
       block_reduce(1.0 / fmax(l_a, 1e-300), 6, true);
     }
     __syncthreads();
+    IPM_TICK(11);
     const double alpha = fmin(1.0, 0.99 * (red[6] > 0.0 ? 1.0 / red[6] : 1e300));
     __syncthreads();
     // ---- pass E: update ----------------------------------------------------------------------------------
@@ -652,6 +679,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     to_u(yv, uu);
     __syncthreads();
+    IPM_TICK(12);
   }
   __syncthreads();
   // ---- backward pass through the optimum (anet_qp_solve_vjp) ---------------------------------------------------
