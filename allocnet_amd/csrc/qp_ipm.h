@@ -557,8 +557,10 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     IPM_TICK(4);
     wave0_factor();
+    __syncthreads();
     IPM_TICK(5);
     wave0_solve(dya);
+    __syncthreads();
     IPM_TICK(6);
     to_u(dya, dua);
     if (tid < 32) red[tid] = 0.0;
@@ -620,8 +622,10 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     node_vector(dyc, 12, true, uu);
     __syncthreads();
     for (int e = tid; e < NY; e += nt) dyc[e] = -dyc[e];
+    __syncthreads();
     IPM_TICK(9);
     wave0_solve(dyc);
+    __syncthreads();
     IPM_TICK(10);
     to_u(dyc, duc);
     if (tid < 32) red[tid] = 0.0;

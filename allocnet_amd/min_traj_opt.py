@@ -24,9 +24,7 @@ class MinTrajOpt:
         self.dim = params["planning"]["dim"]
         self.res = params["planning"]["res"]
         self.D = 2 * self.order
-        self.use_time_factor = params["planning"]["use_time_factor"]
-        if self.use_time_factor:
-            raise NotImplementedError("use_time_factor is false in the reference configuration (utils/params.yaml:24)")
+        self.use_time_factor = params["planning"]["use_time_factor"]      # false in the reference configuration (params.yaml:24)
         self.phy_limits = [params["physical_limits"][k] for k in ("max_vel", "max_acc", "max_jerk")]
         self.phase1_phy_limits = [params["phase1_physical_limits"][k] for k in ("max_vel", "max_acc", "max_jerk", "inf_dis")]
         self._ctx = ctx
@@ -60,10 +58,25 @@ class MinTrajOpt:
         self.ineq_num1 = self.res * const_num
         self.ineq_num2 = self.res * 4 * self.dim * self.seg
         self.ineq_num = self.ineq_num1 + self.ineq_num2
-        self.Times = tf
-        self.path_length = float(np.linalg.norm(self.goal - self.start))
-        if traj_times is not None:
-            self.ref_time_factor = np.asarray(traj_times, dtype=np.float64)
+        if self.use_time_factor:
+            # min_traj_opt.py:113-136: waypoints from the deepest common points of consecutive polytopes, a lower bound
+            # on every segment time from the limits, and the network output as a factor on top of it
+            self.inner_pts = self.get_inner_pts()
+            if self.inner_pts is None:
+                raise ValueError("consecutive polytopes have no common interior point")
+            self.waypts = np.vstack([self.start] + ([self.inner_pts] if len(self.inner_pts) else []) + [self.goal])
+            self.path_length = float(sum(np.linalg.norm(self.waypts[i + 1] - self.waypts[i]) for i in range(len(self.waypts) - 1)))
+            self.time_lb = self.getT_lbs(self.waypts, self.phy_limits[0], self.phy_limits[1])
+            self.Times = self.time_lb + self.time_lb * tf
+            if traj_times is not None:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    self.ref_time_factor = np.asarray(traj_times, dtype=np.float64) / self.time_lb
+        else:
+            self.Times = tf
+            self.path_length = float(np.linalg.norm(self.goal - self.start))
+            if traj_times is not None:
+                self.ref_time_factor = np.asarray(traj_times, dtype=np.float64)
+        tf = self.Times
         lim = self.phase1_phy_limits if phase == 1 else self.phy_limits
         ini = self.start_state.reshape(3, 3)
         fin = self.end_state.reshape(3, 3)
@@ -72,6 +85,48 @@ class MinTrajOpt:
         n1 = self.ineq_num1
         self._limits = (lim[0], lim[1])
         self.params = [Q, A, b, G[:n1], h[:n1], G[n1:], h[n1:]]
+
+
+    # ---- use_time_factor branch (min_traj_opt.py:185-296): host-side preprocessing, as in the reference ----
+    def getT_lbs(self, pts, maxv, maxa):
+        """min_traj_opt.py:195-211.  The reference fills a float32 tensor of five entries from float32 limits; the
+        same roundings are applied here so that Times agrees to the last bit."""
+        times = np.zeros(5, dtype=np.float32)
+        mv, ma = np.float32(maxv), np.float32(maxa)
+        for i in range(pts.shape[0] - 1):
+            dis = (pts[i + 1] - pts[i])
+            vel_t = np.abs((dis / mv))
+            acc_t = np.abs((2 * dis / ma))
+            times[i] = max(float(vel_t.max()), float(np.sqrt(acc_t.max())))
+        return times.astype(np.float64)
+
+    def get_inner_pts(self):
+        """min_traj_opt.py:251-275: one waypoint per pair of consecutive polytopes."""
+        n = self.seg
+        if n <= 1:
+            return np.zeros((0, 3))
+        if n == 2:
+            return (0.5 * (self.start + self.goal)).reshape(1, 3)
+        pts = []
+        for i in range(n - 1):
+            pt = self.get_inner_points(np.vstack((self.hpolys[i], self.hpolys[i + 1])), 0.01)
+            if pt is None:
+                return None
+            pts.append(pt)
+        return np.array(pts)
+
+    @staticmethod
+    def get_inner_points(hpoly, eps=0.001):
+        """min_traj_opt.py:279-296: the point of largest common slack, the 4-variable LP  max d  s.t.  A x + d <= b,
+        d >= 0, through scipy.optimize.linprog exactly as the reference calls it (host-side preprocessing of a branch
+        the reference configuration disables; the batched corridor code has its own deepest-point kernel)."""
+        import scipy.optimize
+        A = np.hstack((hpoly[:, 0:3], np.ones((hpoly.shape[0], 1))))
+        res = scipy.optimize.linprog([0, 0, 0, -1], A_ub=A, b_ub=hpoly[:, 3],
+                                     bounds=[(-np.inf, np.inf)] * 3 + [(0, np.inf)])
+        if res.fun is None:
+            return None
+        return res.x[0:3]
 
 
 class OsqpLayer:

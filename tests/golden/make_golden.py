@@ -44,13 +44,13 @@ def _import_reference():
     return MinTrajOpt, Trajectory
 
 
-def make_params(order, res, vmax=5.0, amax=7.0, vmax1=5.0, amax1=8.0):
+def make_params(order, res, vmax=5.0, amax=7.0, vmax1=5.0, amax1=8.0, use_time_factor=False):
     return {
         "physical_limits": {"max_vel": vmax, "max_acc": amax, "max_jerk": 12.0},
         "phase1_physical_limits": {"max_vel": vmax1, "max_acc": amax1, "max_jerk": 10.0,
                                    "inf_dis": 0.1},
         "planning": {"order": order, "state_dim": 3, "dim": 3, "res": res, "seg": 5,
-                     "var_num": 120, "use_time_factor": False},
+                     "var_num": 120, "use_time_factor": use_time_factor},
     }
 
 
@@ -221,5 +221,34 @@ def main():
               f"size={os.path.getsize(path)/1024:.0f}KB")
 
 
+def main_time_factor():
+    """use_time_factor = True (min_traj_opt.py:113-136, 185-296; disabled in the reference's params.yaml but part of
+    MinTrajOpt.update): waypoints from scipy's LP over consecutive polytopes, the float32 time lower bounds, Times =
+    time_lb (1 + factor), ref_time_factor, the path length along the waypoints -- and the matrices assembled with them."""
+    import torch
+    MinTrajOpt, _ = _import_reference()
+    for name, order, N, res, seed, phase in [("tf_snap_n3", 4, 3, 5, 31, 2), ("tf_jerk_n5", 3, 5, 4, 32, 1), ("tf_snap_n2", 4, 2, 4, 33, 2)]:
+        rng = np.random.default_rng(seed)
+        state, hpolys, T, pts = synth_problem(rng, N, rest=False)
+        factor = np.zeros(5); factor[:N] = rng.uniform(0.2, 1.5, size=N)
+        ref_times = np.zeros(5); ref_times[:N] = rng.uniform(0.8, 2.5, size=N)
+        hp5 = np.zeros((50, 4, 5)); hp5[:, :, :N] = hpolys
+        opt = MinTrajOpt(make_params(order, res, vmax=4.5, amax=7.0, use_time_factor=True))
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt.update(torch.tensor(state), torch.tensor(hp5), torch.tensor(factor), phase=phase,
+                       traj_times=torch.tensor(ref_times), seq_len=5)
+        Q, A, b, G1, h1, G2, h2 = [p.detach().numpy().astype(np.float64) for p in opt.params]
+        out = dict(order=order, N=N, res=res, phase=phase, state=state, hpolys=hp5[:16], factor=factor, ref_times=ref_times,
+                   Times=opt.Times.detach().numpy().astype(np.float64), time_lb=opt.time_lb.detach().numpy().astype(np.float64),
+                   waypts=np.asarray(opt.waypts, dtype=np.float64), path_length=float(opt.path_length),
+                   ref_time_factor=opt.ref_time_factor.detach().numpy().astype(np.float64),
+                   Q=Q, A=A, b=b, G1_sum=G1.sum(), h1=h1, G2_sum=G2.sum(), h2=h2)
+        assert opt.seg == N and not hp5[16:].any()
+        path = os.path.join(OUT, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: Times={out['Times'][:N]} path_length={out['path_length']:.6f} size={os.path.getsize(path)/1024:.0f}KB")
+
+
 if __name__ == "__main__":
     main()
+    main_time_factor()

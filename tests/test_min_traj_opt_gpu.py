@@ -28,6 +28,31 @@ def test_min_traj_opt_update_matches_reference(anet_ctx, path):
         assert np.abs(got - ref).max() <= 4e-16 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("name", ["tf_snap_n3", "tf_jerk_n5", "tf_snap_n2"])
+def test_min_traj_opt_use_time_factor_matches_reference(anet_ctx, name):
+    """use_time_factor = True (min_traj_opt.py:113-136, 185-296): waypoints, time lower bounds, Times, ref_time_factor,
+    path length and the matrices assembled with those times, against fixtures made by the imported reference."""
+    import os
+    import allocnet_amd as aa
+    from tests.util import GOLDEN
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    s, N, res, phase = int(d["order"]), int(d["N"]), int(d["res"]), int(d["phase"])
+    hp50 = np.zeros((50, 4, 5)); hp50[:16] = d["hpolys"]
+    opt = aa.MinTrajOpt(make_params(s, res, vmax=4.5, amax=7.0, use_time_factor=True), ctx=anet_ctx)
+    opt.update(d["state"], hp50, d["factor"], phase=phase, traj_times=d["ref_times"], seq_len=5)
+    assert opt.seg == N
+    assert np.abs(opt.waypts - d["waypts"]).max() <= 1e-9
+    assert np.array_equal(opt.time_lb, d["time_lb"])                 # float32 roundings of the reference reproduced
+    assert np.abs(opt.Times - d["Times"]).max() <= 1e-15
+    assert abs(opt.path_length - float(d["path_length"])) <= 1e-12
+    assert np.allclose(opt.ref_time_factor[:N], d["ref_time_factor"][:N], rtol=1e-15, atol=0)
+    Q, A, b, G1, h1, G2, h2 = opt.params
+    for got, ref in [(Q, d["Q"]), (A, d["A"]), (b, d["b"]), (h1, d["h1"]), (h2, d["h2"])]:
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 4e-16 * max(1.0, np.abs(ref).max())
+    assert abs(G1.sum() - float(d["G1_sum"])) <= 1e-12 * max(1.0, abs(float(d["G1_sum"])))
+    assert abs(G2.sum() - float(d["G2_sum"])) <= 1e-12 * max(1.0, abs(float(d["G2_sum"])))
+
+
 def test_osqp_layer_forward(anet_ctx):
     import allocnet_amd as aa
     from tests.test_qp_solve_gpu import _corridor_problem
