@@ -77,6 +77,8 @@ PROTOTYPES = {
                           + [c_void_p] * 11),
     "anet_qp_solve_vjp_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double]
                               + [c_void_p] * 13),
+    "anet_polytope_depth": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "anet_polytope_depth_dev": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "anet_firi_default_params": (None, [c_void_p]),
     "anet_firi": (c_int, [c_void_p, c_int64, c_int, c_int, c_int] + [c_void_p] * 10),
     "anet_firi_workspace": (c_int64, [c_int64, c_int, c_int]),

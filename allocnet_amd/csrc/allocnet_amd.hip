@@ -1179,6 +1179,39 @@ int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_ro
   return ANET_OK;
 }
 
+int anet_polytope_depth_dev(anet_ctx *ctx, int64_t batch, int max_rows, const double *hpoly, int normalise,
+                            double *depth, double *point, void *stream) {
+  ANET_ON_DEVICE(ctx);
+  if (batch < 0 || max_rows < 1) return fail(ctx, ANET_ERR_INVALID, "anet_polytope_depth: bad batch or max_rows");
+  if ((size_t)max_rows * 4 * sizeof(double) > 60 * 1024) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_polytope_depth: max_rows too large");
+  if (batch == 0) return ANET_OK;
+  if (!hpoly || !depth) return fail(ctx, ANET_ERR_INVALID, "anet_polytope_depth_dev: NULL pointer");
+  anet::DepthArgs a{hpoly, depth, point, batch, max_rows, normalise ? 1 : 0};
+  hipLaunchKernelGGL(anet::k_polytope_depth, dim3((unsigned)batch), dim3(256), sizeof(double) * max_rows * 4, (hipStream_t)stream, a);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+int anet_polytope_depth(anet_ctx *ctx, int64_t batch, int max_rows, const double *hpoly, int normalise,
+                        double *depth, double *point) {
+  ANET_ON_DEVICE(ctx);
+  if (batch < 0 || max_rows < 1) return fail(ctx, ANET_ERR_INVALID, "anet_polytope_depth: bad batch or max_rows");
+  if (batch == 0) return ANET_OK;
+  if (!hpoly || !depth) return fail(ctx, ANET_ERR_INVALID, "anet_polytope_depth: NULL pointer");
+  const size_t n_hp = (size_t)batch * max_rows * 4;
+  int rc = ensure_scratch(ctx, sizeof(double) * (n_hp + 4 * (size_t)batch));
+  if (rc) return rc;
+  double *d_hp = (double *)ctx->scratch, *d_depth = d_hp + n_hp, *d_pt = d_depth + batch;
+  hipStream_t st = ctx->stream;
+  ANET_HIP(ctx, hipMemcpyAsync(d_hp, hpoly, sizeof(double) * n_hp, hipMemcpyHostToDevice, st));
+  rc = anet_polytope_depth_dev(ctx, batch, max_rows, d_hp, normalise, d_depth, point ? d_pt : nullptr, st);
+  if (rc) return rc;
+  ANET_HIP(ctx, hipMemcpyAsync(depth, d_depth, sizeof(double) * batch, hipMemcpyDeviceToHost, st));
+  if (point) ANET_HIP(ctx, hipMemcpyAsync(point, d_pt, sizeof(double) * 3 * batch, hipMemcpyDeviceToHost, st));
+  ANET_HIP(ctx, hipStreamSynchronize(st));
+  return ANET_OK;
+}
+
 int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_lbfgs_params *params) {
   if (!params || params->mem_size <= 0) return -1;
   const int n = 3 * (n_pieces - 1) + n_pieces;

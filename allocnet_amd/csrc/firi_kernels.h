@@ -234,23 +234,17 @@ struct FiriMvieArgs {
   int H;
 };
 
-// firi.hpp:166-222: deepest interior point (Chebyshev centre), rows normalised about it, x0 from (R, p, r)
-__global__ void __launch_bounds__(256) k_firi_mvie_setup(FiriMvieArgs g) {
-  const int64_t b = blockIdx.x;
-  const int tid = threadIdx.x;
-  extern __shared__ double sm[];  // [H][4]: unit normals + offsets
-  __shared__ double s_best[4][5];
-  const int H = g.H, nH = g.nh[b];
-  const bool live = g.ok[b] >= 1 && nH >= 4;
-  for (int r = tid; r < nH; r += 256) {
-    const double *h = g.hpoly + (b * H + r) * 4;
-    const double nrm = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
-    sm[r * 4] = h[0] / nrm; sm[r * 4 + 1] = h[1] / nrm; sm[r * 4 + 2] = h[2] / nrm;
-    sm[r * 4 + 3] = -h[3] / nrm;
-  }
-  __syncthreads();
-  double best = -INFINITY, bx[3] = {0, 0, 0};
-  if (live) {
+// max t  s.t.  n_q.x + t <= b_q  for the nH rows (n_q, b_q) in LDS (`sm`, four doubles per row): the 4-variable LP of
+// sdlp::linprog<4> as firi::maxVolInsEllipsoid (firi.hpp:166-180), geo_utils::findInterior and geo_utils::overlap
+// (geo_utils.hpp:43-85) pose it.  A linear programme attains its optimum at a vertex, so the 256 threads of the
+// workgroup enumerate the C(nH,4) row subsets (pairs (i, j) over the threads, (k, l) inside), solve each 4 x 4 system
+// by a 3 x 3 adjugate, keep the best t seen and scan feasibility only for improving candidates; exact and
+// deterministic.  Every thread returns the optimum (-inf when no vertex is feasible); bounded polytopes assumed.
+__device__ __forceinline__ void lp_deepest_point(const double *sm, const int nH, const int tid, double (*s_best)[5],
+                                                 double &best, double (&bx)[3]) {
+  best = -INFINITY;
+  bx[0] = bx[1] = bx[2] = 0.0;
+  {
     const int P = nH * (nH - 1) / 2;
     for (int pr = tid; pr < P; pr += 256) {
       // unrank the pair (i < j)
@@ -301,6 +295,63 @@ __global__ void __launch_bounds__(256) k_firi_mvie_setup(FiriMvieArgs g) {
   __syncthreads();
   for (int w = 0; w < 4; ++w)
     if (s_best[w][0] > best) { best = s_best[w][0]; bx[0] = s_best[w][1]; bx[1] = s_best[w][2]; bx[2] = s_best[w][3]; }
+}
+
+// geo_utils::findInterior / geo_utils::overlap (geo_utils.hpp:43-85), batched: depth[b] = max t s.t. h.x + t <= -h3 over
+// the non-zero rows of polytope b (rows h0 x + h1 y + h2 z + h3 <= 0, GCOPTER's raw form; all-zero rows are padding),
+// with the rows normalised first (findInterior) or as they are (overlap), and the point that attains it.
+// -inf: empty.  sfc_gen::shortCut (sfc_gen.hpp:188-226) is this test on pairs of stacked polytopes.
+struct DepthArgs {
+  const double *hpoly;  // [B][H][4]
+  double *depth;        // [B]
+  double *point;        // [B][3] or nullptr
+  int64_t B;
+  int H, normalise;
+};
+__global__ void __launch_bounds__(256) k_polytope_depth(DepthArgs g) {
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  extern __shared__ double sm[];  // [H][4] compacted rows
+  __shared__ double s_best[4][5];
+  __shared__ int s_n;
+  if (tid == 0) {  // compact the non-zero rows (H <= a few dozen: serial is fine and keeps the row order)
+    int n = 0;
+    for (int r = 0; r < g.H; ++r) {
+      const double *h = g.hpoly + (b * g.H + r) * 4;
+      if (h[0] == 0.0 && h[1] == 0.0 && h[2] == 0.0) continue;
+      const double sc = g.normalise ? 1.0 / sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]) : 1.0;
+      sm[n * 4] = h[0] * sc; sm[n * 4 + 1] = h[1] * sc; sm[n * 4 + 2] = h[2] * sc; sm[n * 4 + 3] = -h[3] * sc;
+      ++n;
+    }
+    s_n = n;
+  }
+  __syncthreads();
+  double best, bx[3];
+  lp_deepest_point(sm, s_n, tid, s_best, best, bx);
+  if (tid == 0) {
+    g.depth[b] = best;
+    if (g.point) { g.point[b * 3] = bx[0]; g.point[b * 3 + 1] = bx[1]; g.point[b * 3 + 2] = bx[2]; }
+  }
+}
+
+// firi.hpp:166-222: deepest interior point (Chebyshev centre), rows normalised about it, x0 from (R, p, r)
+__global__ void __launch_bounds__(256) k_firi_mvie_setup(FiriMvieArgs g) {
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  extern __shared__ double sm[];  // [H][4]: unit normals + offsets
+  __shared__ double s_best[4][5];
+  const int H = g.H, nH = g.nh[b];
+  const bool live = g.ok[b] >= 1 && nH >= 4;
+  for (int r = tid; r < nH; r += 256) {
+    const double *h = g.hpoly + (b * H + r) * 4;
+    const double nrm = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+    sm[r * 4] = h[0] / nrm; sm[r * 4 + 1] = h[1] / nrm; sm[r * 4 + 2] = h[2] / nrm;
+    sm[r * 4 + 3] = -h[3] / nrm;
+  }
+  __syncthreads();
+  double best, bx[3];
+  if (live) lp_deepest_point(sm, nH, tid, s_best, best, bx);
+  else { best = -INFINITY; bx[0] = bx[1] = bx[2] = 0.0; __syncthreads(); }
   const bool okk = live && best > 0.0 && !isinf(best);
   const int64_t ld = g.ld;
   // MVIE rows about the interior point; zero rows beyond nH (and everywhere for skipped problems)

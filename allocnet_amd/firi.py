@@ -1,5 +1,6 @@
-"""Corridor generation: batched firi::firi (gcopter/firi.hpp:268-416) and the convexCover loop around it
-(gcopter/sfc_gen.hpp:116-186).  Polytopes are in GCOPTER's raw form, rows h with h.[x;1] <= 0;
+"""Corridor generation: batched firi::firi (gcopter/firi.hpp:268-416), the convexCover loop around it
+(gcopter/sfc_gen.hpp:116-186), sfc_gen::shortCut (sfc_gen.hpp:188-226) and the polytope tests it rests on
+(geo_utils::findInterior / overlap, gcopter/geo_utils.hpp:43-85).  Polytopes are in GCOPTER's raw form, rows h with h.[x;1] <= 0;
 `to_planner_form` is the normalise-and-negate step LearningPlanner applies before the QP
 (learning_planner.hpp:293-299)."""
 import ctypes
@@ -141,3 +142,55 @@ def convex_cover(path, points, low_corner, high_corner, progress, rng_range, eps
             out.append(gaps[k])
         out.append(polys[k])
     return out
+
+
+def polytope_depth(hpolys, normalise=True, ctx=None):
+    """anet_polytope_depth on a list of (n_i,4) raw-form polytopes (or a zero-padded (B,H,4) array):
+    depth (B,) = max t s.t. n.x + t <= -h3, and the point (B,3) attaining it.  -inf: empty polytope."""
+    ctx = ctx or default_context()
+    if isinstance(hpolys, np.ndarray) and hpolys.ndim == 3:
+        hp = np.ascontiguousarray(hpolys, dtype=np.float64)
+    else:
+        H = max(1, max((len(h) for h in hpolys), default=1))
+        hp = np.zeros((len(hpolys), H, 4))
+        for i, h in enumerate(hpolys):
+            hp[i, :len(h)] = h
+    B, H, _ = hp.shape
+    depth = np.zeros(B); point = np.zeros((B, 3))
+    ctx.check(ctx.lib.anet_polytope_depth(ctx.handle, B, H, _p(hp), 1 if normalise else 0, _p(depth), _p(point)))
+    return depth, point
+
+
+def find_interior(hpoly, ctx=None):
+    """geo_utils::findInterior (geo_utils.hpp:43-62): (found, interior point) of one raw-form polytope."""
+    d, x = polytope_depth([np.asarray(hpoly, dtype=np.float64)], normalise=True, ctx=ctx)
+    return bool(d[0] > 0.0 and np.isfinite(d[0])), x[0]
+
+
+def overlap(hpoly0, hpoly1, eps=1.0e-6, ctx=None):
+    """geo_utils::overlap (geo_utils.hpp:64-85): do the two polytopes share a ball of 'radius' eps (rows not normalised)."""
+    d, _ = polytope_depth([np.vstack([hpoly0, hpoly1])], normalise=False, ctx=ctx)
+    return bool(d[0] > eps and np.isfinite(d[0]))
+
+
+def short_cut(hpolys, eps=0.1, ctx=None):
+    """sfc_gen::shortCut (sfc_gen.hpp:188-226): walk the corridor from its last polytope, each time jumping to the
+    EARLIEST polytope that still overlaps the current one (consecutive ones always count as overlapping).  The
+    overlap tests of all pairs (i, j < i-1) are independent: one batched call, then the walk on the host.
+    Returns the shortened list."""
+    h = [np.asarray(x, dtype=np.float64) for x in hpolys]
+    if len(h) == 1:
+        h = [h[0], h[0]]
+    M = len(h)
+    pairs = [(i, j) for i in range(M) for j in range(i - 1)]
+    ov = {}
+    if pairs:
+        d, _ = polytope_depth([np.vstack([h[i], h[j]]) for i, j in pairs], normalise=False, ctx=ctx)
+        ov = {pq: bool(dd > eps and np.isfinite(dd)) for pq, dd in zip(pairs, d)}
+    idx = [M - 1]
+    i = M - 1
+    while i > 0:
+        j = next(j for j in range(i) if j == i - 1 or ov[(i, j)])
+        idx.insert(0, j)
+        i = j
+    return [h[k] for k in idx]

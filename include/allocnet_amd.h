@@ -354,6 +354,21 @@ int anet_qp_solve_vjp_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int
                           double *obj, int32_t *status, int32_t *iters, double *residuals, double *grad_T,
                           void *stream);
 
+/* ---- polytope depth: geo_utils::findInterior / geo_utils::overlap, sfc_gen::shortCut --------------------------- */
+/* Replaces the 4-variable linear programme of geo_utils::findInterior and geo_utils::overlap
+ * (src/planner/include/gcopter/geo_utils.hpp:43-85, solved there by sdlp::linprog<4>), batched: for each polytope
+ * (rows h: h0 x + h1 y + h2 z + h3 <= 0, all-zero rows are padding up to max_rows)
+ *     depth = max t  s.t.  n.x + t <= -h3  for every row,   n = h[0:3] / |h[0:3]| (normalise = 1, findInterior)
+ *                                                            or h[0:3]            (normalise = 0, overlap)
+ * and the point x that attains it (point may be NULL).  findInterior(hPoly) is depth > 0; overlap(hPoly0, hPoly1, eps) is
+ * depth > eps of the two polytopes' rows stacked (sfc_gen::shortCut, sfc_gen.hpp:188-226, calls it with eps = 0.1);
+ * depth = -inf for an empty polytope.  Exact: a linear programme attains its optimum at a vertex, the kernel enumerates
+ * them (allocnet_amd/csrc/firi_kernels.h).  Bounded polytopes (corridors always carry their bounding box).             */
+int anet_polytope_depth(anet_ctx *ctx, int64_t batch, int max_rows, const double *hpoly /* [batch][max_rows][4] */,
+                        int normalise, double *depth /* [batch] */, double *point /* [batch][3] or NULL */);
+int anet_polytope_depth_dev(anet_ctx *ctx, int64_t batch, int max_rows, const double *hpoly, int normalise,
+                            double *depth, double *point, void *stream);
+
 /* ---- batched L-BFGS ------------------------------------------------------------------------ */
 /* lbfgs::lbfgs_parameter_t, same fields and defaults (gcopter/lbfgs.hpp:15-129). */
 typedef struct anet_lbfgs_params {

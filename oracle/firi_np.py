@@ -188,3 +188,47 @@ def firi(bd, pc, a, b, iterations=4, epsilon=1e-6, trace=None):
             break
         _, R, p, r = max_vol_ins_ellipsoid(hPoly, R, p, r)
     return True, hPoly
+
+
+def polytope_depth(hPoly, normalise):
+    """geo_utils.hpp:43-85: max t s.t. n.x + t <= -h3 (the LP findInterior and overlap hand to sdlp::linprog<4>),
+    here by scipy's HiGHS.  Returns (depth, x); depth = -inf when infeasible."""
+    from scipy.optimize import linprog
+    h = np.asarray(hPoly, dtype=np.float64)
+    nrm = np.linalg.norm(h[:, :3], axis=1) if normalise else np.ones(len(h))
+    A = np.c_[h[:, :3] / nrm[:, None], np.ones(len(h))]
+    r = linprog(c=[0, 0, 0, -1.0], A_ub=A, b_ub=-h[:, 3] / nrm, bounds=[(None, None)] * 4, method="highs")
+    if r.status != 0:
+        return -np.inf, None
+    return float(r.x[3]), r.x[:3]
+
+
+def find_interior(hPoly):
+    """geo_utils.hpp:43-62"""
+    d, x = polytope_depth(hPoly, True)
+    return d > 0.0 and np.isfinite(d), x
+
+
+def overlap(hPoly0, hPoly1, eps=1.0e-6):
+    """geo_utils.hpp:64-85"""
+    d, _ = polytope_depth(np.vstack([hPoly0, hPoly1]), False)
+    return d > eps and np.isfinite(d)
+
+
+def short_cut(hpolys, eps=0.1):
+    """sfc_gen.hpp:188-226, the loop as written there (deque of indices, i reset inside the inner loop)."""
+    htemp = list(hpolys)
+    if len(htemp) == 1:
+        htemp.insert(0, htemp[0])
+    M = len(htemp)
+    idices = [M - 1]
+    i = M - 1
+    while i >= 0:
+        for j in range(i):
+            ov = overlap(htemp[i], htemp[j], eps) if j < i - 1 else True
+            if ov:
+                idices.insert(0, j)
+                i = j + 1
+                break
+        i -= 1
+    return idices

@@ -2,6 +2,7 @@
 // headers (learning_planner.hpp:203-233): fill a Trajectory<7> from solver output, evaluate it,
 // query its cost; plus the MINCO_S4NU surface.  Prints one JSON object; tests/test_facade_gpu.py
 // checks it against the oracle.  `Mat` stands in for an Eigen matrix (duck typing only).
+#include <cmath>
 #include <cstdio>
 #include <vector>
 
@@ -10,6 +11,7 @@
 #include "allocnet_amd/lbfgs.hpp"
 #include "allocnet_amd/minco.hpp"
 #include "allocnet_amd/qp_solver.hpp"
+#include "allocnet_amd/sfc_gen.hpp"
 #include "allocnet_amd/trajectory.hpp"
 
 struct Mat {  // Eigen-like: (r,c) access, default constructible
@@ -197,6 +199,60 @@ int main() {
       fa(0) = 100.0;
       DynMat h2;
       printf("\"firi_outside\": %d,\n", firi::firi(bd, pc, fa, fb, h2) ? 1 : 0);
+    }
+    {
+      // corridor generation as LearningPlanner::plan writes it (learning_planner.hpp:267-283): convexCover over a
+      // route with a lattice of obstacle points outside a tube, then shortCut; plus the geo_utils tests on the result
+      std::vector<Vec> route, pcv;
+      const double wp[4][3] = {{0.0, 0.0, 1.0}, {4.0, 1.0, 1.5}, {6.0, 4.0, 1.0}, {9.0, 4.5, 2.0}};
+      for (int k = 0; k < 4; ++k) {
+        Vec v(3);
+        for (int c = 0; c < 3; ++c) v(c) = wp[k][c];
+        route.push_back(v);
+      }
+      std::vector<double> flat;
+      for (double x = -2.8; x < 12.0; x += 0.6)
+        for (double y = -2.8; y < 8.0; y += 0.6)
+          for (double z = 0.2; z < 4.0; z += 0.6) {
+            double dmin = 1e9;
+            for (int k = 0; k + 1 < 4; ++k) {
+              const double d[3] = {wp[k + 1][0] - wp[k][0], wp[k + 1][1] - wp[k][1], wp[k + 1][2] - wp[k][2]};
+              double t = ((x - wp[k][0]) * d[0] + (y - wp[k][1]) * d[1] + (z - wp[k][2]) * d[2]) / (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+              t = t < 0 ? 0 : (t > 1 ? 1 : t);
+              const double ex = x - wp[k][0] - t * d[0], ey = y - wp[k][1] - t * d[1], ez = z - wp[k][2] - t * d[2];
+              dmin = std::fmin(dmin, std::sqrt(ex * ex + ey * ey + ez * ez));
+            }
+            if (dmin > 0.7) {
+              Vec v(3);
+              v(0) = x; v(1) = y; v(2) = z;
+              pcv.push_back(v);
+              flat.push_back(x); flat.push_back(y); flat.push_back(z);
+            }
+          }
+      Vec lowc(3), highc(3);
+      lowc(0) = -3.0; lowc(1) = -3.0; lowc(2) = 0.0;
+      highc(0) = 12.0; highc(1) = 8.0; highc(2) = 4.0;
+      std::vector<DynMat> vishPolys;
+      sfc_gen::convexCover(route, pcv, lowc, highc, 2.0, 3.0, vishPolys);
+      printf("\"cover_n\": %zu, \"cover_rows\": [", vishPolys.size());
+      for (size_t k = 0; k < vishPolys.size(); ++k) printf("%s%ld", k ? ", " : "", vishPolys[k].rows());
+      printf("],\n");
+      std::vector<double> cover_flat;
+      for (const DynMat &h : vishPolys) cover_flat.insert(cover_flat.end(), h.a.begin(), h.a.end());
+      print_vec("cover_hpolys", cover_flat);
+      print_vec("cover_pts", flat);
+      sfc_gen::shortCut(vishPolys);
+      printf("\"short_rows\": [");
+      for (size_t k = 0; k < vishPolys.size(); ++k) printf("%s%ld", k ? ", " : "", vishPolys[k].rows());
+      printf("],\n");
+      std::vector<double> short_flat;
+      for (const DynMat &h : vishPolys) short_flat.insert(short_flat.end(), h.a.begin(), h.a.end());
+      print_vec("short_hpolys", short_flat);
+      Vec inner(3);
+      const bool found = geo_utils::findInterior(vishPolys.front(), inner);
+      printf("\"interior_found\": %d, \"overlap_first_two\": %d, \"overlap_ends\": %d,\n", found ? 1 : 0,
+             geo_utils::overlap(vishPolys[0], vishPolys[1]) ? 1 : 0, geo_utils::overlap(vishPolys.front(), vishPolys.back(), 0.1) ? 1 : 0);
+      print_vec("interior", inner.a);
     }
     {
       // the reference's only lbfgs_optimize call, statement for statement (firi.hpp:186-227): optData blob, call-site

@@ -69,12 +69,30 @@ def test_cpp_facade_program():
     # setMethod(interior point): same optimum (OSQP's 1e-3 tolerances leave the ADMM objective within a few 1e-3 of it)
     assert out["qp_ipm_ok"] == 1 and out["qp_ipm_iters"] <= 40
     assert abs(out["qp_ipm_obj"] - out["qp_obj"]) <= 2e-2 * max(1.0, out["qp_obj"])
+    # sfc_gen::convexCover + shortCut + geo_utils facade: the same corridor through the Python mirror (same library,
+    # so identical), the kept indices against the restated shortCut walk, and the corridor's guarantees
+    import allocnet_amd as aa
+    cpts = np.array(out["cover_pts"]).reshape(-1, 3)
+    rows = out["cover_rows"]; flat = np.array(out["cover_hpolys"]).reshape(-1, 4)
+    cover = [flat[sum(rows[:k]):sum(rows[:k + 1])] for k in range(len(rows))]
+    route = [np.array(w) for w in ([0.0, 0.0, 1.0], [4.0, 1.0, 1.5], [6.0, 4.0, 1.0], [9.0, 4.5, 2.0])]
+    ref_cover = aa.convex_cover(route, cpts, [-3, -3, 0], [12, 8, 4], progress=2.0, rng_range=3.0)
+    assert out["cover_n"] == len(ref_cover) and all(np.array_equal(a, b) for a, b in zip(cover, ref_cover))
+    for hpk in cover:
+        assert ((cpts @ hpk[:, :3].T + hpk[:, 3]).max(axis=1) > -2e-6).all()
+    from oracle import firi_np as F
+    idx = F.short_cut(cover, 0.1)
+    srows = out["short_rows"]; sflat = np.array(out["short_hpolys"]).reshape(-1, 4)
+    short = [sflat[sum(srows[:k]):sum(srows[:k + 1])] for k in range(len(srows))]
+    assert len(short) == len(idx) and all(np.array_equal(a, cover[k]) for a, k in zip(short, idx))
+    assert out["interior_found"] == 1 and (short[0] @ np.r_[out["interior"], 1.0]).max() < 0.0
+    assert out["overlap_first_two"] == int(F.overlap(short[0], short[1]))
+    assert out["overlap_ends"] == int(F.overlap(short[0], short[-1], 0.1))
     # firi::firi facade: polytope around the segment (0,0,1)-(2,.5,1.2), lattice points outside, a outside bd -> false
     assert out["firi_ok"] == 1 and out["firi_rows"] >= 6 and out["firi_outside"] == 0
     hp = np.array(out["firi_hpoly"]).reshape(-1, 4); pts = np.array(out["firi_pts"]).reshape(-1, 3)
     assert (hp @ np.array([0.0, 0.0, 1.0, 1.0])).max() <= 1e-6 and (hp @ np.array([2.0, 0.5, 1.2, 1.0])).max() <= 1e-6
     assert ((pts @ hp[:, :3].T + hp[:, 3]).max(axis=1) > -2e-6).all()
-    from oracle import firi_np as F
     bd = np.zeros((6, 4)); lo = [-3.0, -3.0, -2.0]; hi = [5.0, 3.5, 4.0]
     for ax in range(3):
         bd[2 * ax, ax] = 1.0; bd[2 * ax, 3] = -hi[ax]; bd[2 * ax + 1, ax] = -1.0; bd[2 * ax + 1, 3] = lo[ax]

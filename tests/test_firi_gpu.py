@@ -157,3 +157,78 @@ def test_device_pointer_entry_point(anet_ctx):
         assert np.abs(hp[i, :k] - host["hpoly"][i, :k]).max() <= 1e-9 * max(1.0, np.abs(host["hpoly"][i, :k]).max())
         assert (hp[i, k:] == 0).all()
     assert np.abs(out["ellipsoid"].cpu().numpy() - host["ellipsoid"]).max() <= 1e-9
+
+
+def _random_polytope(rng, centre, n_extra):
+    """A box about `centre` cut by random planes that keep the centre inside; raw form, rows NOT normalised."""
+    half = rng.uniform(0.5, 2.0, size=3)
+    rows = []
+    for ax in range(3):
+        e = np.zeros(3); e[ax] = 1.0
+        rows.append(np.r_[e, -(centre[ax] + half[ax])]); rows.append(np.r_[-e, centre[ax] - half[ax]])
+    for _ in range(n_extra):
+        n = rng.standard_normal(3) * rng.uniform(0.3, 3.0)
+        off = rng.uniform(0.2, 1.5) * np.linalg.norm(n)
+        rows.append(np.r_[n, -(n @ centre) - off])
+    return np.array(rows)
+
+
+def test_polytope_depth_matches_the_linear_programme(anet_ctx):
+    """geo_utils::findInterior / overlap: the LP optimum against HiGHS, normalised and raw rows, empty polytopes,
+    padded batches."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(21)
+    polys = [_random_polytope(rng, rng.uniform(-3, 3, size=3), n) for n in (0, 1, 5, 12, 30, 58)]
+    # two empty ones: opposite half-spaces that exclude each other, and a box with a cut beyond it
+    empty = np.array([[1.0, 0, 0, 1.0], [-1.0, 0, 0, 1.0], [0, 1, 0, -1], [0, -1, 0, -1], [0, 0, 1, -1], [0, 0, -1, -1]])
+    polys += [empty, np.vstack([_random_polytope(rng, np.zeros(3), 0), [[1.0, 0, 0, 50.0]]])]
+    for normalise in (True, False):
+        d, x = aa.polytope_depth(polys, normalise=normalise, ctx=anet_ctx)
+        for i, hp in enumerate(polys):
+            d0, _ = F.polytope_depth(hp, normalise)
+            # feasible with depth < 0 still has an LP optimum: compare wherever HiGHS found one
+            assert np.isfinite(d[i]) == np.isfinite(d0), (i, d[i], d0)
+            if np.isfinite(d0):
+                assert abs(d[i] - d0) <= 1e-9 * max(1.0, abs(d0)), (i, normalise, d[i], d0)
+                nrm = np.linalg.norm(hp[:, :3], axis=1) if normalise else 1.0
+                slack = -(hp[:, :3] @ x[i] + hp[:, 3]) / nrm
+                assert slack.min() >= d[i] - 1e-9 * max(1.0, abs(d[i]))           # the point attains the depth
+    ok, pt = aa.find_interior(polys[3], ctx=anet_ctx)
+    assert ok and (polys[3] @ np.r_[pt, 1.0]).max() < 0.0
+    assert not aa.find_interior(polys[-1], ctx=anet_ctx)[0] and not aa.find_interior(empty, ctx=anet_ctx)[0]
+    assert aa.overlap(polys[2], polys[2], ctx=anet_ctx)
+    far = _random_polytope(rng, np.array([40.0, 0, 0]), 3)
+    assert not aa.overlap(polys[2], far, ctx=anet_ctx) and not F.overlap(polys[2], far)
+
+
+def test_short_cut_follows_the_reference_walk(anet_ctx):
+    """sfc_gen::shortCut: the kept indices against the restated loop (oracle/firi_np.py) on chains of polytopes with
+    varying overlap, the single-polytope duplication, and a corridor out of convex_cover."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(8)
+    for trial in range(6):
+        M = int(rng.integers(2, 12))
+        step = rng.uniform(0.3, 2.5)
+        centres = np.cumsum(rng.uniform(0.2, 1.0, size=(M, 3)) * step, axis=0)
+        chain = [_random_polytope(rng, c, int(rng.integers(0, 8))) for c in centres]
+        idx = F.short_cut(chain, 0.1)
+        out = aa.short_cut(chain, ctx=anet_ctx)
+        assert len(out) == len(idx) and all((o == chain[k]).all() for o, k in zip(out, idx)), (trial, idx)
+        assert idx[-1] == M - 1 and idx[0] == 0 and all(a < b for a, b in zip(idx[:-1], idx[1:]))
+    one = [_random_polytope(rng, np.zeros(3), 4)]
+    out = aa.short_cut(one, ctx=anet_ctx)
+    assert len(out) == 2 and (out[0] == one[0]).all() and (out[1] == one[0]).all()
+    # a real corridor: convexCover then shortCut, as LearningPlanner does (learning_planner.hpp:274-283)
+    path = [np.array([0.0, 0.0, 1.0]), np.array([4.0, 1.0, 1.5]), np.array([6.0, 4.0, 1.0]), np.array([9.0, 4.5, 2.0])]
+    pts = rng.uniform([-3, -3, 0], [12, 8, 4], size=(2000, 3))
+    keep = np.ones(len(pts), dtype=bool)
+    for p0, p1 in zip(path[:-1], path[1:]):
+        dd = p1 - p0
+        t = np.clip(((pts - p0) @ dd) / (dd @ dd), 0, 1)
+        keep &= np.linalg.norm(pts - (p0 + t[:, None] * dd), axis=1) > 0.6
+    polys = aa.convex_cover(path, pts[keep], [-3, -3, 0], [12, 8, 4], progress=2.0, rng_range=3.0, ctx=anet_ctx)
+    short = aa.short_cut(polys, ctx=anet_ctx)
+    idx = F.short_cut(polys, 0.1)
+    assert len(short) == len(idx) <= len(polys) and all((o == polys[k]).all() for o, k in zip(short, idx))
+    for h0, h1 in zip(short[:-1], short[1:]):                     # consecutive polytopes of the result still meet
+        assert np.isfinite(F.polytope_depth(np.vstack([h0, h1]), False)[0])
