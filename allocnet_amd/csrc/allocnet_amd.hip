@@ -1226,6 +1226,15 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                          const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
                          int opt_flags, int max_evals, double *work, double *cost, double *coeffs_out,
                          int32_t *status, int32_t *iters, int32_t *evals, void *stream) {
+  return anet_lbfgs_minco_ordered_dev(ctx, s, c, n_pieces, batch, ld, head, tail, wps, T, hpolys, pen, params, opt_flags,
+                                      max_evals, nullptr, work, cost, coeffs_out, status, iters, evals, stream);
+}
+
+int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                                 const double *head, const double *tail, double *wps, double *T,
+                                 const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
+                                 int opt_flags, int max_evals, const int32_t *launch_order, double *work, double *cost,
+                                 double *coeffs_out, int32_t *status, int32_t *iters, int32_t *evals, void *stream) {
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
   if ((rc = check_penalty(ctx, pen))) return rc;
@@ -1270,7 +1279,7 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
       params->mem_size <= 8 && params->past <= 64) {
     anet::PersistArgs pa{};
     pa.head = head; pa.tail = tail; pa.wps = wps; pa.T = T; pa.hpolys = Mrows ? hpolys : nullptr;
-    pa.x = L.x; pa.is = L.is; pa.ds = L.ds; pa.B = batch; pa.ld = ld;
+    pa.x = L.x; pa.is = L.is; pa.ds = L.ds; pa.order = launch_order; pa.B = batch; pa.ld = ld;
     pa.N = N; pa.c = c; pa.nw = nw; pa.nt = nt; pa.M = Mrows; pa.max_evals = max_evals; pa.with_penalty = pen ? 1 : 0;
     if (pen) pa.pp = anet::Penalty{pen->rho, pen->w_corridor, pen->w_vel, pen->w_acc, pen->smooth_mu, pen->max_vel,
                                    pen->max_acc, pen->res, Mrows};

@@ -24,6 +24,7 @@ struct PersistArgs {
   double *x;                                     // [n][ld] start point in, last point out
   int *is;                                       // IS_* rows (results)
   double *ds;                                    // DS_* rows (results)
+  const int32_t *order;                          // workgroup w solves problem order[w] (nullptr: problem w)
   int64_t B, ld;
   int N, c, nw, nt, M, max_evals, with_penalty;
   Penalty pp;
@@ -1010,7 +1011,8 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
   double *rows = smem + persist_lds_fixed_bytes<S, NB>() / sizeof(double);
   constexpr int m = S - 1;
   const int lane = threadIdx.x;
-  const int64_t b = blockIdx.x, ld = a.ld;
+  const int64_t b = a.order ? (int64_t)a.order[blockIdx.x] : (int64_t)blockIdx.x, ld = a.ld;
+  if ((uint64_t)b >= (uint64_t)a.B) return;  // (an out-of-range entry of a caller's order: leave it, touch nothing)
   const int N = a.N, np = a.c - 1, n = a.nw + a.nt;
 
   // ---- problem data -> LDS (batch-minor global: strided, once per problem)

@@ -106,10 +106,20 @@ def lbfgs_minco(head, tail, wps, T, s, hpolys=None, penalty=None, param=None, op
     return dict(wps=wps, T=T, cost=cost, coeffs=coeffs, status=status, iters=iters, evals=evals)
 
 
+def launch_order_from_counts(evals):
+    """Longest first: the launch order for `lbfgs_minco_dev` from the evaluation counts of a previous solve of the same
+    or a similar batch (int32 CUDA tensor in, int32 CUDA permutation out)."""
+    import torch
+    return torch.argsort(evals, descending=True, stable=True).to(torch.int32).contiguous()
+
+
 def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, param=None,
-                    opt=OPT_WAYPOINTS | OPT_TIMES, max_evals=2000, coeffs=None, stream=None, ctx=None):
-    """Device entry point -> anet_lbfgs_minco_dev.  torch CUDA float64 tensors, batch-minor, common row
-    stride; wps and T are updated in place.  Returns dict(cost, status, iters, evals) of device tensors."""
+                    opt=OPT_WAYPOINTS | OPT_TIMES, max_evals=2000, coeffs=None, stream=None, ctx=None, launch_order=None):
+    """Device entry point -> anet_lbfgs_minco_[ordered_]dev.  torch CUDA float64 tensors, batch-minor, common row
+    stride; wps and T are updated in place.  Returns dict(cost, status, iters, evals) of device tensors.
+    launch_order: optional int32 CUDA tensor (B,), a permutation -- the problem each successive workgroup of the
+    one-launch shape takes (`launch_order_from_counts(previous_evals)` when re-solving a similar batch); results
+    do not depend on it, the run time does."""
     import torch
     ctx = ctx or default_context(T.device.index or 0)
     param = param or lbfgs_parameter_t()
@@ -124,9 +134,12 @@ def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, p
     if stream is None:
         stream = torch.cuda.current_stream(dev).cuda_stream
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    ctx.check(ctx.lib.anet_lbfgs_minco_dev(
+    if launch_order is not None and not (launch_order.is_cuda and launch_order.dtype == torch.int32 and
+                                         launch_order.is_contiguous() and launch_order.shape == (B,)):
+        raise ValueError("launch_order: contiguous int32 CUDA tensor of shape (B,)")
+    ctx.check(ctx.lib.anet_lbfgs_minco_ordered_dev(
         ctx.handle, s, c, N, B, ld, p(head), p(tail), p(wps) if N > 1 else None, p(T), p(hpolys),
         ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p) if penalty is not None else None,
-        ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), p(work), p(cost), p(coeffs),
-        p(status), p(iters), p(evals), ctypes.c_void_p(stream)))
+        ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), p(launch_order), p(work), p(cost),
+        p(coeffs), p(status), p(iters), p(evals), ctypes.c_void_p(stream)))
     return dict(cost=cost[:B], status=status[:B], iters=iters[:B], evals=evals[:B])

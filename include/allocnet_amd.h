@@ -433,6 +433,20 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                          const anet_lbfgs_params *params, int opt_flags, int max_evals, double *work,
                          double *cost, double *coeffs_out, int32_t *status, int32_t *iters,
                          int32_t *evals, void *stream);
+/* The same with a launch order for the one-launch shape: launch_order (device, int32 [batch], a permutation of
+ * 0..batch-1, or NULL) names the problem each successive workgroup takes.  Results do not depend on it (problems are
+ * independent); the run time does: a batch larger than the 2048 waves the device holds ends with whichever problem
+ * started late and runs long, so handing over the problems longest-first shortens the run (4096 x 16-segment jerk:
+ * 0.22 s as given, 0.16 s by the true evaluation counts, 0.17 s by the counts of a previous solve of a perturbed copy
+ * of the batch -- the re-solve case of a sampler or a receding-horizon planner: feed evals[] of the last call,
+ * sorted descending).  Entries are not checked beyond their range (an out-of-range entry is skipped, a repeated one
+ * solves its problem twice and leaves another unsolved with its status untouched).  Ignored by the lockstep shape. */
+int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                                 const double *head, const double *tail, double *wps, double *T,
+                                 const double *hpolys, const anet_penalty *pen,
+                                 const anet_lbfgs_params *params, int opt_flags, int max_evals,
+                                 const int32_t *launch_order, double *work, double *cost, double *coeffs_out,
+                                 int32_t *status, int32_t *iters, int32_t *evals, void *stream);
 
 /* ---- corridor generation: batched FIRI ------------------------------------ */
 /* firi::firi + firi::maxVolInsEllipsoid (gcopter/firi.hpp:159-416), the inner step of

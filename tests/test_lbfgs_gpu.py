@@ -303,3 +303,39 @@ def test_minco_lbfgs_one_launch_budget_and_fallbacks(anet_ctx):
     assert (out["cost"] < e0).all() and (out["status"] >= 0).all()
     _, e1 = aa.minco_solve(head, tail, out["wps"], out["T"], s, ctx=anet_ctx)
     assert np.abs(e1 - out["cost"]).max() <= 1e-9 * np.abs(e1).max()
+
+
+def test_minco_lbfgs_launch_order_changes_nothing_but_the_schedule(anet_ctx):
+    """anet_lbfgs_minco_ordered_dev: problems are independent, so any launch order returns bit-identical results;
+    an out-of-range entry is skipped (its problem keeps the status it had)."""
+    import torch
+    import allocnet_amd as aa
+    from tools.bench_configs import to_bm
+    rng = np.random.default_rng(77)
+    s, c, N, M, B = 3, 3, 9, 8, 300
+    head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
+    hp = make_corridors(rng, head, tail, wps, M, tight=1.5)
+    pen = aa.make_penalty(rho=20.0, w_corridor=1e3, w_vel=1e2, w_acc=1e2, smooth_mu=1e-2, max_vel=3.0, max_acc=4.0,
+                          res=8, poly_rows=M)
+    dev = torch.device("cuda", 0)
+    ld = aa.recommended_ld(B)
+
+    def run(order):
+        th, tt, tw, tT = (to_bm(torch, x, B, ld, dev) for x in (head, tail, wps, T))
+        thp = to_bm(torch, hp, B, ld, dev)
+        r = aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, max_evals=400, opt=3,
+                               launch_order=order, ctx=anet_ctx)
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy() for k, v in r.items()}, tw[:, :B].cpu().numpy(), tT[:, :B].cpu().numpy()
+
+    ref, w0, T0 = run(None)
+    perm = torch.from_numpy(np.random.default_rng(1).permutation(B).astype(np.int32)).to(dev)
+    by_count = aa.launch_order_from_counts(torch.from_numpy(ref["evals"]).to(dev))
+    assert sorted(by_count.cpu().tolist()) == list(range(B)) and ref["evals"][by_count.cpu().numpy()[0]] == ref["evals"].max()
+    for order in (perm, by_count):
+        got, w1, T1 = run(order)
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), k
+        assert np.array_equal(w0, w1) and np.array_equal(T0, T1)
+    with pytest.raises(ValueError):
+        run(perm.to(torch.int64))

@@ -76,6 +76,8 @@ def main():
                                  opt=3 | lockstep, ctx=ctx)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if cap == 30000:
+            res_full = res
         st = res["status"].cpu().numpy(); it = res["iters"].cpu().numpy(); ev = res["evals"].cpu().numpy()
         cf = res["cost"].cpu().numpy()
         hist = {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))}
@@ -88,6 +90,27 @@ def main():
             "cost_initial_mean": float(c0.mean()), "cost_final_mean": float(cf.mean()),
             "shape": "launch per evaluation (lockstep)" if lockstep else "one launch, one wave per problem",
             "lbfgs_params": "lbfgs_parameter_t defaults (mem 8, g_eps 1e-5, past 3, delta 1e-6)"}
+    if not lockstep:
+        # the re-solve case: the same batch again with last call's evaluation counts as the launch order
+        # (anet_lbfgs_minco_ordered_dev), and with the counts of a perturbed copy of the batch (~1 cm, 1 %)
+        full = out["config4_lbfgs_B4096_N16_jerk"]
+        rng2 = np.random.default_rng(99)
+        wp2 = wps + 0.01 * rng2.standard_normal(wps.shape); T2 = T * (1.0 + 0.01 * rng2.uniform(-1, 1, size=T.shape))
+        th, tt, tw, tT, thp = (to_bm(torch, x, B, ld, dev) for x in (head, tail, wp2, T2, hp))
+        evp = aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, param=prm, max_evals=30000,
+                                 opt=3, ctx=ctx)["evals"]
+        for key, counts in (("same_batch_counts", res_full["evals"]), ("perturbed_batch_counts", evp)):
+            order = aa.launch_order_from_counts(counts)
+            th, tt, tw, tT, thp = (to_bm(torch, x, B, ld, dev) for x in (head, tail, wps, T, hp))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, param=prm, max_evals=30000,
+                                   opt=3, launch_order=order, ctx=ctx)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            full[f"seconds_with_launch_order_from_{key}"] = dt
+            full[f"identical_results_{key}"] = bool(torch.equal(r["evals"], res_full["evals"]) and
+                                                    torch.equal(r["cost"], res_full["cost"]))
     print(json.dumps(out, indent=1))
 
 

@@ -69,6 +69,17 @@ def main():
         rho = float(spearmanr(f, ev)[0])
         t_f, _ = run(np.argsort(-f) if rho > 0 else np.argsort(f))
         out[f"by_{k}"] = {"spearman": rho, "seconds": t_f}
+    # a re-solve scenario: the counts of a PERTURBED copy of the batch (waypoints moved by ~1 cm, durations by 1 %) as the predictor
+    for label, sw, sT in (("perturbed_1cm_1pct", 0.01, 0.01), ("perturbed_10cm_5pct", 0.1, 0.05)):
+        rng2 = np.random.default_rng(99)
+        pert = [x.copy() for x in data]
+        pert[2] = pert[2] + sw * rng2.standard_normal(pert[2].shape)
+        pert[3] = pert[3] * (1.0 + sT * rng2.uniform(-1, 1, size=pert[3].shape))
+        th, tt, tw, tT, thp = (to_bm(torch, x, B, ld, dev) for x in pert)
+        r2 = aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, param=prm, max_evals=30000, opt=3, ctx=ctx)
+        evp = r2["evals"].cpu().numpy()[:B]
+        t_p, _ = run(np.argsort(-evp))
+        out[f"by_counts_of_{label}"] = {"spearman": float(spearmanr(evp, ev)[0]), "seconds": t_p}
     print(json.dumps(out, indent=1))
 
 
