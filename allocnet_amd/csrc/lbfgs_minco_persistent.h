@@ -335,111 +335,127 @@ struct LbfgsResident {
 //   forward   y_k = rhs_k - H_{k-1}' y_{k-1}     lanes 0..2 = axes: an m x m product per node; operands of the next
 //   scaling   z_k = S_k^-1 y_k                    lanes = (node, axis)          nodes arrive in alternating buffers
 //   backward  x_k = z_k - H_k x_{k+1}             lanes 0..2
+// The two sweeps of the block LDL^T solve, y_k = rhs_k - H_{k-1}' y_{k-1} and x_k = z_k - H_k x_{k+1} (z_k = S_k^-1 y_k), are
+// affine recurrences with m x m matrices: instead of walking the nodes on three lanes they run as PARALLEL SCANS, one DPP row
+// of 16 lanes per axis (row 3 shadows axis 2), lane j = node j+1 forwards and node j backwards (the ends are folded into
+// their neighbours, so 17 nodes fit 16 lanes).  A round combines (M, v) -- "value = M * value(d nodes away) + v" -- with
+// the pair d lanes away: log2(N) rounds of row_shr / row_shl moves and m^3 + m^2 FMAs replace N dependent node steps
+// with their LDS round trips; rounding differs from the walk by a factor below two (tests/prototypes/scan_sweeps.py).
+template <int CTRL, int m>
+__device__ __forceinline__ void scan_round(double (&M)[m][m], double (&v)[m], const bool more) {
+  double Mp[m][m], vp[m];
+#pragma unroll
+  for (int a = 0; a < m; ++a) {
+    vp[a] = dpp_f64<CTRL>(v[a]);
+#pragma unroll
+    for (int b = 0; b < m; ++b) Mp[a][b] = dpp_f64<CTRL>(M[a][b]);
+  }
+#pragma unroll
+  for (int a = 0; a < m; ++a)
+#pragma unroll
+    for (int b = 0; b < m; ++b) v[a] = __builtin_fma(M[a][b], vp[b], v[a]);
+  if (more) {  // (wave-uniform: the last round only needs the values)
+    double Mn[m][m];
+#pragma unroll
+    for (int a = 0; a < m; ++a)
+#pragma unroll
+      for (int b = 0; b < m; ++b) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < m; ++q) acc = __builtin_fma(M[a][q], Mp[q][b], acc);
+        Mn[a][b] = acc;
+      }
+#pragma unroll
+    for (int a = 0; a < m; ++a)
+#pragma unroll
+      for (int b = 0; b < m; ++b) M[a][b] = Mn[a][b];
+  }
+}
+
 template <int S, int NB>
 __device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3][NB + 1][S - 1], const int N,
-                                            const int lane, const int na, const int ax) {
+                                            const int lane, const int, const int) {
   constexpr int m = S - 1;
-  constexpr int CH = (m <= 2) ? 4 : 2;
-  if (lane < 3 && N >= 1) {
-    double yp[m];
+  const int row = lane >> 4, j = lane & 15, ax = row < 3 ? row : 2;
+  const bool valid = j < N;                  // forward node j + 1 <= N, backward node j <= N - 1
+  const int jc = valid ? j : 0;
+  double Hj[m][m], M[m][m], v[m], y0[m], zf[m];
 #pragma unroll
-    for (int l = 0; l < m; ++l) yp[l] = V[lane][0][l];
-    // node k (1..N) needs rhs_k and H_{k-1}
-    auto load = [&](int k0, double (&BH)[CH][m][m], double (&BR)[CH][m]) {
+  for (int a = 0; a < m; ++a) {
+    y0[a] = V[ax][0][a];
+    v[a] = valid ? V[ax][jc + 1][a] : 0.0;
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int kk = (k0 + u <= N) ? k0 + u : N;
-#pragma unroll
-        for (int j = 0; j < m; ++j) {
-          BR[u][j] = V[lane][kk][j];
-#pragma unroll
-          for (int l = 0; l < m; ++l) BH[u][j][l] = Lm.H[kk - 1][j][l];
-        }
-      }
-    };
-    auto step = [&](const int k, const double (&Hk)[m][m], const double (&rk)[m]) {
-      double y[m];
-#pragma unroll
-      for (int l = 0; l < m; ++l) {
-        y[l] = rk[l];
-#pragma unroll
-        for (int j = 0; j < m; ++j) y[l] = __builtin_fma(-Hk[j][l], yp[j], y[l]);
-        V[lane][k][l] = y[l];
-      }
-#pragma unroll
-      for (int l = 0; l < m; ++l) yp[l] = y[l];
-    };
-    double H1[CH][m][m], R1[CH][m], H2[CH][m][m], R2[CH][m];
-    load(1, H1, R1);
-#pragma unroll 1
-    for (int k0 = 1; k0 <= N; k0 += 2 * CH) {
-      load(k0 + CH, H2, R2);
-#pragma unroll
-      for (int u = 0; u < CH; ++u)
-        if (k0 + u <= N) step(k0 + u, H1[u], R1[u]);
-      load(k0 + 2 * CH, H1, R1);
-#pragma unroll
-      for (int u = 0; u < CH; ++u)
-        if (k0 + CH + u <= N) step(k0 + CH + u, H2[u], R2[u]);
-    }
+    for (int b = 0; b < m; ++b) Hj[a][b] = valid ? Lm.H[jc][a][b] : 0.0;
   }
-  __syncthreads();
-  if (na <= N) {
-    double y[m], z[m];
+  // ---- forwards: y_{j+1} = rhs_{j+1} - H_j' y_j; lane 0 takes y_0 = rhs_0 in and starts the chain
 #pragma unroll
-    for (int l = 0; l < m; ++l) y[l] = V[ax][na][l];
+  for (int a = 0; a < m; ++a)
 #pragma unroll
-    for (int j = 0; j < m; ++j) {
-      double acc = 0.0;
+    for (int b = 0; b < m; ++b) M[a][b] = -Hj[b][a];
+  if (j == 0) {
 #pragma unroll
-      for (int l = 0; l < m; ++l) acc = __builtin_fma(Lm.Si[na][j][l], y[l], acc);
-      z[j] = acc;
+    for (int a = 0; a < m; ++a) {
+#pragma unroll
+      for (int b = 0; b < m; ++b) {
+        v[a] = __builtin_fma(M[a][b], y0[b], v[a]);
+      }
     }
 #pragma unroll
-    for (int l = 0; l < m; ++l) V[ax][na][l] = z[l];
+    for (int a = 0; a < m; ++a)
+#pragma unroll
+      for (int b = 0; b < m; ++b) M[a][b] = 0.0;
   }
-  __syncthreads();
-  if (lane < 3 && N >= 1) {
-    double xn[m];
+  if (N > 1) scan_round<0x111, m>(M, v, N > 2);
+  if (N > 2) scan_round<0x112, m>(M, v, N > 4);
+  if (N > 4) scan_round<0x114, m>(M, v, N > 8);
+  if constexpr (NB > 8) {
+    if (N > 8) scan_round<0x118, m>(M, v, false);
+  }
+  // ---- z = S^-1 y on the lane of its node; z_j arrives from the left neighbour, z_0 is computed by lane 0
 #pragma unroll
-    for (int l = 0; l < m; ++l) xn[l] = V[lane][N][l];
-    // node k (N-1..0) needs z_k and H_k; chunk q covers the nodes N-1-q*CH-u
-    auto load = [&](int d0, double (&BH)[CH][m][m], double (&BR)[CH][m]) {
+  for (int a = 0; a < m; ++a) {
+    double acc = 0.0, acc0 = 0.0;
 #pragma unroll
-      for (int u = 0; u < CH; ++u) {
-        const int kk = (N - 1 - d0 - u >= 0) ? N - 1 - d0 - u : 0;
+    for (int b = 0; b < m; ++b) {
+      acc = __builtin_fma(Lm.Si[jc + 1][a][b], v[b], acc);
+      acc0 = __builtin_fma(Lm.Si[0][a][b], y0[b], acc0);
+    }
+    zf[a] = valid ? acc : 0.0;
+    y0[a] = acc0;  // (now z_0)
+  }
 #pragma unroll
-        for (int j = 0; j < m; ++j) {
-          BR[u][j] = V[lane][kk][j];
+  for (int a = 0; a < m; ++a) {
+    const double zl = dpp_f64<0x111>(zf[a]);
+    v[a] = (j == 0) ? y0[a] : zl;
+    if (!valid) v[a] = 0.0;
+  }
+  // ---- backwards: x_j = z_j - H_j x_{j+1}; lane N-1 takes x_N = z_N in and starts the chain
 #pragma unroll
-          for (int l = 0; l < m; ++l) BH[u][j][l] = Lm.H[kk][j][l];
-        }
-      }
-    };
-    auto step = [&](const int k, const double (&Hk)[m][m], const double (&zk)[m]) {
-      double x[m];
+  for (int a = 0; a < m; ++a)
 #pragma unroll
-      for (int j = 0; j < m; ++j) {
-        x[j] = zk[j];
+    for (int b = 0; b < m; ++b) M[a][b] = -Hj[a][b];
+  if (j == N - 1) {
 #pragma unroll
-        for (int l = 0; l < m; ++l) x[j] = __builtin_fma(-Hk[j][l], xn[l], x[j]);
-        V[lane][k][j] = x[j];
-      }
+    for (int a = 0; a < m; ++a)
 #pragma unroll
-      for (int l = 0; l < m; ++l) xn[l] = x[l];
-    };
-    double H1[CH][m][m], R1[CH][m], H2[CH][m][m], R2[CH][m];
-    load(0, H1, R1);
-#pragma unroll 1
-    for (int d0 = 0; d0 < N; d0 += 2 * CH) {
-      load(d0 + CH, H2, R2);
+      for (int b = 0; b < m; ++b) v[a] = __builtin_fma(M[a][b], zf[b], v[a]);
 #pragma unroll
-      for (int u = 0; u < CH; ++u)
-        if (N - 1 - d0 - u >= 0) step(N - 1 - d0 - u, H1[u], R1[u]);
-      load(d0 + 2 * CH, H1, R1);
+    for (int a = 0; a < m; ++a)
 #pragma unroll
-      for (int u = 0; u < CH; ++u)
-        if (N - 1 - d0 - CH - u >= 0) step(N - 1 - d0 - CH - u, H2[u], R2[u]);
+      for (int b = 0; b < m; ++b) M[a][b] = 0.0;
+  }
+  if (N > 1) scan_round<0x101, m>(M, v, N > 2);
+  if (N > 2) scan_round<0x102, m>(M, v, N > 4);
+  if (N > 4) scan_round<0x104, m>(M, v, N > 8);
+  if constexpr (NB > 8) {
+    if (N > 8) scan_round<0x108, m>(M, v, false);
+  }
+  if (valid && row < 3) {
+#pragma unroll
+    for (int a = 0; a < m; ++a) V[ax][j][a] = v[a];
+    if (j == N - 1) {
+#pragma unroll
+      for (int a = 0; a < m; ++a) V[ax][N][a] = zf[a];
     }
   }
   __syncthreads();
@@ -546,6 +562,28 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
       for (int j = 0; j < m; ++j)
 #pragma unroll
         for (int l = 0; l <= j; ++l) Dk[j][l] += Ak[j][l];
+      if constexpr (m == 2) {
+        // 2 x 2: the inverse by its adjugate (same rounding as the LDL^T route -- tests/prototypes/scan_sweeps.py -- one
+        // reciprocal instead of two on the chain), S_k^-1 and H_k = S_k^-1 Ko_k stored right away
+        const double r = fast_rcp(__builtin_fma(Dk[0][0], Dk[1][1], -Dk[1][0] * Dk[1][0]));
+        const double s00 = Dk[1][1] * r, s11 = Dk[0][0] * r, s10 = -Dk[1][0] * r;
+        Lm.Si[k][0][0] = s00; Lm.Si[k][0][1] = s10; Lm.Si[k][1][0] = s10; Lm.Si[k][1][1] = s11;
+        if (k < N) {
+          double W[2][2];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            W[0][b] = __builtin_fma(s00, Kk[0][b], s10 * Kk[1][b]);
+            W[1][b] = __builtin_fma(s10, Kk[0][b], s11 * Kk[1][b]);
+            Lm.H[k][0][b] = W[0][b];
+            Lm.H[k][1][b] = W[1][b];
+          }
+#pragma unroll
+          for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+            for (int bb = 0; bb <= aa; ++bb) Dk[aa][bb] = -__builtin_fma(Kk[0][aa], W[0][bb], Kk[1][aa] * W[1][bb]);
+        }
+        return;
+      }
       double Lk[NLA] = {}, dd[m], dik[m];
 #pragma unroll
       for (int j = 0; j < m; ++j) {
@@ -566,7 +604,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
           Lk[BlkOps<S>::li(i, j)] = v * dik[j];
         }
       }
-      if (k < N) {  // Schur complement seed for node k+1 (the chain continues with it) and H_k
+      if (k < N) {  // Schur complement seed for node k+1: the chain continues with it
         double Y[m][m], Z[m][m];
 #pragma unroll
         for (int l = 0; l < m; ++l) {
@@ -589,28 +627,13 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
             for (int j = 0; j < m; ++j) acc = __builtin_fma(-Y[j][aa], Z[j][bb], acc);
             Dk[aa][bb] = acc;
           }
-#pragma unroll
-        for (int l = 0; l < m; ++l) {  // H_k(:, l) = L^-T Z(:, l)
-          double col[m];
-#pragma unroll
-          for (int j = 0; j < m; ++j) col[j] = Z[j][l];
-          BlkOps<S>::solve_LT(Lk, col);
-#pragma unroll
-          for (int j = 0; j < m; ++j) Lm.H[k][j][l] = col[j];
-        }
       }
+      // the factor of the node, for the lanes that turn it into S_k^-1 and H_k below: [1/d | L] in the slot of S_k^-1
+      double *slot = &Lm.Si[k][0][0];
 #pragma unroll
-      for (int cc = 0; cc < m; ++cc) {  // S_k^-1(:, cc) = L^-T D^-1 L^-1 e_cc
-        double col[m];
+      for (int j = 0; j < m; ++j) slot[j] = dik[j];
 #pragma unroll
-        for (int j = 0; j < m; ++j) col[j] = (j == cc) ? 1.0 : 0.0;
-        BlkOps<S>::solve_L(Lk, col);
-#pragma unroll
-        for (int j = 0; j < m; ++j) col[j] *= dik[j];
-        BlkOps<S>::solve_LT(Lk, col);
-#pragma unroll
-        for (int j = 0; j < m; ++j) Lm.Si[k][j][cc] = col[j];
-      }
+      for (int q = 0; q < BlkOps<S>::nl; ++q) slot[m + q] = Lk[q];
     };
     double A1[CH][m][m], K1[CH][m][m], A2[CH][m][m], K2[CH][m][m];
     load(0, A1, K1);
@@ -627,6 +650,48 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
     }
   }
   __syncthreads();
+  // S_k^-1 = L^-T D^-1 L^-1 and H_k = S_k^-1 Ko_k are off the chain: every node on its own lane (3 x 3 blocks)
+  if (m > 2 && lane <= N) {
+    const int k = lane;
+    double Lk[NLA] = {}, dik[m];
+    const double *slot = &Lm.Si[k][0][0];
+#pragma unroll
+    for (int j = 0; j < m; ++j) dik[j] = slot[j];
+#pragma unroll
+    for (int q = 0; q < BlkOps<S>::nl; ++q) Lk[q] = slot[m + q];
+    if (k < N) {
+#pragma unroll
+      for (int l = 0; l < m; ++l) {
+        double col[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) col[j] = Lm.Kp[k][j][l];
+        BlkOps<S>::solve_L(Lk, col);
+#pragma unroll
+        for (int j = 0; j < m; ++j) col[j] *= dik[j];
+        BlkOps<S>::solve_LT(Lk, col);
+#pragma unroll
+        for (int j = 0; j < m; ++j) Lm.H[k][j][l] = col[j];
+      }
+    }
+    double Sk[m][m];
+#pragma unroll
+    for (int cc = 0; cc < m; ++cc) {
+      double col[m];
+#pragma unroll
+      for (int j = 0; j < m; ++j) col[j] = (j == cc) ? 1.0 : 0.0;
+      BlkOps<S>::solve_L(Lk, col);
+#pragma unroll
+      for (int j = 0; j < m; ++j) col[j] *= dik[j];
+      BlkOps<S>::solve_LT(Lk, col);
+#pragma unroll
+      for (int j = 0; j < m; ++j) Sk[j][cc] = col[j];
+    }
+#pragma unroll
+    for (int j = 0; j < m; ++j)
+#pragma unroll
+      for (int cc = 0; cc < m; ++cc) Lm.Si[k][j][cc] = Sk[j][cc];
+  }
+  if constexpr (m > 2) __syncthreads();
   chain_solve<S, NB>(Lm, Lm.X, N, lane, na, ax);
 
   PERSIST_TICK(2);

@@ -437,7 +437,7 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
  * 0..batch-1, or NULL) names the problem each successive workgroup takes.  Results do not depend on it (problems are
  * independent); the run time does: a batch larger than the 2048 waves the device holds ends with whichever problem
  * started late and runs long, so handing over the problems longest-first shortens the run (4096 x 16-segment jerk:
- * 0.22 s as given, 0.16 s by the true evaluation counts, 0.17 s by the counts of a previous solve of a perturbed copy
+ * 0.19 s as given, 0.12 s by the true evaluation counts, 0.14 s by the counts of a previous solve of a perturbed copy
  * of the batch -- the re-solve case of a sampler or a receding-horizon planner: feed evals[] of the last call,
  * sorted descending).  Entries are not checked beyond their range (an out-of-range entry is skipped, a repeated one
  * solves its problem twice and leaves another unsolved with its status untouched).  Ignored by the lockstep shape. */
