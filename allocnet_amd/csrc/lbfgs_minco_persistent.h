@@ -467,7 +467,7 @@ __device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3
 // NOT yet multiplied by dT/dtau).
 template <int S, int NB>
 __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double *rows, const PersistArgs &a, const int lane,
-                                             double &f_out, double &g_out) {
+                                             const bool refactor, double &f_out, double &g_out) {
   constexpr int m = S - 1, D = 2 * S, NLA = BlkOps<S>::NLA;
   constexpr int G = 64 / NB;
   using F = Factor<S, NB>;
@@ -491,7 +491,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
     rhs_primal_node_rt<S>(k, N, np, rk, rkm, Pm, P0, Pp, hv, tv, y);
 #pragma unroll
     for (int l = 0; l < m; ++l) Lm.X[ax][k][l] = y[l];
-    if (ax == 0) {  // the blocks of the system (minco_core.h Factor::factorize, assembly part)
+    if (ax == 0 && refactor) {  // the blocks of the system (minco_core.h Factor::factorize, assembly part)
       double Ak[m][m];
 #pragma unroll
       for (int j = 0; j < m; ++j)
@@ -537,7 +537,9 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   //      come from LDS a few nodes at a time into alternating register buffers (a load-then-use per node is an LDS
   //      round trip of dead time per node); what the sweeps need of it leaves as S_k^-1 and H_k = S_k^-1 Ko_k, so
   //      the sweeps are bare m x m recurrences (chain_solve) and the products with S_k^-1 run on lanes = (node, axis).
-  if (lane == 0) {
+  // The system depends on the durations only: with the durations fixed (waypoints-only optimisation) it is factorised
+  // by the first evaluation and S_k^-1, H_k stay in LDS for the rest of the run.
+  if (lane == 0 && refactor) {
     constexpr int CH = (m <= 2) ? 4 : 2;
     double Dk[m][m];
 #pragma unroll
@@ -651,7 +653,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   }
   __syncthreads();
   // S_k^-1 = L^-T D^-1 L^-1 and H_k = S_k^-1 Ko_k are off the chain: every node on its own lane (3 x 3 blocks)
-  if (m > 2 && lane <= N) {
+  if (m > 2 && refactor && lane <= N) {
     const int k = lane;
     double Lk[NLA] = {}, dik[m];
     const double *slot = &Lm.Si[k][0][0];
@@ -1114,7 +1116,7 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
     else if (lane < n) Lm.T[lane - a.nw] = forward_T(st.x);
     __syncthreads();
     double f, g;
-    persist_eval<S, NB>(Lm, rows, a, lane, f, g);
+    persist_eval<S, NB>(Lm, rows, a, lane, e == 0 || a.nt > 0, f, g);
     PERSIST_TICK_DECL;
     if (lane >= a.nw && lane < n) g *= dforward_T(st.x);
     st.g = (lane < n) ? g : 0.0;

@@ -90,6 +90,21 @@ def main():
             "cost_initial_mean": float(c0.mean()), "cost_final_mean": float(cf.mean()),
             "shape": "launch per evaluation (lockstep)" if lockstep else "one launch, one wave per problem",
             "lbfgs_params": "lbfgs_parameter_t defaults (mem 8, g_eps 1e-5, past 3, delta 1e-6)"}
+    # the same batch with the durations FIXED (AllocNet's own setting: the network allocates the time, the optimiser does the
+    # spatial part): waypoints only, the system factorised once per problem
+    for rep in range(2):
+        th, tt, tw, tT, thp = (to_bm(torch, x, B, ld, dev) for x in (head, tail, wps, T, hp))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, param=prm, max_evals=30000,
+                               opt=aa.lbfgs.OPT_WAYPOINTS | lockstep, ctx=ctx)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    ev = r["evals"].cpu().numpy(); st = r["status"].cpu().numpy()
+    out["config4_waypoints_only_fixed_durations"] = {
+        "seconds": dt, "trajectories_per_s": B / dt, "evals_mean": float(ev.mean()), "evals_max": int(ev.max()),
+        "status_hist": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
+        "cost_final_mean": float(r["cost"].cpu().numpy().mean())}
     if not lockstep:
         # the re-solve case: the same batch again with last call's evaluation counts as the launch order
         # (anet_lbfgs_minco_ordered_dev), and with the counts of a perturbed copy of the batch (~1 cm, 1 %)
