@@ -105,7 +105,8 @@ def _dfwd(tau):
 
 
 def _bwd(T):
-    return np.where(T > 1, np.sqrt(2 * T - 1) - 1, 1 - np.sqrt(2 / T - 1))
+    big = T > 1                       # (each branch evaluated on its own domain only: no invalid-value warnings)
+    return np.where(big, np.sqrt(2 * np.where(big, T, 1.0) - 1) - 1, 1 - np.sqrt(2 / np.where(big, 1.0, T) - 1))
 
 
 @pytest.mark.parametrize("s,c,N,M", [(4, 3, 4, 8), (3, 3, 5, 6)])
