@@ -89,8 +89,13 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
                           res=20, poly_rows=M)
     cost, gP, gT, work = aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, ctx=ctx)
     m = -(-total // world)                      # padded shard length of the gather (ragged shards)
-    send = torch.zeros(m, device=device, dtype=torch.float64)
-    gathered = torch.empty(world * m, device=device, dtype=torch.float64) if use_dist else None
+    # The all-gather of a step (8 B per trajectory: latency-bound) runs on RCCL's stream while the next
+    # step's evaluation runs on the compute stream: two send / receive buffers, a buffer is reused only after its
+    # collective has completed (work.wait() orders the compute stream behind it on the device, not the host).
+    send = [torch.zeros(m, device=device, dtype=torch.float64) for _ in range(2)]
+    gathered = [torch.empty(world * m, device=device, dtype=torch.float64) for _ in range(2)] if use_dist else None
+    works = [None, None]
+    count = [0]
 
     def step(ev=None):
         if ev is not None:
@@ -100,11 +105,18 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
         if ev is not None:
             ev[1].record()
         if use_dist:
-            send[:B].copy_(cost[:B])
-            dist.all_gather_into_tensor(gathered, send)
+            b = count[0] & 1
+            count[0] += 1
+            if works[b] is not None:
+                works[b].wait()
+            send[b][:B].copy_(cost[:B])
+            works[b] = dist.all_gather_into_tensor(gathered[b], send[b], async_op=True)
 
     def sync():
         if use_dist:
+            for w in works:
+                if w is not None:
+                    w.wait()
             dist.barrier()
         torch.cuda.synchronize()
     for _ in range(warmup):
@@ -120,7 +132,8 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        if not torch.equal(gathered[rank * m:rank * m + B], cost[:B]):
+        last = gathered[(count[0] - 1) & 1]
+        if not torch.equal(last[rank * m:rank * m + B], cost[:B]):
             raise SystemExit("config5: all-gather of costs returned wrong data")
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
     ab = config5_bytes(s, c, N, M)
