@@ -68,6 +68,28 @@ def test_argument_validation(anet_ctx):
     lib = _lib.load()
     rc = lib.anet_minco_solve(anet_ctx.handle, 4, 3, 2, 2, None, None, None, None, None, None)     # NULL inputs
     assert rc == _lib.ANET_ERR_INVALID and b"NULL" in lib.anet_last_error(anet_ctx.handle)
+    # polytope depth: negative batch, no rows, NULL; an empty batch is a no-op; a polytope of padding rows only is empty
+    import ctypes
+    d = np.zeros(1)
+    assert lib.anet_polytope_depth(anet_ctx.handle, -1, 4, None, 1, None, None) == _lib.ANET_ERR_INVALID
+    assert lib.anet_polytope_depth(anet_ctx.handle, 1, 0, None, 1, None, None) == _lib.ANET_ERR_INVALID
+    assert lib.anet_polytope_depth(anet_ctx.handle, 1, 4, None, 1, d.ctypes.data_as(ctypes.c_void_p), None) == _lib.ANET_ERR_INVALID
+    assert lib.anet_polytope_depth(anet_ctx.handle, 0, 4, None, 1, None, None) == _lib.ANET_OK
+    depth, _ = aa.polytope_depth(np.zeros((2, 5, 4)), ctx=anet_ctx)
+    assert np.isneginf(depth).all()
+    # a launch order with out-of-range entries: those workgroups do nothing, the problems they would have taken keep
+    # whatever the caller put into status (torch.empty here, so only the solved ones are checked)
+    import torch
+    from tools.bench_configs import to_bm
+    rng = np.random.default_rng(0)
+    head, tail, wps, T = random_problem(rng, 8, 4, 3, rest=True)
+    dev = torch.device("cuda", 0)
+    ld = aa.recommended_ld(8)
+    th, tt, tw, tT = (to_bm(torch, x, 8, ld, dev) for x in (head, tail, wps, T))
+    order = torch.tensor([0, 1, 2, 3, 4, 5, 99, -7], dtype=torch.int32, device=dev)
+    r = aa.lbfgs_minco_dev(th, tt, tw, tT, 3, 3, 4, 8, max_evals=50, opt=1, launch_order=order, ctx=anet_ctx)
+    torch.cuda.synchronize()
+    assert (r["evals"][:6].cpu().numpy() >= 1).all() and (r["status"][:6].cpu().numpy() != 0x7ffffff0).all()
 
 
 def test_stride_larger_than_batch(anet_ctx):
