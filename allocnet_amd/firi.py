@@ -173,6 +173,13 @@ def overlap(hpoly0, hpoly1, eps=1.0e-6, ctx=None):
     return bool(d[0] > eps and np.isfinite(d[0]))
 
 
+def overlap_pt(hpoly0, hpoly1, eps=1.0e-6, ctx=None):
+    """geo_utils::overlapPt (geo_utils.hpp:88-111): the overlap test and the deepest common point (a waypoint candidate
+    between two consecutive corridor polytopes)."""
+    d, x = polytope_depth([np.vstack([hpoly0, hpoly1])], normalise=False, ctx=ctx)
+    return bool(d[0] > eps and np.isfinite(d[0])), x[0]
+
+
 def short_cut(hpolys, eps=0.1, ctx=None):
     """sfc_gen::shortCut (sfc_gen.hpp:188-226): walk the corridor from its last polytope, each time jumping to the
     EARLIEST polytope that still overlaps the current one (consecutive ones always count as overlapping).  The

@@ -253,6 +253,9 @@ int main() {
       printf("\"interior_found\": %d, \"overlap_first_two\": %d, \"overlap_ends\": %d,\n", found ? 1 : 0,
              geo_utils::overlap(vishPolys[0], vishPolys[1]) ? 1 : 0, geo_utils::overlap(vishPolys.front(), vishPolys.back(), 0.1) ? 1 : 0);
       print_vec("interior", inner.a);
+      Vec mid(3);
+      printf("\"overlap_pt_ok\": %d,\n", geo_utils::overlapPt(vishPolys[0], vishPolys[1], mid) ? 1 : 0);
+      print_vec("overlap_pt", mid.a);
     }
     {
       // the reference's only lbfgs_optimize call, statement for statement (firi.hpp:186-227): optData blob, call-site

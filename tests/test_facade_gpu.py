@@ -88,6 +88,8 @@ def test_cpp_facade_program():
     assert out["interior_found"] == 1 and (short[0] @ np.r_[out["interior"], 1.0]).max() < 0.0
     assert out["overlap_first_two"] == int(F.overlap(short[0], short[1]))
     assert out["overlap_ends"] == int(F.overlap(short[0], short[-1], 0.1))
+    mid = np.r_[out["overlap_pt"], 1.0]
+    assert out["overlap_pt_ok"] == 1 and (short[0] @ mid).max() < 0.0 and (short[1] @ mid).max() < 0.0
     # firi::firi facade: polytope around the segment (0,0,1)-(2,.5,1.2), lattice points outside, a outside bd -> false
     assert out["firi_ok"] == 1 and out["firi_rows"] >= 6 and out["firi_outside"] == 0
     hp = np.array(out["firi_hpoly"]).reshape(-1, 4); pts = np.array(out["firi_pts"]).reshape(-1, 3)

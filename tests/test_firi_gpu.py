@@ -197,6 +197,8 @@ def test_polytope_depth_matches_the_linear_programme(anet_ctx):
     assert ok and (polys[3] @ np.r_[pt, 1.0]).max() < 0.0
     assert not aa.find_interior(polys[-1], ctx=anet_ctx)[0] and not aa.find_interior(empty, ctx=anet_ctx)[0]
     assert aa.overlap(polys[2], polys[2], ctx=anet_ctx)
+    ok2, mid = aa.overlap_pt(polys[2], polys[2], ctx=anet_ctx)
+    assert ok2 and (polys[2] @ np.r_[mid, 1.0]).max() < 0.0
     far = _random_polytope(rng, np.array([40.0, 0, 0]), 3)
     assert not aa.overlap(polys[2], far, ctx=anet_ctx) and not F.overlap(polys[2], far)
 
