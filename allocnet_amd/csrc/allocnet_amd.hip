@@ -1023,7 +1023,13 @@ int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A, double
     auto launch = [&](auto kernel, int waves) {
       hipLaunchKernelGGL(kernel, dim3((unsigned)((batch + waves - 1) / waves)), dim3(64u * waves), 0, s0, la, ma, max_evals);
     };
-    if (m <= 8) launch(anet::k_lbfgs_mvie_persistent<8>, anet::LbfgsWaveShape<8>::kWaves);
+    // everything in registers when it fits (<= 128 rows, mem_size <= 20, past <= 64); else the state goes through memory
+    const bool resident = M <= 128 && m <= 20 && params->past <= 64 && !getenv("ANET_MVIE_STATE_IN_MEMORY");
+    if (resident && m <= 8 && M <= 64) launch(anet::k_lbfgs_mvie_resident<8, 1>, 1);
+    else if (resident && m <= 8) launch(anet::k_lbfgs_mvie_resident<8, 2>, 1);
+    else if (resident && M <= 64) launch(anet::k_lbfgs_mvie_resident<20, 1>, 1);
+    else if (resident) launch(anet::k_lbfgs_mvie_resident<20, 2>, 1);
+    else if (m <= 8) launch(anet::k_lbfgs_mvie_persistent<8>, anet::LbfgsWaveShape<8>::kWaves);
     else if (m <= 20) launch(anet::k_lbfgs_mvie_persistent<20>, anet::LbfgsWaveShape<20>::kWaves);
     else launch(anet::k_lbfgs_mvie_persistent<0>, anet::LbfgsWaveShape<0>::kWaves);
     ANET_HIP(ctx, hipGetLastError());
@@ -1123,10 +1129,16 @@ int anet_firi_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int ma
     ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_ * ld, st));
     hipLaunchKernelGGL(anet::k_firi_mvie_setup, gB, b256, sizeof(double) * H * 4, st, ma);
     ANET_HIP(ctx, hipGetLastError());
-    {  // the whole MVIE optimisation in one launch, one wave per corridor
+    {  // the whole MVIE optimisation in one launch, one wave per corridor; rows and optimiser state in registers when they fit
       constexpr int kw = anet::LbfgsWaveShape<20>::kWaves;
-      hipLaunchKernelGGL(anet::k_lbfgs_mvie_persistent<20>, dim3((unsigned)((batch + kw - 1) / kw)), dim3(64u * kw), 0, st, la, ev,
-                         P.mvie_max_evals);
+      const bool in_memory = getenv("ANET_MVIE_STATE_IN_MEMORY") != nullptr;  // A/B switch (tools/README.md)
+      if (!in_memory && H <= 64 && lp.mem_size <= 20 && lp.past <= 64)
+        hipLaunchKernelGGL((anet::k_lbfgs_mvie_resident<20, 1>), dim3((unsigned)batch), dim3(64), 0, st, la, ev, P.mvie_max_evals);
+      else if (!in_memory && H <= 128 && lp.mem_size <= 20 && lp.past <= 64)
+        hipLaunchKernelGGL((anet::k_lbfgs_mvie_resident<20, 2>), dim3((unsigned)batch), dim3(64), 0, st, la, ev, P.mvie_max_evals);
+      else
+        hipLaunchKernelGGL(anet::k_lbfgs_mvie_persistent<20>, dim3((unsigned)((batch + kw - 1) / kw)), dim3(64u * kw), 0, st, la, ev,
+                           P.mvie_max_evals);
       ANET_HIP(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(anet::k_firi_mvie_finish, g64, b64, 0, st, ma);

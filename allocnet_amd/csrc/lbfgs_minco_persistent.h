@@ -162,7 +162,8 @@ __device__ __forceinline__ void rhs_primal_node_rt(int k, int N, int np, double 
 
 // The register-resident L-BFGS of one problem: lbfgs_update_wave_body (one variable per lane, history carried)
 // without its loads and stores.  pf: lane j holds pf[j] of the past-f ring.
-template <int MR>
+// LAST: the highest lane that can hold a non-zero component (63: any n <= 64; 15: n <= 16, reductions stop after one row).
+template <int MR, int LAST = 63>
 struct LbfgsResident {
   double x, g, d, xp, gp;
   double hs[MR], hy[MR], hys[MR];  // hys: 1 / (y.s) of the slot
@@ -180,10 +181,10 @@ struct LbfgsResident {
     fx = step = finit = dgtest = dstest = mu = nu = pf = 0.0;
     k = bound = count = brackt = touched = evals = phase = 0;
   }
-  __device__ __forceinline__ static double dot(double u, double v) { return wave_sum<63>(u * v); }
+  __device__ __forceinline__ static double dot(double u, double v) { return wave_sum<LAST>(u * v); }
   // |g|_inf / max(1, |x|_inf) < g_epsilon (lbfgs.hpp:520-524, 592-596), the quotient cleared
   __device__ __forceinline__ bool conv_test(const LbfgsP &P) const {
-    return wave_max_nonneg<63>(fabs(g)) < P.g_epsilon * fmax(1.0, wave_max_nonneg<63>(fabs(x)));
+    return wave_max_nonneg<LAST>(fabs(g)) < P.g_epsilon * fmax(1.0, wave_max_nonneg<LAST>(fabs(x)));
   }
   // consumes f = objective at x (gradient already in g); leaves the next point in x.  Returns the lbfgs.hpp
   // return code when the problem stops, 0x7fffffff while it runs.
@@ -330,6 +331,89 @@ struct LbfgsResident {
     return finish;
   }
 };
+
+// firi::maxVolInsEllipsoid's optimisation (firi.hpp:207-227) in one launch with NOTHING in memory between the iterations:
+// one wave per polytope, the rows of A in registers (lane = row, RG groups of 64), the nine variables and the L-BFGS
+// state in LbfgsResident (variable = lane), costMVIE (firi.hpp:86-157) as ten wave sums over the rows.  The variant with
+// the state in memory (k_lbfgs_mvie_persistent: x, g, f and the optimiser state through L1 / L2 every iteration) spent
+// about half of an iteration on those round trips.  Same arithmetic as mvie_eval_wave + lbfgs_update_wave_body.
+template <int MR, int RG>
+__global__ void __launch_bounds__(64) k_lbfgs_mvie_resident(LbfgsArgs la, MvieArgs ma, int max_evals) {
+  const int64_t b = blockIdx.x, ld = la.ld;
+  const int lane = threadIdx.x;
+  if (la.is[(int64_t)IS_DONE * ld + b]) return;  // (corridors FIRI's set-up found empty)
+  double a0[RG], a1[RG], a2[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    const int r = lane + 64 * g;
+    const bool v = r < ma.M;
+    a0[g] = v ? ma.A[(int64_t)r * ld + b] : 0.0;
+    a1[g] = v ? ma.A[(int64_t)(ma.M + r) * ld + b] : 0.0;
+    a2[g] = v ? ma.A[(int64_t)(2 * ma.M + r) * ld + b] : 0.0;
+  }
+  LbfgsResident<MR, 15> st;
+  st.init(lane < 9 ? la.x[(int64_t)lane * ld + b] : 0.0);
+  const double inv_mu = 1.0 / ma.eps;
+  int finish = 0x7fffffff;
+#pragma unroll 1
+  for (int e = 0; e < max_evals; ++e) {
+    double xv[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+      xv[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(st.x), q), __builtin_amdgcn_readlane(__double2loint(st.x), q));
+    const double L00 = xv[3] * xv[3] + 2.220446049250313e-16, L11 = xv[4] * xv[4] + 2.220446049250313e-16,
+                 L22 = xv[5] * xv[5] + 2.220446049250313e-16;
+    const double L10 = xv[6], L21 = xv[7], L20 = xv[8];
+    double cost = 0.0, gdp[3] = {0, 0, 0}, gdr[3] = {0, 0, 0}, gdc[3] = {0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      const double al0 = a0[g] * L00 + a1[g] * L10 + a2[g] * L20, al1 = a1[g] * L11 + a2[g] * L21, al2 = a2[g] * L22;
+      const double nrm = sqrt(al0 * al0 + al1 * al1 + al2 * al2);
+      const double viol = nrm + (a0[g] * xv[0] + a1[g] * xv[1] + a2[g] * xv[2]) - 1.0;
+      if (viol >= 0.0) {
+        double c, dc;
+        smoothed_l1(ma.eps, inv_mu, viol, c, dc);
+        const double inv = 1.0 / nrm;
+        const double adj0 = al0 * inv, adj1 = al1 * inv, adj2 = al2 * inv;
+        const double v0 = dc * a0[g], v1 = dc * a1[g], v2 = dc * a2[g];
+        cost += c;
+        gdp[0] += v0; gdp[1] += v1; gdp[2] += v2;
+        gdr[0] += adj0 * v0; gdr[1] += adj1 * v1; gdr[2] += adj2 * v2;
+        gdc[0] += adj0 * v1;
+        gdc[1] += adj1 * v2;
+        gdc[2] += adj0 * v2;
+      }
+    }
+    cost = wave_sum(cost);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      gdp[q] = wave_sum(gdp[q]);
+      gdr[q] = wave_sum(gdr[q]);
+      gdc[q] = wave_sum(gdc[q]);
+    }
+    cost *= ma.wt;
+    cost -= log(L00) + log(L11) + log(L22);
+    const double Ld[3] = {L00, L11, L22};
+    double g = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      g = (lane == q) ? gdp[q] * ma.wt : g;
+      g = (lane == 3 + q) ? (gdr[q] * ma.wt - 1.0 / Ld[q]) * 2.0 * xv[3 + q] : g;
+      g = (lane == 6 + q) ? gdc[q] * ma.wt : g;
+    }
+    st.g = g;
+    finish = __builtin_amdgcn_readfirstlane(st.update(la.p, lane, cost));
+    if (finish != 0x7fffffff) break;
+  }
+  if (lane < 9) la.x[(int64_t)lane * ld + b] = st.x;
+  if (lane == 0) {
+    la.is[(int64_t)IS_DONE * ld + b] = finish != 0x7fffffff;
+    la.is[(int64_t)IS_RET * ld + b] = finish;
+    la.is[(int64_t)IS_K * ld + b] = st.k;
+    la.is[(int64_t)IS_EVALS * ld + b] = st.evals;
+    la.ds[(int64_t)DS_FX * ld + b] = st.fx;
+  }
+}
 
 // K v = rhs for the three axes at once, in place, given S_k^-1 and H_k (E2):
 //   forward   y_k = rhs_k - H_{k-1}' y_{k-1}     lanes 0..2 = axes: an m x m product per node; operands of the next
