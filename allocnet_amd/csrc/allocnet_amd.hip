@@ -1195,7 +1195,8 @@ int anet_polytope_depth_dev(anet_ctx *ctx, int64_t batch, int max_rows, const do
                             double *depth, double *point, void *stream) {
   ANET_ON_DEVICE(ctx);
   if (batch < 0 || max_rows < 1) return fail(ctx, ANET_ERR_INVALID, "anet_polytope_depth: bad batch or max_rows");
-  if ((size_t)max_rows * 4 * sizeof(double) > 60 * 1024) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_polytope_depth: max_rows too large");
+  // (the vertex enumeration is C(rows, 4): 1.7e8 candidates at 256 rows -- corridor polytopes have a few dozen)
+  if (max_rows > 256) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_polytope_depth: more than 256 rows per polytope");
   if (batch == 0) return ANET_OK;
   if (!hpoly || !depth) return fail(ctx, ANET_ERR_INVALID, "anet_polytope_depth_dev: NULL pointer");
   anet::DepthArgs a{hpoly, depth, point, batch, max_rows, normalise ? 1 : 0};
