@@ -183,7 +183,9 @@ struct LbfgsResident {
   }
   __device__ __forceinline__ static double dot(double u, double v) { return wave_sum<LAST>(u * v); }
   // |g|_inf / max(1, |x|_inf) < g_epsilon (lbfgs.hpp:520-524, 592-596), the quotient cleared
+  // (g_epsilon = 0, the setting of the reference's only call site: a norm is never below zero, the two reductions are skipped)
   __device__ __forceinline__ bool conv_test(const LbfgsP &P) const {
+    if (!(P.g_epsilon > 0.0)) return false;
     return wave_max_nonneg<LAST>(fabs(g)) < P.g_epsilon * fmax(1.0, wave_max_nonneg<LAST>(fabs(x)));
   }
   // consumes f = objective at x (gradient already in g); leaves the next point in x.  Returns the lbfgs.hpp
