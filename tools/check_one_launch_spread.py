@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import allocnet_amd as aa
 from allocnet_amd.synth import corridor_problem
 ctx=aa.Context(0)
-for (s,c,N,M) in ((3,3,16,8),(4,3,8,8),(4,4,16,6),(3,3,5,4)):
+for (s,c,N,M) in ((3,3,16,8),(4,3,8,8),(4,4,16,6),(3,3,5,6)):
     for lo,hi in ((0.5,2.0),(0.05,5.0),(0.02,20.0)):
         rng=np.random.default_rng(5)
         B=200
