@@ -1279,12 +1279,15 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
   double *gP_out = nw ? L.g : w_gP, *gT_out = nt ? L.g + (int64_t)nw * ld : w_gT;
   const double *tau = nt ? L.x + (int64_t)nw * ld : nullptr;
   // One launch, one wave per problem (lbfgs_minco_persistent.h) whenever the problem fits a wave: every problem runs
-  // until ITS OWN stop instead of the batch advancing in lockstep, four launches per evaluation.  Above
-  // ANET_LBFGS_PERSISTENT_MAX_BATCH problems the launch-per-evaluation kernels (all 64 lanes busy in the chains) have
-  // the higher throughput per evaluation step.
+  // until ITS OWN stop instead of the batch advancing in lockstep, four launches per evaluation.  The launch-per-
+  // evaluation kernels (all 64 lanes busy in the chains) have up to twice the throughput per evaluation STEP at batches
+  // of 10^5, but a run to convergence is as long as its slowest member times the whole batch there: 131072 x 8-segment
+  // snap 2.3 s in one launch against 4.1 s in lockstep, 131072 x 16-segment jerk 3.5 s against 10.0 s.  So one launch
+  // at any batch (ANET_LBFGS_PERSISTENT_MAX_BATCH caps it for A/B runs); callers with a small fixed evaluation budget
+  // at a huge batch ask for the lockstep shape (ANET_OPT_LOCKSTEP).
   static const int64_t persist_max_batch = [] {
     const char *e = getenv("ANET_LBFGS_PERSISTENT_MAX_BATCH");
-    return e ? (int64_t)atoll(e) : (int64_t)65536;
+    return e ? (int64_t)atoll(e) : (int64_t)0x7fffffff;
   }();
   const int Mrows = (pen && hpolys) ? pen->poly_rows : 0;
   const size_t row_bytes = sizeof(double) * anet::persist_lds_row_doubles(N, Mrows);

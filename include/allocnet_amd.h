@@ -415,9 +415,10 @@ int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A /* [bat
 #define ANET_OPT_WAYPOINTS 1
 #define ANET_OPT_TIMES 2
 /* Execution shape (same result up to rounding): by default problems that fit one wavefront (orders 3 and 4, at most
- * 64 variables, mem_size <= 8, past <= 64, batch <= 65536) run as ONE launch, one wave per problem, each until its
+ * 64 variables, mem_size <= 8, past <= 64) run as ONE launch, one wave per problem, each until its
  * own stop (lbfgs.hpp:551-709 is one loop per problem); this bit forces the launch-per-evaluation kernels instead,
- * which advance the whole batch in lockstep.                                                          */
+ * which advance the whole batch in lockstep (up to twice the throughput per evaluation step at batches of 10^5, so the
+ * better shape for a small FIXED evaluation budget there; a run to convergence is faster in one launch at any batch). */
 #define ANET_OPT_LOCKSTEP 4
 int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
                      const double *tail, double *wps, double *T, const double *hpolys,
