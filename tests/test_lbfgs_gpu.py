@@ -78,6 +78,24 @@ def test_mvie_history_lengths(anet_ctx, mem):
         assert abs(f[b] - fo) <= 1e-7 * max(1.0, abs(fo))
 
 
+@pytest.mark.parametrize("M", [64, 70, 128, 150])
+def test_mvie_row_counts_across_the_kernel_variants(anet_ctx, M):
+    """The register-resident MVIE kernel holds one or two rows of A per lane (up to 64 / 128 rows); above that the
+    optimiser state goes through memory (k_lbfgs_mvie_persistent).  Same counters and iterates whichever runs."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(200 + M)
+    B = 12
+    A, x0, k = _mvie_batch(rng, B, M)
+    kw = dict(mem_size=18, g_epsilon=0.0, min_step=1e-32, past=3, delta=1e-7, max_iterations=8)
+    x, f, status, iters, evals = aa.lbfgs_mvie(A, x0, param=aa.lbfgs_parameter_t(**kw), ctx=anet_ctx)
+    prm = cbind.lbfgs_default_param(**kw)
+    for b in range(B):
+        ret, xo, fo, it, ev = cbind.lbfgs_mvie(A[b, :k[b]], 1e-2, 1e3, x0[b], prm)
+        assert (status[b], iters[b], evals[b]) == (ret, it, ev), b
+        assert np.abs(x[b] - xo).max() <= 1e-7 * max(1.0, np.abs(xo).max()), b
+        assert abs(f[b] - fo) <= 1e-7 * max(1.0, abs(fo))
+
+
 def test_mvie_error_codes_and_budget(anet_ctx):
     import allocnet_amd as aa
     rng = np.random.default_rng(4)
