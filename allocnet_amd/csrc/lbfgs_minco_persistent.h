@@ -3,9 +3,10 @@
 // slowest member and pays four kernel boundaries per evaluation).
 //
 // The evaluation is the one of k_minco_solve / k_piece_grad / k_minco_propagate, re-mapped onto the 64 lanes of a
-// wave with every intermediate in LDS (about 11 KB per wave at 16 pieces, plus the corridor rows):
-//   * only the bare block-tridiagonal recurrences (factor, forward, backward; primal and adjoint) run on three
-//     lanes (one per axis) -- same elimination order and operand order as minco_core.h;
+// wave with every intermediate in LDS (10-13 KB per wave, plus the corridor rows):
+//   * of the block-tridiagonal solve only the factor's Schur-complement chain is walked node by node (one lane); the
+//     forward / backward sweeps, primal and adjoint, are parallel scans over (node, axis) rows of 16 lanes (chain_solve);
+//     with the durations fixed the factor is computed once per problem;
 //   * everything per node or per piece (right-hand sides, coefficients, adjoint contributions, gradient terms) runs
 //     on lanes = (node | piece, axis);
 //   * the penalty functional runs on lanes = (piece, sample group): each lane takes every G-th sample of its piece
@@ -417,10 +418,7 @@ __global__ void __launch_bounds__(64) k_lbfgs_mvie_resident(LbfgsArgs la, MvieAr
   }
 }
 
-// K v = rhs for the three axes at once, in place, given S_k^-1 and H_k (E2):
-//   forward   y_k = rhs_k - H_{k-1}' y_{k-1}     lanes 0..2 = axes: an m x m product per node; operands of the next
-//   scaling   z_k = S_k^-1 y_k                    lanes = (node, axis)          nodes arrive in alternating buffers
-//   backward  x_k = z_k - H_k x_{k+1}             lanes 0..2
+// K v = rhs for the three axes at once, in place, given S_k^-1 and H_k (E2).
 // The two sweeps of the block LDL^T solve, y_k = rhs_k - H_{k-1}' y_{k-1} and x_k = z_k - H_k x_{k+1} (z_k = S_k^-1 y_k), are
 // affine recurrences with m x m matrices: instead of walking the nodes on three lanes they run as PARALLEL SCANS, one DPP row
 // of 16 lanes per axis (row 3 shadows axis 2), lane j = node j+1 forwards and node j backwards (the ends are folded into
