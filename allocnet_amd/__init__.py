@@ -16,6 +16,6 @@ from .qp import qp_assemble, qp_dims, qp_solve, qp_solve_vjp, qp_settings, QPSol
 from .min_traj_opt import MinTrajOpt, OsqpLayer  # noqa: F401
 from . import firi as _firi_mod  # noqa: F401
 from .firi import (firi, firi_dev, firi_params, convex_cover, polytope_depth, find_interior, overlap,  # noqa: F401
-                   overlap_pt, short_cut)
+                   overlap_pt, short_cut, pack_model_inputs, to_planner_form)
 
 __version__ = "0.1.0"

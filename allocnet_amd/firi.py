@@ -84,6 +84,26 @@ def to_planner_form(hpoly, n_rows):
     return out
 
 
+def pack_model_inputs(ini_pva, fin_pva, hpolys, max_rows=50, max_seg=5):
+    """The tensors LearningPlanner::callModel hands to the time-allocation network (learning_planner.hpp:147-170), which are
+    also what MinTrajOpt.update / OsqpLayer take (min_traj_opt.py:68-90): state (9,2) float32 -- rows px,vx,ax,py,..,
+    column 0 start, column 1 end -- and the corridor (max_rows,4,max_seg) float32, polytope i in [:, :, i] in PLANNER form
+    (`to_planner_form`: unit normals, a.x <= b), zero rows / zero polytopes as padding.  Raises when the corridor is
+    longer than the model takes (the planner gives that try up, learning_planner.hpp:286-290) or a polytope has more
+    rows than the tensor."""
+    ini = np.asarray(ini_pva, dtype=np.float64).reshape(3, 3); fin = np.asarray(fin_pva, dtype=np.float64).reshape(3, 3)
+    if len(hpolys) > max_seg:
+        raise ValueError(f"corridor of {len(hpolys)} polytopes, the model takes {max_seg}")
+    state = np.stack([ini.reshape(9), fin.reshape(9)], axis=1).astype(np.float32)     # row = axis, cols p,v,a -> px,vx,ax,py,..
+    out = np.zeros((max_rows, 4, max_seg), dtype=np.float32)
+    for i, h in enumerate(hpolys):
+        h = np.asarray(h, dtype=np.float64)
+        if h.shape[0] > max_rows:
+            raise ValueError(f"polytope {i} has {h.shape[0]} rows, the model takes {max_rows}")
+        out[:h.shape[0], :, i] = h
+    return state, out
+
+
 def convex_cover(path, points, low_corner, high_corner, progress, rng_range, eps=1.0e-6, max_rows=64, ctx=None):
     """sfc_gen::convexCover (sfc_gen.hpp:116-186): walk the path in steps of at most `progress`, one FIRI
     polytope per step inside the box [segment -/+ range] clipped to the map, plus a gap polytope where
