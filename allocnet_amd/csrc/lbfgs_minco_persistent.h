@@ -463,7 +463,7 @@ __device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3
   const int row = lane >> 4, j = lane & 15, ax = row < 3 ? row : 2;
   const bool valid = j < N;                  // forward node j + 1 <= N, backward node j <= N - 1
   const int jc = valid ? j : 0;
-  double Hj[m][m], M[m][m], v[m], y0[m], zf[m];
+  double Hj[m][m], M[m][m], v[m], y0[m], z0[m], zf[m];
 #pragma unroll
   for (int a = 0; a < m; ++a) {
     y0[a] = V[ax][0][a];
@@ -505,12 +505,12 @@ __device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3
       acc0 = __builtin_fma(Lm.Si[0][a][b], y0[b], acc0);
     }
     zf[a] = valid ? acc : 0.0;
-    y0[a] = acc0;  // (now z_0)
+    z0[a] = acc0;
   }
 #pragma unroll
   for (int a = 0; a < m; ++a) {
     const double zl = dpp_f64<0x111>(zf[a]);
-    v[a] = (j == 0) ? y0[a] : zl;
+    v[a] = (j == 0) ? z0[a] : zl;
     if (!valid) v[a] = 0.0;
   }
   // ---- backwards: x_j = z_j - H_j x_{j+1}; lane N-1 takes x_N = z_N in and starts the chain

@@ -268,7 +268,8 @@ def test_minco_s2nu_16_segments_lbfgs(anet_ctx):
 
 
 @pytest.mark.parametrize("s,c,N,M,res", [(3, 3, 16, 16, 20), (4, 3, 8, 16, 20), (4, 4, 5, 7, 10), (3, 3, 2, 5, 7),
-                                          (3, 3, 1, 4, 6), (4, 3, 12, 50, 9)])
+                                          (3, 3, 1, 4, 6), (4, 3, 12, 50, 9), (4, 2, 7, 6, 10), (4, 2, 1, 5, 8),
+                                          (3, 2, 9, 8, 12)])
 def test_minco_lbfgs_one_launch_agrees_with_lockstep(anet_ctx, s, c, N, M, res):
     """The one-launch kernel (one wave per problem, lbfgs_minco_persistent.h) and the launch-per-evaluation kernels
     are two execution shapes of the same algorithm: at fixed iteration budgets identical counters and return codes,
@@ -296,6 +297,36 @@ def test_minco_lbfgs_one_launch_agrees_with_lockstep(anet_ctx, s, c, N, M, res):
         assert np.abs(a["T"] - b["T"])[same].max() <= tol * 10 * max(1.0, np.abs(b["T"]).max()), mi
         if N > 1:
             assert np.abs(a["wps"] - b["wps"])[same].max() <= tol * 10 * max(1.0, np.abs(b["wps"]).max()), mi
+
+
+def test_minco_lbfgs_one_launch_vs_lockstep_random_shapes(anet_ctx):
+    """Differential fuzz of the two execution shapes over what the fixed cases above leave out: orders 3 / 4, 1..16 pieces,
+    every boundary count 2..s (c = 2 with order 4 once hid an in-place overwrite in the scanned sweeps: the pinned rows of
+    S_0^-1 are identity rows, which masked it for c >= 3), 0..50 corridor rows, 1..40 samples, the three variable sets,
+    history lengths 1 / 3 / 8, `past` 0 / 1 / 3.  Counters identical at budgets <= 2, costs equal to rounding."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(2024)
+    for trial in range(80):
+        s = int(rng.choice([3, 4])); N = int(rng.integers(1, 17))
+        c = int(rng.integers(2, s + 1)) if rng.random() < 0.4 else 3
+        M = int(rng.choice([0, 1, 3, 7, 16, 33, 50])); res = int(rng.integers(1, 41)); B = int(rng.integers(1, 24))
+        opt = int(rng.choice([1, 2, 3])) if N > 1 else 2
+        head, tail, wps, T = random_problem(rng, B, N, c, rest=bool(rng.random() < 0.5))
+        hp = make_corridors(rng, head, tail, wps, M, tight=1.5) if M else None
+        pen = aa.make_penalty(rho=20.0, w_corridor=1e3, w_vel=1e2, w_acc=1e2, smooth_mu=1e-2, max_vel=3.0, max_acc=4.0,
+                              res=res, poly_rows=M)
+        mi = int(rng.choice([1, 2, 5]))
+        prm = aa.lbfgs_parameter_t(g_epsilon=1e-7, delta=1e-9, max_iterations=mi, mem_size=int(rng.choice([1, 3, 8])),
+                                   past=int(rng.choice([0, 1, 3])))
+        a = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=prm, opt=opt, ctx=anet_ctx)
+        b = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=prm, opt=opt | aa.lbfgs.OPT_LOCKSTEP,
+                           ctx=anet_ctx)
+        same = (a["status"] == b["status"]) & (a["iters"] == b["iters"]) & (a["evals"] == b["evals"])
+        rel = np.abs(a["cost"] - b["cost"]) / np.maximum(1e-300, np.abs(b["cost"]))
+        tag = dict(trial=trial, s=s, N=N, c=c, M=M, res=res, B=B, opt=opt, mi=mi, mem=prm.mem_size, past=prm.past)
+        assert np.isfinite(a["cost"]).all(), tag
+        assert same.mean() >= (1.0 if mi <= 2 else 0.6), (tag, same.mean())
+        assert rel[same].max(initial=0.0) <= 1e-7, (tag, rel.max())
 
 
 def test_minco_lbfgs_one_launch_budget_and_fallbacks(anet_ctx):
