@@ -96,6 +96,39 @@ def test_mvie_row_counts_across_the_kernel_variants(anet_ctx, M):
         assert abs(f[b] - fo) <= 1e-7 * max(1.0, abs(fo))
 
 
+def test_mvie_register_resident_vs_state_in_memory_random_shapes(anet_ctx, monkeypatch):
+    """Differential fuzz of the two MVIE kernels (k_lbfgs_mvie_resident / k_lbfgs_mvie_persistent; ANET_MVIE_STATE_IN_MEMORY
+    is read per call): 1..200 rows, histories 1..30, `past` 0..5, with and without the gradient test.  Short budgets:
+    identical counters and iterates; long runs amplify rounding, so their outcome is compared."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(7)
+    for trial in range(50):
+        M = int(rng.choice([1, 4, 6, 9, 18, 40, 63, 64, 65, 100, 128, 129, 200])); B = int(rng.integers(1, 20))
+        A = rng.normal(size=(B, M, 3)); A /= np.linalg.norm(A, axis=2, keepdims=True)
+        if M >= 6:
+            A[:, :6] = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=float)
+        A /= rng.uniform(0.8, 2.5, size=(B, M, 1))
+        k = rng.integers(max(1, M // 2), M + 1, size=B)
+        for b in range(B):
+            A[b, k[b]:] = 0.0
+        x0 = np.tile(np.r_[np.zeros(3), np.sqrt([0.3, 0.3, 0.3]), np.zeros(3)], (B, 1))
+        x0[:, :3] += rng.normal(size=(B, 3)) * 0.02
+        kw = dict(mem_size=int(rng.choice([1, 2, 8, 9, 18, 20, 21, 30])), g_epsilon=float(rng.choice([0.0, 1e-6])),
+                  min_step=1e-32, past=int(rng.choice([0, 1, 3, 5])), delta=1e-7, max_iterations=int(rng.choice([0, 1, 4, 12])))
+        me = int(rng.choice([3, 40, 400]))
+        monkeypatch.delenv("ANET_MVIE_STATE_IN_MEMORY", raising=False)
+        x1, f1, s1, i1, e1 = aa.lbfgs_mvie(A, x0, param=aa.lbfgs_parameter_t(**kw), max_evals=me, ctx=anet_ctx)
+        monkeypatch.setenv("ANET_MVIE_STATE_IN_MEMORY", "1")
+        x2, f2, s2, i2, e2 = aa.lbfgs_mvie(A, x0, param=aa.lbfgs_parameter_t(**kw), max_evals=me, ctx=anet_ctx)
+        tag = (trial, M, B, kw, me)
+        if kw["max_iterations"] in (1, 4) or me == 3:
+            assert (s1 == s2).all() and (i1 == i2).all() and (e1 == e2).all(), tag
+            assert (np.abs(x1 - x2).max(axis=1) <= 1e-9 * np.maximum(1.0, np.abs(x2).max(axis=1))).all(), tag
+        else:
+            done = (s1 != aa.lbfgs.LBFGS_RUNNING) & (s2 != aa.lbfgs.LBFGS_RUNNING) & (s1 >= 0) & (s2 >= 0)
+            assert np.isfinite(f1).all() and (np.abs(f1 - f2)[done] <= 5e-3 * np.maximum(1.0, np.abs(f2))[done]).all(), tag
+
+
 def test_mvie_error_codes_and_budget(anet_ctx):
     import allocnet_amd as aa
     rng = np.random.default_rng(4)
