@@ -412,3 +412,54 @@ def test_backward_pass_through_the_qp(anet_ctx, s, N, M, res):
     # the ADMM method has no factored Newton matrix to reuse: refused, not approximated
     with pytest.raises(aa.AnetError):
         aa.qp_solve_vjp(s, ini, fin, hp, T, gz, settings=aa.qp_settings(method=ADMM), **kw)
+
+
+def test_interior_point_and_backward_pass_random_shapes(anet_ctx):
+    """The default QP method and its backward pass over shapes the fixed cases leave out (orders 3 / 4, 1..8 pieces, 6..16
+    rows, 3..20 samples): optimum against the dense interior-point oracle, the backward pass against a central difference of
+    an arbitrary loss along a random direction in T."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(11)
+    compared = 0
+    for trial in range(30):
+        s = int(rng.choice([3, 4])); N = int(rng.integers(1, 7)); M = int(rng.integers(6, 13)); res = int(rng.integers(3, 11)); B = 3
+        probs = [_corridor_problem(rng, N, M) for _ in range(B)]
+        ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
+        hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs])
+        out = aa.qp_solve(s, ini, fin, hp, T, res=res, max_vel=3.0, max_acc=4.0, ctx=anet_ctx)
+        for b in range(B):
+            Q, A, bb, G, h = _dense(s, ini[b], fin[b], hp[b], T[b], res, 3.0, 4.0)
+            z, lam, nu, fo, it = qp_np.qp_ipm(Q, A, bb, G, h)
+            if it >= 199 or qp_np.kkt_violation(Q, A, bb, G, h, z) > 1e-7:
+                continue
+            compared += 1
+            zg = out["coeffs"][b].reshape(-1)
+            assert out["status"][b] == 1 and abs(out["obj"][b] - fo) <= 1e-5 * max(1.0, fo), (trial, s, N, M, res, b)
+            assert qp_np.kkt_violation(Q, A, bb, G, h, zg) <= 1e-6 * max(1.0, np.abs(h).max())
+    assert compared >= 60
+    rng = np.random.default_rng(5)
+    compared = 0
+    for trial in range(20):
+        s = int(rng.choice([3, 4])); N = int(rng.integers(1, 9)); M = int(rng.integers(6, 17)); res = int(rng.integers(3, 21)); B = 6
+        probs = [_corridor_problem(rng, N, M, margin=float(rng.uniform(0.8, 1.5))) for _ in range(B)]
+        ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
+        hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs])
+        kw = dict(res=res, max_vel=3.0, max_acc=4.0, ctx=anet_ctx)
+        tight = aa.qp_settings(method=aa.qp.QP_METHOD_INTERIOR_POINT, eps_abs=1e-10, eps_rel=1e-10)
+        D = 2 * s
+        w1 = rng.normal(size=(N, 3, D)); w2 = rng.uniform(0, 1, size=(N, 3, D))
+
+        def loss(z):
+            return (w1 * z).sum(axis=(1, 2, 3)) + 0.5 * (w2 * z * z).sum(axis=(1, 2, 3))
+        base = aa.qp_solve(s, ini, fin, hp, T, settings=tight, **kw)
+        out = aa.qp_solve_vjp(s, ini, fin, hp, T, w1[None] + w2[None] * base["coeffs"], **kw)
+        d = rng.normal(size=T.shape) * T * 0.3
+        lp = aa.qp_solve(s, ini, fin, hp, T + 1e-5 * d, settings=tight, **kw)
+        lm = aa.qp_solve(s, ini, fin, hp, T - 1e-5 * d, settings=tight, **kw)
+        ok = (base["status"] == 1) & (lp["status"] == 1) & (lm["status"] == 1) & (out["status"] == 1)
+        fd = (loss(lp["coeffs"]) - loss(lm["coeffs"])) / 2e-5
+        an = (out["grad_T"] * d).sum(axis=1)
+        sc = np.abs(out["grad_T"] * d).sum(axis=1) + 1e-300
+        compared += int(ok.sum())
+        assert (np.abs(an - fd)[ok] <= 1e-3 * sc[ok]).all(), (trial, s, N, M, res, (np.abs(an - fd) / sc)[ok])
+    assert compared >= 60
