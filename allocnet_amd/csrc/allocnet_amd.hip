@@ -1199,7 +1199,14 @@ int anet_polytope_depth_dev(anet_ctx *ctx, int64_t batch, int max_rows, const do
   if (max_rows > 256) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_polytope_depth: more than 256 rows per polytope");
   if (batch == 0) return ANET_OK;
   if (!hpoly || !depth) return fail(ctx, ANET_ERR_INVALID, "anet_polytope_depth_dev: NULL pointer");
-  anet::DepthArgs a{hpoly, depth, point, batch, max_rows, normalise ? 1 : 0};
+  // active-set ascent, one lane per polytope, certified; what it cannot certify (NaN) goes to the vertex enumeration
+  const bool enumerate_all = getenv("ANET_POLYTOPE_DEPTH_ENUMERATE") != nullptr;  // A/B switch
+  anet::DepthArgs a{hpoly, depth, point, batch, max_rows, normalise ? 1 : 0, enumerate_all ? 0 : 1};
+  if (!enumerate_all) {
+    hipLaunchKernelGGL(anet::k_polytope_depth_simplex, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+    ANET_HIP(ctx, hipGetLastError());
+  }
+  if (getenv("ANET_POLYTOPE_DEPTH_NO_FALLBACK")) return ANET_OK;  // diagnostics: NaN marks what the ascent did not certify
   hipLaunchKernelGGL(anet::k_polytope_depth, dim3((unsigned)batch), dim3(256), sizeof(double) * max_rows * 4, (hipStream_t)stream, a);
   ANET_HIP(ctx, hipGetLastError());
   return ANET_OK;

@@ -307,10 +307,136 @@ struct DepthArgs {
   double *point;        // [B][3] or nullptr
   int64_t B;
   int H, normalise;
+  int only_nan;         // k_polytope_depth: only the polytopes whose depth is NaN (left over by the simplex kernel)
 };
+// The same LP by an active-set (simplex) ascent, ONE LANE per polytope: a few dozen steps of O(rows) each, where the
+// enumeration below costs C(rows, 4) candidates (2.3e5 at the 50 rows of two stacked corridor polytopes: milliseconds per
+// workgroup).  From v = (x, t) feasible with the constraints W tight: move along p = the projection of the objective onto
+// the null space of W until the next constraint blocks, add it; at p = 0 the multipliers of G_W' lam = c decide --
+// all >= 0: optimal; else drop the most negative one.  The result is CERTIFIED before it is returned (every row
+// satisfied, multipliers non-negative, p = 0); anything else -- iteration cap at a degenerate vertex, a singular Gram
+// matrix -- leaves NaN in depth[b], which k_polytope_depth takes as its cue to enumerate that polytope.
+__global__ void __launch_bounds__(64) k_polytope_depth_simplex(DepthArgs g) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= g.B) return;
+  const double *hp = g.hpoly + b * g.H * 4;
+  const int H = g.H;
+  auto row = [&](int i, double (&gi)[3], double &bi) -> bool {  // g_i = (gi, 1), right-hand side bi; false: padding
+    const double h0 = hp[i * 4], h1 = hp[i * 4 + 1], h2 = hp[i * 4 + 2], h3 = hp[i * 4 + 3];
+    if (h0 == 0.0 && h1 == 0.0 && h2 == 0.0) return false;
+    const double sc = g.normalise ? 1.0 / sqrt(h0 * h0 + h1 * h1 + h2 * h2) : 1.0;
+    gi[0] = h0 * sc; gi[1] = h1 * sc; gi[2] = h2 * sc; bi = -h3 * sc;
+    return true;
+  };
+  // start: x = 0, t = the smallest right-hand side; that row is tight
+  double v[4] = {0.0, 0.0, 0.0, INFINITY};
+  int W[4] = {-1, -1, -1, -1}, nW = 0, nrows = 0;
+  for (int i = 0; i < H; ++i) {
+    double gi[3], bi;
+    if (!row(i, gi, bi)) continue;
+    ++nrows;
+    if (bi < v[3]) { v[3] = bi; W[0] = i; nW = 1; }
+  }
+  double depth = NAN;
+  if (nrows == 0) {
+    depth = -INFINITY;  // nothing but padding (k_polytope_depth's convention)
+  } else {
+    const int cap = 64 + 4 * nrows;
+    for (int it = 0; it < cap; ++it) {
+      // Gram matrix of the active rows, its Cholesky factor, lam = (G G')^-1 G c with G c = (1, .., 1)
+      double Gw[4][4], bw[4], L[4][4], lam[4];
+      for (int k = 0; k < 4; ++k) {
+        Gw[k][0] = Gw[k][1] = Gw[k][2] = 0.0; Gw[k][3] = 1.0; bw[k] = 0.0;
+        if (k < nW) { double gi[3]; row(W[k], gi, bw[k]); Gw[k][0] = gi[0]; Gw[k][1] = gi[1]; Gw[k][2] = gi[2]; }
+      }
+      bool singular = false;
+      for (int r = 0; r < nW && !singular; ++r)
+        for (int c = 0; c <= r; ++c) {
+          double acc = Gw[r][0] * Gw[c][0] + Gw[r][1] * Gw[c][1] + Gw[r][2] * Gw[c][2] + 1.0;
+          for (int q = 0; q < c; ++q) acc -= L[r][q] * L[c][q];
+          if (r == c) {
+            const double nr2 = Gw[r][0] * Gw[r][0] + Gw[r][1] * Gw[r][1] + Gw[r][2] * Gw[r][2] + 1.0;
+            if (!(acc > 1e-13 * nr2)) { singular = true; break; }
+            L[r][r] = sqrt(acc);
+          } else {
+            L[r][c] = acc / L[c][c];
+          }
+        }
+      if (singular) break;
+      for (int r = 0; r < nW; ++r) {
+        double acc = 1.0;
+        for (int q = 0; q < r; ++q) acc -= L[r][q] * lam[q];
+        lam[r] = acc / L[r][r];
+      }
+      for (int r = nW - 1; r >= 0; --r) {
+        double acc = lam[r];
+        for (int q = r + 1; q < nW; ++q) acc -= L[q][r] * lam[q];
+        lam[r] = acc / L[r][r];
+      }
+      double p[4] = {0.0, 0.0, 0.0, 1.0};
+      for (int k = 0; k < nW; ++k)
+        for (int q = 0; q < 4; ++q) p[q] -= lam[k] * Gw[k][q];
+      const double pn2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3];
+      if (nW < 4 && pn2 > 1e-24) {
+        // ratio test: the first row to become tight along p
+        double alpha = INFINITY;
+        int blk = -1;
+        for (int i = 0; i < H; ++i) {
+          if (i == W[0] || i == W[1] || i == W[2] || i == W[3]) continue;
+          double gi[3], bi;
+          if (!row(i, gi, bi)) continue;
+          const double den = gi[0] * p[0] + gi[1] * p[1] + gi[2] * p[2] + p[3];
+          if (den > 1e-14 * sqrt(pn2 * (gi[0] * gi[0] + gi[1] * gi[1] + gi[2] * gi[2] + 1.0))) {
+            const double a = fmax(0.0, bi - (gi[0] * v[0] + gi[1] * v[1] + gi[2] * v[2] + v[3])) / den;
+            if (a < alpha) { alpha = a; blk = i; }
+          }
+        }
+        if (blk < 0) { depth = INFINITY; break; }  // unbounded: nothing blocks the ascent
+        for (int q = 0; q < 4; ++q) v[q] += alpha * p[q];
+        W[nW++] = blk;
+      } else {
+        int worst = -1;
+        double lmin = -1e-12;
+        for (int k = 0; k < nW; ++k)
+          if (lam[k] < lmin) { lmin = lam[k]; worst = k; }
+        if (worst < 0) {  // candidate optimum: certify it against every row
+          bool ok = pn2 <= 1e-18;
+          if (nW == 4) {  // a vertex: re-solve it from its four tight rows (the steps accumulate rounding), v = G'(G G')^-1 b
+            double mu[4];
+            for (int r = 0; r < 4; ++r) {
+              double acc = bw[r];
+              for (int q = 0; q < r; ++q) acc -= L[r][q] * mu[q];
+              mu[r] = acc / L[r][r];
+            }
+            for (int r = 3; r >= 0; --r) {
+              double acc = mu[r];
+              for (int q = r + 1; q < 4; ++q) acc -= L[q][r] * mu[q];
+              mu[r] = acc / L[r][r];
+            }
+            for (int q = 0; q < 4; ++q) v[q] = mu[0] * Gw[0][q] + mu[1] * Gw[1][q] + mu[2] * Gw[2][q] + mu[3] * Gw[3][q];
+          }
+          for (int i = 0; i < H && ok; ++i) {
+            double gi[3], bi;
+            if (!row(i, gi, bi)) continue;
+            const double r = gi[0] * v[0] + gi[1] * v[1] + gi[2] * v[2] + v[3] - bi;
+            ok = r <= 1e-9 * fmax(1.0, fabs(bi));
+          }
+          if (ok) depth = v[3];
+          break;
+        }
+        for (int k = worst; k + 1 < nW; ++k) W[k] = W[k + 1];
+        W[--nW] = -1;
+      }
+    }
+  }
+  g.depth[b] = depth;
+  if (g.point) { g.point[b * 3] = v[0]; g.point[b * 3 + 1] = v[1]; g.point[b * 3 + 2] = v[2]; }
+}
+
 __global__ void __launch_bounds__(256) k_polytope_depth(DepthArgs g) {
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x;
+  if (g.only_nan && !isnan(g.depth[b])) return;  // certified by k_polytope_depth_simplex
   extern __shared__ double sm[];  // [H][4] compacted rows
   __shared__ double s_best[4][5];
   __shared__ int s_n;

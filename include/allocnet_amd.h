@@ -362,8 +362,10 @@ int anet_qp_solve_vjp_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int
  *                                                            or h[0:3]            (normalise = 0, overlap)
  * and the point x that attains it (point may be NULL).  findInterior(hPoly) is depth > 0; overlap(hPoly0, hPoly1, eps) is
  * depth > eps of the two polytopes' rows stacked (sfc_gen::shortCut, sfc_gen.hpp:188-226, calls it with eps = 0.1);
- * depth = -inf for an empty polytope.  Exact: a linear programme attains its optimum at a vertex, the kernel enumerates
- * them (allocnet_amd/csrc/firi_kernels.h; C(rows, 4) candidates, so max_rows <= 256: ANET_ERR_UNSUPPORTED beyond).
+ * depth = -inf for a polytope of padding rows only, +inf for an unbounded one (the reference's tests read both as false).
+ * Exact: an active-set ascent, one lane per polytope, whose result is certified (feasible, multipliers >= 0) before it is
+ * returned; what it cannot certify falls back to the enumeration of the vertices (allocnet_amd/csrc/firi_kernels.h;
+ * C(rows, 4) candidates, hence max_rows <= 256: ANET_ERR_UNSUPPORTED beyond).
  * Bounded polytopes (corridors always carry their bounding box).                                                       */
 int anet_polytope_depth(anet_ctx *ctx, int64_t batch, int max_rows, const double *hpoly /* [batch][max_rows][4] */,
                         int normalise, double *depth /* [batch] */, double *point /* [batch][3] or NULL */);

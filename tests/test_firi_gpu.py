@@ -234,3 +234,52 @@ def test_short_cut_follows_the_reference_walk(anet_ctx):
     assert len(short) == len(idx) <= len(polys) and all((o == polys[k]).all() for o, k in zip(short, idx))
     for h0, h1 in zip(short[:-1], short[1:]):                     # consecutive polytopes of the result still meet
         assert np.isfinite(F.polytope_depth(np.vstack([h0, h1]), False)[0])
+
+
+def test_polytope_depth_ascent_enumeration_and_highs_agree_on_generated_polytopes(anet_ctx, monkeypatch):
+    """The certified active-set ascent (default), the vertex enumeration (fallback; forced through its A/B switch) and HiGHS
+    on polytopes chosen to be awkward: cubes (degenerate vertices), duplicated / rescaled rows, many cuts, empty sets, stacked
+    boxes, cuts through the centre.  An unbounded set gives +inf, which findInterior / overlap read as false."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(3)
+
+    def box(c, half):
+        rows = []
+        for ax in range(3):
+            e = np.zeros(3); e[ax] = 1
+            rows += [np.r_[e, -(c[ax] + half[ax])], np.r_[-e, c[ax] - half[ax]]]
+        return rows
+    polys = []
+    for t in range(150):
+        kind = t % 6
+        c = rng.uniform(-20, 20, size=3); half = rng.uniform(0.3, 4, size=3)
+        rows = box(c, half)
+        if kind == 1:
+            rows += [r * rng.uniform(0.1, 10) for r in rows[:3]]
+        elif kind == 2:
+            for _ in range(rng.integers(1, 60)):
+                n = rng.standard_normal(3) * rng.uniform(0.2, 5)
+                rows.append(np.r_[n, -(n @ c) - rng.uniform(0.05, 2) * np.linalg.norm(n)])
+        elif kind == 3:
+            n = rng.standard_normal(3); n /= np.linalg.norm(n); rows.append(np.r_[n, -(n @ c) + 10.0])
+        elif kind == 4:
+            rows += box(c + rng.uniform(-1, 1, size=3) * half, rng.uniform(0.3, 4, size=3))
+        elif kind == 5:
+            for _ in range(rng.integers(1, 6)):
+                n = rng.standard_normal(3); rows.append(np.r_[n, -(n @ c)])
+        polys.append(np.array(rows))
+    for normalise in (True, False):
+        monkeypatch.delenv("ANET_POLYTOPE_DEPTH_ENUMERATE", raising=False)
+        d, x = aa.polytope_depth(polys, normalise=normalise, ctx=anet_ctx)
+        monkeypatch.setenv("ANET_POLYTOPE_DEPTH_ENUMERATE", "1")
+        d_e, _ = aa.polytope_depth(polys, normalise=normalise, ctx=anet_ctx)
+        monkeypatch.delenv("ANET_POLYTOPE_DEPTH_ENUMERATE")
+        for i, hp in enumerate(polys):
+            d0, _ = F.polytope_depth(hp, normalise)
+            tol = 1e-8 * max(1.0, abs(d0))
+            assert abs(d[i] - d0) <= tol and abs(d_e[i] - d0) <= tol, (i, normalise, d[i], d_e[i], d0)
+            nrm = np.linalg.norm(hp[:, :3], axis=1) if normalise else 1.0
+            assert (-(hp[:, :3] @ x[i] + hp[:, 3]) / nrm).min() >= d[i] - tol
+    half_space = np.array([[1.0, 0.0, 0.0, -1.0], [0.0, 1.0, 0.0, -1.0]])
+    d, _ = aa.polytope_depth([half_space], ctx=anet_ctx)
+    assert np.isposinf(d[0]) and not aa.find_interior(half_space, ctx=anet_ctx)[0] and not aa.overlap(half_space, half_space, ctx=anet_ctx)
