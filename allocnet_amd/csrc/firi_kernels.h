@@ -316,20 +316,13 @@ struct DepthArgs {
 // all >= 0: optimal; else drop the most negative one.  The result is CERTIFIED before it is returned (every row
 // satisfied, multipliers non-negative, p = 0); anything else -- iteration cap at a degenerate vertex, a singular Gram
 // matrix -- leaves NaN in depth[b], which k_polytope_depth takes as its cue to enumerate that polytope.
-__global__ void __launch_bounds__(64) k_polytope_depth_simplex(DepthArgs g) {
-  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (b >= g.B) return;
-  const double *hp = g.hpoly + b * g.H * 4;
-  const int H = g.H;
-  auto row = [&](int i, double (&gi)[3], double &bi) -> bool {  // g_i = (gi, 1), right-hand side bi; false: padding
-    const double h0 = hp[i * 4], h1 = hp[i * 4 + 1], h2 = hp[i * 4 + 2], h3 = hp[i * 4 + 3];
-    if (h0 == 0.0 && h1 == 0.0 && h2 == 0.0) return false;
-    const double sc = g.normalise ? 1.0 / sqrt(h0 * h0 + h1 * h1 + h2 * h2) : 1.0;
-    gi[0] = h0 * sc; gi[1] = h1 * sc; gi[2] = h2 * sc; bi = -h3 * sc;
-    return true;
-  };
+// row(i, gi, bi) -> false for a padding row, else g_i = (gi, 1) and the right-hand side bi.  Leaves the point in v and returns
+// the certified optimum, +inf (unbounded), -inf (no rows) or NaN (not certified: enumerate).
+template <typename RowFn>
+__device__ __forceinline__ double lp_ascent(RowFn row, const int H, double (&v)[4]) {
+  v[0] = v[1] = v[2] = 0.0;
+  v[3] = INFINITY;
   // start: x = 0, t = the smallest right-hand side; that row is tight
-  double v[4] = {0.0, 0.0, 0.0, INFINITY};
   int W[4] = {-1, -1, -1, -1}, nW = 0, nrows = 0;
   for (int i = 0; i < H; ++i) {
     double gi[3], bi;
@@ -429,6 +422,22 @@ __global__ void __launch_bounds__(64) k_polytope_depth_simplex(DepthArgs g) {
       }
     }
   }
+  return depth;
+}
+
+__global__ void __launch_bounds__(64) k_polytope_depth_simplex(DepthArgs g) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= g.B) return;
+  const double *hp = g.hpoly + b * g.H * 4;
+  auto row = [&](int i, double (&gi)[3], double &bi) -> bool {
+    const double h0 = hp[i * 4], h1 = hp[i * 4 + 1], h2 = hp[i * 4 + 2], h3 = hp[i * 4 + 3];
+    if (h0 == 0.0 && h1 == 0.0 && h2 == 0.0) return false;
+    const double sc = g.normalise ? 1.0 / sqrt(h0 * h0 + h1 * h1 + h2 * h2) : 1.0;
+    gi[0] = h0 * sc; gi[1] = h1 * sc; gi[2] = h2 * sc; bi = -h3 * sc;
+    return true;
+  };
+  double v[4];
+  const double depth = lp_ascent(row, g.H, v);
   g.depth[b] = depth;
   if (g.point) { g.point[b * 3] = v[0]; g.point[b * 3 + 1] = v[1]; g.point[b * 3 + 2] = v[2]; }
 }
@@ -475,9 +484,25 @@ __global__ void __launch_bounds__(256) k_firi_mvie_setup(FiriMvieArgs g) {
     sm[r * 4 + 3] = -h[3] / nrm;
   }
   __syncthreads();
-  double best, bx[3];
-  if (live) lp_deepest_point(sm, nH, tid, s_best, best, bx);
-  else { best = -INFINITY; bx[0] = bx[1] = bx[2] = 0.0; __syncthreads(); }
+  // deepest interior point: the certified ascent on one lane; the vertex enumeration only for what it leaves uncertified
+  double best = -INFINITY, bx[3] = {0.0, 0.0, 0.0};
+  if (live && tid == 0) {
+    auto row = [&](int i, double (&gi)[3], double &bi) -> bool {
+      gi[0] = sm[i * 4]; gi[1] = sm[i * 4 + 1]; gi[2] = sm[i * 4 + 2]; bi = sm[i * 4 + 3];
+      return true;
+    };
+    double v[4];
+    const double d = lp_ascent(row, nH, v);
+    s_best[0][0] = d; s_best[0][1] = v[0]; s_best[0][2] = v[1]; s_best[0][3] = v[2];
+  }
+  __syncthreads();
+  bool certified = false;
+  if (live) {
+    best = s_best[0][0]; bx[0] = s_best[0][1]; bx[1] = s_best[0][2]; bx[2] = s_best[0][3];
+    certified = !isnan(best);
+  }
+  __syncthreads();  // (s_best is reused by the enumeration)
+  if (live && !certified) lp_deepest_point(sm, nH, tid, s_best, best, bx);
   const bool okk = live && best > 0.0 && !isinf(best);
   const int64_t ld = g.ld;
   // MVIE rows about the interior point; zero rows beyond nH (and everywhere for skipped problems)
