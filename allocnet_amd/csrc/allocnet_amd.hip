@@ -1546,10 +1546,11 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     if (tol < 1e-10) tol = 1e-10;                 // (below that the slacks of the touched rows underflow the factorisation)
     // the backward pass differentiates the central path at the barrier parameter the solve stopped at: its error is
     // of that order, so it asks for three more digits (one or two Newton steps)
+    const double tol_plain = tol;
     if (grad_z && tol > 1e-9) tol = 1e-9;
     anet::IpmArgs ia{state, T, hpolys, work, work + mi * batch, coeffs, obj, status, iters,
                      residuals ? residuals : work + 2 * mi * batch, grad_T, grad_z, vjp_T, batch, n_pieces, res, M, max_vel,
-                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200};
+                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200, tol_plain > tol ? tol_plain : 0.0};
     hipStream_t sti = (hipStream_t)stream;
 #ifdef ANET_IPM_PROF
     static long long *d_iprof = nullptr;

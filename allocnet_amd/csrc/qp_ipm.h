@@ -38,6 +38,7 @@ struct IpmArgs {
   int N, R, M;
   double vmax, amax, m34, tol;
   int max_iter;
+  double tol_accept;  // >= tol: once met, at most 8 more Newton steps are spent on reaching tol (0: same as tol)
 #ifdef ANET_IPM_PROF
   long long *prof;  // [16] cycle counters of problem 0 (tools: ANET_BUILD_FLAGS=-DANET_IPM_PROF)
 #endif
@@ -454,7 +455,7 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     }
   };
 
-  int it = 0, status = -2;  // OSQP_MAX_ITER_REACHED unless decided below
+  int it = 0, status = -2, accepted_steps = 0;  // OSQP_MAX_ITER_REACHED unless decided below
   double pres = 0.0, dres = 0.0, mu = 0.0, mu0 = 0.0;
 #ifdef ANET_IPM_PROF
   long long prof_t_ = __builtin_readcyclecounter();
@@ -546,6 +547,11 @@ __global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
     const double objn = red[10];
     // (the duality gap is mu * rows: that, not mu, is what bounds the distance of the objective from the optimum)
     if (pres < a.tol && dres < a.tol && mu * mrows < a.tol * fmax(1.0, 0.5 * fabs(objn))) { status = 1; break; }
+    // The backward pass asks for three digits more than a plain solve; a few percent of the problems stall above that
+    // (and break down after ~150 more steps).  They are solved all the same: stop them a few steps after the accepted
+    // tolerance was met.
+    if (a.tol_accept > a.tol && pres < a.tol_accept && dres < a.tol_accept &&
+        mu * mrows < a.tol_accept * fmax(1.0, 0.5 * fabs(objn)) && ++accepted_steps > 8) { status = 1; break; }
     if (!(mu == mu) || mu > 1e12 * fmax(mu0, 1.0)) { status = -3; break; }  // diverging: no strictly feasible point
     __syncthreads();
     assemble_newton();
