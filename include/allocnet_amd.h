@@ -428,8 +428,9 @@ int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
                      int max_evals, double *cost, double *coeffs_out, int32_t *status, int32_t *iters,
                      int32_t *evals);
 /* Device variant: batch-minor device arrays, workspace from anet_lbfgs_minco_workspace() doubles.
- * status/iters/evals are device int32 arrays [batch].  Enqueues work on `stream` and synchronises it
- * every few evaluations to test for completion.                                                 */
+ * status/iters/evals are device int32 arrays [batch].  The one-launch shape only enqueues kernels on `stream` (no
+ * host-side test for completion, no allocation: it can be captured into a hipGraph); the lockstep shape synchronises
+ * the stream every few evaluations to test for completion.                                         */
 int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_lbfgs_params *params);
 int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                          const double *head, const double *tail, double *wps, double *T,

@@ -225,3 +225,43 @@ def test_device_entry_points_capture_into_a_hip_graph(anet_ctx):
     torch.cuda.synchronize()
     for got, want in zip((co, en, cost, gP, gT), ref):
         assert torch.equal(got[..., :B], want[..., :B])
+
+
+def test_one_launch_lbfgs_captures_into_a_hip_graph(anet_ctx):
+    """The one-launch L-BFGS (anet_lbfgs_minco_dev without ANET_OPT_LOCKSTEP) only enqueues kernels -- no host test for
+    completion, no allocation -- so a receding-horizon loop can capture "restore the initial guess, optimise" once and
+    replay it; every replay reproduces the eager run bit for bit."""
+    import torch
+    import allocnet_amd as aa
+    from tests.util import corridor_problem
+    dev = torch.device("cuda", 0)
+    s, c, N, M, B = 3, 3, 6, 8, 200
+    ld = aa.recommended_ld(B)
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(4), B, N, c, M)
+
+    def bm(x):
+        f = np.ascontiguousarray(x.reshape(B, -1).T)
+        t = torch.zeros(f.shape[0], ld, device=dev, dtype=torch.float64)
+        t[:, :B] = torch.from_numpy(f).to(dev)
+        return t
+    th, tt, tw0, tT0, thp = (bm(x) for x in (head, tail, wps, T, hp))
+    pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0,
+                          res=10, poly_rows=M)
+    tw, tT = tw0.clone(), tT0.clone()
+    eager = aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, max_evals=300, opt=3, ctx=anet_ctx)
+    torch.cuda.synchronize()
+    ref = {k: v.clone() for k, v in eager.items()}
+    ref_w, ref_T = tw.clone(), tT.clone()
+    cap_stream = torch.cuda.Stream(device=dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cap_stream):
+        tw.copy_(tw0); tT.copy_(tT0)
+        out = aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, max_evals=300, opt=3,
+                                 stream=torch.cuda.current_stream(dev).cuda_stream, ctx=anet_ctx)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.equal(tw[:, :B], ref_w[:, :B]) and torch.equal(tT[:, :B], ref_T[:, :B])
+    assert (ref["evals"] > 1).all()
