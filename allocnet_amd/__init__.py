@@ -12,7 +12,8 @@ from . import lbfgs  # noqa: F401
 from .lbfgs import (lbfgs_parameter_t, lbfgs_strerror, lbfgs_mvie, lbfgs_minco, lbfgs_minco_dev,  # noqa: F401
                     launch_order_from_counts)
 from . import qp  # noqa: F401
-from .qp import qp_assemble, qp_dims, qp_solve, qp_solve_vjp, qp_settings, QPSolver, QPConfig  # noqa: F401
+from .qp import (qp_assemble, qp_dims, qp_solve, qp_solve_vjp, qp_solve_dev, qp_solve_vjp_dev, qp_settings,  # noqa: F401
+                 QPSolver, QPConfig)
 from .min_traj_opt import MinTrajOpt, OsqpLayer  # noqa: F401
 from . import firi as _firi_mod  # noqa: F401
 from .firi import (firi, firi_dev, firi_params, convex_cover, polytope_depth, find_interior, overlap,  # noqa: F401

@@ -145,6 +145,69 @@ def qp_solve_vjp(order, iniPVA, finPVA, hPolys, times, grad_z, res=20, max_vel=4
     return dict(coeffs=coeffs, obj=obj, status=status, iters=iters, residuals=resid, grad_T=gT)
 
 
+def _qp_dev_common(order, state, times, hPolys, res, ctx):
+    import torch
+    if not (state.is_cuda and times.is_cuda and hPolys.is_cuda):
+        raise ValueError("CUDA tensors expected")
+    for t in (state, times, hPolys):
+        if t.dtype != torch.float64 or not t.is_contiguous():
+            raise ValueError("float64 contiguous tensors expected")
+    B, N, M, _ = hPolys.shape
+    if state.shape != (B, 2, 3, 3) or times.shape != (B, N):
+        raise ValueError("shape mismatch: state (B,2,3,3) [start PVA, end PVA; row = axis], times (B,N), hPolys (B,N,M,4)")
+    dev = times.device
+    D = 2 * order
+    work = torch.empty(int(ctx.lib.anet_qp_solve_workspace(int(order), N, B, int(res), M)), device=dev, dtype=torch.float64)
+    out = dict(coeffs=torch.empty((B, N, 3, D), device=dev, dtype=torch.float64), obj=torch.empty(B, device=dev, dtype=torch.float64),
+               status=torch.empty(B, device=dev, dtype=torch.int32), iters=torch.empty(B, device=dev, dtype=torch.int32),
+               residuals=torch.empty((B, 2), device=dev, dtype=torch.float64))
+    return B, N, M, work, out
+
+
+def qp_solve_dev(order, state, times, hPolys, res=20, max_vel=4.0, max_acc=6.0, m34=1400.0, settings=None, time_grad=False,
+                 stream=None, ctx=None):
+    """anet_qp_solve[_time_grad]_dev: the batched QPSolver::solve with torch CUDA tensors in and out, nothing through the
+    host, asynchronous on `stream` (default: torch's current stream).  state (B,2,3,3) = [start PVA, end PVA] (row = axis,
+    columns p, v, a), times (B,N), hPolys (B,N,M,4) rows a.x <= b with zero rows as padding.  Returns the dict of
+    `qp_solve` as device tensors (grad_T (B,N) with time_grad=True)."""
+    import torch
+    ctx = ctx or default_context(times.device.index or 0)
+    B, N, M, work, out = _qp_dev_common(order, state, times, hPolys, res, ctx)
+    st = stream if stream is not None else torch.cuda.current_stream(times.device).cuda_stream
+    sp = ctypes.cast(ctypes.pointer(settings), ctypes.c_void_p) if settings is not None else None
+    q = lambda t: ctypes.c_void_p(t.data_ptr())
+    args = (ctx.handle, int(order), N, B, int(res), M, float(max_vel), float(max_acc), float(m34), q(state), q(times), q(hPolys),
+            sp, q(work), q(out["coeffs"]), q(out["obj"]), q(out["status"]), q(out["iters"]), q(out["residuals"]))
+    if time_grad:
+        out["grad_T"] = torch.empty((B, N), device=times.device, dtype=torch.float64)
+        ctx.check(ctx.lib.anet_qp_solve_time_grad_dev(*args, q(out["grad_T"]), ctypes.c_void_p(st)))
+    else:
+        ctx.check(ctx.lib.anet_qp_solve_dev(*args, ctypes.c_void_p(st)))
+    out["_work"] = work
+    return out
+
+
+def qp_solve_vjp_dev(order, state, times, hPolys, grad_z, res=20, max_vel=4.0, max_acc=6.0, m34=1400.0, settings=None,
+                     stream=None, ctx=None):
+    """anet_qp_solve_vjp_dev: solve + backward pass on the device (what a torch.autograd.Function around the layer calls
+    in its backward): grad_z (B,N,3,2s) = d loss / d optimal coefficients -> grad_T (B,N).  Tensors as in `qp_solve_dev`."""
+    import torch
+    ctx = ctx or default_context(times.device.index or 0)
+    B, N, M, work, out = _qp_dev_common(order, state, times, hPolys, res, ctx)
+    if not (grad_z.is_cuda and grad_z.dtype == torch.float64 and grad_z.is_contiguous() and grad_z.shape == out["coeffs"].shape):
+        raise ValueError("grad_z: float64 contiguous CUDA tensor of shape (B,N,3,2s)")
+    st = stream if stream is not None else torch.cuda.current_stream(times.device).cuda_stream
+    sp = ctypes.cast(ctypes.pointer(settings), ctypes.c_void_p) if settings is not None else None
+    q = lambda t: ctypes.c_void_p(t.data_ptr())
+    out["grad_T"] = torch.empty((B, N), device=times.device, dtype=torch.float64)
+    ctx.check(ctx.lib.anet_qp_solve_vjp_dev(ctx.handle, int(order), N, B, int(res), M, float(max_vel), float(max_acc), float(m34),
+                                            q(state), q(times), q(hPolys), sp, q(grad_z), q(work), q(out["coeffs"]), q(out["obj"]),
+                                            q(out["status"]), q(out["iters"]), q(out["residuals"]), q(out["grad_T"]),
+                                            ctypes.c_void_p(st)))
+    out["_work"] = work
+    return out
+
+
 class QPConfig:
     """struct QPConfig (qp_solver.hpp:14-26) without the ros::NodeHandle: the three parameters it reads."""
 

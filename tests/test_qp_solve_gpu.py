@@ -485,3 +485,56 @@ def test_backward_pass_keeps_the_problems_the_plain_solve_solves(anet_ctx):
     # (the plain solve stops at 1e-6 in residuals and gap: its coefficients carry a few 1e-4 of their scale)
     assert np.abs(back["coeffs"] - plain["coeffs"])[both].max() <= 2e-3 * np.abs(plain["coeffs"])[both].max()
     assert np.isfinite(back["grad_T"][both]).all()
+
+
+def test_device_entry_points_and_the_torch_layer(anet_ctx):
+    """qp_solve_dev / qp_solve_vjp_dev (torch CUDA tensors, nothing through the host) reproduce the host-pointer calls, and
+    allocnet_amd.torch_layer.qp_layer -- the OsqpLayer of a torch training loop -- back-propagates a loss of the
+    coefficients AND of the optimal cost to the segment times: against central differences through re-solved QPs."""
+    import torch
+    import allocnet_amd as aa
+    from allocnet_amd.torch_layer import qp_layer
+    rng = np.random.default_rng(31)
+    s, N, M, res, B = 4, 4, 9, 8, 6
+    probs = [_corridor_problem(rng, N, M, margin=1.2) for _ in range(B)]
+    ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
+    hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs])
+    dev = torch.device("cuda", 0)
+    state = torch.from_numpy(np.ascontiguousarray(np.stack([ini, fin], axis=1))).to(dev)
+    thp = torch.from_numpy(np.ascontiguousarray(hp)).to(dev); tT = torch.from_numpy(T.copy()).to(dev)
+    kw = dict(res=res, max_vel=3.0, max_acc=4.0)
+    host = aa.qp_solve(s, ini, fin, hp, T, time_grad=True, ctx=anet_ctx, **kw)
+    devo = aa.qp_solve_dev(s, state, tT, thp, time_grad=True, ctx=anet_ctx, **kw)
+    torch.cuda.synchronize()
+    for k in ("status", "iters"):
+        assert np.array_equal(devo[k].cpu().numpy(), host[k]), k
+    for k in ("coeffs", "obj", "grad_T"):
+        assert np.allclose(devo[k].cpu().numpy(), host[k], rtol=1e-9, atol=1e-11), k
+    gz = rng.normal(size=host["coeffs"].shape)
+    hv = aa.qp_solve_vjp(s, ini, fin, hp, T, gz, ctx=anet_ctx, **kw)
+    dv = aa.qp_solve_vjp_dev(s, state, tT, thp, torch.from_numpy(gz).to(dev), ctx=anet_ctx, **kw)
+    # (the Newton assembly accumulates with LDS atomics: the last bits depend on their order)
+    assert np.allclose(dv["grad_T"].cpu().numpy(), hv["grad_T"], rtol=1e-8, atol=1e-10) and np.array_equal(dv["status"].cpu().numpy(), hv["status"])
+    # the layer
+    w = torch.from_numpy(rng.normal(size=host["coeffs"].shape[1:])).to(dev)
+
+    def loss_of(times):
+        co, obj, st = qp_layer(times, state, thp, order=s, ctx=anet_ctx, **kw)
+        return ((w * co).sum(dim=(1, 2, 3)) + 0.3 * obj), st
+    times = tT.clone().requires_grad_(True)
+    L, st = loss_of(times)
+    ok = (st == 1).cpu().numpy()
+    assert ok.sum() >= 4
+    L.sum().backward()
+    g = times.grad.cpu().numpy()
+    tight = aa.qp_settings(method=aa.qp.QP_METHOD_INTERIOR_POINT, eps_abs=1e-10, eps_rel=1e-10)
+
+    def loss_np(Tn):
+        r = aa.qp_solve(s, ini, fin, hp, Tn, settings=tight, ctx=anet_ctx, **kw)
+        return (w.cpu().numpy() * r["coeffs"]).sum(axis=(1, 2, 3)) + 0.3 * r["obj"]
+    d = rng.normal(size=T.shape) * T * 0.3
+    fd = (loss_np(T + 1e-5 * d) - loss_np(T - 1e-5 * d)) / 2e-5
+    an = (g * d).sum(axis=1)
+    sc = np.abs(g * d).sum(axis=1) + 1e-300
+    assert (np.abs(an - fd)[ok] <= 1e-3 * sc[ok]).all(), (np.abs(an - fd) / sc)[ok]
+    assert (g[~ok] == 0).all()
