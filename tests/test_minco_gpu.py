@@ -172,3 +172,43 @@ def test_wide_spread_solve_touches_only_wide_trajectories(anet_ctx):
     aa.minco.minco_solve_wide_spread_dev(th, tt, tw, tT, s, c, N, B, coeffs=co, energy=en, min_spread=0.0, ctx=anet_ctx)
     allc = co[:, :B].T.cpu().numpy().reshape(B, N, 3, 2 * s)
     assert np.abs(allc[keep] - fast[keep]).max() <= 1e-8 * np.abs(fast[keep]).max()
+
+
+@pytest.mark.parametrize("s,c,N", [(4, 3, 5), (3, 3, 4), (4, 4, 3)])
+def test_torch_minco_layer_gradients(anet_ctx, s, c, N):
+    """allocnet_amd.torch_layer.minco_layer: a loss of the coefficients AND the energy back-propagated to the waypoints and
+    durations (propogateGrad fed by torch) against central differences of the same loss through re-solved trajectories."""
+    import torch
+    import allocnet_amd as aa
+    from allocnet_amd.torch_layer import minco_layer
+    rng = np.random.default_rng(50 + s + N)
+    B = 7
+    head, tail, wps, T = random_problem(rng, B, N, c)
+    dev = torch.device("cuda", 0)
+    ld = aa.recommended_ld(B)
+
+    def bm(a):
+        f = np.ascontiguousarray(a.reshape(B, -1).T)
+        t = torch.zeros(f.shape[0], ld, device=dev, dtype=torch.float64)
+        t[:, :B] = torch.from_numpy(f).to(dev)
+        return t
+    th, tt, tw, tT = bm(head), bm(tail), bm(wps), bm(T)
+    tT[:, B:] = 1.0                                                       # (padding columns: any positive duration)
+    D = 2 * s
+    w = rng.normal(size=(N, 3, D))
+    wb = torch.zeros(N * 3 * D, ld, device=dev, dtype=torch.float64); wb[:, :B] = torch.from_numpy(np.tile(w.reshape(-1, 1), (1, B))).to(dev)
+    tw.requires_grad_(True); tT.requires_grad_(True)
+    co, en = minco_layer(tw, tT, th, tt, s, c, N, B, ctx=anet_ctx)
+    loss = (wb * co)[:, :B].sum() + 0.01 * en[:B].sum()
+    loss.backward()
+    gP = tw.grad[:, :B].cpu().numpy().T.reshape(B, N - 1, 3); gT = tT.grad[:, :B].cpu().numpy().T
+
+    def loss_np(wp_, T_):
+        cc, ee = aa.minco_solve(head, tail, wp_, T_, s, ctx=anet_ctx)
+        return (w[None] * cc).sum(axis=(1, 2, 3)) + 0.01 * ee
+    dP = rng.normal(size=wps.shape); dT = rng.normal(size=T.shape) * T * 0.2
+    h = 1e-6
+    fd = (loss_np(wps + h * dP, T + h * dT) - loss_np(wps - h * dP, T - h * dT)) / (2 * h)
+    an = (gP * dP).sum(axis=(1, 2)) + (gT * dT).sum(axis=1)
+    sc = np.abs(gP * dP).sum(axis=(1, 2)) + np.abs(gT * dT).sum(axis=1)
+    assert (np.abs(an - fd) <= 1e-6 * sc).all(), np.abs(an - fd) / sc
