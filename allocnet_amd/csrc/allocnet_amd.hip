@@ -1307,6 +1307,7 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
     if (pen) pa.pp = anet::Penalty{pen->rho, pen->w_corridor, pen->w_vel, pen->w_acc, pen->smooth_mu, pen->max_vel,
                                    pen->max_acc, pen->res, Mrows};
     else pa.pp = anet::Penalty{0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1, 0};
+    pa.inv_mu = 1.0 / pa.pp.mu; pa.inv_res = 1.0 / (double)pa.pp.res;
     pa.p = to_kernel_params(*params);
 #ifdef ANET_PERSIST_PROF
     static long long *d_prof = nullptr;

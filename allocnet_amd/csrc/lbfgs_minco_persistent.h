@@ -29,6 +29,7 @@ struct PersistArgs {
   int64_t B, ld;
   int N, c, nw, nt, M, max_evals, with_penalty;
   Penalty pp;
+  double inv_mu, inv_res;  // 1 / pp.mu, 1 / pp.res
   LbfgsP p;
 #ifdef ANET_PERSIST_PROF
   long long *prof;  // [16] cycle counters of problem 0 (tools/persist_prof.py)
@@ -813,9 +814,9 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
       if (i < N) {
         const Penalty pp = a.pp;
         const double Ti = Lm.T[i];
-        const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
+        const double inv_mu = a.inv_mu, inv_res = a.inv_res;  // (host-side reciprocals: an IEEE division is ~30 wave instructions)
         const double step = Ti * inv_res;
-        const double rT = 1.0 / Ti, rT2 = rT * rT, rT3 = rT2 * rT;
+        const double rT = Lm.r[i], rT2 = rT * rT, rT3 = rT2 * rT;  // (1 / T_i of E1)
         double ct[3][D];
         {
           double tk = 1.0;
