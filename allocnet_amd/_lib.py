@@ -99,6 +99,7 @@ PROTOTYPES = {
     "anet_lbfgs_minco_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anet_launch_order_from_counts_dev": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "anet_lbfgs_minco_ordered_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

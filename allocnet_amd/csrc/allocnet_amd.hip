@@ -370,6 +370,38 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
 }
 
 // status / iters / evals rows -> caller arrays (device or host destination)
+// Launch order for anet_lbfgs_minco_ordered_dev from the evaluation counts of a previous solve: a counting sort into 4096
+// buckets of 16 evaluations, longest first (the order inside a bucket is whatever the atomics make it: irrelevant here).
+constexpr int kOrderBuckets = 4096;
+__device__ __forceinline__ int order_bucket(int v) {
+  v = v < 0 ? 0 : (v > 65535 ? 65535 : v);
+  return kOrderBuckets - 1 - (v >> 4);  // descending
+}
+__global__ void k_order_hist(const int *counts, int64_t B, int *hist) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b < B) atomicAdd(&hist[order_bucket(counts[b])], 1);
+}
+__global__ void __launch_bounds__(1024) k_order_scan(int *hist) {  // exclusive scan of the 4096 bucket sizes, one workgroup
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  int v[4], sum = 0;
+  for (int q = 0; q < 4; ++q) { v[q] = hist[4 * t + q]; sum += v[q]; }
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int add = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+  for (int q = 0; q < 4; ++q) { hist[4 * t + q] = run; run += v[q]; }
+}
+__global__ void k_order_scatter(const int *counts, int64_t B, int *hist, int *order) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b < B) order[atomicAdd(&hist[order_bucket(counts[b])], 1)] = (int)b;
+}
+
 __global__ void k_lbfgs_results(const int *is, const double *ds, int64_t B, int64_t ld, int *status, int *iters,
                                 int *evals, double *f) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1239,6 +1271,22 @@ int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_l
   // L-BFGS state + cost/grad workspace + gradP + gradT
   return LbfgsLayout::doubles(n, params->mem_size, npf, ld) + anet_minco_cost_grad_workspace(s, n_pieces, ld) +
          (int64_t)n * ld;
+}
+
+int anet_launch_order_from_counts_dev(anet_ctx *ctx, int64_t batch, const int32_t *counts, int32_t *launch_order,
+                                      int32_t *work, void *stream) {
+  ANET_ON_DEVICE(ctx);
+  if (batch < 0 || batch > 0x7fffffff) return fail(ctx, ANET_ERR_INVALID, "anet_launch_order_from_counts: bad batch");
+  if (batch == 0) return ANET_OK;
+  if (!counts || !launch_order || !work) return fail(ctx, ANET_ERR_INVALID, "anet_launch_order_from_counts_dev: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)((batch + 255) / 256)), block(256);
+  ANET_HIP(ctx, hipMemsetAsync(work, 0, sizeof(int) * kOrderBuckets, st));
+  hipLaunchKernelGGL(k_order_hist, grid, block, 0, st, counts, batch, work);
+  hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, st, work);
+  hipLaunchKernelGGL(k_order_scatter, grid, block, 0, st, counts, batch, work, launch_order);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
 }
 
 int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,

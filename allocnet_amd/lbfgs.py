@@ -113,6 +113,22 @@ def launch_order_from_counts(evals):
     return torch.argsort(evals, descending=True, stable=True).to(torch.int32).contiguous()
 
 
+def launch_order_from_counts_dev(evals, stream=None, ctx=None):
+    """The same through the library's own counting sort (anet_launch_order_from_counts_dev: what a C / C++ caller uses;
+    buckets of 16 evaluations, order inside a bucket unspecified)."""
+    import torch
+    ctx = ctx or default_context(evals.device.index or 0)
+    if not (evals.is_cuda and evals.dtype == torch.int32 and evals.is_contiguous() and evals.dim() == 1):
+        raise ValueError("evals: contiguous int32 CUDA vector")
+    order = torch.empty_like(evals)
+    work = torch.empty(4096, device=evals.device, dtype=torch.int32)
+    st = stream if stream is not None else torch.cuda.current_stream(evals.device).cuda_stream
+    ctx.check(ctx.lib.anet_launch_order_from_counts_dev(ctx.handle, evals.numel(), ctypes.c_void_p(evals.data_ptr()),
+                                                        ctypes.c_void_p(order.data_ptr()), ctypes.c_void_p(work.data_ptr()),
+                                                        ctypes.c_void_p(st)))
+    return order
+
+
 def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, param=None,
                     opt=OPT_WAYPOINTS | OPT_TIMES, max_evals=2000, coeffs=None, stream=None, ctx=None, launch_order=None):
     """Device entry point -> anet_lbfgs_minco_[ordered_]dev.  torch CUDA float64 tensors, batch-minor, common row

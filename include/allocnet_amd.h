@@ -453,6 +453,12 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
                                  const int32_t *launch_order, double *work, double *cost, double *coeffs_out,
                                  int32_t *status, int32_t *iters, int32_t *evals, void *stream);
 
+/* launch_order for the call above from the evals[] of a previous solve of the same or a similar batch: longest first, in
+ * buckets of 16 evaluations (device arrays; work: ANET_LAUNCH_ORDER_WORK_INTS int32 of scratch; asynchronous on `stream`). */
+#define ANET_LAUNCH_ORDER_WORK_INTS 4096
+int anet_launch_order_from_counts_dev(anet_ctx *ctx, int64_t batch, const int32_t *counts, int32_t *launch_order,
+                                      int32_t *work, void *stream);
+
 /* ---- corridor generation: batched FIRI ------------------------------------ */
 /* firi::firi + firi::maxVolInsEllipsoid (gcopter/firi.hpp:159-416), the inner step of
  * sfc_gen::convexCover (gcopter/sfc_gen.hpp:116-186): for each corridor segment (a, b), obstacle points

@@ -415,7 +415,10 @@ def test_minco_lbfgs_launch_order_changes_nothing_but_the_schedule(anet_ctx):
     perm = torch.from_numpy(np.random.default_rng(1).permutation(B).astype(np.int32)).to(dev)
     by_count = aa.launch_order_from_counts(torch.from_numpy(ref["evals"]).to(dev))
     assert sorted(by_count.cpu().tolist()) == list(range(B)) and ref["evals"][by_count.cpu().numpy()[0]] == ref["evals"].max()
-    for order in (perm, by_count):
+    lib_order = aa.lbfgs.launch_order_from_counts_dev(torch.from_numpy(ref["evals"]).to(dev), ctx=anet_ctx)
+    lo = lib_order.cpu().numpy()
+    assert sorted(lo.tolist()) == list(range(B)) and (np.diff(ref["evals"][lo] >> 4) <= 0).all()      # longest first, 16 per bucket
+    for order in (perm, by_count, lib_order):
         got, w1, T1 = run(order)
         for k in ref:
             assert np.array_equal(ref[k], got[k]), k
