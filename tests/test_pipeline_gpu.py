@@ -124,3 +124,14 @@ def test_route_to_corridor_to_minco_lbfgs(anet_ctx):
             worst = max(worst, float((hp[0, i, :k, :3] @ p - hp[0, i, :k, 3]).max()))
         t0 += res["T"][0, i]
     assert worst <= 0.05, worst                                                  # soft constraint: centimetres, not metres
+
+
+def test_example_script_runs():
+    """examples/plan_once.py (the reference's online flow, README) exits 0 and reports a solved QP."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "examples", "plan_once.py")], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "solved True" in res.stdout and "trajectory:" in res.stdout
