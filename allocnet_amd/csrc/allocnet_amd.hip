@@ -1616,7 +1616,15 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
       }
     } prof_dump{ctx, d_iprof, sti};
 #endif
-    if (s == 4) {
+    // snap: two workgroups per CU (registers bounded to 256) from this batch on, when two fit the LDS
+    static const int64_t ipm_two_per_cu_min_batch = [] {
+      const char *e = getenv("ANET_IPM_TWO_PER_CU_MIN_BATCH");
+      return e ? (int64_t)atoll(e) : (int64_t)1024;
+    }();
+    if (s == 4 && batch >= ipm_two_per_cu_min_batch && 2 * ldsb <= 160 * 1024) {
+      ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_ipm<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      hipLaunchKernelGGL((anet::k_qp_ipm<4, 2>), dim3((unsigned)batch), dim3(256), ldsb, sti, ia);
+    } else if (s == 4) {
       ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_ipm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
       hipLaunchKernelGGL((anet::k_qp_ipm<4>), dim3((unsigned)batch), dim3(256), ldsb, sti, ia);
     } else {

@@ -65,8 +65,11 @@ inline size_t qp_ipm_lds_bytes(int N, int R, int M) {
                            (size_t)R * 3 * D + 2 * D * D + (size_t)N * D + NS * 30 + (size_t)N * M * 4 + 2 * N + 32);
 }
 
-template <int S>
-__global__ void __launch_bounds__(256) k_qp_ipm(IpmArgs a) {
+// MINB: workgroups per CU the register allocation is bounded for.  The snap kernel needs more than 256 registers to run
+// without spills (one workgroup per CU); bounded to 256 (92 B of scratch) two share a CU, which pays for large batches
+// (4096 x 8 pieces 24.7 -> 18.8 ms) and costs a single problem a quarter of its latency (0.82 -> 1.02 ms): the host picks.
+template <int S, int MINB = 1>
+__global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   constexpr int D = 2 * S, NB = 3 * D, BK = 3 * S;
   const int N = a.N, R = a.R, M = a.M;
   const int NS = N * R, RPS = M + 12;
