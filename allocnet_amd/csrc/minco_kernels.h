@@ -230,8 +230,11 @@ __device__ __forceinline__ double pair_sum(double v) {  // v + the value of the 
 // (trajectory, piece) pairs -- the sample index stays wave-uniform, so the basis table is still read with scalar
 // loads -- and their partial gradients are summed through LDS by wave 0.  A quarter of the dependent chain per lane
 // and four times the waves: at 4096 x 8 pieces the two-lane variant leaves one wave per SIMD.
+#ifndef ANET_PG_MINB
+#define ANET_PG_MINB 2
+#endif
 template <int S, bool SPLIT = false, int SW = 1>
-__global__ void __launch_bounds__(256, SW > 1 ? 1 : 2) k_piece_grad(PieceGradArgs a, const double *__restrict__ tab) {
+__global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(PieceGradArgs a, const double *__restrict__ tab) {
   constexpr int D = 2 * S;
   static_assert(SW == 1 || SPLIT, "the sample split builds on the two-lane variant");
   const int wv = SW > 1 ? (int)(threadIdx.x >> 6) : 0;  // which samples: j = wv, wv + SW, ...
