@@ -81,6 +81,8 @@ PROTOTYPES = {
     "anet_polytope_depth_dev": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "anet_firi_default_params": (None, [c_void_p]),
     "anet_firi": (c_int, [c_void_p, c_int64, c_int, c_int, c_int] + [c_void_p] * 10),
+    "anet_firi_var": (c_int, [c_void_p, c_int64, c_int, c_int, c_int] + [c_void_p] * 11),
+    "anet_firi_var_dev": (c_int, [c_void_p, c_int64, c_int, c_int, c_int] + [c_void_p] * 13),
     "anet_firi_workspace": (c_int64, [c_int64, c_int, c_int]),
     "anet_firi_dev": (c_int, [c_void_p, c_int64, c_int, c_int, c_int] + [c_void_p] * 12),
     "anet_comm_unique_id": (c_int, [c_void_p, c_void_p]),

@@ -1113,6 +1113,14 @@ int anet_firi_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int ma
                   const double *pc, const int32_t *n_points, const double *a, const double *b,
                   const anet_firi_params *params, double *work, double *hpoly, int32_t *n_rows, int32_t *ok,
                   double *ellipsoid, void *stream) {
+  return anet_firi_var_dev(ctx, batch, n_bd, max_points, max_rows, bd, pc, n_points, a, b, nullptr, params, work, hpoly, n_rows,
+                           ok, ellipsoid, stream);
+}
+
+int anet_firi_var_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
+                      const double *pc, const int32_t *n_points, const double *a, const double *b,
+                      const int32_t *iterations, const anet_firi_params *params, double *work, double *hpoly,
+                      int32_t *n_rows, int32_t *ok, double *ellipsoid, void *stream) {
   ANET_ON_DEVICE(ctx);
   anet_firi_params P;
   anet_firi_default_params(&P);
@@ -1153,7 +1161,9 @@ int anet_firi_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int ma
   // wave-per-problem layout of the internal vectors (element i of problem b at [i + b*n]), no "still running" counter
   anet::LbfgsArgs la{L.n, batch, L.ld, L.x, L.g, L.xp, L.gp, L.d, L.lm_s, L.lm_y, L.lm_ys, L.lm_alpha, L.pf, L.ds,
                      L.feval, L.is, to_kernel_params(lp), nullptr, 1, L.n, nullptr, 0};
+  fa.iters = iterations; ma.iters = iterations;
   for (int loop = 0; loop < P.iterations; ++loop) {
+    fa.pass = loop; ma.pass = loop;
     hipLaunchKernelGGL(anet::k_firi_planes, gB, b256, 0, st, fa);
     ANET_HIP(ctx, hipGetLastError());
     if (loop == P.iterations - 1) break;
@@ -1185,6 +1195,12 @@ int anet_firi_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int ma
 int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
               const double *pc, const int32_t *n_points, const double *a, const double *b,
               const anet_firi_params *params, double *hpoly, int32_t *n_rows, int32_t *ok, double *ellipsoid) {
+  return anet_firi_var(ctx, batch, n_bd, max_points, max_rows, bd, pc, n_points, a, b, nullptr, params, hpoly, n_rows, ok, ellipsoid);
+}
+
+int anet_firi_var(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
+                  const double *pc, const int32_t *n_points, const double *a, const double *b, const int32_t *iterations,
+                  const anet_firi_params *params, double *hpoly, int32_t *n_rows, int32_t *ok, double *ellipsoid) {
   if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
   anet_firi_params P;
   anet_firi_default_params(&P);
@@ -1199,12 +1215,13 @@ int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_ro
   const size_t n_bdv = (size_t)batch * n_bd * 4, n_pc = (size_t)batch * Np * 3, n_ab = (size_t)batch * 3;
   const size_t n_hp = (size_t)batch * H * 4, n_ell = (size_t)batch * 15;
   const size_t n_work = (size_t)anet_firi_workspace(batch, max_points, max_rows);
-  rc = ensure_scratch(ctx, sizeof(double) * (n_bdv + n_pc + 2 * n_ab + n_hp + n_ell + n_work + (size_t)(3 * batch) / 2 + 16));
+  rc = ensure_scratch(ctx, sizeof(double) * (n_bdv + n_pc + 2 * n_ab + n_hp + n_ell + n_work + (size_t)(4 * batch) / 2 + 16));
   if (rc) return rc;
   double *d_bd = (double *)ctx->scratch, *d_pc = d_bd + n_bdv, *d_a = d_pc + n_pc, *d_b = d_a + n_ab, *d_hp = d_b + n_ab;
   double *d_el = d_hp + n_hp, *d_work = d_el + n_ell;
-  int *d_np = (int *)(d_work + n_work), *d_nh = d_np + batch, *d_ok = d_nh + batch;
+  int *d_np = (int *)(d_work + n_work), *d_nh = d_np + batch, *d_ok = d_nh + batch, *d_it = d_ok + batch;
   hipStream_t st = ctx->stream;
+  if (iterations) ANET_HIP(ctx, hipMemcpyAsync(d_it, iterations, sizeof(int) * batch, hipMemcpyHostToDevice, st));
   ANET_HIP(ctx, hipMemcpyAsync(d_bd, bd, sizeof(double) * n_bdv, hipMemcpyHostToDevice, st));
   if (max_points > 0) {
     ANET_HIP(ctx, hipMemcpyAsync(d_pc, pc, sizeof(double) * n_pc, hipMemcpyHostToDevice, st));
@@ -1212,8 +1229,8 @@ int anet_firi(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_ro
   }
   ANET_HIP(ctx, hipMemcpyAsync(d_a, a, sizeof(double) * n_ab, hipMemcpyHostToDevice, st));
   ANET_HIP(ctx, hipMemcpyAsync(d_b, b, sizeof(double) * n_ab, hipMemcpyHostToDevice, st));
-  rc = anet_firi_dev(ctx, batch, n_bd, max_points, max_rows, d_bd, d_pc, d_np, d_a, d_b, &P, d_work, d_hp, d_nh, d_ok,
-                     ellipsoid ? d_el : nullptr, st);
+  rc = anet_firi_var_dev(ctx, batch, n_bd, max_points, max_rows, d_bd, d_pc, d_np, d_a, d_b, iterations ? d_it : nullptr, &P,
+                         d_work, d_hp, d_nh, d_ok, ellipsoid ? d_el : nullptr, st);
   if (rc) return rc;
   ANET_HIP(ctx, hipMemcpyAsync(hpoly, d_hp, sizeof(double) * n_hp, hipMemcpyDeviceToHost, st));
   ANET_HIP(ctx, hipMemcpyAsync(n_rows, d_nh, sizeof(int) * batch, hipMemcpyDeviceToHost, st));

@@ -25,9 +25,10 @@ def firi_params(**over):
     return p
 
 
-def firi(bd, pc, a, b, n_points=None, max_rows=64, params=None, ctx=None):
+def firi(bd, pc, a, b, n_points=None, max_rows=64, params=None, ctx=None, iterations=None):
     """Batched firi::firi.  bd (B,Mb,4); pc (B,Np,3) with n_points (B,) valid points each (default: all);
-    a, b (B,3).  Returns dict(hpoly (B,max_rows,4) zero-padded, n_rows (B,), ok (B,), ellipsoid (B,15))."""
+    a, b (B,3).  iterations: optional (B,) int32 pass count per corridor (anet_firi_var; default: params.iterations for
+    all).  Returns dict(hpoly (B,max_rows,4) zero-padded, n_rows (B,), ok (B,), ellipsoid (B,15))."""
     ctx = ctx or default_context()
     bd = np.ascontiguousarray(bd, dtype=np.float64)
     a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
@@ -40,8 +41,14 @@ def firi(bd, pc, a, b, n_points=None, max_rows=64, params=None, ctx=None):
     hp = np.zeros((B, max_rows, 4)); nh = np.zeros(B, dtype=np.int32); ok = np.zeros(B, dtype=np.int32)
     ell = np.zeros((B, 15))
     pp = ctypes.cast(ctypes.pointer(params), ctypes.c_void_p) if params is not None else None
-    ctx.check(ctx.lib.anet_firi(ctx.handle, B, Mb, Np, int(max_rows), _p(bd), _p(pc) if Np else None,
-                                _p(npts) if Np else None, _p(a), _p(b), pp, _p(hp), _p(nh), _p(ok), _p(ell)))
+    its = None
+    if iterations is not None:
+        its = np.ascontiguousarray(iterations, dtype=np.int32)
+        if its.shape != (B,) or (its < 1).any():
+            raise ValueError("iterations: (B,) pass counts >= 1")
+    ctx.check(ctx.lib.anet_firi_var(ctx.handle, B, Mb, Np, int(max_rows), _p(bd), _p(pc) if Np else None,
+                                    _p(npts) if Np else None, _p(a), _p(b), _p(its) if its is not None else None, pp,
+                                    _p(hp), _p(nh), _p(ok), _p(ell)))
     return dict(hpoly=hp, n_rows=nh, ok=ok, ellipsoid=ell)
 
 
@@ -142,20 +149,20 @@ def convex_cover(path, points, low_corner, high_corner, progress, rng_range, eps
     for k, s in enumerate(sel):
         pc[k, :len(s)] = s; npts[k] = len(s)
     A = np.array([s[0] for s in segs]); Bv = np.array([s[1] for s in segs])
-    main = firi(bd, pc, A, Bv, n_points=npts, max_rows=max_rows, ctx=ctx)
-    polys = [main["hpoly"][k, :main["n_rows"][k]] for k in range(B)]
-    # gap polytopes (sfc_gen.hpp:171-179): decided from consecutive results, built in one more batch
-    need = []
+    # One batch: the B segments with the default pass count and, speculatively, the B - 1 gap polytopes of
+    # sfc_gen.hpp:171-179 (firi::firi(bd, pc, a, a, gap, 1): ONE pass, so only a planes kernel each) -- whether a gap
+    # polytope is needed depends on the segments' results, but computing all of them costs less than a second call.
+    jn = list(range(1, B))
+    allr = firi(np.concatenate([bd, bd[jn]]), np.concatenate([pc, pc[jn]]), np.concatenate([A, A[jn]]),
+                np.concatenate([Bv, A[jn]]), n_points=np.concatenate([npts, npts[jn]]), max_rows=max_rows,
+                iterations=np.r_[np.full(B, firi_params().iterations, dtype=np.int32), np.ones(B - 1, dtype=np.int32)], ctx=ctx)
+    polys = [allr["hpoly"][k, :allr["n_rows"][k]] for k in range(B)]
+    gaps = {}
     for k in range(1, B):
         ah = np.r_[segs[k][0], 1.0]
         if 3 <= int((polys[k] @ ah > -eps).sum()) + int((polys[k - 1] @ ah > -eps).sum()):
-            need.append(k)
-    gaps = {}
-    if need:
-        g = firi(bd[need], pc[need], A[need], A[need], n_points=npts[need], max_rows=max_rows,
-                 params=firi_params(iterations=1), ctx=ctx)
-        for q, k in enumerate(need):
-            gaps[k] = g["hpoly"][q, :g["n_rows"][q]]
+            q = B + k - 1
+            gaps[k] = allr["hpoly"][q, :allr["n_rows"][q]]
     out = []
     for k in range(B):
         if k in gaps:

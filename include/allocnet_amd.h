@@ -496,6 +496,18 @@ int anet_firi_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int ma
                   const anet_firi_params *params, double *work, double *hpoly, int32_t *n_rows, int32_t *ok,
                   double *ellipsoid, void *stream);
 
+/* The same with a pass count per corridor: iterations[b] (1 .. params->iterations; NULL: params->iterations for all) -- a
+ * corridor keeps the polytope of its last pass and sits out the rest.  sfc_gen::convexCover (sfc_gen.hpp:163, 176) calls
+ * firi::firi with 4 passes for a segment and with 1 for a gap polytope: with this entry point both kinds go in ONE batch. */
+int anet_firi_var(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
+                  const double *pc, const int32_t *n_points, const double *a, const double *b,
+                  const int32_t *iterations /* [batch] or NULL */, const anet_firi_params *params, double *hpoly,
+                  int32_t *n_rows, int32_t *ok, double *ellipsoid);
+int anet_firi_var_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
+                      const double *pc, const int32_t *n_points, const double *a, const double *b,
+                      const int32_t *iterations, const anet_firi_params *params, double *work, double *hpoly,
+                      int32_t *n_rows, int32_t *ok, double *ellipsoid, void *stream);
+
 /* ---- multi-GPU: all-gather of the per-trajectory costs over RCCL / xGMI --------------------------- */
 /* Trajectories are independent, so a batch shards contiguously across GPUs (one process and one
  * context per GPU) with no collective inside a solve; the only exchange the path has is this

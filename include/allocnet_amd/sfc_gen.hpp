@@ -70,43 +70,43 @@ inline void convexCover(const std::vector<V3> &path, const std::vector<V3> &poin
     for (size_t j = 0; j < sel[k].size(); ++j) pc[(size_t)k * Np * 3 + j] = sel[k][j];
   }
   anet::Context &ctx = anet::Context::thread_default();
-  // one batched firi::firi over `which` segments (b = a when `gap`); grows the row capacity on demand
-  auto run = [&](const std::vector<int> &which, bool gap, std::vector<std::vector<double>> &out) {
-    const int Bn = (int)which.size();
-    std::vector<double> sbd((size_t)Bn * 24), spc((size_t)Bn * Np * 3), sa((size_t)Bn * 3), sb((size_t)Bn * 3);
-    std::vector<int32_t> sn(Bn), nh(Bn), ok(Bn);
-    for (int q = 0; q < Bn; ++q) {
-      const int k = which[q];
-      std::copy(bd.begin() + (size_t)k * 24, bd.begin() + (size_t)(k + 1) * 24, sbd.begin() + (size_t)q * 24);
-      std::copy(pc.begin() + (size_t)k * Np * 3, pc.begin() + (size_t)(k + 1) * Np * 3, spc.begin() + (size_t)q * Np * 3);
-      sn[q] = npts[k];
-      for (int c = 0; c < 3; ++c) {
-        sa[(size_t)q * 3 + c] = A[(size_t)k * 3 + c];
-        sb[(size_t)q * 3 + c] = gap ? A[(size_t)k * 3 + c] : Bv[(size_t)k * 3 + c];
-      }
+  // ONE batch (anet_firi_var): the S segments with firi::firi's default pass count and, speculatively, the S - 1 gap
+  // polytopes firi::firi(bd, pc, a, a, gap, 1) of sfc_gen.hpp:171-179 -- one pass each, i.e. one planes kernel; whether a
+  // gap polytope is used depends on the segments' results, but computing all of them costs less than a second call.
+  const int Bn = 2 * S - 1;
+  std::vector<double> sbd((size_t)Bn * 24), spc((size_t)Bn * Np * 3), sa((size_t)Bn * 3), sb((size_t)Bn * 3);
+  std::vector<int32_t> sn(Bn), its(Bn), nh(Bn), ok(Bn);
+  anet_firi_params prm;
+  anet_firi_default_params(&prm);
+  for (int q = 0; q < Bn; ++q) {
+    const bool gap = q >= S;
+    const int k = gap ? q - S + 1 : q;
+    std::copy(bd.begin() + (size_t)k * 24, bd.begin() + (size_t)(k + 1) * 24, sbd.begin() + (size_t)q * 24);
+    std::copy(pc.begin() + (size_t)k * Np * 3, pc.begin() + (size_t)(k + 1) * Np * 3, spc.begin() + (size_t)q * Np * 3);
+    sn[q] = npts[k];
+    its[q] = gap ? 1 : prm.iterations;
+    for (int c = 0; c < 3; ++c) {
+      sa[(size_t)q * 3 + c] = A[(size_t)k * 3 + c];
+      sb[(size_t)q * 3 + c] = gap ? A[(size_t)k * 3 + c] : Bv[(size_t)k * 3 + c];
     }
-    anet_firi_params prm;
-    anet_firi_default_params(&prm);
-    if (gap) prm.iterations = 1;  // sfc_gen.hpp:176
-    int cap = 64;
-    std::vector<double> hp;
-    for (;;) {
-      hp.assign((size_t)Bn * cap * 4, 0.0);
-      ctx.check(anet_firi(ctx.get(), Bn, 6, (int)Np, cap, sbd.data(), spc.data(), sn.data(), sa.data(), sb.data(), &prm,
-                          hp.data(), nh.data(), ok.data(), nullptr));
-      bool overflow = false;
-      for (int q = 0; q < Bn; ++q) overflow |= ok[q] == -1;
-      if (!overflow || cap >= 6 + (int)Np) break;
-      cap = cap * 4 < 6 + (int)Np ? cap * 4 : 6 + (int)Np;
-    }
-    out.assign(Bn, std::vector<double>());
-    for (int q = 0; q < Bn; ++q)
-      if (ok[q] >= 1) out[q].assign(hp.begin() + (size_t)q * cap * 4, hp.begin() + ((size_t)q * cap + nh[q]) * 4);
+  }
+  int cap = 64;
+  std::vector<double> hp;
+  for (;;) {  // the reference's hPoly can have up to 6 + Np rows; grow on demand
+    hp.assign((size_t)Bn * cap * 4, 0.0);
+    ctx.check(anet_firi_var(ctx.get(), Bn, 6, (int)Np, cap, sbd.data(), spc.data(), sn.data(), sa.data(), sb.data(), its.data(),
+                            &prm, hp.data(), nh.data(), ok.data(), nullptr));
+    bool overflow = false;
+    for (int q = 0; q < Bn; ++q) overflow |= ok[q] == -1;
+    if (!overflow || cap >= 6 + (int)Np) break;
+    cap = cap * 4 < 6 + (int)Np ? cap * 4 : 6 + (int)Np;
+  }
+  auto poly_of = [&](int q) {
+    return ok[q] >= 1 ? std::vector<double>(hp.begin() + (size_t)q * cap * 4, hp.begin() + ((size_t)q * cap + nh[q]) * 4)
+                      : std::vector<double>();
   };
-  std::vector<int> all(S);
-  for (int k = 0; k < S; ++k) all[k] = k;
-  std::vector<std::vector<double>> mainp, gapp;
-  run(all, false, mainp);
+  std::vector<std::vector<double>> mainp(S), gapp;
+  for (int k = 0; k < S; ++k) mainp[k] = poly_of(k);
   // gap polytopes (sfc_gen.hpp:167-179): where the junction point touches 3 or more faces of the two neighbours
   auto touching = [&](const std::vector<double> &h, const double *a) {
     int cnt = 0;
@@ -115,8 +115,10 @@ inline void convexCover(const std::vector<V3> &path, const std::vector<V3> &poin
   };
   std::vector<int> need;
   for (int k = 1; k < S; ++k)
-    if (3 <= touching(mainp[k], &A[(size_t)k * 3]) + touching(mainp[k - 1], &A[(size_t)k * 3])) need.push_back(k);
-  if (!need.empty()) run(need, true, gapp);
+    if (3 <= touching(mainp[k], &A[(size_t)k * 3]) + touching(mainp[k - 1], &A[(size_t)k * 3])) {
+      need.push_back(k);
+      gapp.push_back(poly_of(S + k - 1));
+    }
   auto emit = [&](const std::vector<double> &h) {
     Poly P;
     const int m = (int)(h.size() / 4);

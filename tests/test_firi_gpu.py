@@ -283,3 +283,23 @@ def test_polytope_depth_ascent_enumeration_and_highs_agree_on_generated_polytope
     half_space = np.array([[1.0, 0.0, 0.0, -1.0], [0.0, 1.0, 0.0, -1.0]])
     d, _ = aa.polytope_depth([half_space], ctx=anet_ctx)
     assert np.isposinf(d[0]) and not aa.find_interior(half_space, ctx=anet_ctx)[0] and not aa.overlap(half_space, half_space, ctx=anet_ctx)
+
+
+def test_pass_count_per_corridor_equals_separate_calls(anet_ctx):
+    """anet_firi_var: corridors with their own pass count in one batch (what convexCover needs: 4 passes for a segment,
+    1 for a gap polytope) give exactly what separate calls with a common count give."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(23)
+    cases = [make_case(rng, n) for n in (60, 200, 400, 120, 300, 80)]
+    bd, pc, npts, a, b = pack(cases)
+    its = np.array([4, 1, 2, 1, 4, 3], dtype=np.int32)
+    mixed = aa.firi(bd, pc, a, b, n_points=npts, max_rows=96, iterations=its, ctx=anet_ctx)
+    assert (mixed["ok"] >= 1).all()
+    for k in sorted(set(its.tolist())):
+        sel = np.where(its == k)[0]
+        sep = aa.firi(bd[sel], pc[sel], a[sel], b[sel], n_points=npts[sel], max_rows=96, params=aa.firi_params(iterations=int(k)),
+                      ctx=anet_ctx)
+        assert np.array_equal(sep["n_rows"], mixed["n_rows"][sel]), k
+        assert np.array_equal(sep["hpoly"], mixed["hpoly"][sel]), k
+    with pytest.raises(ValueError):
+        aa.firi(bd, pc, a, b, n_points=npts, iterations=np.zeros(6, dtype=np.int32), ctx=anet_ctx)
