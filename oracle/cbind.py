@@ -13,7 +13,7 @@ _cpu_lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("minco_oracle.c", "lbfgs_oracle.c", "minco_cpu_reduced.cpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("minco_oracle.c", "lbfgs_oracle.c", "minco_costgrad.c", "minco_cpu_reduced.cpp")]
     srcs += [os.path.join(os.path.dirname(_HERE), "allocnet_amd", "csrc", f) for f in ("minco_core.h", "minco_tables.h")]
     outs = (_PATH, _CPU_PATH)
     if force or not all(os.path.exists(o) for o in outs) or any(os.path.getmtime(o) < os.path.getmtime(s) for o in outs for s in srcs):
@@ -63,8 +63,60 @@ def lib():
                                         ctypes.POINTER(LbfgsParam), c_void_p, c_void_p]
         L.oracle_cost_mvie.restype = c_double
         L.oracle_cost_mvie.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
+        L.oracle_minco_cost_grad_batch.restype = c_int
+        L.oracle_minco_cost_grad_batch.argtypes = [c_int, c_int, c_int, c_int64] + [c_void_p] * 5 + \
+            [ctypes.POINTER(Penalty)] + [c_void_p] * 3 + [c_int]
+        L.oracle_lbfgs_minco_batch.restype = c_int
+        L.oracle_lbfgs_minco_batch.argtypes = [c_int, c_int, c_int, c_int64] + [c_void_p] * 5 + \
+            [ctypes.POINTER(Penalty), ctypes.POINTER(LbfgsParam)] + [c_void_p] * 4 + [c_int]
         _lib = L
     return _lib
+
+
+class Penalty(ctypes.Structure):
+    """oracle_penalty (oracle/minco_costgrad.c): weights of the penalty functional on the reference's inequality rows."""
+    _fields_ = [("rho", c_double), ("wc", c_double), ("wv", c_double), ("wa", c_double), ("mu", c_double),
+                ("vmax", c_double), ("amax", c_double), ("res", c_int), ("M", c_int)]
+
+
+def _cg_args(head, tail, wps, T, hpolys, copy=False):
+    head = np.ascontiguousarray(head, dtype=np.float64)
+    tail = np.ascontiguousarray(tail, dtype=np.float64)
+    B, _, c = head.shape
+    T = np.array(T, dtype=np.float64, copy=True) if copy else np.ascontiguousarray(T, dtype=np.float64)
+    N = T.shape[1]
+    wps = np.zeros((B, 0, 3)) if N == 1 else wps
+    wps = np.array(wps, dtype=np.float64, copy=True) if copy else np.ascontiguousarray(wps, dtype=np.float64)
+    hpolys = None if hpolys is None else np.ascontiguousarray(hpolys, dtype=np.float64)
+    return head, tail, wps, T, hpolys, B, c, N
+
+
+def minco_cost_grad_batch(s, head, tail, wps, T, hpolys, rho, res, vmax, amax, wc, wv, wa, mu, nthreads=1):
+    """Classic banded-LU MINCO cost + analytic gradient (oracle/minco_costgrad.c).  head/tail (B,3,c), wps (B,N-1,3),
+    T (B,N), hpolys (B,N,M,4) or None.  Returns cost (B,), gradP (B,N-1,3), gradT (B,N)."""
+    head, tail, wps, T, hpolys, B, c, N = _cg_args(head, tail, wps, T, hpolys)
+    pen = Penalty(rho, wc, wv, wa, mu, vmax, amax, res, 0 if hpolys is None else hpolys.shape[2])
+    cost = np.empty(B); gP = np.empty((B, N - 1, 3)); gT = np.empty((B, N))
+    rc = lib().oracle_minco_cost_grad_batch(s, c, N, B, _p(head), _p(tail), _p(wps), _p(T), _p(hpolys), ctypes.byref(pen),
+                                            _p(cost), _p(gP), _p(gT), nthreads)
+    if rc:
+        raise RuntimeError(f"oracle_minco_cost_grad_batch failed: {rc}")
+    return cost, gP, gT
+
+
+def lbfgs_minco_batch(s, head, tail, wps, T, hpolys, rho, res, vmax, amax, wc, wv, wa, mu, param=None, nthreads=1):
+    """oracle_lbfgs_optimize (lbfgs.hpp:434-717 restated) on the cost above in the variables [waypoints, tau],
+    T = forward_T(tau); one problem per task.  Returns dict(wps, T, cost, status, iters, evals)."""
+    head, tail, wps, T, hpolys, B, c, N = _cg_args(head, tail, wps, T, hpolys, copy=True)
+    pen = Penalty(rho, wc, wv, wa, mu, vmax, amax, res, 0 if hpolys is None else hpolys.shape[2])
+    param = param or lbfgs_default_param()
+    cost = np.empty(B)
+    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); evals = np.empty(B, dtype=np.int32)
+    rc = lib().oracle_lbfgs_minco_batch(s, c, N, B, _p(head), _p(tail), _p(wps), _p(T), _p(hpolys), ctypes.byref(pen),
+                                        ctypes.byref(param), _p(cost), _p(status), _p(iters), _p(evals), nthreads)
+    if rc:
+        raise RuntimeError(f"oracle_lbfgs_minco_batch failed: {rc}")
+    return dict(wps=wps, T=T, cost=cost, status=status, iters=iters, evals=evals)
 
 
 class LbfgsParam(ctypes.Structure):
