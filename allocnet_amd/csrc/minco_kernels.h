@@ -270,7 +270,8 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(P
     //  * no jerk and no per-sample d/dt: the sample times t_j = tau_j T move with T, and since
     //    tau tab[j][d+1][col] = (k-d) tab[j][d][col] the sum over the samples of step tau_j (g_p.v + g_v.a + g_a.j)
     //    is  (1/T) sum_col c~[col] k gN[col] - Rs,  gN the gradient w.r.t. c~ that is accumulated anyway and Rs the
-    //    scalar sum_j (s1.v + 2 T s2.a) over the samples with a violated box row (s1, s2: their weights in gN).
+    //    scalar sum_j (s1.v + 2 T s2.a) over the samples with a violated box row (s1, s2: their weights in gN);
+    //    with v = a1 / T, a = a2 / T^2 that is (1/T) (sum s1 a1 + 2 sum s2 a2): two accumulators, scaled once.
     const Penalty pp = a.pp;
     const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
     const double step = Ti * inv_res;
@@ -291,7 +292,9 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(P
     for (int ax = 0; ax < 3; ++ax)
 #pragma unroll
       for (int col = 0; col < D; ++col) gN[ax][col] = 0.0;
-    double csum = 0.0, Rs = 0.0;  // sum of the sample costs; see above
+    double csum = 0.0, Rs1 = 0.0, Rs2 = 0.0;  // sum of the sample costs; Rs = (Rs1 + 2 Rs2) / T, see above
+    const double kv = rT * inv_mu, ka = rT2 * inv_mu, cv = pp.vmax * inv_mu, ca = pp.amax * inv_mu;
+    const double K1 = step * rT * pp.wv, K2 = step * rT2 * pp.wa;
     // Polytope rows are held in registers, RC at a time, and the sample loop runs inside: re-reading
     // them from L2 for every sample (res x M x 32 B per lane) was the bottleneck of this kernel.
     constexpr int RC = 8;
@@ -342,35 +345,38 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(P
           }
         }
         double cost = wcm * Fs;
-        bool box = false;
-        double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
         if (first) {
-          double vel[3], acc_[3], worst = 0.0;
+          // velocity / acceleration limits in units of mu, straight from the normalised-time sums a1 = sum c~ tab',
+          // a2 = sum c~ tab'':  u = (|a1| / T - vmax) / mu = |a1| kv - cv  (one FMA, |.| is an operand modifier)
+          double a1[3], a2[3], worst = 0.0;
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
-            double a1 = 0.0, a2 = 0.0;
+            double x1 = 0.0, x2 = 0.0;
 #pragma unroll
             for (int col = 0; col < D; ++col) {
-              a1 = __builtin_fma(ct[ax][col], tb[D + col], a1);
-              a2 = __builtin_fma(ct[ax][col], tb[2 * D + col], a2);
+              x1 = __builtin_fma(ct[ax][col], tb[D + col], x1);
+              x2 = __builtin_fma(ct[ax][col], tb[2 * D + col], x2);
             }
-            vel[ax] = a1 * rT;
-            acc_[ax] = a2 * rT2;
-            worst = fmax(worst, fmax(fabs(vel[ax]) - pp.vmax, fabs(acc_[ax]) - pp.amax));
+            a1[ax] = x1;
+            a2[ax] = x2;
+            worst = fmax(worst, fmax(__builtin_fma(fabs(x1), kv, -cv), __builtin_fma(fabs(x2), ka, -ca)));
           }
-          box = __any(worst > 0.0);
-          if (box) {  // only one of +v, -v (+a, -a) can be violated
+          if (__any(worst > 0.0)) {  // only one of +v, -v (+a, -a) can be violated: the slope has the sign of a1 (a2)
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
               double f, df;
-              smoothed_l1_unit((fabs(vel[ax]) - pp.vmax) * inv_mu, f, df);
+              smoothed_l1_unit(__builtin_fma(fabs(a1[ax]), kv, -cv), f, df);
               cost = __builtin_fma(wvm, f, cost);
-              s1[ax] = step * rT * pp.wv * (vel[ax] < 0.0 ? -df : df);
-              smoothed_l1_unit((fabs(acc_[ax]) - pp.amax) * inv_mu, f, df);
+              const double s1 = K1 * copysign(df, a1[ax]);
+              Rs1 = __builtin_fma(s1, a1[ax], Rs1);
+              smoothed_l1_unit(__builtin_fma(fabs(a2[ax]), ka, -ca), f, df);
               cost = __builtin_fma(wam, f, cost);
-              s2[ax] = step * rT2 * pp.wa * (acc_[ax] < 0.0 ? -df : df);
-              Rs = __builtin_fma(s1[ax], vel[ax], Rs);
-              Rs = __builtin_fma(2.0 * Ti * s2[ax], acc_[ax], Rs);
+              const double s2 = K2 * copysign(df, a2[ax]);
+              Rs2 = __builtin_fma(s2, a2[ax], Rs2);
+              // (the gradient of the limit rows goes into gN here, while s1 and s2 are at hand)
+#pragma unroll
+              for (int col = 0; col < D; ++col)
+                gN[ax][col] = __builtin_fma(s2, tb[2 * D + col], __builtin_fma(s1, tb[D + col], gN[ax][col]));
             }
           }
         }
@@ -381,13 +387,6 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(P
             const double s0 = step * wcm * G[ax];
 #pragma unroll
             for (int col = 0; col < D; ++col) gN[ax][col] = __builtin_fma(s0, tb[col], gN[ax][col]);
-          }
-          if (box) {
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax)
-#pragma unroll
-              for (int col = 0; col < D; ++col)
-                gN[ax][col] = __builtin_fma(s2[ax], tb[2 * D + col], __builtin_fma(s1[ax], tb[D + col], gN[ax][col]));
           }
         }
       }
@@ -400,7 +399,7 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(P
 #pragma unroll
         for (int col = 0; col < D; ++col)
           acc = __builtin_fma(ct[ax][col] * (double)(D - 1 - col), gN[ax][col], acc);
-      gT += csum * inv_res + rT * acc - Rs;
+      gT += csum * inv_res + rT * (acc - __builtin_fma(2.0, Rs2, Rs1));
     }
     {  // d/dc = T^k d/dc~
       double tk = 1.0;
@@ -415,11 +414,15 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(P
   if (a.with_energy && half == 0 && wv == 0) {
     // d/dc of sum_{j,k>=S} c_j c_k f_j f_k T^(j+k-2S+1)/(j+k-2S+1) ;  d/dT = (p^(S)(T))^2
     // (the S highest-power coefficients are read again here: the penalty part above has the registers for itself)
+    // ... and only here: tied to a result of the penalty part, or the scheduler issues these loads before the sample
+    // loops and carries the twelve values across them in scratch
+    int64_t be = b;
+    asm volatile("" : "+v"(be) : "v"(pc));
     double ch[3][S];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax)
 #pragma unroll
-      for (int col = 0; col < S; ++col) ch[ax][col] = a.coeffs[(int64_t)((i * 3 + ax) * D + col) * ld + b];
+      for (int col = 0; col < S; ++col) ch[ax][col] = a.coeffs[(int64_t)((i * 3 + ax) * D + col) * ld + be];
     double tp[D];
     tp[0] = 1.0;
 #pragma unroll

@@ -19,6 +19,13 @@ Prints ONE JSON line (rank 0).  `value` is whole-job trajectories/s.  Extra obje
                 dynamic-limit penalties, sharded over the ranks, one cost + gradient evaluation per step, costs
                 all-gathered; every rank takes part, so an N-GPU run measures the configuration BASELINE names for 8 GPUs
 
+  config3       BASELINE.json configs[2]: 4096 x 8-segment min-snap, corridor penalties + time-allocation gradients (seed 1):
+                one cost + gradient evaluation per step at the literal batch and at a saturating one, FP64 roofline,
+                CPU figure (oracle/minco_costgrad.c, classic banded LU + adjoint, all host cores) beside it
+  config4       BASELINE.json configs[3]: 4096 x 16-segment min-jerk, L-BFGS (lbfgs_parameter_t defaults) until every
+                problem stops on its own (seed 2): seconds, trajectories/s, evaluation statistics, status histogram, FP64
+                roofline, CPU figure (oracle_lbfgs_optimize on the C cost + gradient, all host cores, a sample of the batch)
+
 `--workload config5` makes that evaluation the timed main workload instead (same JSON contract; strong scaling:
 the 32768 trajectories are a fixed total).
 """
@@ -64,6 +71,212 @@ def config5_bytes(s, c, N, M):
 
 
 FP64_PEAK_TFLOPS = 74.5        # measured FMA peak, tools/micro/fp64_peak.hip (profiles/r02_fp64_peak.txt); nominal 78.6
+
+
+def host_cores():
+    """Host cores this process may really use: the scheduler affinity AND the cgroup CPU quota (the GPU boxes report 256
+    logical CPUs but run the container with a 16-CPU quota; 256 threads there only oversubscribe 16 cores)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def classic_solve_flops(s, N):
+    """SURVEY.md 8(d) "Algorithmic FLOPs": banded LU of the n = 2sN collocation system with p = q = 2s
+    (2 n p q) and the forward / backward substitution of the three right-hand sides (3 * 2 n (p + q))."""
+    n, p = 2 * s * N, 2 * s
+    return 2 * n * p * p + 3 * 2 * n * 2 * p
+
+
+def cost_grad_flops(s, N, M, res):
+    """Analytic, data-independent FP64 operation count of ONE cost + gradient evaluation of one trajectory (FMA = 2), of the
+    reference formulation -- what any implementation has to do whatever the data:
+      per piece and sample: position, velocity and acceleration of 3 axes (3 x 3 x 2s FMA), the residual of every corridor
+      row (3 FMA + 1 per row) and of the 12 box rows (1 each);
+      the coefficient solve and the adjoint solve through the same factors (classic banded LU: SURVEY 8(d));
+      the energy and its partial gradients (3 axes x s x s FMA, twice).
+    The data-DEPENDENT part (smoothed L1 and gradient accumulation of the rows that are violated) is not counted, so the
+    fraction of the FP64 peak derived from this is a lower bound on useful work."""
+    D = 2 * s
+    per_sample = 3 * 3 * D * 2 + M * 7 + 12
+    return N * res * per_sample + classic_solve_flops(s, N) + 3 * 2 * (2 * s * N) * 2 * D + N * 3 * s * s * 2 * 2
+
+
+def lbfgs_update_flops(n, m):
+    """two-loop recursion with a full history (4 m dot products / axpys of length n), the pair update and the line-search
+    vector operations of one accepted step"""
+    return 4 * m * n * 2 + 10 * n * 2
+
+
+def fp64_roofline(flops_per_launch, seconds, hbm_bytes_per_launch, kernel):
+    ach = flops_per_launch / seconds / 1e12
+    hb = hbm_bytes_per_launch / seconds / 1e9
+    return {"bound": "fp64", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+            "traffic": None, "kernel": kernel, "flops_counted": "analytic, data-independent (bench.cost_grad_flops)",
+            "hbm": {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS,
+                    "note": "compulsory bytes (SURVEY 8(d)) over the same time: not the binding limit"}}
+
+
+PEN = dict(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20)
+PEN_ORACLE = dict(rho=50.0, res=20, vmax=4.0, amax=6.0, wc=1e4, wv=1e3, wa=1e3, mu=1e-2)
+
+
+def _to_bm(torch, a, B, ld, device):
+    import numpy as np
+    f = np.ascontiguousarray(a.reshape(B, -1).T)
+    t = torch.zeros(f.shape[0], ld, device=device, dtype=torch.float64)
+    t[:, :B] = torch.from_numpy(f).to(device)
+    return t
+
+
+def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
+    """BASELINE configs[2] (SURVEY 8(d) "config 3"): B = 4096 x 8-segment min-snap, corridor (M = 16) + limit penalties,
+    gradients w.r.t. waypoints and durations, seed 1.  One step = one cost + gradient evaluation of the whole batch
+    (k_minco_solve -> k_piece_grad -> k_minco_propagate), timed with events on the launch stream."""
+    import numpy as np
+    from allocnet_amd.synth import corridor_problem
+    s, c, N, M = 4, 3, 8, 16
+    out = {"pieces": N, "order": s, "poly_rows": M, "res": PEN["res"], "seed": 1,
+           "unit": "trajectory cost+gradient evaluations/s"}
+    flops = cost_grad_flops(s, N, M, PEN["res"])
+    ab = config5_bytes(s, c, N, M)
+    pen = aa.make_penalty(poly_rows=M, **PEN)
+    host = None
+    for key, B, K in (("b4096", 4096, 200), ("saturating", 1 << 17, 30)):
+        head, tail, wps, T, hp = corridor_problem(np.random.default_rng(1), B, N, c, M)
+        if key == "b4096":
+            host = (head, tail, wps, T, hp)
+        ld = aa.recommended_ld(B)
+        th, tt, tw, tT, thp = (_to_bm(torch, x, B, ld, device) for x in (head, tail, wps, T, hp))
+        cost, gP, gT, work = aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, ctx=ctx)
+        for _ in range(5):
+            aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, work=work, cost=cost, gradP=gP,
+                                   gradT=gT, ctx=ctx)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(K):
+            aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, work=work, cost=cost, gradP=gP,
+                                   gradT=gT, ctx=ctx)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        kms = e0.elapsed_time(e1) / K
+        out[key] = {"batch": B, "ms_per_step": dt * 1e3, "stream_ms_per_step": kms, "value": B / dt,
+                    "roofline": fp64_roofline(B * flops, kms * 1e-3, B * ab,
+                                              "k_piece_grad (+ k_minco_solve, k_minco_propagate)")}
+        if key == "b4096":
+            out[key]["gpu_cost"] = cost[:B].cpu().numpy()
+            out[key]["gpu_gT"] = gT[:, :B].cpu().numpy().T
+    out["flops_per_evaluation"] = flops
+    out["algorithmic_bytes_per_trajectory"] = ab
+    gpu_cost, gpu_gT = out["b4096"].pop("gpu_cost"), out["b4096"].pop("gpu_gT")
+    if cpu_baseline:
+        from oracle import cbind
+        nthreads = host_cores()
+        head, tail, wps, T, hp = host
+        cbind.minco_cost_grad_batch(s, head, tail, wps, T, hp, nthreads=nthreads, **PEN_ORACLE)      # (threads, pages)
+        t0 = time.perf_counter()
+        cc, cgP, cgT = cbind.minco_cost_grad_batch(s, head, tail, wps, T, hp, nthreads=nthreads, **PEN_ORACLE)
+        one = time.perf_counter() - t0
+        reps = max(1, min(200, int(cpu_seconds / max(one, 1e-4))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cbind.minco_cost_grad_batch(s, head, tail, wps, T, hp, nthreads=nthreads, **PEN_ORACLE)
+        rate = 4096 * reps / (time.perf_counter() - t0)
+        out["cpu_baseline"] = {"value": rate, "unit": out["unit"], "cores": nthreads, "kind": "port",
+                               "sample": f"the same 4096 trajectories, {reps} passes, classic banded-LU MINCO + adjoint through "
+                                         f"the same factors + penalty partials in scalar C (oracle/minco_costgrad.c), "
+                                         f"{nthreads} threads",
+                               "gpu_vs_cpu_max_rel_cost_err": float(np.abs(gpu_cost - cc).max() / np.abs(cc).max()),
+                               "gpu_vs_cpu_max_rel_gradT_err": float(np.abs(gpu_gT - cgT).max() / np.abs(cgT).max())}
+    return out
+
+
+def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
+    """BASELINE configs[3] (SURVEY 8(d) "config 4"): B = 4096 x 16-segment min-jerk, L-BFGS with lbfgs_parameter_t
+    defaults (lbfgs.hpp:25-128) on waypoints and durations until every problem stops on its own; seed 2.  One step = the
+    whole optimisation of the whole batch (one launch of k_lbfgs_minco_persistent), inputs resident in HBM."""
+    import numpy as np
+    from allocnet_amd.synth import corridor_problem
+    B, s, c, N, M = 4096, 3, 3, 16, 16
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(2), B, N, c, M)
+    pen = aa.make_penalty(poly_rows=M, **PEN)
+    prm = aa.lbfgs_parameter_t()
+    ld = aa.recommended_ld(B)
+    cap = 40000                                     # a cap, not the stop: every problem must end with its own status
+    th, tt, tw, tT, thp = (_to_bm(torch, x, B, ld, device) for x in (head, tail, wps, T, hp))
+    aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, param=prm, max_evals=50, ctx=ctx)   # warm-up
+    secs = []
+    for rep in range(2):
+        th, tt, tw, tT = (_to_bm(torch, x, B, ld, device) for x in (head, tail, wps, T))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        res = aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, param=prm, max_evals=cap, ctx=ctx)
+        e1.record()
+        torch.cuda.synchronize()
+        secs.append((time.perf_counter() - t0, e0.elapsed_time(e1) * 1e-3))
+    dt, kdt = min(secs)
+    st = res["status"].cpu().numpy(); it = res["iters"].cpu().numpy(); ev = res["evals"].cpu().numpy()
+    cf = res["cost"].cpu().numpy()
+    n = 3 * (N - 1) + N
+    flops = float(ev.sum()) * cost_grad_flops(s, N, M, PEN["res"]) + float(it.sum()) * lbfgs_update_flops(n, prm.mem_size)
+    ab = B * (config5_bytes(s, c, N, M) + 8)        # compulsory: problem data in, optimised waypoints / durations / cost out
+    out = {"batch": B, "pieces": N, "order": s, "poly_rows": M, "res": PEN["res"], "seed": 2,
+           "seconds": dt, "stream_seconds": kdt, "value": B / dt, "unit": "trajectories optimised to convergence/s",
+           "lbfgs_params": {k: getattr(prm, k) for k in ("mem_size", "g_epsilon", "past", "delta", "max_iterations",
+                                                         "max_linesearch", "min_step", "max_step", "f_dec_coeff",
+                                                         "s_curv_coeff", "cautious_factor", "machine_prec")},
+           "max_evals_cap": cap, "iters_mean": float(it.mean()), "iters_max": int(it.max()),
+           "evals_mean": float(ev.mean()), "evals_p50_p90_p99": [float(v) for v in np.percentile(ev, [50, 90, 99])],
+           "evals_max": int(ev.max()), "evaluations_per_s": float(ev.sum()) / dt,
+           "status_hist": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
+           "cost_final_mean": float(cf.mean()), "flops_per_evaluation": cost_grad_flops(s, N, M, PEN["res"]),
+           "roofline": fp64_roofline(flops, kdt, ab, "k_lbfgs_minco_persistent")}
+    out["roofline"]["note"] = ("one launch; run time = the LAST problem to stop (tail), so the fraction mixes kernel quality with "
+                               "the spread of the evaluation counts")
+    if cpu_baseline:
+        from oracle import cbind
+        nthreads = host_cores()
+        ns = int(min(B, max(32, 8 * nthreads)))
+        idx = np.linspace(0, B - 1, ns).astype(int)
+        cp = cbind.lbfgs_default_param()
+        t0 = time.perf_counter()
+        o = cbind.lbfgs_minco_batch(s, head[idx], tail[idx], wps[idx], T[idx], hp[idx], param=cp, nthreads=nthreads,
+                                    **PEN_ORACLE)
+        cdt = time.perf_counter() - t0
+        rel = np.abs(o["cost"] - cf[idx]) / np.abs(o["cost"])
+        out["cpu_baseline"] = {"value": ns / cdt, "unit": out["unit"], "cores": nthreads, "kind": "port",
+                               "sample": f"{ns} of the 4096 problems (strided), each to its own stop: oracle_lbfgs_optimize "
+                                         f"(lbfgs.hpp:434-717 restated) on the classic banded-LU cost + gradient in scalar C "
+                                         f"(oracle/minco_costgrad.c), one problem per task, {nthreads} threads, {cdt:.1f} s",
+                               "evals_mean": float(o["evals"].mean()), "evals_max": int(o["evals"].max()),
+                               "evaluations_per_s": float(o["evals"].sum()) / cdt,
+                               "status_hist": {str(k): int(v) for k, v in zip(*np.unique(o["status"], return_counts=True))},
+                               "gpu_vs_cpu_final_cost_rel_median": float(np.median(rel)),
+                               "gpu_vs_cpu_final_cost_rel_max": float(rel.max()),
+                               "gpu_vs_cpu_same_eval_count_frac": float((o["evals"] == ev[idx]).mean())}
+    return out
 
 
 def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warmup, total=32768):
@@ -137,17 +350,14 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
             raise SystemExit("config5: all-gather of costs returned wrong data")
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
     ab = config5_bytes(s, c, N, M)
-    achieved = B * ab / (kernel_ms * 1e-3) / 1e9
+    roof = fp64_roofline(B * cost_grad_flops(s, N, M, 20), kernel_ms * 1e-3, B * ab,
+                         "k_piece_grad (+ k_minco_solve, k_minco_propagate)")
+    roof.update(kernel_ms=kernel_ms, algorithmic_bytes_per_trajectory=ab, flops_per_evaluation=cost_grad_flops(s, N, M, 20))
     return {"value": total * steps / elapsed, "unit": "trajectory cost+gradient evaluations/s", "total_batch": total,
             "batch_this_rank": B, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kernel_ms, "steps": steps,
             "scaling": "strong", "pieces": N, "order": s, "poly_rows": M, "res": 20,
             "penalty_active_frac": float((cost[:B] > 0).double().mean().item()),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "kernel": "k_piece_grad (+ k_minco_solve, k_minco_propagate)",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_trajectory": ab,
-                         "note": "the evaluation is bound by FP64 issue, not by HBM: k_piece_grad runs at 63 % of the "
-                                 "measured FP64 FMA peak (profiles/r02_cost_grad_counters.txt)",
-                         "fp64_peak_tflops_measured": FP64_PEAK_TFLOPS}}
+            "roofline": roof}
 
 
 def synth_batch_minor(torch, B, ld, N, c, seed, device):
@@ -326,6 +536,11 @@ def main():
     if c5 is not None:
         out["config5"] = c5
     if world == 1 and not args.main_only:
+        # BASELINE configs[2] and configs[3] are single-GPU configurations: the north-star loop (cost + gradient, L-BFGS)
+        del coeffs
+        out["config3"] = run_config3(torch, aa, ctx, device, not args.no_cpu_baseline, 0.25 * args.cpu_seconds)
+        out["config4"] = run_config4(torch, aa, ctx, device, not args.no_cpu_baseline, 0.5 * args.cpu_seconds)
+        coeffs = torch.empty(N * 3 * D, ld, device=device, dtype=torch.float64)
         # literal configs[1]: B = 1024 (launch-latency bound; reported, not the headline)
         b2 = 1024
         K2 = 200
@@ -408,7 +623,7 @@ def main():
 
         if not args.no_cpu_baseline:
             from oracle import cbind
-            nthreads = os.cpu_count() or 1
+            nthreads = host_cores()
 
             def time_cpu(fn, seconds):
                 """rate of `fn`: a sample of at most 2 M trajectories (sized from two probes), solved repeatedly for about

@@ -47,3 +47,24 @@ def test_cli_refuses_to_run_without_a_gpu_or_reports():
                          capture_output=True, text=True, timeout=300)
     assert res.returncode != 0
     assert "needs a GPU" in (res.stderr + res.stdout)
+
+
+def test_north_star_loop_bookkeeping():
+    """config3 / config4 sub-objects (BASELINE configs[2] / configs[3]): analytic FLOP counts, the FP64 roofline object's
+    keys, and that the config5 line is no longer labelled HBM-bound."""
+    import bench
+    assert bench.classic_solve_flops(4, 8) == 2 * 64 * 8 * 8 + 3 * 2 * 64 * 16 == 14336      # SURVEY 8(d): 8.2 k + 6.1 k
+    f = bench.cost_grad_flops(4, 8, 16, 20)
+    assert f == 8 * 20 * (144 + 112 + 12) + 14336 + 6144 + 1536 == 64896
+    assert bench.cost_grad_flops(3, 16, 16, 20) > f
+    r = bench.fp64_roofline(74.5e12, 2.0, 8e12, "k")
+    assert r["bound"] == "fp64" and r["unit"] == "TFLOP/s" and abs(r["frac"] - 0.5) < 1e-12 and "traffic" in r
+    assert abs(r["hbm"]["frac"] - 0.5) < 1e-12 and r["peak"] == bench.FP64_PEAK_TFLOPS
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'out["config3"] = run_config3' in src and 'out["config4"] = run_config4' in src
+    assert '"bound": "hbm"' not in src[src.index("def run_config5"):src.index("def synth_batch_minor")]
+    # the oracle is only reached from the cpu_baseline legs
+    for fn in ("run_config3", "run_config4"):
+        body = src[src.index(f"def {fn}"):]
+        body = body[:body.index("\ndef ", 10)]
+        assert body.index("from oracle import cbind") > body.index("if cpu_baseline:")

@@ -1,0 +1,52 @@
+"""bench.py itself under the driver's GPU tests: the RCCL code path (a single-rank process group) of both workloads and
+the JSON contract of the default line with the north-star-loop sub-objects, so that a SCALE run is never the first
+execution of that code."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _bench(args, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, env=e, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = res.stdout.strip().splitlines()[-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("workload,port", [("solve", "29531"), ("config5", "29532")])
+def test_rccl_path_single_rank(workload, port):
+    out = _bench(["--main-only", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--workload", workload,
+                  "--batch", "65536"], env={"ANET_BENCH_FORCE_DIST": "1", "MASTER_PORT": port})
+    for k in KEYS:
+        assert k in out, k
+    assert "allgather(costs)" in out["config"]["parallelism"]
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
+    assert out["roofline"]["bound"] == ("hbm" if workload == "solve" else "fp64")
+    assert 0 < out["roofline"]["frac"] < 1
+
+
+def test_default_line_carries_the_north_star_loop():
+    """configs[1] headline + config3 / config4 / config5 sub-objects, each with a roofline; CPU baselines off here (the
+    driver's own bench run times them)."""
+    out = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--batch", "65536"])
+    for k in KEYS:
+        assert k in out, k
+    c3, c4, c5 = out["config3"], out["config4"], out["config5"]
+    for leg in (c3["b4096"], c3["saturating"], c4, c5):
+        r = leg["roofline"]
+        assert r["bound"] == "fp64" and 0 < r["frac"] < 1 and 0 < r["hbm"]["frac"] < 1
+    assert c3["b4096"]["batch"] == 4096 and c4["batch"] == 4096
+    # every problem of configs[3] stopped on its own (LBFGS_CONVERGENCE = 0 / LBFGS_STOP = 1)
+    assert set(c4["status_hist"]) <= {"0", "1"} and sum(c4["status_hist"].values()) == 4096
+    assert c4["evals_max"] < c4["max_evals_cap"]
