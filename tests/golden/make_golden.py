@@ -249,6 +249,66 @@ def main_time_factor():
         print(f"{name}: Times={out['Times'][:N]} path_length={out['path_length']:.6f} size={os.path.getsize(path)/1024:.0f}KB")
 
 
+def main_vjp():
+    """Backward pass through the inequality QP (layers.py:120-147, 225-243): d loss / d Times for a seeded smooth loss of
+    the optimal coefficients, loss(z) = w1.z + 1/2 sum w2 z^2.
+
+    The reference installs the hook  grad <- -J^-1 grad  with
+        J = [[Q, G'diag(lam), A'], [G, diag(Gz - h), 0], [A, 0, 0]]                     (layers.py:129-134)
+    on y = (z, lam, nu).  J is the TRANSPOSE of the Jacobian dF/dy of the KKT residual
+        F(y; T) = (Qz + G'lam + A'nu,  lam * (Gz - h),  Az - b),
+    so  w = -J^-1 [dloss/dz; 0; 0]  is the adjoint vector and  d loss / d T = w' dF/dT  at fixed y (implicit function
+    theorem: F(y*(T), T) = 0).  The reference stops at the detached leaf z; carried through, the contraction with dF/dT
+    is taken here by torch.autograd THROUGH THE REFERENCE'S OWN Q(T), A(T), b(T), G(T), h(T) (MinTrajOpt.update with Times
+    on the tape).  The optimum (z, lam, nu) of the reference-assembled matrices comes from the float64 interior-point
+    oracle (oracle/qp_np.py), everything else is the reference's matrices and layers.py's J."""
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.qp_np import qp_ipm
+    MinTrajOpt, _ = _import_reference()
+    for name, order, N, res, seed, phase in [("vjp_snap_n3", 4, 3, 6, 45, 2), ("vjp_jerk_n4", 3, 4, 5, 41, 1),
+                                             ("vjp_snap_n2", 4, 2, 8, 41, 2), ("vjp_snap_n3b", 4, 3, 8, 50, 1)]:
+        rng = np.random.default_rng(seed)
+        state, hpolys, T, pts = synth_problem(rng, N, M_max=9, rest=False)
+        seglen = np.linalg.norm(np.diff(pts, axis=0), axis=1)
+        T = seglen / rng.uniform(2.0, 3.0, size=N)          # brisk enough for active limits, slow enough to be feasible
+        D = 2 * order
+        Tt = torch.tensor(T, dtype=torch.float64, requires_grad=True)
+        opt = MinTrajOpt(make_params(order, res))
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt.update(torch.tensor(state), torch.tensor(hpolys), Tt, phase=phase, seq_len=N)
+        Qt, At, bt, G1t, h1t, G2t, h2t = opt.params
+        Gt = torch.vstack([G1t, G2t]); ht = torch.hstack([h1t, h2t])          # layers.py:68-70
+        Q, A, b, G, h = [x.detach().numpy().astype(np.float64) for x in (Qt, At, bt, Gt, ht)]
+        z, lam, nu, obj, it = qp_ipm(Q, A, b, G, h, tol=1e-12, max_iter=300)
+        assert it < 300, (name, "QP oracle did not converge")
+        g = G @ z - h
+        active = int((lam > 1e-6).sum())
+        assert active >= 2, (name, active, "too few active inequalities: the fixture would not exercise the inequality rows")
+        n, mg, me = Q.shape[0], G.shape[0], A.shape[0]
+        w1 = rng.normal(size=n); w2 = rng.uniform(0.0, 1.0, size=n)
+        gz = w1 + w2 * z
+        J = np.block([[Q, G.T * lam[None, :], A.T],
+                      [G, np.diag(g), np.zeros((mg, me))],
+                      [A, np.zeros((me, mg + me))]])                                # layers.py:129-134
+        rhs = np.r_[gz, np.zeros(mg + me)]
+        w = -np.linalg.solve(J, rhs)                                                 # layers.py:139
+        zt, lt, nt, wt = (torch.tensor(x) for x in (z, lam, nu, w))
+        F = torch.hstack([Qt @ zt + Gt.T @ lt + At.T @ nt, lt * (Gt @ zt - ht), At @ zt - bt])
+        (gT,) = torch.autograd.grad(wt @ F, opt.Times)
+        m_rows = [int(np.sum(np.linalg.norm(hpolys[:, :, i], axis=1) > 0)) for i in range(N)]
+        out = dict(order=order, N=N, res=res, phase=phase, state=state, hpolys=hpolys[:16], m_rows=np.array(m_rows), T=T,
+                   w1=w1, w2=w2, z=z, lam_max=float(lam.max()), n_active=active, obj=float(obj), hook_grad_z=w[:n],
+                   dloss_dT=gT.detach().numpy().astype(np.float64), kkt_cond=float(np.linalg.cond(J)))
+        assert not hpolys[16:].any()
+        path = os.path.join(OUT, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: n={n} mg={mg} active={active} obj={obj:.6g} cond(J)={out['kkt_cond']:.1e} dloss_dT={out['dloss_dT']} "
+              f"size={os.path.getsize(path)/1024:.0f}KB")
+
+
 if __name__ == "__main__":
-    main()
-    main_time_factor()
+    if "--only-vjp" not in sys.argv:
+        main()
+        main_time_factor()
+    main_vjp()
