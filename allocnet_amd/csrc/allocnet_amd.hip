@@ -77,11 +77,25 @@ int hip_fail(anet_ctx *ctx, hipError_t e, const char *what) {
   } while (0)
 
 // Every entry point makes the context's device current first: allocations made inside *_dev calls (counters, basis
-// tables) and the launches must land on the context's GPU, not on whatever device the calling thread used last.
+// tables) and the launches must land on the context's GPU, not on whatever device the calling thread used last.  The
+// caller's current device is put back on the way out (a multi-GPU torch process keeps allocating on ITS device), and
+// nothing is switched when the context's device is current already.
+struct DeviceGuard {
+  int prev = -1;
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 #define ANET_ON_DEVICE(ctx)                                                   \
+  DeviceGuard anet_device_guard_;                                             \
   do {                                                                        \
     if (!(ctx)) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");        \
-    ANET_HIP(ctx, hipSetDevice((ctx)->device));                               \
+    int cur_ = -1;                                                            \
+    ANET_HIP(ctx, hipGetDevice(&cur_));                                       \
+    if (cur_ != (ctx)->device) {                                              \
+      ANET_HIP(ctx, hipSetDevice((ctx)->device));                             \
+      anet_device_guard_.prev = cur_;                                         \
+    }                                                                         \
   } while (0)
 
 int ensure_scratch(anet_ctx *ctx, size_t bytes) {
@@ -402,6 +416,19 @@ __global__ void k_order_scatter(const int *counts, int64_t B, int *hist, int *or
   if (b < B) order[atomicAdd(&hist[order_bucket(counts[b])], 1)] = (int)b;
 }
 
+// 1 where the durations of a trajectory spread over more than min_spread (max T > min_spread min T)
+__global__ void k_spread_flags(const double *T, int64_t B, int64_t ld, int N, double min_spread, int32_t *flags) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  double lo = T[b], hi = lo;
+  for (int i = 1; i < N; ++i) {
+    const double t = T[(int64_t)i * ld + b];
+    lo = fmin(lo, t);
+    hi = fmax(hi, t);
+  }
+  flags[b] = hi > min_spread * lo ? 1 : 0;
+}
+
 __global__ void k_lbfgs_results(const int *is, const double *ds, int64_t B, int64_t ld, int *status, int *iters,
                                 int *evals, double *f) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -483,7 +510,7 @@ int64_t anet_recommended_ld(int64_t batch) {
 int anet_dev_alloc(anet_ctx *ctx, size_t n_doubles, double **out) {
   if (!ctx || !out) return fail(ctx, ANET_ERR_INVALID, "anet_dev_alloc: NULL argument");
   *out = nullptr;
-  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  ANET_ON_DEVICE(ctx);
   hipError_t e = hipMalloc((void **)out, sizeof(double) * (n_doubles ? n_doubles : 1));
   if (e != hipSuccess) return fail(ctx, ANET_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
   return ANET_OK;
@@ -493,12 +520,14 @@ void anet_dev_free(double *p) {
 }
 int anet_dev_upload(anet_ctx *ctx, double *dst_dev, const double *src_host, size_t n_doubles) {
   if (!ctx || !dst_dev || !src_host) return fail(ctx, ANET_ERR_INVALID, "anet_dev_upload: NULL argument");
+  ANET_ON_DEVICE(ctx);
   ANET_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, sizeof(double) * n_doubles, hipMemcpyHostToDevice, ctx->stream));
   ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ANET_OK;
 }
 int anet_dev_download(anet_ctx *ctx, double *dst_host, const double *src_dev, size_t n_doubles) {
   if (!ctx || !dst_host || !src_dev) return fail(ctx, ANET_ERR_INVALID, "anet_dev_download: NULL argument");
+  ANET_ON_DEVICE(ctx);
   ANET_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, sizeof(double) * n_doubles, hipMemcpyDeviceToHost, ctx->stream));
   ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ANET_OK;
@@ -532,8 +561,9 @@ int anet_to_traj_major_dev(anet_ctx *ctx, int64_t batch, int64_t nfield, int64_t
   return ANET_OK;
 }
 
+// (callers make the context's device current first: ANET_ON_DEVICE in front of every call)
 static int check_solve_args(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch) {
-  ANET_ON_DEVICE(ctx);
+  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
   if (s < 2 || s > 4) return fail(ctx, ANET_ERR_INVALID, "order s must be 2, 3 or 4");
   if (c < 1 || c > s) return fail(ctx, ANET_ERR_INVALID, "boundary derivative count c must be in [1, s]");
   if (n_pieces < 1 || n_pieces > ANET_MAX_PIECES)
@@ -545,6 +575,7 @@ static int check_solve_args(anet_ctx *ctx, int s, int c, int n_pieces, int64_t b
 int anet_minco_solve_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                          const double *head, const double *tail, const double *wps, const double *T,
                          double *coeffs, double *energy, void *stream) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
   if (batch == 0) return ANET_OK;
@@ -562,6 +593,7 @@ int anet_minco_solve_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
 int anet_minco_solve_wide_spread_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                                      const double *head, const double *tail, const double *wps, const double *T,
                                      double min_spread, double *coeffs, double *energy, void *stream) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
   if (batch == 0) return ANET_OK;
@@ -589,6 +621,7 @@ int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
 int anet_traj_eval_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
                        const double *coeffs, const double *T, int nq, const double *tq, int deriv,
                        double *out, void *stream) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
   if (rc) return rc;
   if (deriv < 0 || deriv > 3 || nq < 0) return fail(ctx, ANET_ERR_INVALID, "anet_traj_eval: deriv in [0,3], nq >= 0");
@@ -606,6 +639,7 @@ int anet_traj_eval_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_
 
 int anet_traj_cost_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
                        const double *coeffs, const double *T, double m34, double *cost, void *stream) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
   if (rc) return rc;
   if (batch == 0) return ANET_OK;
@@ -691,7 +725,7 @@ struct Stager {
   }
 };
 int make_stager(anet_ctx *ctx, int64_t batch, int64_t max_field, int64_t total_fields, Stager *st) {
-  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  // (the entry point that stages has made the context's device current: ANET_ON_DEVICE)
   const int64_t ld = batch == 1 ? 1 : anet_recommended_ld(batch);
   int rc = ensure_scratch(ctx, sizeof(double) * (size_t)(batch * max_field + total_fields * ld));
   if (rc) return rc;
@@ -707,6 +741,7 @@ int make_stager(anet_ctx *ctx, int64_t batch, int64_t max_field, int64_t total_f
 int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
                      const double *tail, const double *wps, const double *T, double *coeffs,
                      double *energy) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
   if (batch == 0) return ANET_OK;
@@ -755,6 +790,7 @@ int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
 
 int anet_traj_eval(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
                    const double *T, int nq, const double *tq, int deriv, double *out) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
   if (rc) return rc;
   if (batch == 0 || nq <= 0) return nq < 0 ? fail(ctx, ANET_ERR_INVALID, "nq < 0") : ANET_OK;
@@ -776,6 +812,7 @@ int anet_traj_eval(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const doub
 
 int anet_traj_cost(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
                    const double *T, double m34, double *cost) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
   if (rc) return rc;
   if (batch == 0) return ANET_OK;
@@ -809,6 +846,7 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
                                  const double *coeffs, const double *T, const double *hpolys,
                                  const anet_penalty *pen, int with_energy, double *gdC, double *gdT,
                                  double *piece_cost, void *stream) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
   if (rc) return rc;
   if ((rc = check_penalty(ctx, pen))) return rc;
@@ -868,6 +906,7 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
 int anet_minco_propagate_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                                   const double *T, const double *coeffs, const double *gdC,
                                   const double *gdT, double *gradP, double *gradT, void *stream) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
   if (batch == 0) return ANET_OK;
@@ -888,6 +927,7 @@ static int cost_grad_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t
                               const double *T, const double *hpolys, const anet_penalty *pen,
                               double *work, double *cost, double *gradP, double *gradT,
                               double *coeffs_out, void *stream, const double *tau) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
   if ((rc = check_penalty(ctx, pen))) return rc;
@@ -923,6 +963,7 @@ int anet_minco_cost_grad(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                          const double *tail, const double *wps, const double *T, const double *hpolys,
                          const anet_penalty *pen, double *cost, double *gradP, double *gradT,
                          double *coeffs_out) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
   if ((rc = check_penalty(ctx, pen))) return rc;
@@ -1210,7 +1251,7 @@ int anet_firi_var(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int ma
   if (batch == 0) return ANET_OK;
   if (!bd || (max_points > 0 && (!pc || !n_points)) || !a || !b || !hpoly || !n_rows)
     return fail(ctx, ANET_ERR_INVALID, "anet_firi: NULL pointer");
-  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  ANET_ON_DEVICE(ctx);
   const int H = max_rows, Np = max_points > 0 ? max_points : 1;
   const size_t n_bdv = (size_t)batch * n_bd * 4, n_pc = (size_t)batch * Np * 3, n_ab = (size_t)batch * 3;
   const size_t n_hp = (size_t)batch * H * 4, n_ell = (size_t)batch * 15;
@@ -1221,7 +1262,12 @@ int anet_firi_var(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int ma
   double *d_el = d_hp + n_hp, *d_work = d_el + n_ell;
   int *d_np = (int *)(d_work + n_work), *d_nh = d_np + batch, *d_ok = d_nh + batch, *d_it = d_ok + batch;
   hipStream_t st = ctx->stream;
-  if (iterations) ANET_HIP(ctx, hipMemcpyAsync(d_it, iterations, sizeof(int) * batch, hipMemcpyHostToDevice, st));
+  if (iterations) {  // (host array: checked here; the device variant clamps instead, it cannot look without a synchronisation)
+    for (int64_t b = 0; b < batch; ++b)
+      if (iterations[b] < 1 || iterations[b] > P.iterations)
+        return fail(ctx, ANET_ERR_INVALID, "anet_firi_var: iterations[b] must be in [1, params->iterations]");
+    ANET_HIP(ctx, hipMemcpyAsync(d_it, iterations, sizeof(int) * batch, hipMemcpyHostToDevice, st));
+  }
   ANET_HIP(ctx, hipMemcpyAsync(d_bd, bd, sizeof(double) * n_bdv, hipMemcpyHostToDevice, st));
   if (max_points > 0) {
     ANET_HIP(ctx, hipMemcpyAsync(d_pc, pc, sizeof(double) * n_pc, hipMemcpyHostToDevice, st));
@@ -1306,6 +1352,28 @@ int anet_launch_order_from_counts_dev(anet_ctx *ctx, int64_t batch, const int32_
   return ANET_OK;
 }
 
+int anet_minco_spread_flags_dev(anet_ctx *ctx, int n_pieces, int64_t batch, int64_t ld, const double *T, double min_spread,
+                                int32_t *flags, void *stream) {
+  ANET_ON_DEVICE(ctx);
+  if (n_pieces < 1 || batch < 0) return fail(ctx, ANET_ERR_INVALID, "anet_minco_spread_flags_dev: n_pieces >= 1, batch >= 0");
+  if (batch == 0) return ANET_OK;
+  if (!T || !flags || ld < batch) return fail(ctx, ANET_ERR_INVALID, "anet_minco_spread_flags_dev: NULL pointer or ld < batch");
+  hipLaunchKernelGGL(k_spread_flags, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, batch, ld,
+                     n_pieces, min_spread > 0.0 ? min_spread : kWideSpread, flags);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+// Coefficients of the RETURNED waypoints / durations: the fast (reduced-system) solve, then the pivoted collocation solve
+// for the trajectories whose optimised durations spread over more than kWideSpread -- inside the optimisation loop the
+// cost and its gradient keep the reduced system's accuracy envelope, what is handed back does not.
+static int final_coeffs(anet_ctx *ctx, int s, int c, int N, int64_t batch, int64_t ld, const double *head, const double *tail,
+                        const double *wps, const double *T, double *coeffs_out, hipStream_t st) {
+  int rc = anet_minco_solve_dev(ctx, s, c, N, batch, ld, head, tail, wps, T, coeffs_out, nullptr, st);
+  if (rc) return rc;
+  return anet_minco_solve_wide_spread_dev(ctx, s, c, N, batch, ld, head, tail, wps, T, kWideSpread, coeffs_out, nullptr, st);
+}
+
 int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                          const double *head, const double *tail, double *wps, double *T,
                          const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
@@ -1320,6 +1388,7 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
                                  const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
                                  int opt_flags, int max_evals, const int32_t *launch_order, double *work, double *cost,
                                  double *coeffs_out, int32_t *status, int32_t *iters, int32_t *evals, void *stream) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
   if ((rc = check_penalty(ctx, pen))) return rc;
@@ -1380,6 +1449,9 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
     ANET_HIP(ctx, hipMemsetAsync(d_prof, 0, 16 * sizeof(long long), st));
     pa.prof = d_prof;
 #endif
+    // a caller-supplied launch order is not checked: a problem it skips (out-of-range or repeated entries) must report
+    // ANET_LBFGS_RUNNING with zero counters, not whatever the workspace held
+    if (launch_order) ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * ld, st));
     auto launch = [&](auto kernel, size_t fixed_bytes) {
       hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
     };
@@ -1411,8 +1483,7 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
       ANET_HIP(ctx, hipGetLastError());
       hipLaunchKernelGGL(k_lbfgs_results, g256, b256, 0, st, L.is, L.ds, batch, ld, status, iters, evals, cost);
       ANET_HIP(ctx, hipGetLastError());
-      if (coeffs_out) return anet_minco_solve_dev(ctx, s, c, N, batch, ld, head, tail, wps, T, coeffs_out, nullptr, st);
-      return ANET_OK;
+      return coeffs_out ? final_coeffs(ctx, s, c, N, batch, ld, head, tail, wps, T, coeffs_out, st) : ANET_OK;
     }
   }
   rc = lbfgs_drive(ctx, L, batch, *params, max_evals, st, [&]() -> int {
@@ -1426,8 +1497,7 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
   ANET_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_lbfgs_results, g256, b256, 0, st, L.is, L.ds, batch, ld, status, iters, evals, cost);
   ANET_HIP(ctx, hipGetLastError());
-  if (coeffs_out) return anet_minco_solve_dev(ctx, s, c, N, batch, ld, head, tail, wps, T, coeffs_out, nullptr, st);
-  return ANET_OK;
+  return coeffs_out ? final_coeffs(ctx, s, c, N, batch, ld, head, tail, wps, T, coeffs_out, st) : ANET_OK;
 }
 
 int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
@@ -1435,6 +1505,7 @@ int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
                      const anet_penalty *pen, const anet_lbfgs_params *params, int opt_flags,
                      int max_evals, double *cost, double *coeffs_out, int32_t *status, int32_t *iters,
                      int32_t *evals) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
   if ((rc = check_penalty(ctx, pen))) return rc;
@@ -1536,13 +1607,12 @@ int anet_qp_assemble(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res,
                      double max_acc, double m34, int float_time, int row_order, const double *state,
                      const double *T, const double *hpolys, const int32_t *rows, double *Q, double *A,
                      double *b, double *G, double *h) {
-  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  ANET_ON_DEVICE(ctx);
   if ((s != 3 && s != 4) || n_pieces < 1 || batch < 0 || res < 1 || M < 0 || !rows)
     return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: bad argument");
   if (batch == 0) return ANET_OK;
   anet_qp_dims dm;
   if (anet_qp_dims_of(s, n_pieces, res, rows, &dm)) return fail(ctx, ANET_ERR_INVALID, "anet_qp_assemble: bad row counts");
-  ANET_HIP(ctx, hipSetDevice(ctx->device));
   const size_t n_state = 18 * (size_t)batch, n_T = (size_t)n_pieces * batch, n_hp = (size_t)batch * n_pieces * M * 4;
   const size_t n_rows = ((size_t)n_pieces * batch + 1) / 2;  // int32 pairs in doubles
   const size_t nQ = (size_t)(dm.n * dm.n) * batch, nA = (size_t)(dm.m_e * dm.n) * batch, nb = (size_t)dm.m_e * batch;
@@ -1713,12 +1783,11 @@ static int qp_solve_host_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch,
                               const double *hpolys, const anet_qp_settings *settings, double *coeffs, double *obj,
                               int32_t *status, int32_t *iters, double *residuals, double *grad_T,
                               const double *grad_z = nullptr) {
-  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  ANET_ON_DEVICE(ctx);
   if ((s != 3 && s != 4) || n_pieces < 1 || batch < 0 || res < 1 || M < 0)
     return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad argument");
   if (batch == 0) return ANET_OK;
   if (!state || !T || (M > 0 && !hpolys) || !coeffs) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: NULL pointer");
-  ANET_HIP(ctx, hipSetDevice(ctx->device));
   const size_t n = (size_t)3 * 2 * s * n_pieces;
   const size_t n_state = 18 * (size_t)batch, n_T = (size_t)n_pieces * batch, n_hp = (size_t)batch * n_pieces * M * 4;
   const size_t n_work = (size_t)anet_qp_solve_workspace(s, n_pieces, batch, res, M);
@@ -1777,6 +1846,7 @@ int anet_qp_solve_vjp(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
 
 int anet_traj_cost_grad_T_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
                               const double *coeffs, const double *T, double m34, double *gradT, void *stream) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
   if (rc) return rc;
   if (batch == 0) return ANET_OK;
@@ -1793,6 +1863,7 @@ int anet_traj_cost_grad_T_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch,
 
 int anet_traj_cost_grad_T(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
                           const double *T, double m34, double *gradT) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
   if (rc) return rc;
   if (batch == 0) return ANET_OK;
@@ -1866,7 +1937,7 @@ int anet_comm_init(anet_ctx *ctx, int nranks, int rank, const unsigned char id[A
   if (ctx->comm) return fail(ctx, ANET_ERR_INVALID, "anet_comm_init: communicator already initialised");
   int rc = load_rccl(ctx);
   if (rc) return rc;
-  ANET_HIP(ctx, hipSetDevice(ctx->device));
+  ANET_ON_DEVICE(ctx);
   ncclUniqueId u;
   memcpy(&u, id, ANET_COMM_ID_BYTES);
   ncclResult_t r = g_rccl.CommInitRank(&ctx->comm, nranks, u, rank);
@@ -1900,6 +1971,7 @@ int anet_comm_destroy(anet_ctx *ctx) {
 
 int anet_traj_max_rate_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
                            const double *coeffs, const double *T, int which, double *rate, void *stream) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
   if (rc) return rc;
   if (which != 1 && which != 2) return fail(ctx, ANET_ERR_INVALID, "anet_traj_max_rate: which must be 1 (velocity) or 2 (acceleration)");
@@ -1917,6 +1989,7 @@ int anet_traj_max_rate_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, in
 
 int anet_traj_max_rate(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
                        const double *T, int which, double *rate) {
+  ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, 1, n_pieces, batch);
   if (rc) return rc;
   if (batch == 0) return ANET_OK;

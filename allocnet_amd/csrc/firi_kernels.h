@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) k_firi_planes(FiriArgs g) {
   __shared__ double s_row[4], s_red_d[4], s_fw[9], s_p[3], s_fa[3], s_fb[3];
   __shared__ int s_red_j[4], s_state[4];  // [0] completed, [1] nH, [2] overflow
   if (g.ok[b] < 1) return;
-  if (g.iters && g.pass >= g.iters[b]) return;  // this corridor has had its passes
+  if (g.iters && g.pass >= max(g.iters[b], 1)) return;  // this corridor has had its passes (counts below 1 count as 1)
   const int N = min(max(g.npts[b], 0), g.Np), M = g.Mb;  // counts beyond the padded capacity are clamped
   const double *E = g.ell + b * kFiriEll;
   const double eps = g.eps;
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(256) k_firi_mvie_setup(FiriMvieArgs g) {
   extern __shared__ double sm[];  // [H][4]: unit normals + offsets
   __shared__ double s_best[4][5];
   const int H = g.H, nH = g.nh[b];
-  const bool live = g.ok[b] >= 1 && nH >= 4 && !(g.iters && g.pass + 1 >= g.iters[b]);
+  const bool live = g.ok[b] >= 1 && nH >= 4 && !(g.iters && g.pass + 1 >= max(g.iters[b], 1));
   for (int r = tid; r < nH; r += 256) {
     const double *h = g.hpoly + (b * H + r) * 4;
     const double nrm = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);

@@ -82,7 +82,8 @@ def lbfgs_mvie(A, x0, smooth_eps=1.0e-2, penalty_wt=1.0e3, param=None, max_evals
 def lbfgs_minco(head, tail, wps, T, s, hpolys=None, penalty=None, param=None, opt=OPT_WAYPOINTS | OPT_TIMES,
                 max_evals=2000, want_coeffs=True, ctx=None):
     """Batched spatial-temporal trajectory optimisation: L-BFGS on the MINCO cost
-    (anet_lbfgs_minco).  Returns dict(wps, T, cost, coeffs, status, iters, evals)."""
+    (anet_lbfgs_minco).  Returns dict(wps, T, cost, coeffs, status, iters, evals, wide_spread); wide_spread[b] marks the
+    problems whose optimised durations spread over more than 50 (coefficients re-solved by the pivoted collocation solve)."""
     ctx = ctx or default_context()
     param = param or lbfgs_parameter_t()
     head = np.ascontiguousarray(head, dtype=np.float64)
@@ -103,7 +104,10 @@ def lbfgs_minco(head, tail, wps, T, s, hpolys=None, penalty=None, param=None, op
         ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p) if penalty is not None else None,
         ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), _ptr(cost), _ptr(coeffs),
         _ptr(status), _ptr(iters), _ptr(evals)))
-    return dict(wps=wps, T=T, cost=cost, coeffs=coeffs, status=status, iters=iters, evals=evals)
+    # problems whose optimised durations spread over more than 50: their returned coefficients come from the pivoted
+    # collocation solve (the cost and gradients inside the loop keep the reduced system's accuracy envelope)
+    wide = T.max(axis=1) > 50.0 * T.min(axis=1)
+    return dict(wps=wps, T=T, cost=cost, coeffs=coeffs, status=status, iters=iters, evals=evals, wide_spread=wide)
 
 
 def launch_order_from_counts(evals):
@@ -158,4 +162,6 @@ def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, p
         ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p) if penalty is not None else None,
         ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), p(launch_order), p(work), p(cost),
         p(coeffs), p(status), p(iters), p(evals), ctypes.c_void_p(stream)))
-    return dict(cost=cost[:B], status=status[:B], iters=iters[:B], evals=evals[:B])
+    wide = torch.empty(ld, device=dev, dtype=torch.int32)
+    ctx.check(ctx.lib.anet_minco_spread_flags_dev(ctx.handle, N, B, ld, p(T), 0.0, p(wide), ctypes.c_void_p(stream)))
+    return dict(cost=cost[:B], status=status[:B], iters=iters[:B], evals=evals[:B], wide_spread=wide[:B])

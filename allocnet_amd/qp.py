@@ -227,7 +227,7 @@ class QPSolver:
         self._method = QP_METHOD_INTERIOR_POINT
 
     def setMethod(self, method):
-        """Extension: QP_METHOD_ADMM (default, OSQP's algorithm and tolerances) or QP_METHOD_INTERIOR_POINT."""
+        """Extension: QP_METHOD_INTERIOR_POINT (default since ABI 2) or QP_METHOD_ADMM (OSQP's algorithm and tolerances)."""
         if method not in (QP_METHOD_ADMM, QP_METHOD_INTERIOR_POINT):
             raise ValueError("unknown method")
         self._method = method

@@ -21,12 +21,17 @@ class _QPSolve(torch.autograd.Function):
         fctx.save_for_backward(t, state, hpolys, out["grad_T"], out["status"])
         fctx.meta = (order, res, max_vel, max_acc, m34, anet_ctx)
         fctx.mark_non_differentiable(out["status"])
+        # undefined output gradients stay None: a loss that only uses `obj` must not pay the second QP solve of the
+        # backward pass through the coefficients
+        fctx.set_materialize_grads(False)
         return out["coeffs"], out["obj"], out["status"]
 
     @staticmethod
     def backward(fctx, g_coeffs, g_obj, _g_status):
         t, state, hpolys, env, status = fctx.saved_tensors
         order, res, max_vel, max_acc, m34, anet_ctx = fctx.meta
+        if not fctx.needs_input_grad[0]:
+            return (None,) * 9
         grad = torch.zeros_like(t)
         if g_coeffs is not None:
             back = qp_solve_vjp_dev(order, state, t, hpolys, g_coeffs.contiguous(), res=res, max_vel=max_vel,
@@ -60,16 +65,18 @@ class _MincoSolve(torch.autograd.Function):
         ld = T.stride(0)
         coeffs = torch.empty(N * 3 * 2 * s, ld, device=T.device, dtype=torch.float64)
         energy = torch.empty(ld, device=T.device, dtype=torch.float64)
-        minco_solve_dev(head, tail, wps.detach(), T.detach(), s, c, N, B, coeffs=coeffs, energy=energy, ctx=actx)
+        minco_solve_dev(head, tail, wps.detach() if wps is not None else None, T.detach(), s, c, N, B, coeffs=coeffs,
+                        energy=energy, ctx=actx)            # (one piece: no interior waypoints, wps may be None)
         fctx.save_for_backward(T.detach(), coeffs)
-        fctx.meta = (s, c, N, B, actx, wps.shape)
+        fctx.meta = (s, c, N, B, actx)
+        fctx.set_materialize_grads(False)
         return coeffs, energy
 
     @staticmethod
     def backward(fctx, g_coeffs, g_energy):
         import ctypes
         T, coeffs = fctx.saved_tensors
-        s, c, N, B, actx, wshape = fctx.meta
+        s, c, N, B, actx = fctx.meta
         ld = T.stride(0)
         dev = T.device
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

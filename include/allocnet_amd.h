@@ -113,6 +113,11 @@ int anet_minco_solve_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
 int anet_minco_solve_wide_spread_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                                      const double *head, const double *tail, const double *wps, const double *T,
                                      double min_spread, double *coeffs, double *energy, void *stream);
+/* flags[b] (device int32 [batch]) = 1 where the durations of trajectory b spread over more than min_spread (max T >
+ * min_spread * min T; min_spread <= 0 selects the library's own threshold of 50), 0 elsewhere: which trajectories the
+ * call above redoes, and which results of anet_lbfgs_minco[_dev] had their returned coefficients re-solved that way. */
+int anet_minco_spread_flags_dev(anet_ctx *ctx, int n_pieces, int64_t batch, int64_t ld, const double *T /* [N][ld] */,
+                                double min_spread, int32_t *flags, void *stream);
 int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch,
                      const double *head,  /* [batch][3][c]     */
                      const double *tail,  /* [batch][3][c]     */
@@ -413,7 +418,13 @@ int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A /* [bat
 
 /* Objective = the MINCO cost  int (p^(s))^2 + rho*sum(T) + J_pen  (anet_minco_cost_grad) over the
  * interior waypoints (opt_flags bit 0) and/or the durations (bit 1), the durations through the
- * smooth bijection T(tau) so the problem is unconstrained.  wps and T are in/out.               */
+ * smooth bijection T(tau) so the problem is unconstrained.  wps and T are in/out.
+ * Accuracy: inside the loop the cost and its gradient come from the reduced (Hermite / block-tridiagonal) system, whose
+ * error grows with the spread of the durations (1e-8 up to max T / min T = 100, 5e-4 on snap coefficients at 10^3:
+ * DESIGN.md section 2) -- the optimiser is free to walk there when ANET_OPT_TIMES is set.  What is RETURNED does not
+ * carry that envelope: coeffs_out of a problem whose optimised durations spread over more than 50 are re-solved by the
+ * pivoted collocation solve (anet_minco_solve_wide_spread_dev); anet_minco_spread_flags_dev on the returned T tells
+ * which problems those were.                                                                     */
 #define ANET_OPT_WAYPOINTS 1
 #define ANET_OPT_TIMES 2
 /* Execution shape (same result up to rounding): by default problems that fit one wavefront (orders 3 and 4, at most
@@ -498,7 +509,10 @@ int anet_firi_dev(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int ma
 
 /* The same with a pass count per corridor: iterations[b] (1 .. params->iterations; NULL: params->iterations for all) -- a
  * corridor keeps the polytope of its last pass and sits out the rest.  sfc_gen::convexCover (sfc_gen.hpp:163, 176) calls
- * firi::firi with 4 passes for a segment and with 1 for a gap polytope: with this entry point both kinds go in ONE batch. */
+ * firi::firi with 4 passes for a segment and with 1 for a gap polytope: with this entry point both kinds go in ONE batch.
+ * The host variant rejects counts outside [1, params->iterations]; the device variant cannot look at them without a
+ * synchronisation and clamps instead (below 1 -> one pass, above params->iterations -> params->iterations).
+ * Consumers test ok >= 1: ok = 2 is a usable corridor whose inner MVIE optimisation ran into mvie_max_evals. */
 int anet_firi_var(anet_ctx *ctx, int64_t batch, int n_bd, int max_points, int max_rows, const double *bd,
                   const double *pc, const int32_t *n_points, const double *a, const double *b,
                   const int32_t *iterations /* [batch] or NULL */, const anet_firi_params *params, double *hpoly,

@@ -425,3 +425,54 @@ def test_minco_lbfgs_launch_order_changes_nothing_but_the_schedule(anet_ctx):
         assert np.array_equal(w0, w1) and np.array_equal(T0, T1)
     with pytest.raises(ValueError):
         run(perm.to(torch.int64))
+    # an order that is NOT a permutation (entry 5 twice, problem 7 never): the skipped problem reports RUNNING with zero
+    # counters and keeps its start point -- never whatever the workspace held
+    bad = torch.arange(B, dtype=torch.int32, device=dev)
+    bad[7] = 5
+    got, w1, T1 = run(bad)
+    assert got["status"][7] == aa.lbfgs.LBFGS_RUNNING and got["iters"][7] == 0 and got["evals"][7] == 0
+    assert np.array_equal(w1[:, 7], wps[7].reshape(-1)) and np.allclose(T1[:, 7], T[7], rtol=1e-14, atol=0)   # (T -> tau -> T)
+    keep = np.arange(B) != 7
+    for k in ("status", "iters", "evals", "cost"):
+        assert np.array_equal(ref[k][keep], got[k][keep]), k
+
+
+def test_returned_coefficients_of_wide_spread_durations_come_from_the_pivoted_solve(anet_ctx):
+    """Durations that spread over more than 10^3 at the end of an optimisation: the coefficients anet_lbfgs_minco hands
+    back are those of the pivoted collocation solve (<= 1e-6 of the classic banded-LU oracle), not of the reduced system the
+    loop itself works with, and the problem is flagged."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(9)
+    s, c, N, B = 4, 3, 6, 24
+    seg = np.tile(np.array([0.004, 9.0, 0.004, 7.0, 0.004, 8.0]), (B, 1)) * rng.uniform(0.8, 1.2, size=(B, N))
+    d = rng.normal(size=(B, N, 3)); d /= np.linalg.norm(d, axis=2, keepdims=True)
+    pts = np.concatenate([np.zeros((B, 1, 3)), np.cumsum(d * seg[:, :, None], axis=1)], axis=1)
+    head = np.zeros((B, 3, c)); tail = np.zeros((B, 3, c))
+    head[:, :, 0] = pts[:, 0]; tail[:, :, 0] = pts[:, N]
+    wps = pts[:, 1:N].copy()
+    T = np.where(seg < 0.1, 0.012, 30.0) * rng.uniform(0.9, 1.1, size=(B, N))
+    T[B // 2:] = rng.uniform(0.8, 1.6, size=(B - B // 2, N))           # second half: ordinary durations
+    pen = aa.make_penalty(rho=1e-6, w_corridor=0.0, w_vel=0.0, w_acc=0.0, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=4,
+                          poly_rows=0)
+    out = aa.lbfgs_minco(head, tail, wps, T, s, penalty=pen, param=aa.lbfgs_parameter_t(max_iterations=3), max_evals=60,
+                         ctx=anet_ctx)
+    spread = out["T"].max(axis=1) / out["T"].min(axis=1)
+    assert (spread[:B // 2] > 1e3).all() and (spread[B // 2:] < 50).all(), spread
+    assert out["wide_spread"][:B // 2].all() and not out["wide_spread"][B // 2:].any()
+    co, _ = cbind.minco_solve_batch(s, head, tail, out["wps"], out["T"])
+    for b in range(B):
+        err = np.abs(out["coeffs"][b] - co[b]).max() / np.abs(co[b]).max()
+        assert err <= 1e-6, (b, spread[b], err)
+    # the same through the device entry point: flags from anet_minco_spread_flags_dev
+    import torch
+    from tools.bench_configs import to_bm
+    dev = torch.device("cuda", 0)
+    ld = aa.recommended_ld(B)
+    th, tt, tw, tT = (to_bm(torch, x, B, ld, dev) for x in (head, tail, wps, T))
+    coeffs = torch.empty(N * 3 * 2 * s, ld, device=dev, dtype=torch.float64)
+    r = aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, penalty=pen, param=aa.lbfgs_parameter_t(max_iterations=3),
+                           max_evals=60, coeffs=coeffs, ctx=anet_ctx)
+    torch.cuda.synchronize()
+    assert np.array_equal(r["wide_spread"].cpu().numpy().astype(bool), out["wide_spread"])
+    cd = coeffs[:, :B].cpu().numpy().T.reshape(B, N, 3, 2 * s)
+    assert np.abs(cd - out["coeffs"]).max() <= 1e-12 * np.abs(out["coeffs"]).max()

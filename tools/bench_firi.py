@@ -27,7 +27,7 @@ def main():
         t0 = time.perf_counter()
         res = aa.firi(bd, pc, a, b, n_points=npts, max_rows=96, ctx=ctx)
         dt = time.perf_counter() - t0
-        out[f"firi_B{B}_Np{Np}"] = {"seconds": dt, "corridors_per_s": B / dt, "ok_frac": float((res["ok"] == 1).mean()),
+        out[f"firi_B{B}_Np{Np}"] = {"seconds": dt, "corridors_per_s": B / dt, "ok_frac": float((res["ok"] >= 1).mean()),
                                      "rows_mean": float(res["n_rows"].mean()), "rows_max": int(res["n_rows"].max())}
     print(json.dumps(out, indent=1))
 
