@@ -459,7 +459,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   };
 
   int it = 0, status = -2, accepted_steps = 0;  // OSQP_MAX_ITER_REACHED unless decided below
-  double pres = 0.0, dres = 0.0, mu = 0.0, mu0 = 0.0, pres_mark = INFINITY;
+  double pres = 0.0, dres = 0.0, mu = 0.0, mu0 = 0.0, pres_mark = INFINITY, mu_mark = INFINITY, alpha_win = 0.0;
+  int stalled_windows = 0;
 #ifdef ANET_IPM_PROF
   long long prof_t_ = __builtin_readcyclecounter();
 #endif
@@ -557,10 +558,19 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         mu * mrows < a.tol_accept * fmax(1.0, 0.5 * fabs(objn)) && ++accepted_steps > 8) { status = 1; break; }
     if (!(mu == mu) || mu > 1e12 * fmax(mu0, 1.0)) { status = -3; break; }  // diverging: no strictly feasible point
     // ... which half of the infeasible problems only reach after ~100 steps of a primal residual that no longer moves
-    // (5e-3, 5.9e-3 -> 5.5e-3 over ten steps; a feasible problem loses a decade per few steps by then): call it early.
+    // (5e-3, 5.9e-3 -> 5.5e-3 over ten steps; a feasible problem loses a decade per few steps by then): call it early,
+    // but not on the primal residual alone -- a feasible problem in a tight corridor can crawl for a while with short
+    // Mehrotra steps.  The verdict needs, over TWO consecutive windows of ten steps, (1) a primal residual that lost
+    // less than 30 % per window, (2) no step longer than half the way to the boundary, and (3) a complementarity
+    // measure that did not halve either: the iteration is then pinned against the boundary by rows it cannot satisfy.
+    // Anything else keeps iterating and is left to the divergence test above or to the iteration limit.
     if (it % 10 == 0) {
-      if (it >= 20 && pres > 1e-4 && pres > 0.7 * pres_mark) { status = -3; break; }
+      const bool stall = it >= 20 && pres > 1e-4 && pres > 0.7 * pres_mark && alpha_win < 0.5 && mu > 0.5 * mu_mark;
+      stalled_windows = stall ? stalled_windows + 1 : 0;
+      if (stalled_windows >= 2) { status = -3; break; }
       pres_mark = pres;
+      mu_mark = mu;
+      alpha_win = 0.0;
     }
     __syncthreads();
     assemble_newton();
@@ -677,6 +687,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     IPM_TICK(11);
     const double alpha = fmin(1.0, 0.99 * (red[6] > 0.0 ? 1.0 / red[6] : 1e300));
+    alpha_win = fmax(alpha_win, alpha);
     __syncthreads();
     // ---- pass E: update ----------------------------------------------------------------------------------
     for (int smp = tid; smp < NS; smp += nt) {

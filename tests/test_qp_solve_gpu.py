@@ -538,3 +538,36 @@ def test_device_entry_points_and_the_torch_layer(anet_ctx):
     sc = np.abs(g * d).sum(axis=1) + 1e-300
     assert (np.abs(an - fd)[ok] <= 1e-3 * sc[ok]).all(), (np.abs(an - fd) / sc)[ok]
     assert (g[~ok] == 0).all()
+
+
+def test_narrow_feasible_corridors_are_not_called_infeasible(anet_ctx):
+    """The early PRIMAL_INFEASIBLE verdict of the interior point needs three signals over two windows (stalled primal
+    residual, short steps, complementarity not falling): tight corridors, where a feasible problem crawls at first, must
+    not trip it.  384 five-piece snap problems in corridors 5-30 cm wide; feasibility from the OTHER method (ADMM run long).
+    And the verdict still comes early where the problem certainly is infeasible (the end point cannot be reached within
+    the velocity box): status -3, not the iteration limit."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(123)
+    s, N, M, B, res = 4, 5, 10, 384, 10
+    probs = [_corridor_problem(rng, N, M, margin=float(rng.uniform(0.05, 0.3))) for _ in range(B)]
+    ini = np.array([p[0] for p in probs]); fin = np.array([p[1] for p in probs])
+    hp = np.array([p[2] for p in probs]); T = np.array([p[3] for p in probs]) * rng.uniform(0.7, 1.3, size=(B, 1))
+    kw = dict(res=res, max_vel=4.0, max_acc=6.0, ctx=anet_ctx)
+    dflt = aa.qp_solve(s, ini, fin, hp, T, **kw)
+    ref = aa.qp_solve(s, ini, fin, hp, T, settings=aa.qp_settings(method=ADMM, eps_abs=1e-6, eps_rel=1e-6, max_iter=200000), **kw)
+    feas = ref["status"] == 1
+    assert feas.sum() >= 150, feas.sum()
+    missed = feas & (dflt["status"] != 1)
+    print("narrow corridors: feasible", int(feas.sum()), "missed", int(missed.sum()), "statuses",
+          dict(zip(*np.unique(dflt["status"], return_counts=True))), "iters max", int(dflt["iters"][feas].max()))
+    assert not (feas & (dflt["status"] == -3)).any(), np.nonzero(feas & (dflt["status"] == -3))[0]
+    assert missed.sum() <= 0.005 * feas.sum()
+    both = feas & (dflt["status"] == 1)
+    assert (np.abs(dflt["obj"][both] - ref["obj"][both]) <= 1e-3 * np.maximum(1.0, ref["obj"][both])).all()
+    # certainly infeasible: the straight-line distance cannot be covered inside the per-axis velocity box
+    dist = np.abs(fin[:, :, 0] - ini[:, :, 0]).max(axis=1)
+    Tbad = T * (dist / (4.0 * T.sum(axis=1)) * 0.5)[:, None] * 0.0 + T * (0.5 * dist / 4.0 / T.sum(axis=1))[:, None]
+    assert (dist / Tbad.sum(axis=1) > 4.0 * 1.9).all()
+    bad = aa.qp_solve(s, ini, fin, hp, Tbad, **kw)
+    assert (bad["status"] == -3).all(), dict(zip(*np.unique(bad["status"], return_counts=True)))
+    assert bad["iters"].max() <= 120, bad["iters"].max()
