@@ -800,8 +800,17 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
 
   PERSIST_TICK(3);
   // ---- E4: penalty functional, lanes = (piece, sample group).  A lane holds NS samples of its piece at a time: their
-  //      positions first, then the corridor rows are walked ONCE for all of them (four rows per LDS round trip, one
-  //      wave-uniform test per row), then velocity / acceleration / jerk, the box rows and the gradient per sample.
+  //      positions first, then the corridor rows are walked ONCE for all of them (four rows per LDS round trip), then the
+  //      velocity / acceleration limits and the gradient per sample.  Same arithmetic as k_piece_grad (minco_kernels.h):
+  //      * everything in units of mu: the rows are staged divided by mu, u = a.p - b, the smoothed L1 is mu F(u) with
+  //        F(u) = uc^3 (1 - uc/2) + max(u - 1, 0), F' = uc^2 (3 - 2 uc), uc = clamp(u, 0, 1); a limit is
+  //        u = |a1| kv - cv straight from the normalised-time sum a1 = sum c~ tb' (kv = 1 / (T mu), cv = vmax / mu);
+  //      * gradient w.r.t. c~_k = c_k T^k accumulated per sample, scaled to d/dc once at the end;
+  //      * no jerk and no per-sample d/dt: tau tb^(d+1)[col] = (k - d) tb^(d)[col], so the sample-time part of dJ/dT is
+  //        (1/T) (sum_col c~[col] k gN[col] - sum_j (s1 a1 + 2 s2 a2)), gN being accumulated anyway;
+  //      (One wave-uniform test per (row, sample slot) instead of one per row was measured: a row is violated by 0.5 % of
+  //      the (lane, sample) pairs, so the per-row test is true four times out of five and the finer one once in four -- but
+  //      a lone wave pays ~25 cycles per branch: 12.3 k cycles against 11.0 k for this phase.)
   {
     const int i = lane / G, grp = lane - G * i;
     constexpr int NS = (G == 4) ? 5 : 3;  // G * NS >= 20 samples (planner.yaml:21) in one pass
@@ -816,7 +825,10 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
         const double Ti = Lm.T[i];
         const double inv_mu = a.inv_mu, inv_res = a.inv_res;  // (host-side reciprocals: an IEEE division is ~30 wave instructions)
         const double step = Ti * inv_res;
-        const double rT = Lm.r[i], rT2 = rT * rT, rT3 = rT2 * rT;  // (1 / T_i of E1)
+        const double rT = Lm.r[i], rT2 = rT * rT;  // (1 / T_i of E1)
+        const double wcm = pp.wc * pp.mu, wvm = pp.wv * pp.mu, wam = pp.wa * pp.mu;
+        const double kv = rT * inv_mu, ka = rT2 * inv_mu, cv = pp.vmax * inv_mu, ca = pp.amax * inv_mu;
+        const double K0 = step * wcm, K1 = step * rT * pp.wv, K2 = step * rT2 * pp.wa;
         double ct[3][D];
         {
           double tk = 1.0;
@@ -827,18 +839,19 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
             tk *= Ti;
           }
         }
-        const int M4 = a.hpolys ? (a.M + 3) & ~3 : 0;  // rows per piece in LDS, zero rows up to a multiple of four
+        const int M4 = a.hpolys ? (a.M + 3) & ~3 : 0;  // rows per piece in LDS (divided by mu), zero rows up to a multiple of four
         const double *rp = rows + (size_t)i * (4 * (size_t)M4 + 4);
         const bool all_ok = pp.res % (G * NS) == 0;  // every lane has a full set of samples in every pass
+        double csum = 0.0, Rs1 = 0.0, Rs2 = 0.0;
         for (int base = 0; base < pp.res; base += G * NS) {
-          double tau[NS], pos[NS][3], gp[NS][3], cs[NS];
+          double tau[NS], pos[NS][3], gp[NS][3], Fs[NS];
           bool ok[NS];
 #pragma unroll
           for (int sI = 0; sI < NS; ++sI) {
             const int j = base + grp + sI * G;
             ok[sI] = j < pp.res;
             tau[sI] = (double)j * inv_res;
-            cs[sI] = 0.0;
+            Fs[sI] = 0.0;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
               double acc = ct[q][0];
@@ -858,20 +871,17 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
             for (int u = 0; u < 4; ++u) {
               double viol[NS], worst = 0.0;
 #pragma unroll
-              for (int sI = 0; sI < NS; ++sI)
-                viol[sI] = __builtin_fma(h[u][0], pos[sI][0], __builtin_fma(h[u][1], pos[sI][1], h[u][2] * pos[sI][2])) - h[u][3];
-              if (!all_ok) {
-#pragma unroll
-                for (int sI = 0; sI < NS; ++sI) viol[sI] = ok[sI] ? viol[sI] : -1.0;
+              for (int sI = 0; sI < NS; ++sI) {
+                viol[sI] = __builtin_fma(h[u][0], pos[sI][0], __builtin_fma(h[u][1], pos[sI][1], __builtin_fma(h[u][2], pos[sI][2], -h[u][3])));
+                if (!all_ok) viol[sI] = ok[sI] ? viol[sI] : -1.0;
+                worst = fmax(worst, viol[sI]);
               }
-#pragma unroll
-              for (int sI = 0; sI < NS; ++sI) worst = fmax(worst, viol[sI]);
-              if (__any(worst > 0.0)) {
+              if (__any(worst > 0.0)) {  // (one test per row: a lone wave pays ~25 cycles per branch, more than the skipped work)
 #pragma unroll
                 for (int sI = 0; sI < NS; ++sI) {
                   double f, df;
-                  smoothed_l1_clamped(pp.mu, inv_mu, viol[sI], f, df);
-                  cs[sI] += f;
+                  smoothed_l1_unit(viol[sI], f, df);
+                  Fs[sI] += f;
                   gp[sI][0] = __builtin_fma(df, h[u][0], gp[sI][0]);
                   gp[sI][1] = __builtin_fma(df, h[u][1], gp[sI][1]);
                   gp[sI][2] = __builtin_fma(df, h[u][2], gp[sI][2]);
@@ -881,96 +891,70 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
           }
 #pragma unroll
           for (int sI = 0; sI < NS; ++sI) {
-            // basis rows of the sample: tb[d][col] = k!/(k-d)! tau^(k-d), k = D-1-col (tb[0][col] = pw[k])
+            // basis rows of the sample: tb^(d)[col] = k!/(k-d)! tau^(k-d), k = D-1-col (tb^(0)[col] = pw[k])
             double pw[D];
             pw[0] = 1.0;
 #pragma unroll
             for (int e = 1; e < D; ++e) pw[e] = pw[e - 1] * tau[sI];
-            auto basis = [&](const int d, const int col) {
-              const int k = D - 1 - col;
-              double fct = 1.0;
+            double tb1[D], tb2[D];  // (the entries with k < d are not touched: D - 1 and D - 2 columns take part)
 #pragma unroll
-              for (int q = 0; q < d; ++q) fct *= (double)(k - q);
-              return (k >= d) ? fct * pw[k >= d ? k - d : 0] : 0.0;
-            };
-            double tb1[D], tb2[D], vel[3], acc_[3];
+            for (int col = 0; col < D - 1; ++col) tb1[col] = (double)(D - 1 - col) * pw[D - 2 - col];
 #pragma unroll
-            for (int col = 0; col < D; ++col) {
-              tb1[col] = basis(1, col);
-              tb2[col] = basis(2, col);
-            }
+            for (int col = 0; col < D - 2; ++col) tb2[col] = (double)((D - 1 - col) * (D - 2 - col)) * pw[D - 3 - col];
+            double a1[3], a2[3], worst = 0.0;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-              double a1 = 0.0, a2 = 0.0;
+              double x1 = 0.0, x2 = 0.0;
 #pragma unroll
-              for (int col = 0; col < D; ++col) {
-                a1 = __builtin_fma(ct[q][col], tb1[col], a1);
-                a2 = __builtin_fma(ct[q][col], tb2[col], a2);
-              }
-              vel[q] = a1 * rT;
-              acc_[q] = a2 * rT2;
-            }
-            double ex[2][3], worst = 0.0;  // excess over the velocity / acceleration box (only one of +-v can be violated)
+              for (int col = 0; col < D - 1; ++col) x1 = __builtin_fma(ct[q][col], tb1[col], x1);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              ex[0][q] = fabs(vel[q]) - pp.vmax;
-              ex[1][q] = fabs(acc_[q]) - pp.amax;
+              for (int col = 0; col < D - 2; ++col) x2 = __builtin_fma(ct[q][col], tb2[col], x2);
+              a1[q] = x1;
+              a2[q] = x2;
+              worst = fmax(worst, fmax(__builtin_fma(fabs(x1), kv, -cv), __builtin_fma(fabs(x2), ka, -ca)));
             }
-            if (!all_ok) {
+            if (!all_ok) worst = ok[sI] ? worst : 0.0;
+            double cost = wcm * Fs[sI];
+            if (__any(worst > 0.0)) {  // only one of +v, -v (+a, -a) can be violated: the slope has the sign of a1 (a2)
+              const double live = (all_ok || ok[sI]) ? 1.0 : 0.0;
 #pragma unroll
               for (int q = 0; q < 3; ++q) {
-                ex[0][q] = ok[sI] ? ex[0][q] : -1.0;
-                ex[1][q] = ok[sI] ? ex[1][q] : -1.0;
+                double f, df;
+                smoothed_l1_unit(__builtin_fma(fabs(a1[q]), kv, -cv), f, df);
+                if (!all_ok) { f *= live; df *= live; }
+                cost = __builtin_fma(wvm, f, cost);
+                const double s1 = K1 * copysign(df, a1[q]);
+                Rs1 = __builtin_fma(s1, a1[q], Rs1);
+                smoothed_l1_unit(__builtin_fma(fabs(a2[q]), ka, -ca), f, df);
+                if (!all_ok) { f *= live; df *= live; }
+                cost = __builtin_fma(wam, f, cost);
+                const double s2 = K2 * copysign(df, a2[q]);
+                Rs2 = __builtin_fma(s2, a2[q], Rs2);
+#pragma unroll
+                for (int col = 0; col < D - 1; ++col) gC[q][col] = __builtin_fma(s1, tb1[col], gC[q][col]);
+#pragma unroll
+                for (int col = 0; col < D - 2; ++col) gC[q][col] = __builtin_fma(s2, tb2[col], gC[q][col]);
               }
             }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) worst = fmax(worst, fmax(ex[0][q], ex[1][q]));
-            const bool box = __any(worst > 0.0);
-            const bool cor = __any(cs[sI] > 0.0);
-            if (box || cor) {
-              double cost = pp.wc * cs[sI];
-              double g0[3], dt = 0.0;  // d cost / d t = g_p.v + g_v.a + g_a.j
+            if (__any(cost > 0.0)) {
+              csum += cost;
 #pragma unroll
               for (int q = 0; q < 3; ++q) {
-                g0[q] = pp.wc * gp[sI][q];
-                dt = __builtin_fma(g0[q], vel[q], dt);
-              }
-#pragma unroll
-              for (int q = 0; q < 3; ++q) {
-                const double s0 = step * g0[q];
+                const double s0 = K0 * gp[sI][q];
 #pragma unroll
                 for (int col = 0; col < D; ++col) gC[q][col] = __builtin_fma(s0, pw[D - 1 - col], gC[q][col]);
               }
-              if (box) {  // (rare once the limits hold: the jerk is only needed for the time derivative of the acceleration rows)
-                double jer[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                  double a3 = 0.0;
-#pragma unroll
-                  for (int col = 0; col < D; ++col) a3 = __builtin_fma(ct[q][col], basis(3, col), a3);
-                  jer[q] = a3 * rT3;
-                }
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                  double f, df;
-                  smoothed_l1_clamped(pp.mu, inv_mu, ex[0][q], f, df);
-                  cost = __builtin_fma(pp.wv, f, cost);
-                  const double g1 = pp.wv * (vel[q] < 0.0 ? -1.0 : 1.0) * df;
-                  smoothed_l1_clamped(pp.mu, inv_mu, ex[1][q], f, df);
-                  cost = __builtin_fma(pp.wa, f, cost);
-                  const double g2 = pp.wa * (acc_[q] < 0.0 ? -1.0 : 1.0) * df;
-                  dt = __builtin_fma(g1, acc_[q], dt);
-                  dt = __builtin_fma(g2, jer[q], dt);
-                  const double s1 = step * g1 * rT, s2 = step * g2 * rT2;
-#pragma unroll
-                  for (int col = 0; col < D; ++col)
-                    gC[q][col] = __builtin_fma(s2, tb2[col], __builtin_fma(s1, tb1[col], gC[q][col]));
-                }
-              }
-              pc = __builtin_fma(step, cost, pc);
-              gT += cost * inv_res + step * dt * tau[sI];
             }
           }
+        }
+        pc = step * csum;
+        {  // d/dT at fixed c: the quadrature weight T/res and the sample times tau_j T (gC still holds d/dc~)
+          double acc = 0.0;
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int col = 0; col < D - 1; ++col) acc = __builtin_fma(ct[q][col] * (double)(D - 1 - col), gC[q][col], acc);
+          gT = csum * inv_res + rT * (acc - __builtin_fma(2.0, Rs2, Rs1));
         }
         {  // d/dc = T^k d/dc~
           double tk = 1.0;
@@ -1186,7 +1170,7 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
     const int per = 4 * a.M, per4 = 4 * ((a.M + 3) & ~3);
     for (int e = lane; e < N * per4; e += 64) {
       const int i = e / per4, w = e - per4 * i;
-      rows[(size_t)i * (per4 + 4) + w] = (w < per) ? a.hpolys[(int64_t)(i * per + w) * ld + b] : 0.0;
+      rows[(size_t)i * (per4 + 4) + w] = (w < per) ? a.hpolys[(int64_t)(i * per + w) * ld + b] * a.inv_mu : 0.0;  // (in units of mu: E4)
     }
   }
   LbfgsResident<MR> st;
