@@ -882,7 +882,6 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
       tab = t.d;
     }
   }
-  static const bool pf_enabled = [] { const char *e = getenv("ANET_PIECE_PREFETCH"); return e ? atoi(e) != 0 : true; }();  // (A/B runs)
   // ANET_PIECE_SW_MAX_PAIRS overrides (tuning / A-B runs)
   static const int64_t sw_max_pairs = [] { const char *e = getenv("ANET_PIECE_SW_MAX_PAIRS"); return e ? (int64_t)atoll(e) : kPieceSampleSplitMaxPairs; }();
   if (pen && batch <= axis_variant_max_batch() && batch * n_pieces <= sw_max_pairs) {
@@ -896,10 +895,6 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
     if (s == 2) hipLaunchKernelGGL((anet::k_piece_grad<2, true>), g2, block, 0, st, a, tab);
     else if (s == 3) hipLaunchKernelGGL((anet::k_piece_grad<3, true>), g2, block, 0, st, a, tab);
     else hipLaunchKernelGGL((anet::k_piece_grad<4, true>), g2, block, 0, st, a, tab);
-  } else if (a.hpolys && pen && pen->poly_rows > 8 && pf_enabled) {  // second chunk of corridor rows prefetched into LDS
-    if (s == 2) hipLaunchKernelGGL((anet::k_piece_grad<2, false, 1, true>), grid, block, 0, st, a, tab);
-    else if (s == 3) hipLaunchKernelGGL((anet::k_piece_grad<3, false, 1, true>), grid, block, 0, st, a, tab);
-    else hipLaunchKernelGGL((anet::k_piece_grad<4, false, 1, true>), grid, block, 0, st, a, tab);
   } else if (s == 2) hipLaunchKernelGGL((anet::k_piece_grad<2, false>), grid, block, 0, st, a, tab);
   else if (s == 3) hipLaunchKernelGGL((anet::k_piece_grad<3, false>), grid, block, 0, st, a, tab);
   else hipLaunchKernelGGL((anet::k_piece_grad<4, false>), grid, block, 0, st, a, tab);

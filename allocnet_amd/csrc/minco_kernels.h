@@ -233,15 +233,10 @@ __device__ __forceinline__ double pair_sum(double v) {  // v + the value of the 
 #ifndef ANET_PG_MINB
 #define ANET_PG_MINB 2
 #endif
-// PF (large batches, no split): the corridor rows of the SECOND pass are requested at the very start, straight into LDS
-// (global_load_lds: no registers, the wave does not wait), so that pass begins with 64 LDS reads instead of a full
-// round trip to HBM in the middle of the kernel -- with two waves per SIMD every such wait is half covered at best.
-// A value arrives as its two dwords, [field][half][lane] per wave: 16 KB per wave, 64 KB per workgroup, two per CU.
-template <int S, bool SPLIT = false, int SW = 1, bool PF = false>
+template <int S, bool SPLIT = false, int SW = 1>
 __global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(PieceGradArgs a, const double *__restrict__ tab) {
   constexpr int D = 2 * S;
   static_assert(SW == 1 || SPLIT, "the sample split builds on the two-lane variant");
-  static_assert(!PF || (!SPLIT && SW == 1), "the prefetch is built for the one-lane-per-piece form");
   const int wv = SW > 1 ? (int)(threadIdx.x >> 6) : 0;  // which samples: j = wv, wv + SW, ...
   const int64_t gid = SW > 1 ? (int64_t)blockIdx.x * 64 + (threadIdx.x & 63) : (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int half = SPLIT ? (int)(gid & 1) : 0;
@@ -251,25 +246,6 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(P
   const int64_t b = live ? bq : 0;  // (SPLIT: idle pairs compute on trajectory 0 and store nothing: the DPP sum needs both lanes)
   const int i = blockIdx.y;
   const int64_t ld = a.ld;
-  constexpr int kPfRows = 8;  // = RC below
-  __shared__ unsigned int pf_lds[PF ? 4 : 1][PF ? kPfRows * 4 * 2 : 1][PF ? 64 : 1];
-  if constexpr (PF) {
-    if (a.with_penalty && a.hpolys) {
-      const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#pragma unroll
-      for (int r = 0; r < kPfRows; ++r) {
-        const int rr = kPfRows + r;
-        if (rr < a.pp.M) {  // (wave-uniform)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const unsigned int *gp = (const unsigned int *)(a.hpolys + (int64_t)((i * a.pp.M + rr) * 4 + q) * ld + b);
-            __builtin_amdgcn_global_load_lds(gp, &pf_lds[wave][(r * 4 + q) * 2][0], 4, 0, 0);
-            __builtin_amdgcn_global_load_lds(gp + 1, &pf_lds[wave][(r * 4 + q) * 2 + 1][0], 4, 0, 0);
-          }
-        }
-      }
-    }
-  }
   const double Ti = a.T[(int64_t)i * ld + b];
   double c[3][D], gC[3][D];
 #pragma unroll
@@ -331,28 +307,13 @@ __global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(P
     for (int pass = 0; pass < npass; ++pass) {
       const int ch = half + cstep * pass;
       double hr[RC][4];
-      static_assert(RC == kPfRows, "the prefetch holds one chunk of rows");
-      if (PF && ch == 1) {  // this chunk was requested at the start of the kernel and sits in LDS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
 #pragma unroll
-        for (int r = 0; r < RC; ++r) {
-          const bool ok = RC + r < pp.M;
+      for (int r = 0; r < RC; ++r) {
+        const int rr = ch * RC + r;
+        const bool ok = a.hpolys && rr < pp.M;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const unsigned int lo = pf_lds[wave][(r * 4 + q) * 2][lane], hi = pf_lds[wave][(r * 4 + q) * 2 + 1][lane];
-            hr[r][q] = ok ? __hiloint2double((int)hi, (int)lo) : 0.0;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-          const int rr = ch * RC + r;
-          const bool ok = a.hpolys && rr < pp.M;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            hr[r][q] = ok ? a.hpolys[(int64_t)((i * pp.M + rr) * 4 + q) * ld + b] : 0.0;
-        }
+        for (int q = 0; q < 4; ++q)
+          hr[r][q] = ok ? a.hpolys[(int64_t)((i * pp.M + rr) * 4 + q) * ld + b] : 0.0;
       }
 #pragma unroll
       for (int r = 0; r < RC; ++r)
