@@ -98,6 +98,22 @@ def test_cpp_facade_program():
     bd = np.zeros((6, 4)); lo = [-3.0, -3.0, -2.0]; hi = [5.0, 3.5, 4.0]
     for ax in range(3):
         bd[2 * ax, ax] = 1.0; bd[2 * ax, 3] = -hi[ax]; bd[2 * ax + 1, ax] = -1.0; bd[2 * ax + 1, 3] = lo[ax]
-    tr = []
-    ok0, hp0 = F.firi(bd, pts, np.array([0.0, 0.0, 1.0]), np.array([2.0, 0.5, 1.2]), trace=tr)
-    assert ok0 and abs(hp.shape[0] - hp0.shape[0]) <= 2
+    # The four passes of firi::firi differ between the two sides only through the MVIE optimiser's stopping point, so
+    # the comparison that can be exact is made exact: ONE pass (no optimiser between the seed ellipsoid and the planes)
+    # through the same library gives the restatement's rows, same count, same order, to rounding ...
+    a0, b0 = np.array([0.0, 0.0, 1.0]), np.array([2.0, 0.5, 1.2])
+    ok1, hp1 = F.firi(bd, pts, a0, b0, iterations=1)
+    one = aa.firi(bd[None], pts[None], a0[None], b0[None], iterations=np.array([1], dtype=np.int32))
+    n1 = int(one["n_rows"][0])
+    assert ok1 and one["ok"][0] >= 1 and n1 == hp1.shape[0]
+    assert np.abs(one["hpoly"][0, :n1] - hp1).max() <= 1e-9 * np.abs(hp1).max()
+    # ... and after the four passes both polytopes hold the segment, exclude every point, and have the same volume scale
+    # (the facade's is the library's own 4-pass result: identical to the Python mirror)
+    ok0, hp0 = F.firi(bd, pts, a0, b0)
+    four = aa.firi(bd[None], pts[None], a0[None], b0[None])
+    n4 = int(four["n_rows"][0])
+    assert ok0 and n4 == hp.shape[0] and np.array_equal(four["hpoly"][0, :n4], hp)
+    assert ((pts @ hp0[:, :3].T + hp0[:, 3]).max(axis=1) > -2e-6).all()
+    # (row COUNTS after four passes may differ by a plane or two: a plane that is just redundant for one side's ellipsoid
+    #  is just not for the other's, whose MVIE optimisation stopped 1e-3 away -- hence no equality here)
+    assert abs(n4 - hp0.shape[0]) <= 2
