@@ -1383,11 +1383,11 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
                                       max_evals, nullptr, work, cost, coeffs_out, status, iters, evals, stream);
 }
 
-int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
-                                 const double *head, const double *tail, double *wps, double *T,
-                                 const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
-                                 int opt_flags, int max_evals, const int32_t *launch_order, double *work, double *cost,
-                                 double *coeffs_out, int32_t *status, int32_t *iters, int32_t *evals, void *stream) {
+static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                               const double *head, const double *tail, double *wps, double *T,
+                               const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
+                               int opt_flags, int max_evals, double min_duration, const int32_t *launch_order, double *work,
+                               double *cost, double *coeffs_out, int32_t *status, int32_t *iters, int32_t *evals, void *stream) {
   ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
@@ -1443,6 +1443,8 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
     else pa.pp = anet::Penalty{0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1, 0};
     pa.inv_mu = 1.0 / pa.pp.mu; pa.inv_res = 1.0 / (double)pa.pp.res;
     pa.p = to_kernel_params(*params);
+    pa.step_bound = (min_duration > 0.0 && nt > 0) ? 1 : 0;  // (gcopter's backwardT, minco_core.h backward_T)
+    pa.tau_min = min_duration > 1.0 ? sqrt(2.0 * min_duration - 1.0) - 1.0 : (min_duration > 0.0 ? 1.0 - sqrt(2.0 / min_duration - 1.0) : 0.0);
 #ifdef ANET_PERSIST_PROF
     static long long *d_prof = nullptr;
     if (!d_prof) ANET_HIP(ctx, hipMalloc((void **)&d_prof, 16 * sizeof(long long)));
@@ -1486,6 +1488,9 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
       return coeffs_out ? final_coeffs(ctx, s, c, N, batch, ld, head, tail, wps, T, coeffs_out, st) : ANET_OK;
     }
   }
+  if (min_duration > 0.0 && nt > 0)
+    return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_lbfgs_minco_bounded: the step bound is built into the one-launch shape only "
+                                            "(orders 3 / 4, <= 64 variables, mem_size <= 8, no ANET_OPT_LOCKSTEP)");
   rc = lbfgs_drive(ctx, L, batch, *params, max_evals, st, [&]() -> int {
     return cost_grad_dev_impl(ctx, s, c, N, batch, ld, head, tail, wps_eval, T, hpolys, pen, w_cg, L.feval, gP_out,
                               gT_out, nullptr, st, tau);
@@ -1500,11 +1505,30 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
   return coeffs_out ? final_coeffs(ctx, s, c, N, batch, ld, head, tail, wps, T, coeffs_out, st) : ANET_OK;
 }
 
-int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
-                     const double *tail, double *wps, double *T, const double *hpolys,
-                     const anet_penalty *pen, const anet_lbfgs_params *params, int opt_flags,
-                     int max_evals, double *cost, double *coeffs_out, int32_t *status, int32_t *iters,
-                     int32_t *evals) {
+int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                                 const double *head, const double *tail, double *wps, double *T,
+                                 const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
+                                 int opt_flags, int max_evals, const int32_t *launch_order, double *work, double *cost,
+                                 double *coeffs_out, int32_t *status, int32_t *iters, int32_t *evals, void *stream) {
+  return lbfgs_minco_dev_impl(ctx, s, c, n_pieces, batch, ld, head, tail, wps, T, hpolys, pen, params, opt_flags, max_evals, 0.0,
+                              launch_order, work, cost, coeffs_out, status, iters, evals, stream);
+}
+
+int anet_lbfgs_minco_bounded_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                                 const double *head, const double *tail, double *wps, double *T,
+                                 const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
+                                 int opt_flags, int max_evals, double min_duration, const int32_t *launch_order, double *work,
+                                 double *cost, double *coeffs_out, int32_t *status, int32_t *iters, int32_t *evals, void *stream) {
+  if (ctx && !(min_duration >= 0.0)) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_minco_bounded_dev: min_duration must be >= 0");
+  return lbfgs_minco_dev_impl(ctx, s, c, n_pieces, batch, ld, head, tail, wps, T, hpolys, pen, params, opt_flags, max_evals,
+                              min_duration, launch_order, work, cost, coeffs_out, status, iters, evals, stream);
+}
+
+static int lbfgs_minco_host_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
+                                 const double *tail, double *wps, double *T, const double *hpolys,
+                                 const anet_penalty *pen, const anet_lbfgs_params *params, int opt_flags,
+                                 int max_evals, double min_duration, double *cost, double *coeffs_out, int32_t *status,
+                                 int32_t *iters, int32_t *evals) {
   ANET_ON_DEVICE(ctx);
   int rc = check_solve_args(ctx, s, c, n_pieces, batch);
   if (rc) return rc;
@@ -1531,8 +1555,8 @@ int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
   if (nhp && (rc = st.upload(hpolys, nhp, &d_hp))) return rc;
   double *d_co = st.reserve(nco), *d_work = st.reserve(wdoubles), *d_cost = st.reserve(1);
   int *d_res = (int *)st.reserve(3);
-  rc = anet_lbfgs_minco_dev(ctx, s, c, N, batch, st.ld, d_head, d_tail, d_wps, d_T, d_hp, pen, params, opt_flags,
-                            max_evals, d_work, d_cost, coeffs_out ? d_co : nullptr, d_res, d_res + st.ld,
+  rc = lbfgs_minco_dev_impl(ctx, s, c, N, batch, st.ld, d_head, d_tail, d_wps, d_T, d_hp, pen, params, opt_flags,
+                            max_evals, min_duration, nullptr, d_work, d_cost, coeffs_out ? d_co : nullptr, d_res, d_res + st.ld,
                             d_res + 2 * st.ld, ctx->stream);
   if (rc) return rc;
   hipStream_t s0 = ctx->stream;
@@ -1545,6 +1569,25 @@ int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
   if (coeffs_out && (rc = st.download(d_co, nco, coeffs_out))) return rc;
   ANET_HIP(ctx, hipStreamSynchronize(s0));
   return ANET_OK;
+}
+
+int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
+                     const double *tail, double *wps, double *T, const double *hpolys,
+                     const anet_penalty *pen, const anet_lbfgs_params *params, int opt_flags,
+                     int max_evals, double *cost, double *coeffs_out, int32_t *status, int32_t *iters,
+                     int32_t *evals) {
+  return lbfgs_minco_host_impl(ctx, s, c, n_pieces, batch, head, tail, wps, T, hpolys, pen, params, opt_flags, max_evals, 0.0,
+                               cost, coeffs_out, status, iters, evals);
+}
+
+int anet_lbfgs_minco_bounded(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
+                             const double *tail, double *wps, double *T, const double *hpolys,
+                             const anet_penalty *pen, const anet_lbfgs_params *params, int opt_flags,
+                             int max_evals, double min_duration, double *cost, double *coeffs_out, int32_t *status,
+                             int32_t *iters, int32_t *evals) {
+  if (ctx && !(min_duration >= 0.0)) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_minco_bounded: min_duration must be >= 0");
+  return lbfgs_minco_host_impl(ctx, s, c, n_pieces, batch, head, tail, wps, T, hpolys, pen, params, opt_flags, max_evals,
+                               min_duration, cost, coeffs_out, status, iters, evals);
 }
 
 // ---- QP assembly entry points --------------------------------------------------------------------

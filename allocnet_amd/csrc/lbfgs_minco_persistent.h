@@ -31,6 +31,8 @@ struct PersistArgs {
   Penalty pp;
   double inv_mu, inv_res;  // 1 / pp.mu, 1 / pp.res
   LbfgsP p;
+  int step_bound;  // 1: every line search is bounded so that the durations stay >= the minimum behind tau_min
+  double tau_min;  // backward_T(minimum duration)
 #ifdef ANET_PERSIST_PROF
   long long *prof;  // [16] cycle counters of problem 0 (tools/persist_prof.py)
 #endif
@@ -165,9 +167,18 @@ __device__ __forceinline__ void rhs_primal_node_rt(int k, int N, int np, double 
 // The register-resident L-BFGS of one problem: lbfgs_update_wave_body (one variable per lane, history carried)
 // without its loads and stores.  pf: lane j holds pf[j] of the past-f ring.
 // LAST: the highest lane that can hold a non-zero component (63: any n <= 64; 15: n <= 16, reductions stop after one row).
+// lbfgs_optimize's proc_stepbound (lbfgs.hpp:221-224, 557-565) as a built-in: the largest step along d that keeps the variables
+// of lanes [lo, hi) at or above xmin -- for the MINCO objective the duration variables tau and xmin = backward_T(minimum
+// duration), so that no line search ever leaves T >= T_min.  on = 0: no bound (step_max = max_step, as with a NULL callback).
+struct StepBound {
+  int on, lo, hi;
+  double xmin;
+};
+
 template <int MR, int LAST = 63>
 struct LbfgsResident {
   double x, g, d, xp, gp;
+  double smax;  // stpmax of the current line search: min(step bound, max_step)
   double hs[MR], hy[MR], hys[MR];  // hys: 1 / (y.s) of the slot
   double fx, step, finit, dgtest, dstest, mu, nu, pf;
   int k, bound, count, brackt, touched, evals, phase;
@@ -180,7 +191,7 @@ struct LbfgsResident {
       hs[it] = hy[it] = 0.0;
       hys[it] = 1.0;
     }
-    fx = step = finit = dgtest = dstest = mu = nu = pf = 0.0;
+    fx = step = finit = dgtest = dstest = mu = nu = pf = smax = 0.0;
     k = bound = count = brackt = touched = evals = phase = 0;
   }
   __device__ __forceinline__ static double dot(double u, double v) { return wave_sum<LAST>(u * v); }
@@ -192,7 +203,7 @@ struct LbfgsResident {
   }
   // consumes f = objective at x (gradient already in g); leaves the next point in x.  Returns the lbfgs.hpp
   // return code when the problem stops, 0x7fffffff while it runs.
-  __device__ __forceinline__ int update(const LbfgsP &P, const int lane, const double f) {
+  __device__ __forceinline__ int update(const LbfgsP &P, const int lane, const double f, const StepBound sb = StepBound{0, 0, 0, 0.0}) {
     const int m = P.mem_size;
     ++evals;
     bool start_ls = false;
@@ -235,12 +246,12 @@ struct LbfgsResident {
             step = brackt ? 0.5 * (mu + nu) : step * 2.0;
             if (step < P.min_step) {
               err = LBERR_MINIMUMSTEP;
-            } else if (step > P.max_step) {
+            } else if (step > smax) {
               if (touched) {
                 err = LBERR_MAXIMUMSTEP;
               } else {
                 touched = 1;
-                step = P.max_step;
+                step = smax;
               }
             }
           }
@@ -312,9 +323,19 @@ struct LbfgsResident {
         }
       }
     }
-    if (start_ls) {  // entry of line_search_lewisoverton (lbfgs.hpp:287-305)
+    if (start_ls) {  // lbfgs.hpp:553-565, then the entry of line_search_lewisoverton (lbfgs.hpp:287-305)
       xp = x;
       gp = g;
+      smax = P.max_step;
+      if (sb.on) {  // step_max = proc_stepbound(xp, d); step_max = min(step_max, max_step); step = step < step_max ? step : step_max / 2
+        const bool mine = lane >= sb.lo && lane < sb.hi && d < 0.0;
+        const double room = x - sb.xmin;
+        const double q = mine ? -d / (room > 1e-300 ? room : 1e-300) : 0.0;
+        const double worst = wave_max_nonneg<LAST>(q);
+        const double bnd = worst > 0.0 ? 1.0 / worst : INFINITY;
+        smax = bnd < P.max_step ? bnd : P.max_step;
+        step = step < smax ? step : 0.5 * smax;
+      }
       const double dginit = dot(g, d);
       if (!(step > 0.0)) {
         finish = LBERR_INVALIDPARAMETERS;
@@ -325,7 +346,7 @@ struct LbfgsResident {
         dgtest = P.f_dec_coeff * dginit;
         dstest = P.s_curv_coeff * dginit;
         mu = 0.0;
-        nu = P.max_step;
+        nu = smax;
         count = 0;
         brackt = 0;
         touched = 0;
@@ -1189,7 +1210,7 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
     PERSIST_TICK_DECL;
     if (lane >= a.nw && lane < n) g *= dforward_T(st.x);
     st.g = (lane < n) ? g : 0.0;
-    finish = st.update(a.p, lane, f);
+    finish = st.update(a.p, lane, f, StepBound{a.step_bound, a.nw, n, a.tau_min});
     finish = __builtin_amdgcn_readfirstlane(finish);
     PERSIST_TICK(9);
     if (finish != 0x7fffffff) break;

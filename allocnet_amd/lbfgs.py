@@ -80,10 +80,12 @@ def lbfgs_mvie(A, x0, smooth_eps=1.0e-2, penalty_wt=1.0e3, param=None, max_evals
 
 
 def lbfgs_minco(head, tail, wps, T, s, hpolys=None, penalty=None, param=None, opt=OPT_WAYPOINTS | OPT_TIMES,
-                max_evals=2000, want_coeffs=True, ctx=None):
+                max_evals=2000, want_coeffs=True, ctx=None, min_duration=0.0):
     """Batched spatial-temporal trajectory optimisation: L-BFGS on the MINCO cost
     (anet_lbfgs_minco).  Returns dict(wps, T, cost, coeffs, status, iters, evals, wide_spread); wide_spread[b] marks the
-    problems whose optimised durations spread over more than 50 (coefficients re-solved by the pivoted collocation solve)."""
+    problems whose optimised durations spread over more than 50 (coefficients re-solved by the pivoted collocation solve).
+    min_duration > 0: lbfgs_optimize's step bound (lbfgs.hpp:557-565) with the built-in minimum-duration bound -- no line
+    search leaves T_i >= min_duration (anet_lbfgs_minco_bounded)."""
     ctx = ctx or default_context()
     param = param or lbfgs_parameter_t()
     head = np.ascontiguousarray(head, dtype=np.float64)
@@ -99,11 +101,11 @@ def lbfgs_minco(head, tail, wps, T, s, hpolys=None, penalty=None, param=None, op
     cost = np.empty(B)
     coeffs = np.empty((B, N, 3, 2 * s)) if want_coeffs else None
     status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); evals = np.empty(B, dtype=np.int32)
-    ctx.check(ctx.lib.anet_lbfgs_minco(
+    ctx.check(ctx.lib.anet_lbfgs_minco_bounded(
         ctx.handle, s, c, N, B, _ptr(head), _ptr(tail), _ptr(wps), _ptr(T), _ptr(hpolys),
         ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p) if penalty is not None else None,
-        ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), _ptr(cost), _ptr(coeffs),
-        _ptr(status), _ptr(iters), _ptr(evals)))
+        ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), float(min_duration), _ptr(cost),
+        _ptr(coeffs), _ptr(status), _ptr(iters), _ptr(evals)))
     # problems whose optimised durations spread over more than 50: their returned coefficients come from the pivoted
     # collocation solve (the cost and gradients inside the loop keep the reduced system's accuracy envelope)
     wide = T.max(axis=1) > 50.0 * T.min(axis=1)
@@ -134,12 +136,13 @@ def launch_order_from_counts_dev(evals, stream=None, ctx=None):
 
 
 def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, param=None,
-                    opt=OPT_WAYPOINTS | OPT_TIMES, max_evals=2000, coeffs=None, stream=None, ctx=None, launch_order=None):
+                    opt=OPT_WAYPOINTS | OPT_TIMES, max_evals=2000, coeffs=None, stream=None, ctx=None, launch_order=None,
+                    min_duration=0.0):
     """Device entry point -> anet_lbfgs_minco_[ordered_]dev.  torch CUDA float64 tensors, batch-minor, common row
     stride; wps and T are updated in place.  Returns dict(cost, status, iters, evals) of device tensors.
     launch_order: optional int32 CUDA tensor (B,), a permutation -- the problem each successive workgroup of the
     one-launch shape takes (`launch_order_from_counts(previous_evals)` when re-solving a similar batch); results
-    do not depend on it, the run time does."""
+    do not depend on it, the run time does.  min_duration: as in `lbfgs_minco`."""
     import torch
     ctx = ctx or default_context(T.device.index or 0)
     param = param or lbfgs_parameter_t()
@@ -157,10 +160,11 @@ def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, p
     if launch_order is not None and not (launch_order.is_cuda and launch_order.dtype == torch.int32 and
                                          launch_order.is_contiguous() and launch_order.shape == (B,)):
         raise ValueError("launch_order: contiguous int32 CUDA tensor of shape (B,)")
-    ctx.check(ctx.lib.anet_lbfgs_minco_ordered_dev(
+    ctx.check(ctx.lib.anet_lbfgs_minco_bounded_dev(
         ctx.handle, s, c, N, B, ld, p(head), p(tail), p(wps) if N > 1 else None, p(T), p(hpolys),
         ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p) if penalty is not None else None,
-        ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), p(launch_order), p(work), p(cost),
+        ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(opt), int(max_evals), float(min_duration), p(launch_order),
+        p(work), p(cost),
         p(coeffs), p(status), p(iters), p(evals), ctypes.c_void_p(stream)))
     wide = torch.empty(ld, device=dev, dtype=torch.int32)
     ctx.check(ctx.lib.anet_minco_spread_flags_dev(ctx.handle, N, B, ld, p(T), 0.0, p(wide), ctypes.c_void_p(stream)))

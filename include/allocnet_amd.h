@@ -463,6 +463,25 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
                                  const anet_lbfgs_params *params, int opt_flags, int max_evals,
                                  const int32_t *launch_order, double *work, double *cost, double *coeffs_out,
                                  int32_t *status, int32_t *iters, int32_t *evals, void *stream);
+/* The same with lbfgs_optimize's step bound (lbfgs.hpp:221-224 lbfgs_stepbound_t, applied as lbfgs.hpp:557-565:
+ * step_max = min(proc_stepbound(xp, d), max_step); step = step < step_max ? step : step_max / 2; the line search then runs
+ * with that step_max) -- a host callback cannot run inside the kernels, so the one bound with a use is built in: a MINIMUM
+ * DURATION.  min_duration > 0 bounds every line search to the largest step along the search direction that keeps every
+ * duration variable tau_i >= backward_T(min_duration), i.e. T_i >= min_duration: 1 / max_i(-d_i / (tau_i - tau_min)) over the
+ * duration variables that move down.  min_duration = 0: no bound (identical to the calls above).  One-launch shape only
+ * (problems that fit a wave, no ANET_OPT_LOCKSTEP): ANET_ERR_UNSUPPORTED otherwise.  Start durations below the minimum make
+ * the first bound 0 and the run end with LBFGSERR_INVALIDPARAMETERS, as the reference's loop would.                  */
+int anet_lbfgs_minco_bounded(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
+                             const double *tail, double *wps, double *T, const double *hpolys,
+                             const anet_penalty *pen, const anet_lbfgs_params *params, int opt_flags,
+                             int max_evals, double min_duration, double *cost, double *coeffs_out, int32_t *status,
+                             int32_t *iters, int32_t *evals);
+int anet_lbfgs_minco_bounded_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
+                                 const double *head, const double *tail, double *wps, double *T,
+                                 const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
+                                 int opt_flags, int max_evals, double min_duration, const int32_t *launch_order, double *work,
+                                 double *cost, double *coeffs_out, int32_t *status, int32_t *iters, int32_t *evals,
+                                 void *stream);
 
 /* launch_order for the call above from the evals[] of a previous solve of the same or a similar batch: longest first, in
  * buckets of 16 evaluations (device arrays; work: ANET_LAUNCH_ORDER_WORK_INTS int32 of scratch; asynchronous on `stream`). */

@@ -104,7 +104,9 @@ inline std::vector<int> lbfgs_optimize_mvie(int batch, int M, const std::vector<
 // &firi::costMVIE, no step bound, no progress monitor, `instance` = firi's optData blob {int M; double smoothEps,
 // penaltyWt; double A[3 M] column-major} (firi.hpp:186-200).  Runs anet_lbfgs_mvie with a batch of one; x and f are
 // updated like the reference's, the return value is its return code.  Any other host callback is refused: there is no
-// CPU L-BFGS in this library (batched device objectives: lbfgs_optimize_mvie above, anet_lbfgs_minco).
+// CPU L-BFGS in this library (batched device objectives: lbfgs_optimize_mvie above, anet_lbfgs_minco).  The step-bound
+// mechanism itself (lbfgs.hpp:557-565) is there for the MINCO objective as a built-in bound, a minimum duration:
+// anet_lbfgs_minco_bounded[_dev](..., min_duration, ...).
 template <class V>
 inline int lbfgs_optimize(V &x, double &f, lbfgs_evaluate_t<V> proc_evaluate, lbfgs_stepbound_t<V> proc_stepbound,
                           lbfgs_progress_t<V> proc_progress, void *instance, const lbfgs_parameter_t &param) {

@@ -68,7 +68,7 @@ def lib():
             [ctypes.POINTER(Penalty)] + [c_void_p] * 3 + [c_int]
         L.oracle_lbfgs_minco_batch.restype = c_int
         L.oracle_lbfgs_minco_batch.argtypes = [c_int, c_int, c_int, c_int64] + [c_void_p] * 5 + \
-            [ctypes.POINTER(Penalty), ctypes.POINTER(LbfgsParam)] + [c_void_p] * 4 + [c_int]
+            [ctypes.POINTER(Penalty), ctypes.POINTER(LbfgsParam)] + [c_void_p] * 4 + [c_int, c_double]
         _lib = L
     return _lib
 
@@ -104,16 +104,19 @@ def minco_cost_grad_batch(s, head, tail, wps, T, hpolys, rho, res, vmax, amax, w
     return cost, gP, gT
 
 
-def lbfgs_minco_batch(s, head, tail, wps, T, hpolys, rho, res, vmax, amax, wc, wv, wa, mu, param=None, nthreads=1):
+def lbfgs_minco_batch(s, head, tail, wps, T, hpolys, rho, res, vmax, amax, wc, wv, wa, mu, param=None, nthreads=1,
+                      min_duration=0.0):
     """oracle_lbfgs_optimize (lbfgs.hpp:434-717 restated) on the cost above in the variables [waypoints, tau],
-    T = forward_T(tau); one problem per task.  Returns dict(wps, T, cost, status, iters, evals)."""
+    T = forward_T(tau); one problem per task.  min_duration > 0: with the minimum-duration step bound as lbfgs_optimize's
+    proc_stepbound (lbfgs.hpp:557-565).  Returns dict(wps, T, cost, status, iters, evals)."""
     head, tail, wps, T, hpolys, B, c, N = _cg_args(head, tail, wps, T, hpolys, copy=True)
     pen = Penalty(rho, wc, wv, wa, mu, vmax, amax, res, 0 if hpolys is None else hpolys.shape[2])
     param = param or lbfgs_default_param()
     cost = np.empty(B)
     status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); evals = np.empty(B, dtype=np.int32)
     rc = lib().oracle_lbfgs_minco_batch(s, c, N, B, _p(head), _p(tail), _p(wps), _p(T), _p(hpolys), ctypes.byref(pen),
-                                        ctypes.byref(param), _p(cost), _p(status), _p(iters), _p(evals), nthreads)
+                                        ctypes.byref(param), _p(cost), _p(status), _p(iters), _p(evals), nthreads,
+                                        float(min_duration))
     if rc:
         raise RuntimeError(f"oracle_lbfgs_minco_batch failed: {rc}")
     return dict(wps=wps, T=T, cost=cost, status=status, iters=iters, evals=evals)

@@ -65,7 +65,7 @@ static int line_search(int n, double *x, double *f, double *g, double *stp, cons
   dgtest = param->f_dec_coeff * dginit;
   dstest = param->s_curv_coeff * dginit;
   for (;;) {
-    for (int i = 0; i < n; ++i) x[i] = xp[i] + *stp * s[i];
+    for (int i = 0; i < n; ++i) x[i] = fma(*stp, s[i], xp[i]); /* x = xp + stp * s (lbfgs.hpp:308), fused as the kernels do */
     *f = eval(inst, x, g, n);
     ++count; ++*evals;
     if (isinf(*f) || isnan(*f)) return LBFGSERR_INVALID_FUNCVAL;
@@ -85,10 +85,18 @@ static int line_search(int n, double *x, double *f, double *g, double *stp, cons
   }
 }
 
+typedef double (*oracle_stepbound_t)(void *instance, const double *xp, const double *d, int n);
+
 /* lbfgs.hpp:434-717.  iters/evals (may be NULL) receive the iteration count k and the number of
- * objective evaluations. */
+ * objective evaluations.  stepbound (may be NULL): lbfgs_stepbound_t, applied as lbfgs.hpp:557-565 does. */
+int oracle_lbfgs_optimize_sb(int n, double *x, double *f, oracle_eval_t eval, oracle_stepbound_t stepbound, void *inst,
+                             const oracle_lbfgs_param *param, int *iters, int *evals_out);
 int oracle_lbfgs_optimize(int n, double *x, double *f, oracle_eval_t eval, void *inst,
                           const oracle_lbfgs_param *param, int *iters, int *evals_out) {
+  return oracle_lbfgs_optimize_sb(n, x, f, eval, NULL, inst, param, iters, evals_out);
+}
+int oracle_lbfgs_optimize_sb(int n, double *x, double *f, oracle_eval_t eval, oracle_stepbound_t stepbound, void *inst,
+                             const oracle_lbfgs_param *param, int *iters, int *evals_out) {
   int ret, i, j, k = 0, ls, end, bound, evals = 0;
   double step, fx, ys, yy, gnorm_inf, xnorm_inf, beta, rate, cau;
   const int m = param->mem_size;
@@ -120,7 +128,13 @@ int oracle_lbfgs_optimize(int n, double *x, double *f, oracle_eval_t eval, void 
     k = 1; end = 0; bound = 0;
     for (;;) {
       memcpy(xp, x, sizeof(double) * n); memcpy(gp, g, sizeof(double) * n);
-      ls = line_search(n, x, &fx, g, &step, d, xp, gp, param->min_step, param->max_step, eval, inst, param, &evals);
+      double step_max = param->max_step;
+      if (stepbound) { /* lbfgs.hpp:557-565 */
+        step_max = stepbound(inst, xp, d, n);
+        step_max = step_max < param->max_step ? step_max : param->max_step;
+        step = step < step_max ? step : 0.5 * step_max;
+      }
+      ls = line_search(n, x, &fx, g, &step, d, xp, gp, param->min_step, step_max, eval, inst, param, &evals);
       if (ls < 0) { memcpy(x, xp, sizeof(double) * n); memcpy(g, gp, sizeof(double) * n); ret = ls; break; }
       gnorm_inf = maxabs(g, n); xnorm_inf = maxabs(x, n);
       if (gnorm_inf / fmax(1.0, xnorm_inf) < param->g_epsilon) { ret = LBFGS_CONVERGENCE; break; }

@@ -46,8 +46,9 @@ typedef struct {
   double min_step, max_step, f_dec_coeff, s_curv_coeff, cautious_factor, machine_prec;
 } oracle_lbfgs_param;
 typedef double (*oracle_eval_t)(void *instance, const double *x, double *g, int n);
-int oracle_lbfgs_optimize(int n, double *x, double *f, oracle_eval_t eval, void *inst, const oracle_lbfgs_param *param,
-                          int *iters, int *evals_out);
+typedef double (*oracle_stepbound_t)(void *instance, const double *xp, const double *d, int n);
+int oracle_lbfgs_optimize_sb(int n, double *x, double *f, oracle_eval_t eval, oracle_stepbound_t stepbound, void *inst,
+                             const oracle_lbfgs_param *param, int *iters, int *evals_out);
 
 /* k!/(k-j)! for k < 8, j <= 8 (0 when j > k) */
 static const double FALL[8][9] = {
@@ -309,7 +310,24 @@ typedef struct {
   const double *head, *tail, *hpolys;
   const oracle_penalty *pp;
   int rc;
+  double tau_min; /* backward_T(minimum duration) of the step bound */
 } obj_t;
+
+/* lbfgs_stepbound_t (lbfgs.hpp:221-224) for a minimum duration: the largest step along d that keeps every duration
+ * variable at or above tau_min = backward_T(T_min), i.e. every T_i >= T_min;  1 / max_i (-d_i / (tau_i - tau_min)) over the
+ * duration variables that move down (the form the kernel evaluates: one wave maximum and one division). */
+static double obj_stepbound(void *inst, const double *xp, const double *d, int n) {
+  obj_t *o = (obj_t *)inst;
+  const int nw = 3 * (o->N - 1);
+  double worst = 0.0;
+  for (int i = nw; i < n; ++i)
+    if (d[i] < 0.0) {
+      const double room = xp[i] - o->tau_min;
+      const double q = -d[i] / (room > 1e-300 ? room : 1e-300);
+      if (q > worst) worst = q;
+    }
+  return worst > 0.0 ? 1.0 / worst : INFINITY;
+}
 
 /* x = [waypoints (N-1) x 3, tau N] */
 static double obj_eval(void *inst, const double *x, double *g, int n) {
@@ -336,6 +354,7 @@ typedef struct {
   int64_t *next;
   pthread_mutex_t *mu;
   int rc;
+  double min_duration; /* > 0: L-BFGS with the minimum-duration step bound */
 } batch_t;
 
 static void *batch_run(void *arg) {
@@ -359,12 +378,14 @@ static void *batch_run(void *arg) {
         if (rc) j->rc = rc;
       } else {
         double x[3 * MAXN + MAXN];
-        obj_t o = {j->s, c, N, j->head + b * 3 * c, j->tail + b * 3 * c, hp, j->pp, 0};
+        obj_t o = {j->s, c, N, j->head + b * 3 * c, j->tail + b * 3 * c, hp, j->pp, 0,
+                   j->min_duration > 0.0 ? bwd_T(j->min_duration) : 0.0};
         memcpy(x, j->wps + b * nw, sizeof(double) * nw);
         for (int i = 0; i < N; ++i) x[nw + i] = bwd_T(j->T[b * N + i]);
         double f = 0.0;
         int it = 0, ev = 0;
-        const int ret = oracle_lbfgs_optimize(nw + N, x, &f, obj_eval, &o, j->param, &it, &ev);
+        const int ret = oracle_lbfgs_optimize_sb(nw + N, x, &f, obj_eval, j->min_duration > 0.0 ? obj_stepbound : NULL, &o,
+                                                 j->param, &it, &ev);
         if (o.rc) j->rc = o.rc;
         memcpy(j->wps + b * nw, x, sizeof(double) * nw);
         for (int i = 0; i < N; ++i) j->T[b * N + i] = fwd_T(x[nw + i]);
@@ -418,14 +439,16 @@ int oracle_minco_cost_grad_batch(int s, int c, int N, int64_t B, const double *h
 }
 
 /* L-BFGS (lbfgs.hpp:434-717 as restated by oracle_lbfgs_optimize) on each of B trajectories; wps and T are updated in
- * place, cost / status / iters / evals per trajectory. */
+ * place, cost / status / iters / evals per trajectory.  min_duration > 0: with lbfgs_optimize's proc_stepbound set to the
+ * minimum-duration bound above (lbfgs.hpp:557-565). */
 int oracle_lbfgs_minco_batch(int s, int c, int N, int64_t B, const double *head, const double *tail, double *wps, double *T,
                              const double *hpolys, const oracle_penalty *pp, const oracle_lbfgs_param *param, double *cost,
-                             int *status, int *iters, int *evals, int nthreads) {
+                             int *status, int *iters, int *evals, int nthreads, double min_duration) {
   batch_t j;
   memset(&j, 0, sizeof(j));
   j.s = s; j.c = c; j.N = N; j.mode = 1; j.B = B;
   j.head = head; j.tail = tail; j.hpolys = hpolys; j.wps = wps; j.T = T; j.pp = pp; j.param = param;
   j.cost = cost; j.status = status; j.iters = iters; j.evals = evals;
+  j.min_duration = min_duration;
   return run_batch(&j, nthreads);
 }

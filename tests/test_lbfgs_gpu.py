@@ -476,3 +476,52 @@ def test_returned_coefficients_of_wide_spread_durations_come_from_the_pivoted_so
     assert np.array_equal(r["wide_spread"].cpu().numpy().astype(bool), out["wide_spread"])
     cd = coeffs[:, :B].cpu().numpy().T.reshape(B, N, 3, 2 * s)
     assert np.abs(cd - out["coeffs"]).max() <= 1e-12 * np.abs(out["coeffs"]).max()
+
+
+def test_minco_lbfgs_step_bound_keeps_a_minimum_duration(anet_ctx):
+    """lbfgs_optimize's proc_stepbound (lbfgs.hpp:557-565) with the built-in minimum-duration bound
+    (anet_lbfgs_minco_bounded): a cost that wants short durations (large rho) drives them below T_min without the bound and
+    never with it; (status, iterations, evaluations) and iterates equal the C restatement of lbfgs_optimize WITH the same
+    bound as its proc_stepbound callback."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(31)
+    s, c, N, M, B = 3, 3, 6, 8, 96
+    head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
+    hp = make_corridors(rng, head, tail, wps, M, tight=2.0)
+    T = rng.uniform(1.2, 2.0, size=(B, N))
+    kw = dict(res=8, vmax=3.0, amax=4.0, wc=1e3, wv=1.0, wa=1.0, mu=1e-2)
+    rho = 400.0                      # time is expensive: the optimiser shortens the pieces
+    pen = aa.make_penalty(rho=rho, w_corridor=kw["wc"], w_vel=kw["wv"], w_acc=kw["wa"], smooth_mu=kw["mu"],
+                          max_vel=kw["vmax"], max_acc=kw["amax"], res=kw["res"], poly_rows=M)
+    Tmin = 0.9
+    free = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
+    assert (free["T"].min(axis=1) < Tmin).sum() >= B // 4          # the bound has something to do
+    for budget in (4, 15, 0):
+        prm = aa.lbfgs_parameter_t(max_iterations=budget)
+        out = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=prm, max_evals=3000, min_duration=Tmin,
+                             ctx=anet_ctx)
+        assert (out["T"] >= Tmin * (1 - 1e-12)).all(), out["T"].min()
+        ref = cbind.lbfgs_minco_batch(s, head, tail, wps, T, hp, rho, nthreads=4, min_duration=Tmin,
+                                      param=cbind.lbfgs_default_param(max_iterations=budget), **kw)
+        assert (ref["T"] >= Tmin * (1 - 1e-12)).all()
+        same = (out["status"] == ref["status"]) & (out["iters"] == ref["iters"]) & (out["evals"] == ref["evals"])
+        # A duration that a line search has put ON the bound leaves the next bound at rounding level (room = tau - tau_min
+        # is +-1 ulp): such a problem ends with a failed line search on both sides -- step below min_step on one, step_max
+        # tried twice on the other, whichever way its last bit fell -- at the same point.  That pair of outcomes is one class.
+        stuck = np.isin(out["status"], (-1011, -1010)) & np.isin(ref["status"], (-1011, -1010)) & (out["iters"] == ref["iters"])
+        agree = same | stuck
+        assert same.mean() >= 0.85 and agree.mean() >= (0.97 if budget else 0.75), (budget, same.mean(), agree.mean())
+        rel = np.abs(out["cost"] - ref["cost"]) / np.abs(ref["cost"])
+        assert rel[agree].max() <= 1e-6, (budget, rel[agree].max())
+        if budget:
+            assert np.abs(out["T"][agree] - ref["T"][agree]).max() <= 1e-6
+    # the bound is active, not decorative: some problem ends ON the minimum, and the bounded optimum costs more
+    assert (np.abs(out["T"] - Tmin).min(axis=1) < 1e-6).sum() >= 1
+    assert out["cost"].mean() > free["cost"].mean()
+    # min_duration = 0 is the unbounded call, bit for bit
+    again = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, min_duration=0.0, ctx=anet_ctx)
+    assert np.array_equal(again["cost"], free["cost"]) and np.array_equal(again["evals"], free["evals"])
+    # refused where it is not built in
+    with pytest.raises(aa.AnetError):
+        aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=50, min_duration=Tmin,
+                       opt=aa.lbfgs.OPT_WAYPOINTS | aa.lbfgs.OPT_TIMES | aa.lbfgs.OPT_LOCKSTEP, ctx=anet_ctx)
