@@ -258,7 +258,7 @@ def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
     if cpu_baseline:
         from oracle import cbind
         nthreads = host_cores()
-        ns = int(min(B, max(32, 8 * nthreads)))
+        ns = int(min(B, max(64, 64 * nthreads)))
         idx = np.linspace(0, B - 1, ns).astype(int)
         cp = cbind.lbfgs_default_param()
         t0 = time.perf_counter()
