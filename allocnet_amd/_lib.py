@@ -52,6 +52,10 @@ PROTOTYPES = {
                                           c_double, c_void_p, c_void_p]),
     "anet_traj_cost_grad_T": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_double, c_void_p]),
     "anet_minco_spread_flags_dev": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_double, c_void_p, c_void_p]),
+    "anet_minco_sample_costs_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
+    "anet_minco_sample_costs": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_double, c_void_p]),
     "anet_minco_partial_grads_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "anet_minco_propagate_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p,

@@ -16,6 +16,7 @@
 #include "../../include/allocnet_amd.h"
 #include "minco_core.h"
 #include "minco_kernels.h"
+#include "minco_sample_kernel.h"
 #include "minco_dense_kernels.h"
 #include "traj_kernels.h"
 #include "rate_kernels.h"
@@ -197,6 +198,30 @@ int launch_solve(anet_ctx *ctx, const anet::SolveArgs &a, hipStream_t st) {
     hipLaunchKernelGGL((anet::k_minco_solve<S, 8>), grid, block, 0, st, a);
   else
     hipLaunchKernelGGL((anet::k_minco_solve<S, 16>), grid, block, 0, st, a);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+template <int S>
+static int launch_sample(anet_ctx *ctx, const anet::SampleArgs &a, hipStream_t st) {
+  const dim3 grid((unsigned)((a.B + anet::kSolveBlock - 1) / anet::kSolveBlock)), block(anet::kSolveBlock);
+  bool done = true;
+  if constexpr (S == 4) {
+    if (a.N == 8 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_sample<4, 8, true, 2>), grid, block, 0, st, a);
+    else if (a.N == 5 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_sample<4, 5, true, 2>), grid, block, 0, st, a);
+    else done = false;
+  } else if constexpr (S == 3) {
+    if (a.N == 16 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_sample<3, 16, true, 2>), grid, block, 0, st, a);
+    else if (a.N == 5 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_sample<3, 5, true, 2>), grid, block, 0, st, a);
+    else done = false;
+  } else {
+    done = false;
+  }
+  if (!done) {
+    if (a.N <= 4) hipLaunchKernelGGL((anet::k_minco_sample<S, 4>), grid, block, 0, st, a);
+    else if (a.N <= 8) hipLaunchKernelGGL((anet::k_minco_sample<S, 8>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((anet::k_minco_sample<S, 16>), grid, block, 0, st, a);
+  }
   ANET_HIP(ctx, hipGetLastError());
   return ANET_OK;
 }
@@ -590,6 +615,26 @@ int anet_minco_solve_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
   }
 }
 
+int anet_minco_sample_costs_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t problems, int64_t samples_per_problem,
+                                int64_t ld, int64_t ldp, const double *head, const double *tail, const double *wps,
+                                const double *T, double rho, double *cost, void *stream) {
+  ANET_ON_DEVICE(ctx);
+  if (problems < 0 || samples_per_problem < 1) return fail(ctx, ANET_ERR_INVALID, "anet_minco_sample_costs: problems >= 0, samples_per_problem >= 1");
+  const int64_t total = problems * samples_per_problem;
+  int rc = check_solve_args(ctx, s, c, n_pieces, total);
+  if (rc) return rc;
+  if (total == 0) return ANET_OK;
+  if (!head || !tail || !T || !cost || (n_pieces > 1 && !wps) || ld < total || ldp < problems)
+    return fail(ctx, ANET_ERR_INVALID, "anet_minco_sample_costs_dev: NULL pointer, ld < problems * samples_per_problem or ldp < problems");
+  anet::SampleArgs a{head, tail, wps, T, cost, total, ld, ldp, samples_per_problem, n_pieces, c, rho};
+  hipStream_t st = (hipStream_t)stream;
+  switch (s) {
+    case 2: return launch_sample<2>(ctx, a, st);
+    case 3: return launch_sample<3>(ctx, a, st);
+    default: return launch_sample<4>(ctx, a, st);
+  }
+}
+
 int anet_minco_solve_wide_spread_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                                      const double *head, const double *tail, const double *wps, const double *T,
                                      double min_spread, double *coeffs, double *energy, void *stream) {
@@ -784,6 +829,34 @@ int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, c
   }
   if (energy) ANET_HIP(ctx, hipMemcpyAsync(energy, d_en, sizeof(double) * batch, hipMemcpyDeviceToHost, ctx->stream));
   if (coeffs) return st.download(d_co, n_co, coeffs);
+  ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ANET_OK;
+}
+
+int anet_minco_sample_costs(anet_ctx *ctx, int s, int c, int n_pieces, int64_t samples, const double *head,
+                            const double *tail, const double *wps, const double *T, double rho, double *cost) {
+  ANET_ON_DEVICE(ctx);
+  int rc = check_solve_args(ctx, s, c, n_pieces, samples);
+  if (rc) return rc;
+  if (samples == 0) return ANET_OK;
+  if (!head || !tail || !T || !cost || (n_pieces > 1 && !wps)) return fail(ctx, ANET_ERR_INVALID, "anet_minco_sample_costs: NULL pointer");
+  const int N = n_pieces;
+  const int64_t npb = 6 * (int64_t)c + 3 * (int64_t)(N - 1);   // the one problem: head, tail, waypoints (ldp = 1)
+  Stager st;
+  rc = make_stager(ctx, samples, N, N + 1 + (npb + samples - 1) / samples + 1, &st);
+  if (rc) return rc;
+  double *d_T;
+  if ((rc = st.upload(T, N, &d_T))) return rc;
+  if ((rc = st.flush())) return rc;
+  double *d_cost = st.reserve(1);
+  double *d_prob = st.reserve((npb + samples - 1) / samples + 1);
+  ANET_HIP(ctx, hipMemcpyAsync(d_prob, head, sizeof(double) * 3 * c, hipMemcpyHostToDevice, ctx->stream));
+  ANET_HIP(ctx, hipMemcpyAsync(d_prob + 3 * c, tail, sizeof(double) * 3 * c, hipMemcpyHostToDevice, ctx->stream));
+  if (N > 1) ANET_HIP(ctx, hipMemcpyAsync(d_prob + 6 * c, wps, sizeof(double) * 3 * (N - 1), hipMemcpyHostToDevice, ctx->stream));
+  rc = anet_minco_sample_costs_dev(ctx, s, c, N, 1, samples, st.ld, 1, d_prob, d_prob + 3 * c, d_prob + 6 * c, d_T, rho, d_cost,
+                                   ctx->stream);
+  if (rc) return rc;
+  ANET_HIP(ctx, hipMemcpyAsync(cost, d_cost, sizeof(double) * samples, hipMemcpyDeviceToHost, ctx->stream));
   ANET_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ANET_OK;
 }

@@ -87,6 +87,41 @@ def minco_solve_wide_spread_dev(head, tail, wps, T, s, c, N, B, coeffs=None, ene
     return coeffs, energy
 
 
+def minco_sample_costs(head, tail, wps, T_samples, s, rho=0.0, ctx=None):
+    """Time-allocation sampling for ONE problem (anet_minco_sample_costs): head / tail (3, c), wps (N-1, 3), T_samples
+    (K, N) candidate duration vectors -> cost (K,) = int (p^(s))^2 + rho * sum T of each candidate, one launch."""
+    ctx = ctx or default_context()
+    head = _f64c(head); tail = _f64c(tail)
+    T = _f64c(T_samples)
+    K, N = T.shape
+    c = head.shape[1]
+    wps = _f64c(wps if N > 1 else np.zeros((0, 3)))
+    if head.shape != (3, c) or tail.shape != (3, c) or wps.shape != (max(N - 1, 0), 3):
+        raise ValueError("head / tail (3, c), wps (N-1, 3), T_samples (K, N)")
+    cost = np.empty(K)
+    ctx.check(ctx.lib.anet_minco_sample_costs(ctx.handle, int(s), c, N, K, _ptr(head), _ptr(tail), _ptr(wps), _ptr(T),
+                                              float(rho), _ptr(cost)))
+    return cost
+
+
+def minco_sample_costs_dev(head, tail, wps, T, s, c, N, problems, samples_per_problem, rho=0.0, cost=None, stream=None,
+                           ctx=None):
+    """Device entry point -> anet_minco_sample_costs_dev: head / tail (3c, ldp), wps ((N-1)*3, ldp) per PROBLEM, T (N, ld)
+    per SAMPLE (torch CUDA float64, batch-minor); sample b belongs to problem b // samples_per_problem.  Returns cost
+    (problems * samples_per_problem,)."""
+    import torch
+    ctx = ctx or default_context(T.device.index or 0)
+    total = problems * samples_per_problem
+    cost = cost if cost is not None else torch.empty(total, device=T.device, dtype=torch.float64)
+    if stream is None:
+        stream = torch.cuda.current_stream(T.device).cuda_stream
+    ctx.check(ctx.lib.anet_minco_sample_costs_dev(ctx.handle, int(s), int(c), int(N), int(problems), int(samples_per_problem),
+                                                  T.stride(0), head.stride(0), _tptr(head), _tptr(tail),
+                                                  _tptr(wps) if N > 1 else None, _tptr(T), float(rho), _tptr(cost),
+                                                  ctypes.c_void_p(stream)))
+    return cost
+
+
 class MINCO:
     """Batched MINCO_S{s}NU mirror: setConditions -> setParameters -> getCoeffs/getEnergy."""
 

@@ -608,6 +608,34 @@ def main():
         out["config1_b1024"]["streams8"] = {"value": b2 * K2 * ns / dt8, "ms_per_launch": dt8 / (K2 * ns) * 1e3,
                                             "hbm_frac": b2 * abytes / (dt8 / (K2 * ns)) / 1e9 / HBM_PEAK_GBS,
                                             "note": "1024-trajectory launches round-robin on 8 streams"}
+        # ... and what a sampler of time allocations should call instead of K launches of 1024 replicated problems: ONE
+        # launch over K candidate duration vectors of few problems (anet_minco_sample_costs_dev: problem data per problem,
+        # durations per sample, only the cost comes back)
+        try:
+            Ks = 1 << 20
+            lds_ = aa.recommended_ld(Ks)
+            g2 = torch.Generator(device=device); g2.manual_seed(7)
+            Ts = 0.5 + 1.5 * torch.rand(N, lds_, generator=g2, device=device, dtype=torch.float64)
+            smp = {}
+            for label, P_ in (("one_problem", 1), ("1024_problems", 1024)):
+                ph, pt, pw = (x[:, :max(P_, 8)].contiguous() for x in (head, tail, wps))
+                cst = aa.minco_sample_costs_dev(ph, pt, pw, Ts, s, c, N, P_, Ks // P_, rho=1.0, ctx=ctx)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    aa.minco_sample_costs_dev(ph, pt, pw, Ts, s, c, N, P_, Ks // P_, rho=1.0, cost=cst, ctx=ctx)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 20
+                smp[label] = {"samples": Ks, "ms_per_launch": ms, "value": Ks / (ms * 1e-3),
+                              "hbm_frac": Ks * 8 * (N + 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "fp64_frac_at_4.1_kflop_per_sample": Ks * 4100.0 / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+            smp["note"] = ("time-allocation samples/s in one launch; 8 (N + 1) bytes per sample, so the launch is bound by its "
+                           "FP64 work (~4.1 kFLOP per 8-segment snap sample in the reduced form)")
+            out["config1_b1024"]["sampler"] = smp
+        except Exception as exc:
+            out["config1_b1024"]["sampler"] = {"error": str(exc)[:200]}
         # PCIe-inclusive host API
         import numpy as np
         from allocnet_amd.synth import random_problem

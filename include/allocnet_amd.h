@@ -118,6 +118,22 @@ int anet_minco_solve_wide_spread_dev(anet_ctx *ctx, int s, int c, int n_pieces, 
  * call above redoes, and which results of anet_lbfgs_minco[_dev] had their returned coefficients re-solved that way. */
 int anet_minco_spread_flags_dev(anet_ctx *ctx, int n_pieces, int64_t batch, int64_t ld, const double *T /* [N][ld] */,
                                 double min_spread, int32_t *flags, void *stream);
+
+/* Time-allocation sampling (north star: "batch of candidate trajectories / time-allocation samples"): MANY candidate
+ * duration vectors for FEW problems in ONE launch.  A sampler does not have 1024 different problems -- the literal
+ * BASELINE configs[1] batch, launch-bound at 2 MB per launch -- it has one problem (boundary states, waypoints) and K
+ * candidate duration vectors.  Sample b (0 <= b < problems * samples_per_problem) belongs to problem b / samples_per_problem;
+ * head / tail / wps are per PROBLEM (batch-minor with row stride ldp >= problems), T per SAMPLE (row stride ld); the only
+ * output is cost[b] = int (p^(s))^2 + rho * sum T (rho = 0: the energy of MINCO_S*NU::getEnergy), 8 (N + 1) bytes of
+ * traffic per sample instead of the 1920 of a full solve.  No counterpart in the reference (it solves one trajectory per
+ * call, learning_planner.hpp:196); upstream's use is a loop over setParameters / getEnergy.                         */
+int anet_minco_sample_costs_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t problems, int64_t samples_per_problem,
+                                int64_t ld, int64_t ldp, const double *head /* [3c][ldp] */, const double *tail,
+                                const double *wps /* [(N-1)*3][ldp] */, const double *T /* [N][ld] */, double rho,
+                                double *cost /* [problems * samples_per_problem] */, void *stream);
+/* Host variant for ONE problem: head / tail [3][c], wps [N-1][3], T [samples][N] (trajectory-major), cost [samples]. */
+int anet_minco_sample_costs(anet_ctx *ctx, int s, int c, int n_pieces, int64_t samples, const double *head,
+                            const double *tail, const double *wps, const double *T, double rho, double *cost);
 int anet_minco_solve(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch,
                      const double *head,  /* [batch][3][c]     */
                      const double *tail,  /* [batch][3][c]     */

@@ -62,6 +62,19 @@ class MINCO_SNU {
     }
   }
 
+  // Extension (no upstream counterpart; upstream's use is a loop over setParameters / getEnergy): the cost
+  // int (p^(S))^2 + rho * sum T of K candidate time allocations of THIS problem (conditions and waypoints as last set),
+  // one launch.  candidateTs: K x N, row k = the durations of candidate k.
+  template <class MT>
+  inline void sampleTimeAllocations(const MT &candidateTs, const int K, const double rho, std::vector<double> &costs) const {
+    std::vector<double> Ts((size_t)K * N);
+    for (int k = 0; k < K; ++k)
+      for (int i = 0; i < N; ++i) Ts[(size_t)k * N + i] = candidateTs(k, i);
+    costs.assign(K, 0.0);
+    anet::Context &ctx = anet::Context::thread_default();
+    ctx.check(anet_minco_sample_costs(ctx.get(), S, c, N, K, head.data(), tail.data(), wps.data(), Ts.data(), rho, costs.data()));
+  }
+
   inline void getEnergy(double &e) const { e = energy; }  // int (p^(S))^2 dt, all axes
   inline double getEnergy() const { return energy; }
   // piece-major, axis, coefficient (highest power first): the reference's flatten order

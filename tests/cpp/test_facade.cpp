@@ -108,6 +108,15 @@ int main() {
     print_vec("gradT", gradT);
     print_vec("gdT", gdT);
     printf("\"energy\": %.17g,\n", opt.getEnergy());
+    {  // time-allocation sampling: 6 candidate duration vectors of the same problem, one launch; candidate 0 = ts
+      const int K = 6;
+      Mat cand(K, N);
+      for (int k = 0; k < K; ++k)
+        for (int i = 0; i < N; ++i) cand(k, i) = 1.0 + 0.15 * k * ((i % 2) ? 1.0 : -0.5);
+      std::vector<double> scost;
+      opt.sampleTimeAllocations(cand, K, 2.0, scost);
+      print_vec("sample_costs", scost);
+    }
     printf("\"traj_cost_1400\": %.17g,\n", copy.getTrajCost(4));
     printf("\"traj_cost_1440\": %.17g,\n", copy.getTrajCost(4, 1440.0));
     printf("\"pos\": [%.17g, %.17g, %.17g],\n", mid.x, mid.y, mid.z);

@@ -27,6 +27,15 @@ def test_cpp_facade_program():
     co, e, *_ = onp.minco_dense_solve(s, head, tail, wps, T)
     assert rel_err(np.array(out["coeffs"]).reshape(N, 3, 8), co) < 1e-9
     assert abs(out["energy"] - e) <= 1e-9 * e
+    # MINCO_S4NU::sampleTimeAllocations: candidate 0 is the durations of the solve above (cost = energy + rho * sum T), the
+    # others against the oracle
+    from oracle import cbind
+    sc = np.array(out["sample_costs"])
+    assert sc.shape == (6,) and abs(sc[0] - (e + 2.0 * 8.0)) <= 1e-9 * sc[0]
+    for k in range(1, 6):
+        Tk = np.array([1.0 + 0.15 * k * (1.0 if i % 2 else -0.5) for i in range(8)])
+        _, ek = cbind.minco_solve_batch(4, head[None], tail[None], wps.T[None], Tk[None], want_coeffs=False)
+        assert abs(sc[k] - (ek[0] + 2.0 * Tk.sum())) <= 1e-9 * sc[k], k
     assert abs(out["traj_cost_1440"] - 0.5 * e) <= 1e-9 * e
     assert abs(out["traj_cost_1400"] - onp.traj_cost(co, T, s, 1400.0)) <= 1e-9 * e
     eC, eT = onp.energy_partials(s, co, T)

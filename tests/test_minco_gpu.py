@@ -212,3 +212,44 @@ def test_torch_minco_layer_gradients(anet_ctx, s, c, N):
     an = (gP * dP).sum(axis=(1, 2)) + (gT * dT).sum(axis=1)
     sc = np.abs(gP * dP).sum(axis=(1, 2)) + np.abs(gT * dT).sum(axis=1)
     assert (np.abs(an - fd) <= 1e-6 * sc).all(), np.abs(an - fd) / sc
+
+
+@pytest.mark.parametrize("s,c,N", [(4, 3, 8), (3, 3, 16), (4, 3, 5), (4, 4, 7), (3, 2, 3), (2, 2, 4), (3, 3, 1)])
+def test_time_allocation_sampling_matches_the_replicated_solve(anet_ctx, s, c, N):
+    """anet_minco_sample_costs[_dev]: K candidate duration vectors for P problems in one launch; the cost of every sample
+    equals energy + rho * sum T of a full solve of the replicated problem (same arithmetic: to rounding), the C oracle
+    agrees to 1e-9, and the argmin over a problem's samples is the oracle's."""
+    import torch
+    import allocnet_amd as aa
+    rng = np.random.default_rng(300 + 10 * N + s)
+    P, K, rho = 5, 1000, 3.0
+    head, tail, wps, _ = random_problem(rng, P, N, c)
+    T = rng.uniform(0.4, 2.5, size=(P, K, N))
+    # host variant, one problem
+    cost0 = aa.minco_sample_costs(head[0], tail[0], wps[0], T[0], s, rho=rho, ctx=anet_ctx)
+    rep = lambda x: np.repeat(x[0:1], K, axis=0)
+    _, e0 = aa.minco_solve(rep(head), rep(tail), rep(wps), T[0], s, ctx=anet_ctx)
+    ref0 = e0 + rho * T[0].sum(axis=1)
+    assert np.abs(cost0 - ref0).max() <= 1e-13 * np.abs(ref0).max()
+    _, eo = cbind.minco_solve_batch(s, rep(head), rep(tail), rep(wps), T[0], want_coeffs=False)
+    oc = eo + rho * T[0].sum(axis=1)
+    assert np.abs(cost0 - oc).max() <= 1e-9 * np.abs(oc).max()
+    assert int(np.argmin(cost0)) == int(np.argmin(oc))
+    # device variant, P problems x K samples, problem data with its own row stride
+    dev = torch.device("cuda", 0)
+    ld, ldp = aa.recommended_ld(P * K), 8
+    def bm(a, n, stride):
+        f = np.ascontiguousarray(a.reshape(n, -1).T)
+        t = torch.zeros(f.shape[0], stride, device=dev, dtype=torch.float64)
+        t[:, :n] = torch.from_numpy(f).to(dev)
+        return t
+    th, tt = bm(head, P, ldp), bm(tail, P, ldp)
+    tw = bm(wps, P, ldp) if N > 1 else None
+    tT = bm(T.reshape(P * K, N), P * K, ld)
+    cost = aa.minco_sample_costs_dev(th, tt, tw, tT, s, c, N, P, K, rho=rho, ctx=anet_ctx).cpu().numpy().reshape(P, K)
+    for p in range(P):
+        repp = lambda x: np.repeat(x[p:p + 1], K, axis=0)
+        _, ep = aa.minco_solve(repp(head), repp(tail), repp(wps), T[p], s, ctx=anet_ctx)
+        refp = ep + rho * T[p].sum(axis=1)
+        assert np.abs(cost[p] - refp).max() <= 1e-13 * np.abs(refp).max(), p
+    assert np.array_equal(cost[0], cost0)
