@@ -233,8 +233,11 @@ __device__ __forceinline__ double pair_sum(double v) {  // v + the value of the 
 #ifndef ANET_PG_MINB
 #define ANET_PG_MINB 2
 #endif
+#ifndef ANET_PG_SW_MINB
+#define ANET_PG_SW_MINB 1  // workgroups per CU the sample-split variant is register-bounded for
+#endif
 template <int S, bool SPLIT = false, int SW = 1>
-__global__ void __launch_bounds__(256, SW > 1 ? 1 : ANET_PG_MINB) k_piece_grad(PieceGradArgs a, const double *__restrict__ tab) {
+__global__ void __launch_bounds__(256, SW > 1 ? ANET_PG_SW_MINB : ANET_PG_MINB) k_piece_grad(PieceGradArgs a, const double *__restrict__ tab) {
   constexpr int D = 2 * S;
   static_assert(SW == 1 || SPLIT, "the sample split builds on the two-lane variant");
   const int wv = SW > 1 ? (int)(threadIdx.x >> 6) : 0;  // which samples: j = wv, wv + SW, ...
