@@ -557,16 +557,25 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     if (a.tol_accept > a.tol && pres < a.tol_accept && dres < a.tol_accept &&
         mu * mrows < a.tol_accept * fmax(1.0, 0.5 * fabs(objn)) && ++accepted_steps > 8) { status = 1; break; }
     if (!(mu == mu) || mu > 1e12 * fmax(mu0, 1.0)) { status = -3; break; }  // diverging: no strictly feasible point
-    // ... which half of the infeasible problems only reach after ~100 steps of a primal residual that no longer moves
-    // (5e-3, 5.9e-3 -> 5.5e-3 over ten steps; a feasible problem loses a decade per few steps by then): call it early,
-    // but not on the primal residual alone -- a feasible problem in a tight corridor can crawl for a while with short
-    // Mehrotra steps.  The verdict needs, over TWO consecutive windows of ten steps, (1) a primal residual that lost
-    // less than 30 % per window, (2) no step longer than half the way to the boundary, and (3) a complementarity
-    // measure that did not halve either: the iteration is then pinned against the boundary by rows it cannot satisfy.
+    // ... which half of the infeasible problems only reach after ~100 steps: their primal residual creeps down by 10-25 %
+    // per ten steps (5e-4 -> 2e-5 over a hundred), every step is short, and the complementarity measure GROWS from window
+    // to window (0.3, 3, 10, 20, 60, ... 1e12) where a feasible problem's falls.  Call it early, but not on the primal
+    // residual alone -- a feasible problem in a tight corridor can crawl for a while with short Mehrotra steps.  The
+    // verdict needs TWO consecutive windows of ten steps in which no step was longer than half the way to the boundary and
+    // either (a) the complementarity measure grew by more than 20 % while the primal residual (above the tolerance) lost
+    // less than half -- a hard FEASIBLE problem also grows its complementarity measure at first, but its residual falls
+    // by 50-90 % per window (traces: tools/qp_verdicts.py sets) --, or
+    // (b) the primal residual (above 1e-4) lost less than 30 % and the complementarity measure did not halve.
     // Anything else keeps iterating and is left to the divergence test above or to the iteration limit.
+#ifdef ANET_IPM_TRACE
+    if (tid == 0 && blockIdx.x == ANET_IPM_TRACE && it % 5 == 0)
+      printf("ipm trace it %d pres %.3e dres %.3e mu %.3e alpha_win %.3f obj %.6e\n", it, pres, dres, mu, alpha_win, objn);
+#endif
     if (it % 10 == 0) {
-      const bool stall = it >= 20 && pres > 1e-4 && pres > 0.7 * pres_mark && alpha_win < 0.5 && mu > 0.5 * mu_mark;
-      stalled_windows = stall ? stalled_windows + 1 : 0;
+      const bool shortsteps = it >= 20 && alpha_win < 0.5;
+      const bool growth = shortsteps && pres > a.tol && pres > 0.5 * pres_mark && mu > 1.2 * mu_mark;
+      const bool stall = shortsteps && pres > 1e-4 && pres > 0.7 * pres_mark && mu > 0.5 * mu_mark;
+      stalled_windows = (growth || stall) ? stalled_windows + 1 : 0;
       if (stalled_windows >= 2) { status = -3; break; }
       pres_mark = pres;
       mu_mark = mu;
