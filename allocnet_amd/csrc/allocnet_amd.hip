@@ -1802,7 +1802,12 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     if (grad_z && tol > 1e-9) tol = 1e-9;
     anet::IpmArgs ia{state, T, hpolys, work, work + mi * batch, coeffs, obj, status, iters,
                      residuals ? residuals : work + 2 * mi * batch, grad_T, grad_z, vjp_T, batch, n_pieces, res, M, max_vel,
-                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200, tol_plain > tol ? tol_plain : 0.0};
+                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200, tol_plain > tol ? tol_plain : 0.0, 0};
+    static const int ipm_twist_min_pieces = [] {
+      const char *e = getenv("ANET_IPM_TWIST_MIN_PIECES");
+      return e ? atoi(e) : 2;
+    }();
+    ia.twist_min_pieces = ipm_twist_min_pieces;
     hipStream_t sti = (hipStream_t)stream;
 #ifdef ANET_IPM_PROF
     static long long *d_iprof = nullptr;
@@ -1819,21 +1824,23 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
       }
     } prof_dump{ctx, d_iprof, sti};
 #endif
-    // snap: two workgroups per CU (registers bounded to 256) from this batch on, when two fit the LDS
+    // two workgroups per CU (registers bounded to 256) from this batch on, when two fit the LDS
     static const int64_t ipm_two_per_cu_min_batch = [] {
       const char *e = getenv("ANET_IPM_TWO_PER_CU_MIN_BATCH");
       return e ? (int64_t)atoll(e) : (int64_t)1024;
     }();
-    if (s == 4 && batch >= ipm_two_per_cu_min_batch && 2 * ldsb <= 160 * 1024) {
-      ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_ipm<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-      hipLaunchKernelGGL((anet::k_qp_ipm<4, 2>), dim3((unsigned)batch), dim3(256), ldsb, sti, ia);
-    } else if (s == 4) {
-      ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_ipm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-      hipLaunchKernelGGL((anet::k_qp_ipm<4>), dim3((unsigned)batch), dim3(256), ldsb, sti, ia);
-    } else {
-      ANET_HIP(ctx, hipFuncSetAttribute((const void *)anet::k_qp_ipm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-      hipLaunchKernelGGL((anet::k_qp_ipm<3>), dim3((unsigned)batch), dim3(256), ldsb, sti, ia);
-    }
+    const bool two_per_cu = batch >= ipm_two_per_cu_min_batch && 2 * ldsb <= 160 * 1024;
+    auto launch_ipm = [&](auto kern) -> int {
+      ANET_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+      hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(256), ldsb, sti, ia);
+      return ANET_OK;
+    };
+    int rc_l;
+    if (s == 4) rc_l = two_per_cu ? launch_ipm(anet::k_qp_ipm<4, 2>) : launch_ipm(anet::k_qp_ipm<4, 1>);
+    // (jerk: the unbounded instantiation needs <= 256 registers as it is -- two workgroups per CU -- and the compiler
+    //  schedules it for latency; the bounded one is 18 % slower per problem at the same occupancy)
+    else rc_l = launch_ipm(anet::k_qp_ipm<3, 1>);
+    if (rc_l != ANET_OK) return rc_l;
     ANET_HIP(ctx, hipGetLastError());
     return ANET_OK;
   }

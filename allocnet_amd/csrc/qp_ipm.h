@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "minco_core.h"  // fast_rcp
 #include "qp_admm.h"    // qblk1, fallf
 
@@ -39,6 +41,7 @@ struct IpmArgs {
   double vmax, amax, m34, tol;
   int max_iter;
   double tol_accept;  // >= tol: once met, at most 8 more Newton steps are spent on reaching tol (0: same as tol)
+  int twist_min_pieces;  // chains of at least this many pieces are factored from both ends (two waves), shorter ones from one
 #ifdef ANET_IPM_PROF
   long long *prof;  // [16] cycle counters of problem 0 (tools: ANET_BUILD_FLAGS=-DANET_IPM_PROF)
 #endif
@@ -56,6 +59,29 @@ struct IpmArgs {
 #else
 #define IPM_TICK(slot) do {} while (0)
 #endif
+
+// A row of the QP as a sample sees it: (c0, c1, c2) . (derivative `dsel` of the three axes) <= bound.  Corridor rows are
+// general half-spaces on the position; the twelve box rows of a sample are +-v_ax <= vmax T, +-a_ax <= amax T^2 -- one
+// axis and a sign, known at compile time once the visit is unrolled, so nothing is multiplied by their zeros.
+struct IpmCorridorRow {
+  double c0, c1, c2;
+  static constexpr int dsel = 0;
+  __device__ __forceinline__ double dot(const double (&v)[3]) const { return c0 * v[0] + c1 * v[1] + c2 * v[2]; }
+  __device__ __forceinline__ void axpy(double t, double *g) const { g[0] += t * c0; g[1] += t * c1; g[2] += t * c2; }
+  // w c c' into the per-sample weights: [0..5] the symmetric 3 x 3 of the corridor rows
+  __device__ __forceinline__ void weights(double w, double *A) const {
+    A[0] += w * c0 * c0; A[1] += w * c0 * c1; A[2] += w * c0 * c2;
+    A[3] += w * c1 * c1; A[4] += w * c1 * c2; A[5] += w * c2 * c2;
+  }
+};
+struct IpmBoxRow {
+  int ax, dsel;  // dsel: 1 velocity, 2 acceleration
+  double sgn;
+  __device__ __forceinline__ double dot(const double (&v)[3]) const { return sgn * v[ax]; }
+  __device__ __forceinline__ void axpy(double t, double *g) const { g[ax] += sgn * t; }
+  // [6..8] velocity, [9..11] acceleration: diagonal weights per axis
+  __device__ __forceinline__ void weights(double w, double *A) const { A[3 + dsel * 3 + ax] += w; }
+};
 
 template <int S>
 inline size_t qp_ipm_lds_bytes(int N, int R, int M) {
@@ -184,9 +210,17 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   }
   __syncthreads();
   auto pinned = [&](int k, int d) { return (k == 0 || k == N) && d < 3; };
+  // The sample a thread owns (and with it i, j, its LDS rows and its slack / multiplier addresses) does not change from
+  // one Newton step to the next, so the compiler hoists all of that out of the iteration loop and carries it through
+  // every phase in registers the phases themselves need.  An opaque copy of tid per pass keeps it local.
+  auto fresh_tid = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    return t;
+  };
   // u_i of a node vector
   auto to_u = [&](const double *y, double *u) {
-    for (int e = tid; e < N * NB; e += nt) {
+    for (int e = fresh_tid(); e < N * NB; e += nt) {
       const int i = e / NB, ax = (e % NB) / D, m = e % D;
       u[e] = (m < S) ? y[i * BK + ax * S + m] : sc[i * D + m] * y[(i + 1) * BK + ax * S + (m - S)];
     }
@@ -206,24 +240,79 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         s3[d][ax] = v;
       }
   };
-  // Visit the live rows of a sample of piece i: fn(q, dsel, c0, c1, c2, bound) with the row = (c0,c1,c2).(derivative
-  // dsel of the three axes).  The box rows are unrolled so that dsel and the axis are compile-time constants
-  // inside fn (private arrays indexed by them stay in registers); all-zero corridor rows are inert padding.
+  // Visit the live rows of a sample of piece i: fn(q, row, bound), row an IpmCorridorRow or an IpmBoxRow.  The box rows
+  // are unrolled so that dsel, the axis and the sign are compile-time constants inside fn (private arrays indexed by
+  // them stay in registers); all-zero corridor rows are inert padding.
   auto for_rows = [&](int i, auto &&fn) {
     for (int q = 0; q < M; ++q) {
       const double *hq = hp_l + ((size_t)i * M + q) * 4;
       const double c0 = hq[0], c1 = hq[1], c2 = hq[2];
       if (c0 == 0.0 && c1 == 0.0 && c2 == 0.0) continue;
-      fn(q, 0, c0, c1, c2, hq[3]);
+      fn(q, IpmCorridorRow{c0, c1, c2}, hq[3]);
     }
     const double hvv = a.vmax * Tn[i], hva = a.amax * Tn[i] * Tn[i];
 #pragma unroll
     for (int qq = 0; qq < 12; ++qq) {
       const int axsel = qq / 4, w4 = qq % 4, dsel = 1 + (w4 & 1);
       const double sgn = (w4 < 2) ? 1.0 : -1.0;
-      fn(M + qq, dsel, axsel == 0 ? sgn : 0.0, axsel == 1 ? sgn : 0.0, axsel == 2 ? sgn : 0.0, dsel == 1 ? hvv : hva);
+      fn(M + qq, IpmBoxRow{axsel, dsel, sgn}, dsel == 1 ? hvv : hva);
     }
   };
+  // The same visit WITH the slack and the multiplier of each row: fn(q, row, bound, sl, lm).  The row state
+  // lives in global memory (L2), one round trip is ~1-2 k cycles, and a row needs ~40 instructions: loaded where they are
+  // used -- what the plain loop compiles to, and all it CAN compile to in the updating pass, whose stores may alias the
+  // next loads -- the 28 rows of a sample are 28 exposed round trips and the five row passes of a Newton step are pure
+  // L2 latency.  Here the loads of a group of rows (eight corridor rows, six box rows) are issued together, ahead of the
+  // arithmetic of the group; STORE writes sl, lm back (the caller's fn changes them) after the group.
+  auto for_rows_sl = [&](int i, int smp, auto store_tag, auto &&fn) {
+    constexpr bool STORE = decltype(store_tag)::value;
+    double *sp = slg + smp, *lp = lmg + smp;
+    constexpr int GC = 8, GB = 6;
+    for (int q0 = 0; q0 < M; q0 += GC) {
+      double sl[GC], lm[GC];
+#pragma unroll
+      for (int g = 0; g < GC; ++g) {
+        const int q = q0 + g < M ? q0 + g : M - 1;
+        sl[g] = sp[(int64_t)q * NS];
+        lm[g] = lp[(int64_t)q * NS];
+      }
+#pragma unroll
+      for (int g = 0; g < GC; ++g) {
+        const int q = q0 + g;
+        if (q >= M) break;
+        const double *hq = hp_l + ((size_t)i * M + q) * 4;
+        const double c0 = hq[0], c1 = hq[1], c2 = hq[2];
+        if (c0 == 0.0 && c1 == 0.0 && c2 == 0.0) continue;
+        fn(q, IpmCorridorRow{c0, c1, c2}, hq[3], sl[g], lm[g]);
+        if (STORE) {
+          sp[(int64_t)q * NS] = sl[g];
+          lp[(int64_t)q * NS] = lm[g];
+        }
+      }
+    }
+    const double hvv = a.vmax * Tn[i], hva = a.amax * Tn[i] * Tn[i];
+#pragma unroll
+    for (int g0 = 0; g0 < 12; g0 += GB) {
+      double sl[GB], lm[GB];
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+        sl[g] = sp[(int64_t)(M + g0 + g) * NS];
+        lm[g] = lp[(int64_t)(M + g0 + g) * NS];
+      }
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+        const int qq = g0 + g, axsel = qq / 4, w4 = qq % 4, dsel = 1 + (w4 & 1);
+        const double sgn = (w4 < 2) ? 1.0 : -1.0;
+        fn(M + qq, IpmBoxRow{axsel, dsel, sgn}, dsel == 1 ? hvv : hva, sl[g], lm[g]);
+        if (STORE) {
+          sp[(int64_t)(M + qq) * NS] = sl[g];
+          lp[(int64_t)(M + qq) * NS] = lm[g];
+        }
+      }
+    }
+  };
+  using RowsLoad = std::integral_constant<bool, false>;
+  using RowsUpdate = std::integral_constant<bool, true>;
   auto block_reduce = [&](double v, int slot, bool is_min) {  // red[slot] must have been initialised before a barrier
     for (int o = 32; o > 0; o >>= 1) {
       const double w = __shfl_xor(v, o);
@@ -237,7 +326,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
 
   // ---- initial slacks / multipliers
   int64_t nrows_local = 0;
-  for (int smp = tid; smp < NS; smp += nt) {
+  for (int smp = fresh_tid(); smp < NS; smp += nt) {
     const int i = smp / R, j = smp % R;
     double s3[3][3];
     state_of(uu, i, j, s3);
@@ -245,8 +334,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       slg[smp + (int64_t)q * NS] = 1.0;
       lmg[smp + (int64_t)q * NS] = 0.0;
     }
-    for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
-      const double gy = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2];
+    for_rows(i, [&](int q, auto row, double hv) {
+      const double gy = row.dot(s3[row.dsel]);
       slg[smp + (int64_t)q * NS] = fmax(hv - gy, 1.0);
       lmg[smp + (int64_t)q * NS] = 1.0;
       ++nrows_local;
@@ -262,7 +351,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   // assemble the node-space vector  out_k = sum over the pieces touching knot k of sc * (qs Hobj u + sum_j gamma_j h_j)
   // (gamma at acc offset `goff`; with_obj adds the cost gradient); pinned components are zeroed
   auto node_vector = [&](double *out, int goff, bool with_obj, const double *u) {
-    for (int e = tid; e < NY; e += nt) {
+    for (int e = fresh_tid(); e < NY; e += nt) {
       const int k = e / BK, ax = (e / S) % 3, d = e % S;
       double v = 0.0;
       if (!pinned(k, d)) {
@@ -288,50 +377,79 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     }
   };
 
-  // Block Cholesky of (Dg, Of) in place and block forward/backward substitution, by wave 0 alone, IN REGISTERS:
-  // lane r holds row r of the current block, values of other lanes arrive as wave-uniform scalars through
-  // v_readlane (lane indices are compile-time constants after unrolling).  The blocks are 9x9 / 12x12 and every
-  // step depends on the previous one: going through LDS (write, read back) for each column cost ~10x more.
+  // TWISTED block Cholesky of (Dg, Of) in place, K = T T': the chain of knots is eliminated from BOTH ends towards the
+  // middle knot PT by two waves at once -- wave 0 walks k = 0 .. PT-1 (T has the blocks L_k on and L_{k+1,k} below the
+  // diagonal), wave 1 walks k = N .. PT+1 (L_k on and M_{k-1} = A_{k,k-1}' L_k^-T ABOVE the diagonal) --, then wave 0
+  // factors the middle block, which takes a Schur update from either side.  No fill-in, the same flops, half the
+  // sequential depth (every step of a chain depends on the previous one, and the chain is what this phase costs).
+  // Of[k] ends up holding L_{k+1,k} for k < PT and M_k for k >= PT, both row-major.
+  // Within a block everything is IN REGISTERS: lane r holds row r of the current block, values of other lanes arrive as
+  // wave-uniform scalars through v_readlane (lane indices are compile-time constants after unrolling).  The blocks are
+  // 9x9 / 12x12: going through LDS (write, read back) for each column cost ~10x more.
   auto rl = [](double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
   };
-  auto wave0_factor = [&]() {
-    if (tid < 64) {
-      const int lane = tid;
-      const bool act = lane < BK;
-      double Lp[BK];  // row `lane` of L_{k,k-1}
+  const int PT = N >= a.twist_min_pieces ? N / 2 : N;  // PT = N: one chain, the classic order
+  // Dr (row `lane` of an SPD block) -> row `lane` of its Cholesky factor; dinv = 1 / diagonal (wave-uniform)
+  auto chol_rows = [&](const int lane, double (&Dr)[BK], double (&dinv)[BK]) {
 #pragma unroll
-      for (int q = 0; q < BK; ++q) Lp[q] = 0.0;
-      for (int k = 0; k <= N; ++k) {
+    for (int c = 0; c < BK; ++c) {
+      // pivot and its reciprocal from v_rsq_f64 + two Newton steps (a sqrt and a division cost ~70 instructions
+      // on this sequential path, twelve times per block)
+      const double dcc = fmax(rl(Dr[c], c), 1e-300);
+      double rs = __builtin_amdgcn_rsq(dcc);
+      rs = rs * __builtin_fma(-0.5 * dcc * rs, rs, 1.5);
+      rs = rs * __builtin_fma(-0.5 * dcc * rs, rs, 1.5);
+      dinv[c] = rs;
+      const double piv = dcc * rs;
+      Dr[c] = (lane == c) ? piv : Dr[c] * dinv[c];  // column c of L (rows > c); upper part is never read
+#pragma unroll
+      for (int c2 = c + 1; c2 < BK; ++c2) Dr[c2] -= Dr[c] * rl(Dr[c], c2);
+    }
+  };
+  // Dr -= (row `lane` of X) X' for a BK x BK block X stored row-major in LDS (the other rows: broadcast reads)
+  auto schur_rows = [&](const double (&Xr)[BK], const double *X, double (&Dr)[BK]) {
+#pragma unroll
+    for (int c = 0; c < BK; ++c) {
+      double v = 0.0;
+#pragma unroll
+      for (int q = 0; q < BK; ++q) v += Xr[q] * X[c * BK + q];
+      Dr[c] -= v;
+    }
+  };
+  // One copy of the block code serves both chains and the middle knot (this kernel is instruction-cache bound as it
+  // is): phase 0 walks the chains, phase 1 -- behind a barrier -- is wave 0 on knot PT with a Schur update from each side.
+  auto twisted_factor = [&]() {
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, in an SGPR
+    int lane = tid & 63;
+    asm volatile("" : "+v"(lane));  // (keeps the per-lane LDS addresses of this phase from being hoisted out of the Newton loop)
+    const bool act = lane < BK;
+    const int dir = wv == 0 ? 1 : -1, kfrom = wv == 0 ? 0 : N;
+#pragma nounroll
+    for (int ph = 0; ph < 2; ++ph) {
+      if (ph == 1) __syncthreads();
+      if (wv >= 2 || (ph == 1 && wv == 1)) continue;
+      const int kbeg = ph == 0 ? kfrom : PT, kend = ph == 0 ? PT : PT + 1;  // (the chain of phase 1: knot PT, one step of +1)
+      const int stepk = ph == 0 ? dir : 1;
+#pragma nounroll
+      for (int k = kbeg; k != kend; k += stepk) {
         double *Dk = Dg + (size_t)k * BK * BK;
-        double Dr[BK];
+        double Dr[BK], dinv[BK], Lp[BK];
 #pragma unroll
         for (int c = 0; c < BK; ++c) Dr[c] = act ? Dk[lane * BK + c] : (c == 0 ? 1.0 : 0.0);
-        if (k > 0) {  // Schur update: D_k -= L_{k,k-1} L_{k,k-1}' (the other rows of L_{k,k-1}: LDS broadcast reads)
-          const double *Lq = Of + (size_t)(k - 1) * BK * BK;
+        // Schur updates: from the knot eliminated before this one in its chain; the middle knot from both sides
+        const int src0 = ph == 0 ? (k == kfrom ? -1 : (dir > 0 ? k - 1 : k)) : (PT > 0 ? PT - 1 : -1);
+        const int src1 = ph == 0 ? -1 : (PT < N ? PT : -1);
+#pragma nounroll
+        for (int u = 0; u < 2; ++u) {
+          const int src = u == 0 ? src0 : src1;
+          if (src < 0) continue;
+          const double *X = Of + (size_t)src * BK * BK;
 #pragma unroll
-          for (int c = 0; c < BK; ++c) {
-            double v = 0.0;
-#pragma unroll
-            for (int q = 0; q < BK; ++q) v += Lp[q] * Lq[c * BK + q];
-            Dr[c] -= v;
-          }
+          for (int q = 0; q < BK; ++q) Lp[q] = act ? X[lane * BK + q] : 0.0;
+          schur_rows(Lp, X, Dr);
         }
-        double dinv[BK];  // 1 / L[c][c], wave-uniform
-#pragma unroll
-        for (int c = 0; c < BK; ++c) {
-          // pivot and its reciprocal from v_rsq_f64 + two Newton steps (a sqrt and a division cost ~70 instructions
-          // on this sequential path, twelve times per block)
-          const double dcc = fmax(rl(Dr[c], c), 1e-300);
-          double rs = __builtin_amdgcn_rsq(dcc);
-          rs = rs * __builtin_fma(-0.5 * dcc * rs, rs, 1.5);
-          rs = rs * __builtin_fma(-0.5 * dcc * rs, rs, 1.5);
-          dinv[c] = rs;
-          const double piv = dcc * rs;
-          Dr[c] = (lane == c) ? piv : Dr[c] * dinv[c];  // column c of L (rows > c); upper part is never read
-#pragma unroll
-          for (int c2 = c + 1; c2 < BK; ++c2) Dr[c2] -= Dr[c] * rl(Dr[c], c2);
-        }
+        chol_rows(lane, Dr, dinv);
         if (act) {
 #pragma unroll
           for (int c = 0; c < BK; ++c) Dk[lane * BK + c] = Dr[c];
@@ -340,73 +458,93 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
 #pragma unroll
           for (int c = 0; c < BK; ++c) dinvd[k * BK + c] = dinv[c];
         }
-        if (k < N) {  // L_{k+1,k} = A_{k+1,k} L_k^-T, row by row (forward substitution over the columns)
-          double *Lo = Of + (size_t)k * BK * BK;
+        if (ph == 1) continue;
+        // the block towards the next knot of the chain: L_{k+1,k} = A_{k+1,k} L_k^-T (rows of A), or
+        // M_{k-1} = A_{k,k-1}' L_k^-T (columns of A), row by row: forward substitution over the columns
+        double *Lo = Of + (size_t)(dir > 0 ? k : k - 1) * BK * BK;
+        const int st_c = dir > 0 ? 1 : BK, st_l = dir > 0 ? BK : 1;
 #pragma unroll
-          for (int c = 0; c < BK; ++c) Lp[c] = act ? Lo[lane * BK + c] : 0.0;
+        for (int c = 0; c < BK; ++c) Lp[c] = act ? Lo[lane * st_l + c * st_c] : 0.0;
 #pragma unroll
-          for (int c = 0; c < BK; ++c) {
-            double v = Lp[c];
+        for (int c = 0; c < BK; ++c) {
+          double v = Lp[c];
 #pragma unroll
-            for (int q = 0; q < c; ++q) v -= Lp[q] * Dk[c * BK + q];  // L_k[c][q], just stored: LDS broadcast read
-            Lp[c] = v * dinv[c];
-          }
-          if (act) {
+          for (int q = 0; q < c; ++q) v -= Lp[q] * Dk[c * BK + q];  // L_k[c][q], just stored: LDS broadcast read
+          Lp[c] = v * dinv[c];
+        }
+        if (act) {
 #pragma unroll
-            for (int c = 0; c < BK; ++c) Lo[lane * BK + c] = Lp[c];
-          }
+          for (int c = 0; c < BK; ++c) Lo[lane * BK + c] = Lp[c];
         }
       }
     }
   };
-  auto wave0_solve = [&](double *x) {  // x <- K^-1 x
-    if (tid < 64) {
-      const int lane = tid;
-      const bool act = lane < BK;
-      double zp = 0.0;
-      for (int k = 0; k <= N; ++k) {  // forward: L z = x
-        const double *Dk = Dg + (size_t)k * BK * BK;
+  // x <- K^-1 x with the twisted factor: T z = x from both ends to the middle, T'x = z from the middle outwards
+  auto twisted_solve = [&](double *x) {
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, in an SGPR
+    int lane = tid & 63;
+    asm volatile("" : "+v"(lane));  // (keeps the per-lane LDS addresses of this phase from being hoisted out of the Newton loop)
+    const bool act = lane < BK;
+    const int dir = wv == 0 ? 1 : -1, kfrom = wv == 0 ? 0 : N;
+    // ---- forward: phase 0 the chains, phase 1 (behind a barrier) wave 0 on the middle knot
+#pragma nounroll
+    for (int ph = 0; ph < 2; ++ph) {
+      if (ph == 1) __syncthreads();
+      if (wv >= 2 || (ph == 1 && wv == 1)) continue;
+      const int kbeg = ph == 0 ? kfrom : PT, kend = ph == 0 ? PT : PT + 1, stepk = ph == 0 ? dir : 1;
+#pragma nounroll
+      for (int k = kbeg; k != kend; k += stepk) {
         double xr = act ? x[k * BK + lane] : 0.0;
+        const int src0 = ph == 0 ? (k == kfrom ? -1 : (dir > 0 ? k - 1 : k)) : (PT > 0 ? PT - 1 : -1);
+        const int src1 = ph == 0 ? -1 : (PT < N ? PT : -1);
+        const int nb0 = ph == 0 ? k - dir : PT - 1, nb1 = PT + 1;
+#pragma nounroll
+        for (int u = 0; u < 2; ++u) {
+          const int src = u == 0 ? src0 : src1;
+          if (src < 0) continue;
+          const double *X = Of + (size_t)src * BK * BK, *v = x + (u == 0 ? nb0 : nb1) * BK;
+          double sdot = 0.0;
+#pragma unroll
+          for (int q = 0; q < BK; ++q) sdot += (act ? X[lane * BK + q] : 0.0) * v[q];
+          xr -= sdot;
+        }
+        const double *Dk = Dg + (size_t)k * BK * BK;
         double Dr[BK];
 #pragma unroll
         for (int c = 0; c < BK; ++c) Dr[c] = act ? Dk[lane * BK + c] : (c == 0 ? 1.0 : 0.0);
-        if (k > 0) {
-          const double *Lo = Of + (size_t)(k - 1) * BK * BK;
-          double Or[BK];
-#pragma unroll
-          for (int q = 0; q < BK; ++q) Or[q] = act ? Lo[lane * BK + q] : 0.0;
-#pragma unroll
-          for (int q = 0; q < BK; ++q) xr -= Or[q] * x[(k - 1) * BK + q];
-        }
 #pragma unroll
         for (int c = 0; c < BK; ++c) {
           const double zc = rl(xr, c) * dinvd[k * BK + c];
           xr = (lane == c) ? zc : (lane > c ? xr - Dr[c] * zc : xr);
         }
-        zp = xr;
         if (act) x[k * BK + lane] = xr;
       }
-      double xn = 0.0;
-      for (int k = N; k >= 0; --k) {  // backward: L' x = z
-        const double *Dk = Dg + (size_t)k * BK * BK;
+    }
+    // ---- backward: phase 0 wave 0 on the middle knot (its own forward result: no barrier needed), phase 1 the chains
+#pragma nounroll
+    for (int ph = 0; ph < 2; ++ph) {
+      if (ph == 1) __syncthreads();
+      if (wv >= 2 || (ph == 0 && wv == 1)) continue;
+      const int kbeg = ph == 0 ? PT : PT - dir, kend = ph == 0 ? PT - 1 : kfrom - dir, stepk = ph == 0 ? -1 : -dir;
+#pragma nounroll
+      for (int k = kbeg; k != kend; k += stepk) {
         double xr = act ? x[k * BK + lane] : 0.0;
+        if (ph == 1) {
+          const double *X = Of + (size_t)(dir > 0 ? k : k - 1) * BK * BK, *v = x + (k + dir) * BK;
+          double sdot = 0.0;
+#pragma unroll
+          for (int q = 0; q < BK; ++q) sdot += (act ? X[q * BK + lane] : 0.0) * v[q];
+          xr -= sdot;
+        }
+        const double *Dk = Dg + (size_t)k * BK * BK;
         double Dc[BK];  // column `lane` of L_k: Dc[c] = L_k[c][lane]
 #pragma unroll
         for (int c = 0; c < BK; ++c) Dc[c] = act ? Dk[c * BK + lane] : (c == 0 ? 1.0 : 0.0);
-        if (k < N) {
-          const double *Lo = Of + (size_t)k * BK * BK;  // L_{k+1,k}
-          double Oc[BK];
-#pragma unroll
-          for (int q = 0; q < BK; ++q) Oc[q] = act ? Lo[q * BK + lane] : 0.0;
-#pragma unroll
-          for (int q = 0; q < BK; ++q) xr -= Oc[q] * x[(k + 1) * BK + q];
-        }
 #pragma unroll
         for (int c = BK - 1; c >= 0; --c) {
           const double xc = rl(xr, c) * dinvd[k * BK + c];
           xr = (lane == c) ? xc : (lane < c ? xr - Dc[c] * xc : xr);
         }
-        xn = xr;
         if (act) x[k * BK + lane] = xr;
       }
     }
@@ -418,9 +556,9 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     // samples (six corridor 3x3 entries, three velocity, three acceleration weights) are formed once and
     // scattered to the nine axis pairs of the node blocks -- 18 LDS reads per 12 results, where one thread per
     // matrix entry needed 9 per result.
-    for (int e = tid; e < (2 * N + 1) * BK * BK; e += nt) Dg[e] = 0.0;  // Of follows Dg
+    for (int e = fresh_tid(); e < (2 * N + 1) * BK * BK; e += nt) Dg[e] = 0.0;  // Of follows Dg
     __syncthreads();
-    for (int w = tid; w < N * D * D; w += nt) {
+    for (int w = fresh_tid(); w < N * D * D; w += nt) {
       const int i = w / (D * D), m = (w / D) % D, m2 = w % D;
       if (m < S && m2 >= S) continue;  // upper off-diagonal block: the transpose of the stored one
       double Sa[6] = {0, 0, 0, 0, 0, 0}, Sd[3] = {0, 0, 0};
@@ -446,7 +584,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         }
     }
     __syncthreads();
-    for (int e = tid; e < (2 * N + 1) * BK * BK; e += nt) {  // pinned components, diagonal regularisation
+    for (int e = fresh_tid(); e < (2 * N + 1) * BK * BK; e += nt) {  // pinned components, diagonal regularisation
       const int blk = e / (BK * BK), r = (e % (BK * BK)) / BK, c = e % BK;
       const bool diag = blk <= N;
       const int k = diag ? blk : blk - (N + 1);
@@ -470,30 +608,22 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     if (tid < 32) red[tid] = 0.0;
     __syncthreads();
     double l_mu = 0.0, l_pres = 0.0, l_h = 0.0;
-    for (int smp = tid; smp < NS; smp += nt) {
+    for (int smp = fresh_tid(); smp < NS; smp += nt) {
       const int i = smp / R, j = smp % R;
       double s3[3][3];
       state_of(uu, i, j, s3);
       double A_[30];
 #pragma unroll
       for (int q = 0; q < 30; ++q) A_[q] = 0.0;
-      for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
-        const double gy = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2];
-        const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
+      for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
+        const double gy = row.dot(s3[row.dsel]);
         const double rg = gy + sl - hv, w = lm * fast_rcp(sl), t = lm + w * (gy - hv);
         l_mu += sl * lm;
         l_pres = fmax(l_pres, fabs(rg));
         l_h = fmax(l_h, fabs(hv));
-        if (dsel == 0) {
-          A_[0] += w * c0 * c0; A_[1] += w * c0 * c1; A_[2] += w * c0 * c2;
-          A_[3] += w * c1 * c1; A_[4] += w * c1 * c2; A_[5] += w * c2 * c2;
-        } else {
-          A_[3 + dsel * 3 + 0] += w * c0 * c0;
-          A_[3 + dsel * 3 + 1] += w * c1 * c1;
-          A_[3 + dsel * 3 + 2] += w * c2 * c2;
-        }
-        A_[12 + dsel * 3 + 0] += t * c0; A_[12 + dsel * 3 + 1] += t * c1; A_[12 + dsel * 3 + 2] += t * c2;
-        A_[21 + dsel * 3 + 0] += lm * c0; A_[21 + dsel * 3 + 1] += lm * c1; A_[21 + dsel * 3 + 2] += lm * c2;
+        row.weights(w, A_);
+        row.axpy(t, A_ + 12 + row.dsel * 3);
+        row.axpy(lm, A_ + 21 + row.dsel * 3);
       });
       double *as = acc + (size_t)smp * 30;
 #pragma unroll
@@ -512,13 +642,13 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     {
       double l_rd = 0.0;
-      for (int e = tid; e < NY; e += nt) l_rd = fmax(l_rd, fabs(rhs[e]));
+      for (int e = fresh_tid(); e < NY; e += nt) l_rd = fmax(l_rd, fabs(rhs[e]));
       if (tid < 32) red[8 + (tid & 7)] = 0.0;
       __syncthreads();
       block_reduce(1.0 / fmax(l_rd, 1e-300), 8, true);
       // scale of the dual residual: |P y| in node space
       double l_py = 0.0;
-      for (int e = tid; e < NY; e += nt) {
+      for (int e = fresh_tid(); e < NY; e += nt) {
         const int k = e / BK, ax = (e / S) % 3, d = e % S;
         double v = 0.0;
         for (int side = 0; side < 2; ++side) {
@@ -536,7 +666,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       block_reduce(1.0 / fmax(l_py, 1e-300), 9, true);
       // y'Py, the scale of the complementarity test
       double l_obj = 0.0;
-      for (int e = tid; e < N * NB; e += nt) {
+      for (int e = fresh_tid(); e < N * NB; e += nt) {
         const int i = e / NB, ax = (e % NB) / D, m = e % D;
         const double *ui = uu + (size_t)i * NB + ax * D;
         double g = 0.0;
@@ -587,13 +717,13 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     // affine right-hand side: -(P y + q) - G'(lambda + w (Gy - h))
     node_vector(dya, 12, true, uu);
     __syncthreads();
-    for (int e = tid; e < NY; e += nt) dya[e] = -dya[e];
+    for (int e = fresh_tid(); e < NY; e += nt) dya[e] = -dya[e];
     __syncthreads();
     IPM_TICK(4);
-    wave0_factor();
+    twisted_factor();
     __syncthreads();
     IPM_TICK(5);
-    wave0_solve(dya);
+    twisted_solve(dya);
     __syncthreads();
     IPM_TICK(6);
     to_u(dya, dua);
@@ -602,15 +732,14 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     // ---- pass B: affine step length and the three sums of (s + a ds)'(lambda + a dlambda) -----------------
     {
       double l_ap = 0.0, l_s1 = 0.0, l_s2 = 0.0;  // l_ap: max of -ds/s, -dl/lambda = 1 / (step to the boundary)
-      for (int smp = tid; smp < NS; smp += nt) {
+      for (int smp = fresh_tid(); smp < NS; smp += nt) {
         const int i = smp / R, j = smp % R;
         double s3[3][3], d3[3][3];
         state_of(uu, i, j, s3);
         state_of(dua, i, j, d3);
-        for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
-          const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
-          const double rg = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2] + sl - hv;
-          const double ds = -rg - (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
+        for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
+          const double rg = row.dot(s3[row.dsel]) + sl - hv;
+          const double ds = -rg - row.dot(d3[row.dsel]);
           const double dl = -lm - (lm * fast_rcp(sl)) * ds;
           // step to the boundary: the largest of -ds/s, -dl/lambda over the rows is 1/alpha (no division per row)
           l_ap = fmax(l_ap, fmax(-ds * fast_rcp(sl), -dl * fast_rcp(lm)));
@@ -635,22 +764,21 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     const double mu_target = fmax(sigma * mu, 0.1 * a.tol * fmax(1.0, 0.5 * fabs(objn)) / mrows);
     __syncthreads();
     // ---- pass C: corrector right-hand side (same factor) ----------------------------------------------
-    for (int smp = tid; smp < NS; smp += nt) {
+    for (int smp = fresh_tid(); smp < NS; smp += nt) {
       const int i = smp / R, j = smp % R;
       double s3[3][3], d3[3][3], G_[9];
       state_of(uu, i, j, s3);
       state_of(dua, i, j, d3);
 #pragma unroll
       for (int q = 0; q < 9; ++q) G_[q] = 0.0;
-      for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
-        const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
-        const double rg = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2] + sl - hv;
-        const double ds = -rg - (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
+      for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
+        const double rg = row.dot(s3[row.dsel]) + sl - hv;
+        const double ds = -rg - row.dot(d3[row.dsel]);
         const double isl = fast_rcp(sl);
         const double dl = -lm - (lm * isl) * ds;
         const double rc = sl * lm + ds * dl - mu_target;
         const double t = lm + (lm * rg - rc) * isl;
-        G_[dsel * 3 + 0] += t * c0; G_[dsel * 3 + 1] += t * c1; G_[dsel * 3 + 2] += t * c2;
+        row.axpy(t, G_ + row.dsel * 3);
       });
       double *as = acc + (size_t)smp * 30 + 12;
 #pragma unroll
@@ -660,10 +788,10 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     IPM_TICK(8);
     node_vector(dyc, 12, true, uu);
     __syncthreads();
-    for (int e = tid; e < NY; e += nt) dyc[e] = -dyc[e];
+    for (int e = fresh_tid(); e < NY; e += nt) dyc[e] = -dyc[e];
     __syncthreads();
     IPM_TICK(9);
-    wave0_solve(dyc);
+    twisted_solve(dyc);
     __syncthreads();
     IPM_TICK(10);
     to_u(dyc, duc);
@@ -671,28 +799,27 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     // ---- pass D: step length of the combined direction -----------------------------------------------
     // slack / multiplier directions of the combined step for one row
-    auto final_dir = [&](int dsel, double c0, double c1, double c2, double hv, const double (&s3)[3][3], const double (&d3)[3][3],
+    auto final_dir = [&](auto row, double hv, const double (&s3)[3][3], const double (&d3)[3][3],
                          const double (&e3)[3][3], double sl, double lm, double &ds, double &dl) {
-      const double rg = c0 * s3[dsel][0] + c1 * s3[dsel][1] + c2 * s3[dsel][2] + sl - hv;
-      const double dsa = -rg - (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
+      const double rg = row.dot(s3[row.dsel]) + sl - hv;
+      const double dsa = -rg - row.dot(d3[row.dsel]);
       const double isl = fast_rcp(sl);
       const double dla = -lm - (lm * isl) * dsa;
       const double rc = sl * lm + dsa * dla - mu_target;
-      ds = -rg - (c0 * e3[dsel][0] + c1 * e3[dsel][1] + c2 * e3[dsel][2]);
+      ds = -rg - row.dot(e3[row.dsel]);
       dl = (-rc - lm * ds) * isl;
     };
     {
       double l_a = 0.0;  // 1 / (step to the boundary)
-      for (int smp = tid; smp < NS; smp += nt) {
+      for (int smp = fresh_tid(); smp < NS; smp += nt) {
         const int i = smp / R, j = smp % R;
         double s3[3][3], d3[3][3], e3[3][3];
         state_of(uu, i, j, s3);
         state_of(dua, i, j, d3);
         state_of(duc, i, j, e3);
-        for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
-          const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
+        for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
           double ds, dl;
-          final_dir(dsel, c0, c1, c2, hv, s3, d3, e3, sl, lm, ds, dl);
+          final_dir(row, hv, s3, d3, e3, sl, lm, ds, dl);
           l_a = fmax(l_a, fmax(-ds * fast_rcp(sl), -dl * fast_rcp(lm)));
         });
       }
@@ -704,22 +831,21 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     alpha_win = fmax(alpha_win, alpha);
     __syncthreads();
     // ---- pass E: update ----------------------------------------------------------------------------------
-    for (int smp = tid; smp < NS; smp += nt) {
+    for (int smp = fresh_tid(); smp < NS; smp += nt) {
       const int i = smp / R, j = smp % R;
       double s3[3][3], d3[3][3], e3[3][3];
       state_of(uu, i, j, s3);
       state_of(dua, i, j, d3);
       state_of(duc, i, j, e3);
-      for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double hv) {
-        const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
+      for_rows_sl(i, smp, RowsUpdate{}, [&](int q, auto row, double hv, double &sl, double &lm) {
         double ds, dl;
-        final_dir(dsel, c0, c1, c2, hv, s3, d3, e3, sl, lm, ds, dl);
-        slg[smp + (int64_t)q * NS] = sl + alpha * ds;
-        lmg[smp + (int64_t)q * NS] = lm + alpha * dl;
+        final_dir(row, hv, s3, d3, e3, sl, lm, ds, dl);
+        sl += alpha * ds;
+        lm += alpha * dl;
       });
     }
     __syncthreads();
-    for (int e = tid; e < NY; e += nt) yv[e] += alpha * dyc[e];
+    for (int e = fresh_tid(); e < NY; e += nt) yv[e] += alpha * dyc[e];
     __syncthreads();
     to_u(yv, uu);
     __syncthreads();
@@ -749,22 +875,13 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     for (int i = 0; i < N; ++i)
       for (int m = 0; m < D; ++m) pmax = fmax(pmax, qsv[i] * Hobj[m * D + m] * sc[i * D + m] * sc[i * D + m]);
     const double w_act = 1.0e4 * pmax;
-    for (int smp = tid; smp < NS; smp += nt) {
+    for (int smp = fresh_tid(); smp < NS; smp += nt) {
       const int i = smp / R;
       double A_[12];
 #pragma unroll
       for (int q = 0; q < 12; ++q) A_[q] = 0.0;
-      for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double) {
-        const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
-        const double w = (lm > sl) ? w_act : 0.0;
-        if (dsel == 0) {
-          A_[0] += w * c0 * c0; A_[1] += w * c0 * c1; A_[2] += w * c0 * c2;
-          A_[3] += w * c1 * c1; A_[4] += w * c1 * c2; A_[5] += w * c2 * c2;
-        } else {
-          A_[3 + dsel * 3 + 0] += w * c0 * c0;
-          A_[3 + dsel * 3 + 1] += w * c1 * c1;
-          A_[3 + dsel * 3 + 2] += w * c2 * c2;
-        }
+      for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double, double sl, double lm) {
+        row.weights((lm > sl) ? w_act : 0.0, A_);
       });
       double *as = acc + (size_t)smp * 30;
 #pragma unroll
@@ -773,9 +890,9 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     assemble_newton();
     __syncthreads();
-    wave0_factor();
+    twisted_factor();
     // g_u = d loss / d u_i (duc), g_y (dyc)
-    for (int e = tid; e < N * NB; e += nt) {
+    for (int e = fresh_tid(); e < N * NB; e += nt) {
       const int i = e / NB, ax = (e % NB) / D, m = e % D;
       double v = 0.0, tk = 1.0;
       const double rT = 1.0 / Tn[i];
@@ -786,7 +903,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       duc[e] = v;
     }
     __syncthreads();
-    for (int e = tid; e < NY; e += nt) {
+    for (int e = fresh_tid(); e < NY; e += nt) {
       const int k = e / BK, ax = (e / S) % 3, d = e % S;
       double v = 0.0;
       if (!pinned(k, d)) {
@@ -795,8 +912,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       }
       dyc[e] = v;
     }
-    for (int i = tid; i < 3 * N; i += nt) rhs[i] = 0.0;
-    for (int smp = tid; smp < NS; smp += nt) {
+    for (int i = fresh_tid(); i < 3 * N; i += nt) rhs[i] = 0.0;
+    for (int smp = fresh_tid(); smp < NS; smp += nt) {
       double *as = acc + (size_t)smp * 30 + 12;
 #pragma unroll
       for (int q = 0; q < 9; ++q) as[q] = 0.0;
@@ -811,24 +928,23 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     for (int pass = 0; pass < 4; ++pass) {
       node_vector(dya, 12, false, uu);
       __syncthreads();
-      for (int e = tid; e < NY; e += nt) dya[e] = -dyc[e] - dya[e];
+      for (int e = fresh_tid(); e < NY; e += nt) dya[e] = -dyc[e] - dya[e];
       __syncthreads();
-      wave0_solve(dya);
+      twisted_solve(dya);
       __syncthreads();
       to_u(dya, dua);
       __syncthreads();
-      for (int smp = tid; smp < NS; smp += nt) {
+      for (int smp = fresh_tid(); smp < NS; smp += nt) {
         const int i = smp / R, j = smp % R;
         double d3[3][3], G_[9], bsv = 0.0, bsa = 0.0;
         state_of(dua, i, j, d3);
 #pragma unroll
         for (int q = 0; q < 9; ++q) G_[q] = 0.0;
-        for_rows(i, [&](int q, int dsel, double c0, double c1, double c2, double) {
-          const double sl = slg[smp + (int64_t)q * NS], lm = lmg[smp + (int64_t)q * NS];
-          const double dl = ((lm > sl) ? w_act : 0.0) * (c0 * d3[dsel][0] + c1 * d3[dsel][1] + c2 * d3[dsel][2]);
-          G_[dsel * 3 + 0] += dl * c0; G_[dsel * 3 + 1] += dl * c1; G_[dsel * 3 + 2] += dl * c2;
-          if (dsel == 1) bsv += dl;
-          if (dsel == 2) bsa += dl;
+        for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double, double sl, double lm) {
+          const double dl = ((lm > sl) ? w_act : 0.0) * row.dot(d3[row.dsel]);
+          row.axpy(dl, G_ + row.dsel * 3);
+          if (row.dsel == 1) bsv += dl;
+          if (row.dsel == 2) bsa += dl;
         });
         double *as = acc + (size_t)smp * 30 + 12;
 #pragma unroll
@@ -838,7 +954,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       }
       __syncthreads();
     }
-    for (int e = tid; e < N * NB; e += nt) {
+    for (int e = fresh_tid(); e < N * NB; e += nt) {
       const int i = e / NB, ax = (e % NB) / D, m = e % D, d = m % S;
       const double *ui = uu + (size_t)i * NB + ax * D, *vi = dua + (size_t)i * NB + ax * D;
       double hu = 0.0, hv = 0.0;
@@ -875,7 +991,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       }
     }
     __syncthreads();
-    for (int i = tid; i < N; i += nt)
+    for (int i = fresh_tid(); i < N; i += nt)
       a.vjpT[b * N + i] = rhs[i] - (a.vmax * rhs[N + i] + 2.0 * a.amax * Tn[i] * rhs[2 * N + i]);
     __syncthreads();
   }
@@ -885,9 +1001,9 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   // y_N[d] = fin_d T_N-1^d, and the box bounds vmax T_i, amax T_i^2.  (acc[21..29] holds G'lambda per sample
   // for the iterate the loop stopped at.)
   if (a.gradT) {
-    for (int i = tid; i < N; i += nt) rhs[i] = 0.0;
+    for (int i = fresh_tid(); i < N; i += nt) rhs[i] = 0.0;
     __syncthreads();
-    for (int e = tid; e < N * NB; e += nt) {
+    for (int e = fresh_tid(); e < N * NB; e += nt) {
       const int i = e / NB, ax = (e % NB) / D, m = e % D, d = m % S;
       const double *ui = uu + (size_t)i * NB + ax * D;
       double hu = 0.0;
@@ -912,7 +1028,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         atomicAdd(&rhs[0], c / Tn[0]);
       }
     }
-    for (int smp = tid; smp < NS; smp += nt) {
+    for (int smp = fresh_tid(); smp < NS; smp += nt) {
       const int i = smp / R;
       double sv = 0.0, sa = 0.0;
       for (int qq = 0; qq < 12; ++qq) {
@@ -923,11 +1039,11 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       atomicAdd(&rhs[i], -(a.vmax * sv + 2.0 * a.amax * Tn[i] * sa));
     }
     __syncthreads();
-    for (int i = tid; i < N; i += nt) a.gradT[b * N + i] = rhs[i];
+    for (int i = fresh_tid(); i < N; i += nt) a.gradT[b * N + i] = rhs[i];
     __syncthreads();
   }
   // ---- report: coefficients c = Hm u / T^k, objective in original units ---------------------------------
-  for (int e = tid; e < N * NB; e += nt) {
+  for (int e = fresh_tid(); e < N * NB; e += nt) {
     const int i = e / NB, ax = (e % NB) / D, col = e % D, k = D - 1 - col;
     const double *ui = uu + (size_t)i * NB + ax * D;
     double v = 0.0;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Device-side time of the batched QP solve (anet_qp_solve_dev, interior point), inputs resident, HIP events:
-    gpurun -- 'python tools/time_qp_dev.py'          (s, N, M, B as in tools/bench_qp.py)"""
+    gpurun -- 'python tools/time_qp_dev.py'          [s,N,M,B ...]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -8,7 +8,8 @@ import torch
 import allocnet_amd as aa
 from allocnet_amd.synth import corridor_problem
 ctx = aa.Context(0); dev = torch.device("cuda", 0)
-for (s, N, M, B) in [(4, 8, 16, 4096), (3, 5, 16, 4096), (3, 16, 16, 1024), (4, 5, 16, 4096)]:
+SHAPES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(4, 8, 16, 4096), (3, 5, 16, 4096), (3, 16, 16, 1024), (4, 5, 16, 4096)]  # s,N,M,B
+for (s, N, M, B) in SHAPES:
     head, tail, wps, T, hp = corridor_problem(np.random.default_rng(1), B, N, 3, M)
     state = np.stack([head, tail], axis=1)[..., :3]                      # (B,2,3,3)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
