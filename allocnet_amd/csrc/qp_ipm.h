@@ -377,6 +377,53 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     }
   };
 
+  // What a Newton step needs besides the factor -- the dual residual P y + q + G'lambda with its scale |P y|, y'P y and
+  // the affine right-hand side -(P y + q) - G'(lambda + w (G y - h)) -- depends on pass A only, as the Newton matrix
+  // does: the two waves that have no part in the factorisation compute all of it while the chains are walked (one visit of
+  // the per-sample sums for both vectors; maxima and sums into red[8..10], zeroed at the top of the step).
+  auto side_vectors = [&]() {
+    const int t2 = fresh_tid() - 128;
+    double l_rd = 0.0, l_py = 0.0, l_obj = 0.0;
+    for (int e = t2; e < NY; e += 128) {
+      const int k = e / BK, ax = (e / S) % 3, d = e % S;
+      double vp = 0.0, vr = 0.0, va = 0.0;
+      for (int side = 0; side < 2; ++side) {
+        const int i = side == 0 ? k : k - 1;  // piece whose start (side 0) / end (side 1) is knot k
+        if (i < 0 || i >= N) continue;
+        const int m = side == 0 ? d : S + d;
+        const double qs = qsv[i];
+        const double *ui = uu + (size_t)i * NB + ax * D;
+        double g = 0.0;
+        for (int m2 = 0; m2 < D; ++m2) g += qs * Hobj[m * D + m2] * ui[m2];
+        double gr = g, ga = g;
+        for (int j = 0; j < R; ++j) {
+          const double *ac = acc + (size_t)(i * R + j) * 30;
+          const double *hj = ht + (size_t)j * 3 * D;
+          gr += ac[21 + ax] * hj[m] + ac[24 + ax] * hj[D + m] + ac[27 + ax] * hj[2 * D + m];
+          ga += ac[12 + ax] * hj[m] + ac[15 + ax] * hj[D + m] + ac[18 + ax] * hj[2 * D + m];
+        }
+        const double scm = sc[i * D + m];
+        vp += scm * g;
+        vr += scm * gr;
+        va += scm * ga;
+      }
+      const bool pin = pinned(k, d);
+      l_rd = fmax(l_rd, pin ? 0.0 : fabs(vr));
+      l_py = fmax(l_py, fabs(vp));
+      dya[e] = -(pin ? 0.0 : va);
+    }
+    for (int e = t2; e < N * NB; e += 128) {
+      const int i = e / NB, ax = (e % NB) / D, m = e % D;
+      const double *ui = uu + (size_t)i * NB + ax * D;
+      double g = 0.0;
+      for (int m2 = 0; m2 < D; ++m2) g += Hobj[m * D + m2] * ui[m2];
+      l_obj += qsv[i] * ui[m] * g;
+    }
+    block_reduce(1.0 / fmax(l_rd, 1e-300), 8, true);
+    block_reduce(1.0 / fmax(l_py, 1e-300), 9, true);  // scale of the dual residual: |P y| in node space
+    block_reduce(l_obj, 10, false);                   // y'P y, the scale of the complementarity test
+  };
+
   // TWISTED block Cholesky of (Dg, Of) in place, K = T T': the chain of knots is eliminated from BOTH ends towards the
   // middle knot PT by two waves at once -- wave 0 walks k = 0 .. PT-1 (T has the blocks L_k on and L_{k+1,k} below the
   // diagonal), wave 1 walks k = N .. PT+1 (L_k on and M_{k-1} = A_{k,k-1}' L_k^-T ABOVE the diagonal) --, then wave 0
@@ -419,7 +466,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   };
   // One copy of the block code serves both chains and the middle knot (this kernel is instruction-cache bound as it
   // is): phase 0 walks the chains, phase 1 -- behind a barrier -- is wave 0 on knot PT with a Schur update from each side.
-  auto twisted_factor = [&]() {
+  // `side`: work for the two waves that have no part in the factorisation, done while the chains are walked (no barriers in it).
+  auto twisted_factor = [&](auto &&side) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, in an SGPR
     int lane = tid & 63;
     asm volatile("" : "+v"(lane));  // (keeps the per-lane LDS addresses of this phase from being hoisted out of the Newton loop)
@@ -428,7 +476,11 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
 #pragma nounroll
     for (int ph = 0; ph < 2; ++ph) {
       if (ph == 1) __syncthreads();
-      if (wv >= 2 || (ph == 1 && wv == 1)) continue;
+      if (wv >= 2) {
+        if (ph == 0) side();
+        continue;
+      }
+      if (ph == 1 && wv == 1) continue;
       const int kbeg = ph == 0 ? kfrom : PT, kend = ph == 0 ? PT : PT + 1;  // (the chain of phase 1: knot PT, one step of +1)
       const int stepk = ph == 0 ? dir : 1;
 #pragma nounroll
@@ -637,47 +689,15 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     mu = red[0] / mrows;
     if (it == 0) mu0 = mu;
     pres = red[1] / fmax(1.0, red[2]);
-    // ---- dual residual (node space) and the Newton matrix -------------------------------------------
-    node_vector(rhs, 21, true, uu);  // P y + q + G'lambda
+    // ---- the Newton matrix and its factor; beside the factorisation the dual residual and the affine right-hand side
     __syncthreads();
-    {
-      double l_rd = 0.0;
-      for (int e = fresh_tid(); e < NY; e += nt) l_rd = fmax(l_rd, fabs(rhs[e]));
-      if (tid < 32) red[8 + (tid & 7)] = 0.0;
-      __syncthreads();
-      block_reduce(1.0 / fmax(l_rd, 1e-300), 8, true);
-      // scale of the dual residual: |P y| in node space
-      double l_py = 0.0;
-      for (int e = fresh_tid(); e < NY; e += nt) {
-        const int k = e / BK, ax = (e / S) % 3, d = e % S;
-        double v = 0.0;
-        for (int side = 0; side < 2; ++side) {
-          const int i = side == 0 ? k : k - 1;
-          if (i < 0 || i >= N) continue;
-          const int m = side == 0 ? d : S + d;
-          const double qs = qsv[i];
-          const double *ui = uu + (size_t)i * NB + ax * D;
-          double g = 0.0;
-          for (int m2 = 0; m2 < D; ++m2) g += qs * Hobj[m * D + m2] * ui[m2];
-          v += sc[i * D + m] * g;
-        }
-        l_py = fmax(l_py, fabs(v));
-      }
-      block_reduce(1.0 / fmax(l_py, 1e-300), 9, true);
-      // y'Py, the scale of the complementarity test
-      double l_obj = 0.0;
-      for (int e = fresh_tid(); e < N * NB; e += nt) {
-        const int i = e / NB, ax = (e % NB) / D, m = e % D;
-        const double *ui = uu + (size_t)i * NB + ax * D;
-        double g = 0.0;
-        for (int m2 = 0; m2 < D; ++m2) g += Hobj[m * D + m2] * ui[m2];
-        l_obj += qsv[i] * ui[m] * g;
-      }
-      block_reduce(l_obj, 10, false);
-      __syncthreads();
-      dres = red[8] / fmax(1.0, red[9]);
-    }
-    IPM_TICK(2);
+    assemble_newton();
+    __syncthreads();
+    IPM_TICK(3);
+    twisted_factor(side_vectors);
+    __syncthreads();
+    IPM_TICK(5);
+    dres = red[8] / fmax(1.0, red[9]);
     const double objn = red[10];
     // (the duality gap is mu * rows: that, not mu, is what bounds the distance of the objective from the optimum)
     if (pres < a.tol && dres < a.tol && mu * mrows < a.tol * fmax(1.0, 0.5 * fabs(objn))) { status = 1; break; }
@@ -711,18 +731,6 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       mu_mark = mu;
       alpha_win = 0.0;
     }
-    __syncthreads();
-    assemble_newton();
-    IPM_TICK(3);
-    // affine right-hand side: -(P y + q) - G'(lambda + w (Gy - h))
-    node_vector(dya, 12, true, uu);
-    __syncthreads();
-    for (int e = fresh_tid(); e < NY; e += nt) dya[e] = -dya[e];
-    __syncthreads();
-    IPM_TICK(4);
-    twisted_factor();
-    __syncthreads();
-    IPM_TICK(5);
     twisted_solve(dya);
     __syncthreads();
     IPM_TICK(6);
@@ -890,7 +898,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     assemble_newton();
     __syncthreads();
-    twisted_factor();
+    twisted_factor([] {});
     // g_u = d loss / d u_i (duc), g_y (dyc)
     for (int e = fresh_tid(); e < N * NB; e += nt) {
       const int i = e / NB, ax = (e % NB) / D, m = e % D;

@@ -211,6 +211,123 @@ def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
     return out
 
 
+def qp_newton_step_flops(s, N, M, res):
+    """Analytic FP64 operation count of ONE Newton step of the interior-point QP in Hermite node coordinates (FMA = 2),
+    profiles/r03_qp_ipm_roofline.txt: five row passes at ~30 operations per row, the states of u and du at every sample in
+    every pass, the assembly of A'WA from the per-sample weights, the block Cholesky and the two block substitutions."""
+    D, BK = 2 * s, 3 * s
+    rows = N * res * (M + 12)
+    passes = 5 * 30 * rows
+    states = 11 * N * res * 9 * D * 2
+    assembly = N * D * D * res * 12 * 2
+    chol = (N + 1) * (BK ** 3 // 3 + 2 * BK ** 3) + 2 * 2 * (2 * N + 1) * BK * BK
+    return passes + states + assembly + chol
+
+
+def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
+    """The reference's ONLINE solve (SURVEY 8(a) a6 / 8(f)2): the inequality QP QPSolver::solve hands to OSQP
+    (planner/qp_solver.hpp:119-358) -- corridor rows and velocity / acceleration boxes at `res` samples per piece -- for
+    4096 problems in one launch of k_qp_ipm (interior point; one workgroup per problem), inputs resident, events on the
+    launch stream.  Shapes: 8-segment min-snap (BASELINE's problem size) and the planner's own 5 pieces
+    (learning_planner.hpp:179), SURVEY 8(d) corridor generator, seed 1, durations x 1.5."""
+    import numpy as np
+    from allocnet_amd.synth import corridor_problem
+    out = {"unit": "QP solves/s", "seed": 1, "res": 20, "poly_rows": 16, "max_vel": 4.0, "max_acc": 6.0, "method": "interior point",
+           "note": "a batch lasts as long as its slowest problem; ~1.5 % of the generator's problems are infeasible (status -3)"}
+    host = None
+    for key, s, N, B in (("snap8", 4, 8, 4096), ("jerk5", 3, 5, 4096)):
+        M = 16
+        head, tail, wps, T, hp = corridor_problem(np.random.default_rng(1), B, N, 3, M)
+        state = np.ascontiguousarray(np.stack([head, tail], axis=1)[..., :3])
+        T = T * 1.5
+        if key == "snap8":
+            host = (s, N, M, state, T, hp)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        st, tT, thp = t(state), t(T), t(hp)
+        r = aa.qp_solve_dev(s, st, tT, thp, ctx=ctx)
+        torch.cuda.synchronize()
+        K = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(K):
+            r = aa.qp_solve_dev(s, st, tT, thp, ctx=ctx)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / K
+        iters = r["iters"].double()
+        solved = float((r["status"] == 1).double().mean())
+        flops = float(iters.sum()) * qp_newton_step_flops(s, N, M, 20)
+        ach = flops / (ms * 1e-3) / 1e12
+        out[key] = {"order": s, "pieces": N, "batch": B, "ms_per_batch": ms, "value": B / (ms * 1e-3), "solved_frac": solved,
+                    "newton_steps_mean": float(iters.mean()), "newton_steps_max": int(iters.max()),
+                    "roofline": {"bound": "fp64", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": ach / FP64_PEAK_TFLOPS, "traffic": None, "kernel": "k_qp_ipm",
+                                 "flops_counted": "analytic per Newton step (bench.qp_newton_step_flops) x the steps taken",
+                                 "note": "latency-bound: block-Cholesky chains and row passes of one 256-thread workgroup per "
+                                         "problem, two problems per CU (LDS); nowhere near a throughput roofline"}}
+        if key == "snap8":
+            out[key]["gpu_obj"] = r["obj"].cpu().numpy()
+            out[key]["gpu_status"] = r["status"].cpu().numpy()
+    gpu_obj, gpu_status = out["snap8"].pop("gpu_obj"), out["snap8"].pop("gpu_status")
+    if cpu_baseline:
+        # dense Mehrotra interior point in numpy / LAPACK (oracle/qp_np.py) on the reference's assembled Q, A, b, G, h
+        from oracle import qp_np, minco_np as onp
+        s, N, M, state, T, hp = host
+        D = 2 * s
+        n = 3 * D * N
+
+        def dense(b):
+            st9 = np.zeros((9, 2))
+            for ax in range(3):
+                st9[3 * ax:3 * ax + 3, 0] = state[b, 0, ax]
+                st9[3 * ax:3 * ax + 3, 1] = state[b, 1, ax]
+            Q, A, bb, G1, h1, G2, h2 = onp.qp_assemble(s, st9, np.transpose(hp[b], (1, 2, 0)), np.full(N, M), T[b], 20, 4.0, 6.0)
+            G = np.zeros((G1.shape[0] + G2.shape[0], n))
+            r_ = 0
+            for i in range(N):
+                for _ in range(20):
+                    G[r_:r_ + M, i * 3 * D:(i + 1) * 3 * D] = G1[r_:r_ + M]
+                    r_ += M
+            r2 = 0
+            for i in range(N):
+                for _ in range(20):
+                    for j in range(3):
+                        G[r_ + r2:r_ + r2 + 4, i * 3 * D + j * D:i * 3 * D + (j + 1) * D] = G2[r2:r2 + 4]
+                        r2 += 4
+            hh = np.r_[h1, h2]
+            keep = (np.abs(G).sum(axis=1) > 0) | (hh != 0)
+            return Q, A, bb, G[keep], hh[keep]
+        t_asm = t_sol = 0.0
+        done, rel = 0, []
+        nthreads = host_cores()
+        try:                                    # LAPACK's threads = the cores this process may really use
+            from threadpoolctl import threadpool_limits
+            threadpool_limits(limits=nthreads)
+        except Exception:
+            pass
+        t_all = time.perf_counter()
+        for b in range(0, 4096, 64):
+            t0 = time.perf_counter()
+            Q, A, bb, G, h = dense(b)
+            t1 = time.perf_counter()
+            z, lam, nu, fo, it = qp_np.qp_ipm(Q, A, bb, G, h, tol=1e-8)
+            t2 = time.perf_counter()
+            t_asm += t1 - t0
+            t_sol += t2 - t1
+            done += 1
+            if it < 199 and gpu_status[b] == 1:
+                rel.append(abs(gpu_obj[b] - fo) / max(1.0, abs(fo)))
+            if time.perf_counter() - t_all > cpu_seconds and done >= 3:
+                break
+        out["cpu_baseline"] = {"value": done / t_sol, "unit": "QP solves/s", "cores": nthreads, "kind": "port",
+                               "sample": f"{done} of the 4096 8-segment snap problems (every 64th): dense Mehrotra interior point "
+                                         f"in numpy / LAPACK with {nthreads} threads, one problem at a time (oracle/qp_np.py) on the matrices of qp_solver.hpp:119-296 restated "
+                                         f"(oracle/minco_np.qp_assemble), solve time only ({t_sol:.1f} s; assembly {t_asm:.1f} s "
+                                         f"not counted); OSQP itself is not in the image",
+                               "gpu_vs_cpu_max_rel_obj_err": float(max(rel)) if rel else None, "compared": len(rel)}
+    return out
+
+
 def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
     """BASELINE configs[3] (SURVEY 8(d) "config 4"): B = 4096 x 16-segment min-jerk, L-BFGS with lbfgs_parameter_t
     defaults (lbfgs.hpp:25-128) on waypoints and durations until every problem stops on its own; seed 2.  One step = the
@@ -540,6 +657,7 @@ def main():
         del coeffs
         out["config3"] = run_config3(torch, aa, ctx, device, not args.no_cpu_baseline, 0.25 * args.cpu_seconds)
         out["config4"] = run_config4(torch, aa, ctx, device, not args.no_cpu_baseline, 0.5 * args.cpu_seconds)
+        out["qp_solve"] = run_qp(torch, aa, ctx, device, not args.no_cpu_baseline, 0.5 * args.cpu_seconds)
         coeffs = torch.empty(N * 3 * D, ld, device=device, dtype=torch.float64)
         # literal configs[1]: B = 1024 (launch-latency bound; reported, not the headline)
         b2 = 1024

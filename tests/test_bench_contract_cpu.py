@@ -68,3 +68,19 @@ def test_north_star_loop_bookkeeping():
         body = src[src.index(f"def {fn}"):]
         body = body[:body.index("\ndef ", 10)]
         assert body.index("from oracle import cbind") > body.index("if cpu_baseline:")
+
+
+def test_qp_solve_bookkeeping():
+    """qp_solve sub-object (the reference's online solve): analytic operation count of a Newton step and
+    that the oracle is reached from the cpu_baseline leg only."""
+    import bench
+    f = bench.qp_newton_step_flops(4, 8, 16, 20)
+    rows = 8 * 20 * 28
+    assert f == 5 * 30 * rows + 11 * 160 * 9 * 8 * 2 + 8 * 64 * 20 * 12 * 2 + 9 * (576 + 2 * 1728) + 4 * 17 * 144
+    assert 1.0e6 < f < 2.5e6                         # profiles/r03_qp_ipm_roofline.txt: ~2 MFLOP per step
+    assert bench.qp_newton_step_flops(3, 5, 16, 20) < f
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'out["qp_solve"] = run_qp' in src
+    body = src[src.index("def run_qp"):]
+    body = body[:body.index("\ndef ", 10)]
+    assert body.index("from oracle import qp_np") > body.index("if cpu_baseline:")
