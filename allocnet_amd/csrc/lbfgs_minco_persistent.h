@@ -572,14 +572,27 @@ __device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3
 // component (lane < nw: waypoint coordinate lane = 3 (k-1) + axis; lane in [nw, nw+nt): dJ/dT of piece lane - nw,
 // NOT yet multiplied by dT/dtau).
 template <int S, int NB>
-__device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double *rows, const PersistArgs &a, const int lane,
+__device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double *rows, const PersistArgs &a, const int lane_in,
                                              const bool refactor, double &f_out, double &g_out) {
+  // (an opaque copy: what the phases derive from the lane index -- node, axis, piece, sample group, LDS addresses -- is the
+  //  same in every evaluation, and hoisted out of the evaluation loop it is carried through the optimiser's update in
+  //  registers that has none to spare)
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
   constexpr int m = S - 1, D = 2 * S, NLA = BlkOps<S>::NLA;
   constexpr int G = 64 / NB;
   using F = Factor<S, NB>;
   const int N = a.N, np = a.c - 1;
-  const int na = lane / 3, ax = lane - 3 * na;  // (node | piece, axis) mapping of the per-node / per-piece phases
+  int na = lane / 3, ax = lane - 3 * na;  // (node | piece, axis) mapping of the per-node / per-piece phases
   PERSIST_TICK_DECL;
+  // (every phase starts from an opaque lane index of its own: its addresses die with it instead of being computed once,
+  //  ahead of the first phase, and carried through all of them)
+#define PERSIST_PHASE()                  \
+  do {                                   \
+    asm volatile("" : "+v"(lane));       \
+    na = lane / 3;                       \
+    ax = lane - 3 * na;                  \
+  } while (0)
 
   // ---- E1: 1/T and the primal right-hand sides, lanes = (node, axis)
   if (na <= N) {
@@ -638,6 +651,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   __syncthreads();
 
   PERSIST_TICK(1);
+  PERSIST_PHASE();
   // ---- E2: block LDL^T factorisation of the Schur complements S_k = A_k - Ko_{k-1}' S_{k-1}^-1 Ko_{k-1}, one lane.
   //      This is the only part that is sequential in earnest: per node two (three) reciprocals in a row.  Its inputs
   //      come from LDS a few nodes at a time into alternating register buffers (a load-then-use per node is an LDS
@@ -803,6 +817,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   chain_solve<S, NB>(Lm, Lm.X, N, lane, na, ax);
 
   PERSIST_TICK(2);
+  PERSIST_PHASE();
   // ---- E3: coefficients and energy share of every (piece, axis)
   if (na < N) {
     const int i = na;
@@ -820,6 +835,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   __syncthreads();
 
   PERSIST_TICK(3);
+  PERSIST_PHASE();
   // ---- E4: penalty functional, lanes = (piece, sample group).  A lane holds NS samples of its piece at a time: their
   //      positions first, then the corridor rows are walked ONCE for all of them (four rows per LDS round trip), then the
   //      velocity / acceleration limits and the gradient per sample.  Same arithmetic as k_piece_grad (minco_kernels.h):
@@ -1007,6 +1023,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   __syncthreads();
 
   PERSIST_TICK(4);
+  PERSIST_PHASE();
   // ---- E5: energy part of dJ/dc, node-state adjoint contributions and the direct dPhi/dT term; lanes = (piece, axis)
   double x0s[S], x1s[S];  // node states of this lane's piece (position, derivatives), reused by E7
 #pragma unroll
@@ -1091,6 +1108,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   __syncthreads();
 
   PERSIST_TICK(5);
+  PERSIST_PHASE();
   // ---- E6: adjoint solve K lam = g_x|free (pinned rows 0): right-hand sides on lanes = (node, axis), then the sweeps
   if (na <= N) {
     const int k = na;
@@ -1106,6 +1124,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   chain_solve<S, NB>(Lm, Lm.X, N, lane, na, ax);
 
   PERSIST_TICK(6);
+  PERSIST_PHASE();
   // ---- E7: position-row term and -lam' (dW/dT) x of every (piece, axis)
   if (na < N) {
     const int k = na;
@@ -1143,6 +1162,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   __syncthreads();
 
   PERSIST_TICK(7);
+  PERSIST_PHASE();
   // ---- E8: total gradient component of this lane and the cost
   double g = 0.0;
   if (lane < a.nw) {
@@ -1159,6 +1179,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   __syncthreads();  // (the next evaluation overwrites P / T)
   PERSIST_TICK(8);
 }
+#undef PERSIST_PHASE
 
 // MR: history slots in registers (mem_size <= MR).
 template <int S, int NB, int MR>
