@@ -350,7 +350,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
 
   // assemble the node-space vector  out_k = sum over the pieces touching knot k of sc * (qs Hobj u + sum_j gamma_j h_j)
   // (gamma at acc offset `goff`; with_obj adds the cost gradient); pinned components are zeroed
-  auto node_vector = [&](double *out, int goff, bool with_obj, const double *u) {
+  // (goff2 >= 0: gamma_j + w2 * gamma2_j with gamma2 at acc offset goff2; `sgn` scales the result)
+  auto node_vector = [&](double *out, int goff, bool with_obj, const double *u, int goff2 = -1, double w2 = 0.0, double sgn = 1.0) {
     for (int e = fresh_tid(); e < NY; e += nt) {
       const int k = e / BK, ax = (e / S) % 3, d = e % S;
       double v = 0.0;
@@ -365,15 +366,24 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
             const double *ui = u + (size_t)i * NB + ax * D;
             for (int m2 = 0; m2 < D; ++m2) g += qs * Hobj[m * D + m2] * ui[m2];
           }
-          for (int j = 0; j < R; ++j) {
-            const double *ga = acc + (size_t)(i * R + j) * 30 + goff;
-            const double *hj = ht + (size_t)j * 3 * D;
-            g += ga[ax] * hj[m] + ga[3 + ax] * hj[D + m] + ga[6 + ax] * hj[2 * D + m];
+          if (goff2 < 0) {
+            for (int j = 0; j < R; ++j) {
+              const double *ga = acc + (size_t)(i * R + j) * 30 + goff;
+              const double *hj = ht + (size_t)j * 3 * D;
+              g += ga[ax] * hj[m] + ga[3 + ax] * hj[D + m] + ga[6 + ax] * hj[2 * D + m];
+            }
+          } else {
+            for (int j = 0; j < R; ++j) {
+              const double *ga = acc + (size_t)(i * R + j) * 30 + goff, *gb = acc + (size_t)(i * R + j) * 30 + goff2;
+              const double *hj = ht + (size_t)j * 3 * D;
+              g += (ga[ax] + w2 * gb[ax]) * hj[m] + (ga[3 + ax] + w2 * gb[3 + ax]) * hj[D + m] +
+                   (ga[6 + ax] + w2 * gb[6 + ax]) * hj[2 * D + m];
+            }
           }
           v += sc[i * D + m] * g;
         }
       }
-      out[e] = v;
+      out[e] = sgn * v;
     }
   };
 
@@ -737,23 +747,41 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     to_u(dya, dua);
     if (tid < 32) red[tid] = 0.0;
     __syncthreads();
-    // ---- pass B: affine step length and the three sums of (s + a ds)'(lambda + a dlambda) -----------------
+    // ---- pass B: the affine step length, the three sums of (s + a ds)'(lambda + a dlambda), AND the corrector's right-hand
+    //      side.  A corrector row contributes c t with
+    //        t = lambda + (lambda rg - rc) / s,  rc = s lambda + ds dlambda - mu_target
+    //          = [lambda + (lambda rg - s lambda - ds dlambda) / s]  +  mu_target / s  =  t0 + mu_target / s,
+    //      and only mu_target waits for the sums of this very pass: the per-sample sums of c t0 (slots 12..20) and of c / s
+    //      (slots 0..8: the weights there were consumed by the assembly) are taken here and combined when the node vector
+    //      is formed -- no second visit of the rows (it was a pass of its own, the third of five).
     {
       double l_ap = 0.0, l_s1 = 0.0, l_s2 = 0.0;  // l_ap: max of -ds/s, -dl/lambda = 1 / (step to the boundary)
       for (int smp = fresh_tid(); smp < NS; smp += nt) {
         const int i = smp / R, j = smp % R;
-        double s3[3][3], d3[3][3];
+        double s3[3][3], d3[3][3], G0[9], G1[9];
         state_of(uu, i, j, s3);
         state_of(dua, i, j, d3);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) G0[q] = G1[q] = 0.0;
         for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
           const double rg = row.dot(s3[row.dsel]) + sl - hv;
           const double ds = -rg - row.dot(d3[row.dsel]);
-          const double dl = -lm - (lm * fast_rcp(sl)) * ds;
+          const double isl = fast_rcp(sl);
+          const double dl = -lm - (lm * isl) * ds;
           // step to the boundary: the largest of -ds/s, -dl/lambda over the rows is 1/alpha (no division per row)
-          l_ap = fmax(l_ap, fmax(-ds * fast_rcp(sl), -dl * fast_rcp(lm)));
+          l_ap = fmax(l_ap, fmax(-ds * isl, -dl * fast_rcp(lm)));
           l_s1 += sl * dl + lm * ds;
           l_s2 += ds * dl;
+          const double t0 = lm + (lm * rg - sl * lm - ds * dl) * isl;
+          row.axpy(t0, G0 + row.dsel * 3);
+          row.axpy(isl, G1 + row.dsel * 3);
         });
+        double *as = acc + (size_t)smp * 30;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          as[12 + q] = G0[q];
+          as[q] = G1[q];
+        }
       }
       block_reduce(1.0 / fmax(l_ap, 1e-300), 3, true);
       block_reduce(l_s1, 4, false);
@@ -770,33 +798,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     // pushed to mu ~ 1e-20, where lambda / s spans forty decades, the Newton matrix is numerically singular and the dual
     // residual bounces between 1e-9 and 10 for the rest of the iteration budget (tests/golden/vjp_snap_n2.npz).
     const double mu_target = fmax(sigma * mu, 0.1 * a.tol * fmax(1.0, 0.5 * fabs(objn)) / mrows);
-    __syncthreads();
-    // ---- pass C: corrector right-hand side (same factor) ----------------------------------------------
-    for (int smp = fresh_tid(); smp < NS; smp += nt) {
-      const int i = smp / R, j = smp % R;
-      double s3[3][3], d3[3][3], G_[9];
-      state_of(uu, i, j, s3);
-      state_of(dua, i, j, d3);
-#pragma unroll
-      for (int q = 0; q < 9; ++q) G_[q] = 0.0;
-      for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
-        const double rg = row.dot(s3[row.dsel]) + sl - hv;
-        const double ds = -rg - row.dot(d3[row.dsel]);
-        const double isl = fast_rcp(sl);
-        const double dl = -lm - (lm * isl) * ds;
-        const double rc = sl * lm + ds * dl - mu_target;
-        const double t = lm + (lm * rg - rc) * isl;
-        row.axpy(t, G_ + row.dsel * 3);
-      });
-      double *as = acc + (size_t)smp * 30 + 12;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) as[q] = G_[q];
-    }
-    __syncthreads();
-    IPM_TICK(8);
-    node_vector(dyc, 12, true, uu);
-    __syncthreads();
-    for (int e = fresh_tid(); e < NY; e += nt) dyc[e] = -dyc[e];
+    // ---- corrector right-hand side (same factor)
+    node_vector(dyc, 12, true, uu, 0, mu_target, -1.0);
     __syncthreads();
     IPM_TICK(9);
     twisted_solve(dyc);
