@@ -1802,7 +1802,7 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     if (grad_z && tol > 1e-9) tol = 1e-9;
     anet::IpmArgs ia{state, T, hpolys, work, work + mi * batch, coeffs, obj, status, iters,
                      residuals ? residuals : work + 2 * mi * batch, grad_T, grad_z, vjp_T, batch, n_pieces, res, M, max_vel,
-                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200, tol_plain > tol ? tol_plain : 0.0, 0};
+                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200, tol_plain > tol ? tol_plain : 0.0, 0.1 * tol, 0};
     static const int ipm_twist_min_pieces = [] {
       const char *e = getenv("ANET_IPM_TWIST_MIN_PIECES");
       return e ? atoi(e) : 2;
@@ -1836,10 +1836,12 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
       return ANET_OK;
     };
     int rc_l;
-    if (s == 4) rc_l = two_per_cu ? launch_ipm(anet::k_qp_ipm<4, 2>) : launch_ipm(anet::k_qp_ipm<4, 1>);
-    // (jerk: the unbounded instantiation needs <= 256 registers as it is -- two workgroups per CU -- and the compiler
-    //  schedules it for latency; the bounded one is 18 % slower per problem at the same occupancy)
-    else rc_l = launch_ipm(anet::k_qp_ipm<3, 1>);
+    // Shapes that put two workgroups on a CU visit the rows once more per step instead of carrying the next step's sums
+    // through the updating pass (registers: qp_ipm.h FUSE); a lone problem, a small batch or a problem whose LDS fills the
+    // CU takes the fused form.  (jerk: the unbounded instantiation needs <= 256 registers as it is -- two workgroups per CU
+    // -- and the compiler schedules it for latency; bounded to 256 it is 18 % slower per problem at the same occupancy)
+    if (s == 4) rc_l = two_per_cu ? launch_ipm(anet::k_qp_ipm<4, 2, false>) : launch_ipm(anet::k_qp_ipm<4, 1, true>);
+    else rc_l = two_per_cu ? launch_ipm(anet::k_qp_ipm<3, 1, false>) : launch_ipm(anet::k_qp_ipm<3, 1, true>);
     if (rc_l != ANET_OK) return rc_l;
     ANET_HIP(ctx, hipGetLastError());
     return ANET_OK;

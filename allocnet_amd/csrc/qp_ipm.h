@@ -41,6 +41,7 @@ struct IpmArgs {
   double vmax, amax, m34, tol;
   int max_iter;
   double tol_accept;  // >= tol: once met, at most 8 more Newton steps are spent on reaching tol (0: same as tol)
+  double tol_tenth;      // 0.1 tol (a kernel argument: computed in the kernel it is a loop invariant parked in registers)
   int twist_min_pieces;  // chains of at least this many pieces are factored from both ends (two waves), shorter ones from one
 #ifdef ANET_IPM_PROF
   long long *prof;  // [16] cycle counters of problem 0 (tools: ANET_BUILD_FLAGS=-DANET_IPM_PROF)
@@ -94,7 +95,9 @@ inline size_t qp_ipm_lds_bytes(int N, int R, int M) {
 // MINB: workgroups per CU the register allocation is bounded for.  The snap kernel needs more than 256 registers to run
 // without spills (one workgroup per CU); bounded to 256 (92 B of scratch) two share a CU, which pays for large batches
 // (4096 x 8 pieces 24.7 -> 18.8 ms) and costs a single problem a quarter of its latency (0.82 -> 1.02 ms): the host picks.
-template <int S, int MINB = 1>
+// FUSE: the updating pass of a step also forms the per-sample sums of the NEXT step (one row pass fewer, 6 % of a lone
+// problem's latency) -- at the price of registers: with two workgroups per CU it spills, so the throughput shapes visit the rows again.
+template <int S, int MINB = 1, bool FUSE = (MINB == 1)>
 __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   constexpr int D = 2 * S, NB = 3 * D, BK = 3 * S;
   const int N = a.N, R = a.R, M = a.M;
@@ -209,6 +212,12 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     dyc[e] = 0.0;
   }
   __syncthreads();
+  // A value every lane holds alike (read from red[], or computed from such) moved to SGPRs: the scalars of the iteration
+  // (residuals, complementarity, their marks, step lengths) live across the whole Newton loop, and as VALU results they
+  // would each occupy a register pair of every lane.
+  auto uni = [](double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
   auto pinned = [&](int k, int d) { return (k == 0 || k == N) && d < 3; };
   // The sample a thread owns (and with it i, j, its LDS rows and its slack / multiplier addresses) does not change from
   // one Newton step to the next, so the compiler hoists all of that out of the iteration loop and carries it through
@@ -267,7 +276,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   auto for_rows_sl = [&](int i, int smp, auto store_tag, auto &&fn) {
     constexpr bool STORE = decltype(store_tag)::value;
     double *sp = slg + smp, *lp = lmg + smp;
-    constexpr int GC = 8, GB = 6;
+    // (the updating pass also forms the next iterate's sums -- 30 accumulators on top of three state sets: smaller groups)
+    constexpr int GC = (STORE && FUSE) ? 4 : 8, GB = (STORE && FUSE) ? 4 : 6;
     for (int q0 = 0; q0 < M; q0 += GC) {
       double sl[GC], lm[GC];
 #pragma unroll
@@ -345,7 +355,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   __syncthreads();
   block_reduce((double)nrows_local, 0, false);
   __syncthreads();
-  const double mrows = fmax(red[0], 1.0);
+  const double mrows = uni(fmax(red[0], 1.0));
   __syncthreads();
 
   // assemble the node-space vector  out_k = sum over the pieces touching knot k of sc * (qs Hobj u + sum_j gamma_j h_j)
@@ -665,10 +675,22 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   long long prof_t_ = __builtin_readcyclecounter();
 #endif
   IPM_TICK(0);
-  for (it = 0; it < a.max_iter; ++it) {
-    // ---- pass A: residuals, weights, right-hand-side pieces per sample ---------------------------
-    if (tid < 32) red[tid] = 0.0;
-    __syncthreads();
+  // ---- pass A: residuals, weights, right-hand-side pieces per sample.  A row of the iterate (gy = its value, sl, lm):
+  auto row_A = [&](auto row, double hv, double gy, double sl, double lm, double *A_, double &l_mu, double &l_pres, double &l_h) {
+    const double rg = gy + sl - hv, w = lm * fast_rcp(sl), t = lm + w * (gy - hv);
+    l_mu += sl * lm;
+    l_pres = fmax(l_pres, fabs(rg));
+    l_h = fmax(l_h, fabs(hv));
+    row.weights(w, A_);
+    row.axpy(t, A_ + 12 + row.dsel * 3);
+    row.axpy(lm, A_ + 21 + row.dsel * 3);
+  };
+  // As a pass of its own for the starting point of the FUSE form (every later iterate gets it from the updating pass of
+  // the step that produced it: the rows are in registers there, and their values at the new point are gy + alpha ge);
+  // red[0..2] must be zero.  (The unfused form has the same pass written out at the top of its loop: called through this
+  // lambda there, the bounded instantiation came out 14 % slower -- 13.2 against 11.6 ms for 4096 8-segment problems --
+  // from an identical instruction mix; rocprofv3 and the cycle counters of the sections show nothing else that differs.)
+  auto pass_A = [&]() {
     double l_mu = 0.0, l_pres = 0.0, l_h = 0.0;
     for (int smp = fresh_tid(); smp < NS; smp += nt) {
       const int i = smp / R, j = smp % R;
@@ -678,14 +700,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
 #pragma unroll
       for (int q = 0; q < 30; ++q) A_[q] = 0.0;
       for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
-        const double gy = row.dot(s3[row.dsel]);
-        const double rg = gy + sl - hv, w = lm * fast_rcp(sl), t = lm + w * (gy - hv);
-        l_mu += sl * lm;
-        l_pres = fmax(l_pres, fabs(rg));
-        l_h = fmax(l_h, fabs(hv));
-        row.weights(w, A_);
-        row.axpy(t, A_ + 12 + row.dsel * 3);
-        row.axpy(lm, A_ + 21 + row.dsel * 3);
+        row_A(row, hv, row.dot(s3[row.dsel]), sl, lm, A_, l_mu, l_pres, l_h);
       });
       double *as = acc + (size_t)smp * 30;
 #pragma unroll
@@ -694,21 +709,61 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     block_reduce(l_mu, 0, false);
     block_reduce(1.0 / fmax(l_pres, 1e-300), 1, true);  // max via min of reciprocals -> stored as max
     block_reduce(1.0 / fmax(l_h, 1e-300), 2, true);
+  };
+  if (tid < 32) red[tid] = 0.0;
+  __syncthreads();
+  if constexpr (FUSE) {
+    pass_A();
     __syncthreads();
+  }
+  for (it = 0; it < a.max_iter; ++it) {
+    if constexpr (!FUSE) {
+      // ---- pass A: residuals, weights, right-hand-side pieces per sample
+      if (tid < 32) red[tid] = 0.0;
+      __syncthreads();
+      double l_mu = 0.0, l_pres = 0.0, l_h = 0.0;
+      for (int smp = fresh_tid(); smp < NS; smp += nt) {
+        const int i = smp / R, j = smp % R;
+        double s3[3][3];
+        state_of(uu, i, j, s3);
+        double A_[30];
+#pragma unroll
+        for (int q = 0; q < 30; ++q) A_[q] = 0.0;
+        for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
+          const double gy = row.dot(s3[row.dsel]);
+          const double rg = gy + sl - hv, w = lm * fast_rcp(sl), t = lm + w * (gy - hv);
+          l_mu += sl * lm;
+          l_pres = fmax(l_pres, fabs(rg));
+          l_h = fmax(l_h, fabs(hv));
+          row.weights(w, A_);
+          row.axpy(t, A_ + 12 + row.dsel * 3);
+          row.axpy(lm, A_ + 21 + row.dsel * 3);
+        });
+        double *as = acc + (size_t)smp * 30;
+#pragma unroll
+        for (int q = 0; q < 30; ++q) as[q] = A_[q];
+      }
+      block_reduce(l_mu, 0, false);
+      block_reduce(1.0 / fmax(l_pres, 1e-300), 1, true);  // max via min of reciprocals -> stored as max
+      block_reduce(1.0 / fmax(l_h, 1e-300), 2, true);
+      __syncthreads();
+    }
     IPM_TICK(1);
-    mu = red[0] / mrows;
+    mu = uni(red[0] / mrows);
     if (it == 0) mu0 = mu;
-    pres = red[1] / fmax(1.0, red[2]);
-    // ---- the Newton matrix and its factor; beside the factorisation the dual residual and the affine right-hand side
+    pres = uni(red[1] / fmax(1.0, red[2]));
     __syncthreads();
+    if constexpr (FUSE)
+      if (tid < 32) red[tid] = 0.0;  // (red[8..10]: the side vectors' sums; the barriers of the assembly lie in between)
+    // ---- the Newton matrix and its factor; beside the factorisation the dual residual and the affine right-hand side
     assemble_newton();
     __syncthreads();
     IPM_TICK(3);
     twisted_factor(side_vectors);
     __syncthreads();
     IPM_TICK(5);
-    dres = red[8] / fmax(1.0, red[9]);
-    const double objn = red[10];
+    dres = uni(red[8] / fmax(1.0, red[9]));
+    const double objn = uni(red[10]);
     // (the duality gap is mu * rows: that, not mu, is what bounds the distance of the objective from the optimum)
     if (pres < a.tol && dres < a.tol && mu * mrows < a.tol * fmax(1.0, 0.5 * fabs(objn))) { status = 1; break; }
     // The backward pass asks for three digits more than a plain solve; a few percent of the problems stall above that
@@ -790,14 +845,14 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     IPM_TICK(7);
     const double a_aff = fmin(1.0, red[3] > 0.0 ? 1.0 / red[3] : 1.0);
-    const double mu_aff = (mu * mrows + a_aff * red[4] + a_aff * a_aff * red[5]) / mrows;
+    const double mu_aff = uni((mu * mrows + a_aff * red[4] + a_aff * a_aff * red[5]) / mrows);
     double sigma = mu_aff / mu;
     sigma = sigma * sigma * sigma;
     // Centring target sigma mu, but never below a tenth of the complementarity the stopping test asks for: a problem that
     // has met the primal and complementarity tests while its dual residual is still a digit short would otherwise be
     // pushed to mu ~ 1e-20, where lambda / s spans forty decades, the Newton matrix is numerically singular and the dual
     // residual bounces between 1e-9 and 10 for the rest of the iteration budget (tests/golden/vjp_snap_n2.npz).
-    const double mu_target = fmax(sigma * mu, 0.1 * a.tol * fmax(1.0, 0.5 * fabs(objn)) / mrows);
+    const double mu_target = uni(fmax(sigma * mu, a.tol_tenth * fmax(1.0, 0.5 * fabs(objn)) / mrows));
     // ---- corrector right-hand side (same factor)
     node_vector(dyc, 12, true, uu, 0, mu_target, -1.0);
     __syncthreads();
@@ -838,22 +893,58 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     }
     __syncthreads();
     IPM_TICK(11);
-    const double alpha = fmin(1.0, 0.99 * (red[6] > 0.0 ? 1.0 / red[6] : 1e300));
-    alpha_win = fmax(alpha_win, alpha);
+    const double alpha = uni(fmin(1.0, 0.99 * (red[6] > 0.0 ? 1.0 / red[6] : 1e300)));
+    alpha_win = uni(fmax(alpha_win, alpha));
     __syncthreads();
-    // ---- pass E: update ----------------------------------------------------------------------------------
-    for (int smp = fresh_tid(); smp < NS; smp += nt) {
-      const int i = smp / R, j = smp % R;
-      double s3[3][3], d3[3][3], e3[3][3];
-      state_of(uu, i, j, s3);
-      state_of(dua, i, j, d3);
-      state_of(duc, i, j, e3);
-      for_rows_sl(i, smp, RowsUpdate{}, [&](int q, auto row, double hv, double &sl, double &lm) {
-        double ds, dl;
-        final_dir(row, hv, s3, d3, e3, sl, lm, ds, dl);
-        sl += alpha * ds;
-        lm += alpha * dl;
-      });
+    if constexpr (!FUSE) {
+      // ---- pass E: update
+      for (int smp = fresh_tid(); smp < NS; smp += nt) {
+        const int i = smp / R, j = smp % R;
+        double s3[3][3], d3[3][3], e3[3][3];
+        state_of(uu, i, j, s3);
+        state_of(dua, i, j, d3);
+        state_of(duc, i, j, e3);
+        for_rows_sl(i, smp, RowsUpdate{}, [&](int q, auto row, double hv, double &sl, double &lm) {
+          double ds, dl;
+          final_dir(row, hv, s3, d3, e3, sl, lm, ds, dl);
+          sl += alpha * ds;
+          lm += alpha * dl;
+        });
+      }
+    } else
+    // ---- pass E: update, and pass A of the new iterate --------------------------------------------------------
+    {
+      double l_mu = 0.0, l_pres = 0.0, l_h = 0.0;
+      for (int smp = fresh_tid(); smp < NS; smp += nt) {
+        const int i = smp / R, j = smp % R;
+        double s3[3][3], d3[3][3], e3[3][3];
+        state_of(uu, i, j, s3);
+        state_of(dua, i, j, d3);
+        state_of(duc, i, j, e3);
+        double A_[30];
+#pragma unroll
+        for (int q = 0; q < 30; ++q) A_[q] = 0.0;
+        for_rows_sl(i, smp, RowsUpdate{}, [&](int q, auto row, double hv, double &sl, double &lm) {
+          // (final_dir, with the two row values kept: the row at the new point is gy + alpha ge)
+          const double gy = row.dot(s3[row.dsel]), ge = row.dot(e3[row.dsel]);
+          const double rg = gy + sl - hv;
+          const double dsa = -rg - row.dot(d3[row.dsel]);
+          const double isl = fast_rcp(sl);
+          const double dla = -lm - (lm * isl) * dsa;
+          const double rc = sl * lm + dsa * dla - mu_target;
+          const double ds = -rg - ge;
+          const double dl = (-rc - lm * ds) * isl;
+          sl += alpha * ds;
+          lm += alpha * dl;
+          row_A(row, hv, gy + alpha * ge, sl, lm, A_, l_mu, l_pres, l_h);
+        });
+        double *as = acc + (size_t)smp * 30;
+#pragma unroll
+        for (int q = 0; q < 30; ++q) as[q] = A_[q];
+      }
+      block_reduce(l_mu, 0, false);  // (red[0..2] are zero since the barrier ahead of pass D)
+      block_reduce(1.0 / fmax(l_pres, 1e-300), 1, true);
+      block_reduce(1.0 / fmax(l_h, 1e-300), 2, true);
     }
     __syncthreads();
     for (int e = fresh_tid(); e < NY; e += nt) yv[e] += alpha * dyc[e];

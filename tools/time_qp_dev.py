@@ -22,4 +22,4 @@ for (s, N, M, B) in SHAPES:
         e0.record(); r = aa.qp_solve_dev(s, st, tT, thp, ctx=ctx); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     print("s", s, "N", N, "B", B, "ms", ["%.2f" % x for x in ts], "solved %.3f" % float((r["status"] == 1).double().mean()),
-          "iters mean %.1f" % float(r["iters"].double().mean()), flush=True)
+          "iters mean %.1f max %d" % (float(r["iters"].double().mean()), int(r["iters"].max())), flush=True)
