@@ -11,8 +11,18 @@
 //  * piece i sees u_i = [y_i ; (T_i/T_i+1)^d y_i+1]; every row of the QP is a Hermite basis function (or a
 //    derivative) at tau_j = j/res contracted with a 3-vector, so A'WA is assembled from per-sample 3x3 /
 //    3-vector weights and one table of 3*res*2s numbers; Q, A, G are never formed.
-//  * Mehrotra predictor-corrector; the two solves of a step share one block Cholesky, done by wave 0 in LDS
-//    while the other waves wait (12 x 12 blocks: too small to split further).
+//  * Mehrotra predictor-corrector; the two solves of a step share one block Cholesky.  What is sequential in a step
+//    is kept short and what is idle is given work (round 3):
+//      - TWISTED factorisation: the chain of knots is eliminated from both ends towards the middle by two waves at
+//        once (half the sequential depth of the factor and of both substitutions, no fill-in);
+//      - the dual residual, its scales and the affine right-hand side are formed by the other two waves meanwhile;
+//      - the rows of the QP are visited three or four times per step, not five: the corrector's right-hand side is
+//        t0 + mu_target / s with both per-sample sums taken in the affine pass, and (FUSE) the updating pass forms the
+//        next step's sums from the rows it holds;
+//      - slacks and multipliers (global memory, L2) are loaded a group of rows at a time ahead of the arithmetic; the
+//        twelve box rows of a sample multiply no zeros;
+//      - every phase starts from an opaque thread index and the scalars of the iteration live in SGPRs: what is the
+//        same in every Newton step is not hoisted out of the loop into registers the phases need.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

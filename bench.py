@@ -310,7 +310,10 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
             t0 = time.perf_counter()
             Q, A, bb, G, h = dense(b)
             t1 = time.perf_counter()
-            z, lam, nu, fo, it = qp_np.qp_ipm(Q, A, bb, G, h, tol=1e-8)
+            try:
+                z, lam, nu, fo, it = qp_np.qp_ipm(Q, A, bb, G, h, tol=1e-8)
+            except (ValueError, FloatingPointError, np.linalg.LinAlgError):   # an infeasible problem that blew up: timed all the same
+                fo, it = float("nan"), 199
             t2 = time.perf_counter()
             t_asm += t1 - t0
             t_sol += t2 - t1

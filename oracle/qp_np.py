@@ -35,8 +35,12 @@ def qp_ipm(Q, A, b, G, h, tol=1e-10, max_iter=200):
             best = (merit, it, (z.copy(), lam.copy(), nu.copy()))
         elif it - best[1] >= 15:
             break
-        W = lam / s
-        H = Q + G.T @ (W[:, None] * G) + reg * np.eye(n)
+        with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+            W = lam / s
+            H = Q + G.T @ (W[:, None] * G) + reg * np.eye(n)
+        if not np.isfinite(H).all():      # an infeasible problem: slacks underflow while the multipliers grow
+            it = max_iter
+            break
         K = np.block([[H, A.T], [A, -1e-13 * np.eye(me)]])
         lu = lu_factor(K)
 

@@ -571,3 +571,61 @@ def test_narrow_feasible_corridors_are_not_called_infeasible(anet_ctx):
     bad = aa.qp_solve(s, ini, fin, hp, Tbad, **kw)
     assert (bad["status"] == -3).all(), dict(zip(*np.unique(bad["status"], return_counts=True)))
     assert bad["iters"].max() <= 120, bad["iters"].max()
+
+
+def test_interior_point_launch_forms_agree(anet_ctx):
+    """The interior point has two forms (csrc/qp_ipm.h): batches that put two workgroups on a CU visit the rows four times per
+    Newton step, smaller ones (and lone problems) carry the next step's sums through the updating pass (FUSE).  Same method,
+    same problems: the same verdicts, Newton steps within one and the same optimum -- on BASELINE's 8-segment snap problems
+    and on the planner's five jerk pieces, 1024 at once against four times 256."""
+    import allocnet_amd as aa
+    from allocnet_amd.synth import corridor_problem
+    for (s, N) in ((4, 8), (3, 5)):
+        B, M = 1024, 16
+        head, tail, wps, T, hp = corridor_problem(np.random.default_rng(7), B, N, 3, M)
+        T = T * 1.5
+        one = aa.qp_solve(s, head, tail, hp, T, res=20, max_vel=4.0, max_acc=6.0, ctx=anet_ctx)
+        parts = [aa.qp_solve(s, head[k:k + 256], tail[k:k + 256], hp[k:k + 256], T[k:k + 256], res=20, max_vel=4.0, max_acc=6.0,
+                             ctx=anet_ctx) for k in range(0, B, 256)]
+        st = np.concatenate([p["status"] for p in parts])
+        it = np.concatenate([p["iters"] for p in parts])
+        obj = np.concatenate([p["obj"] for p in parts])
+        co = np.concatenate([p["coeffs"] for p in parts])
+        assert (st == one["status"]).all()
+        ok = one["status"] == 1
+        assert ok.mean() > 0.95
+        assert np.abs(it[ok] - one["iters"][ok]).max() <= 1
+        assert (np.abs(obj[ok] - one["obj"][ok]) <= 2e-6 * np.maximum(1.0, np.abs(one["obj"][ok]))).all()
+        scale = np.abs(one["coeffs"][ok]).reshape(ok.sum(), -1).max(axis=1)
+        err = np.abs(co[ok] - one["coeffs"][ok]).reshape(ok.sum(), -1).max(axis=1)
+        assert (err <= 1e-4 * np.maximum(1.0, scale)).all()
+
+
+def test_twisted_and_classic_elimination_orders_agree():
+    """The block Cholesky of a Newton step eliminates the chain of knots from both ends (two waves); ANET_IPM_TWIST_MIN_PIECES
+    above the piece count restores the one-chain order.  Both are exact factorisations of the same matrix: the solves must
+    agree to rounding.  (The switch is read once per process: two child processes.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); import allocnet_amd as aa\n"
+            "from allocnet_amd.synth import corridor_problem\n"
+            "out = {}\n"
+            "for (s, N, B) in ((4, 8, 96), (3, 5, 96), (4, 1, 32), (3, 16, 32)):\n"
+            "    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(11), B, N, 3, 16)\n"
+            "    r = aa.qp_solve(s, head, tail, hp, T * 1.5, res=20, max_vel=4.0, max_acc=6.0)\n"
+            "    out['%%d_%%d' %% (s, N)] = dict(status=r['status'].tolist(), iters=r['iters'].tolist(), obj=r['obj'].tolist())\n"
+            "print(json.dumps(out))\n") % root
+    res = {}
+    for name, val in (("twisted", "2"), ("classic", "1000")):
+        env = dict(os.environ, ANET_IPM_TWIST_MIN_PIECES=val)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[name] = json.loads(p.stdout.strip().splitlines()[-1])
+    for key in res["twisted"]:
+        a, b = res["twisted"][key], res["classic"][key]
+        assert a["status"] == b["status"], key
+        sa, oa, ob = np.array(a["status"]), np.array(a["obj"]), np.array(b["obj"])
+        ok = sa == 1
+        assert ok.mean() > 0.7, key           # (a single piece with both ends pinned is often infeasible under the limits)
+        assert np.abs(np.array(a["iters"])[ok] - np.array(b["iters"])[ok]).max() <= 1, key
+        assert (np.abs(oa[ok] - ob[ok]) <= 1e-6 * np.maximum(1.0, np.abs(ob[ok]))).all(), key
