@@ -16,7 +16,9 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liballocnet_amd.so")
 SOURCES = ["allocnet_amd.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ldl",
+# -amdgpu-mfma-vgpr-form: the one MFMA of the library (the FP64 Schur update of k_qp_ipm) keeps its accumulator in VGPRs; in
+# AGPRs it pushes the jerk instantiation past 256 registers in total, i.e. from two workgroups per CU to one.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ldl", "-mllvm", "-amdgpu-mfma-vgpr-form",
          "-I", os.path.join(ROOT, "include")]
 
 

@@ -484,19 +484,28 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       for (int c2 = c + 1; c2 < BK; ++c2) Dr[c2] -= Dr[c] * rl(Dr[c], c2);
     }
   };
-  // Dr -= (row `lane` of X) X' for a BK x BK block X stored row-major in LDS (the other rows: broadcast reads)
-  auto schur_rows = [&](const double (&Xr)[BK], const double *X, double (&Dr)[BK]) {
+  // D -= X X' for BK x BK blocks in LDS (X row-major), by the whole wave on the matrix cores: v_mfma_f64_16x16x4_f64 takes
+  // A[i = lane & 15][k = lane >> 4] and B[k = lane >> 4][j = lane & 15] -- for X X' the same register, X[lane & 15][4 ks + (lane >> 4)],
+  // zero outside the block -- and leaves C[row = (lane >> 4) + 4 r][col = lane & 15] in its r-th result; every entry of D is
+  // touched by exactly one (lane, r).  Three instructions and three LDS reads per lane instead of BK^2 FMAs with BK^2
+  // broadcast reads on BK of the 64 lanes -- on the one path of a Newton step that is sequential in earnest.
+  // (LDS instructions of one wave execute in order: the row loads that follow see the update.)
+  typedef double d4_t __attribute__((ext_vector_type(4)));
+  auto schur_mfma = [&](const int lane, const double *X, double *Dk) {
+    const int li = lane & 15, lk = lane >> 4;
+    d4_t c4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int c = 0; c < BK; ++c) {
-      double v = 0.0;
+    for (int ks = 0; ks < (BK + 3) / 4; ++ks) {
+      const int k = 4 * ks + lk;
+      const double x = (li < BK && k < BK) ? X[li * BK + k] : 0.0;
+      c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, c4, 0, 0, 0);
+    }
 #pragma unroll
-      for (int q = 0; q < BK; ++q) v += Xr[q] * X[c * BK + q];
-      Dr[c] -= v;
+    for (int r = 0; r < 4; ++r) {
+      const int row = lk + 4 * r;
+      if (row < BK && li < BK) Dk[row * BK + li] -= c4[r];
     }
   };
-  // One copy of the block code serves both chains and the middle knot (this kernel is instruction-cache bound as it
-  // is): phase 0 walks the chains, phase 1 -- behind a barrier -- is wave 0 on knot PT with a Schur update from each side.
-  // `side`: work for the two waves that have no part in the factorisation, done while the chains are walked (no barriers in it).
   auto twisted_factor = [&](auto &&side) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, in an SGPR
     int lane = tid & 63;
@@ -517,8 +526,6 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       for (int k = kbeg; k != kend; k += stepk) {
         double *Dk = Dg + (size_t)k * BK * BK;
         double Dr[BK], dinv[BK], Lp[BK];
-#pragma unroll
-        for (int c = 0; c < BK; ++c) Dr[c] = act ? Dk[lane * BK + c] : (c == 0 ? 1.0 : 0.0);
         // Schur updates: from the knot eliminated before this one in its chain; the middle knot from both sides
         const int src0 = ph == 0 ? (k == kfrom ? -1 : (dir > 0 ? k - 1 : k)) : (PT > 0 ? PT - 1 : -1);
         const int src1 = ph == 0 ? -1 : (PT < N ? PT : -1);
@@ -526,11 +533,10 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         for (int u = 0; u < 2; ++u) {
           const int src = u == 0 ? src0 : src1;
           if (src < 0) continue;
-          const double *X = Of + (size_t)src * BK * BK;
-#pragma unroll
-          for (int q = 0; q < BK; ++q) Lp[q] = act ? X[lane * BK + q] : 0.0;
-          schur_rows(Lp, X, Dr);
+          schur_mfma(lane, Of + (size_t)src * BK * BK, Dk);
         }
+#pragma unroll
+        for (int c = 0; c < BK; ++c) Dr[c] = act ? Dk[lane * BK + c] : (c == 0 ? 1.0 : 0.0);
         chol_rows(lane, Dr, dinv);
         if (act) {
 #pragma unroll
