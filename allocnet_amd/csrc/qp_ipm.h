@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
           const double isl = fast_rcp(sl);
           const double dl = -lm - (lm * isl) * ds;
           // step to the boundary: the largest of -ds/s, -dl/lambda over the rows is 1/alpha (no division per row)
-          l_ap = fmax(l_ap, fmax(-ds * isl, -dl * fast_rcp(lm)));
+          l_ap = fmax(l_ap, fmax(-ds * isl, -dl * __builtin_amdgcn_rcp(lm)));  // (a step length: the raw reciprocal does, 1e-7)
           l_s1 += sl * dl + lm * ds;
           l_s2 += ds * dl;
           const double t0 = lm + (lm * rg - sl * lm - ds * dl) * isl;
@@ -902,7 +902,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
           double ds, dl;
           final_dir(row, hv, s3, d3, e3, sl, lm, ds, dl);
-          l_a = fmax(l_a, fmax(-ds * fast_rcp(sl), -dl * fast_rcp(lm)));
+          l_a = fmax(l_a, fmax(-ds * __builtin_amdgcn_rcp(sl), -dl * __builtin_amdgcn_rcp(lm)));  // (raw reciprocals: 0.99 of it is taken)
         });
       }
       block_reduce(1.0 / fmax(l_a, 1e-300), 6, true);
