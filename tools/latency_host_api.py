@@ -21,3 +21,11 @@ print("traj.getPos  B=1 : %.1f us" % timeit(lambda: traj.getPos(1.234)))
 print("traj_cost    B=1 : %.1f us" % timeit(lambda: traj.getTrajCost(3)))
 pen = aa.make_penalty(rho=10.0, w_corridor=100.0, w_vel=10.0, w_acc=10.0, res=20, poly_rows=0)
 print("cost_grad    B=1 : %.1f us" % timeit(lambda: aa.minco_cost_grad(head, tail, wps, T, 3, penalty=pen, ctx=ctx)))
+# QPSolver::solve as the planner calls it (learning_planner.hpp:196): one problem, host pointers in and out
+from allocnet_amd.synth import corridor_problem
+for (s, N) in ((3, 5), (4, 5), (4, 8)):
+    h1, t1, w1, T1, hp1 = corridor_problem(np.random.default_rng(1), 1, N, 3, 16)
+    r = aa.qp_solve(s, h1, t1, hp1, T1 * 1.5, res=20, max_vel=4.0, max_acc=6.0, ctx=ctx)
+    print("qp_solve     B=1 : %.1f us  (s=%d, %d pieces, 16 rows, res 20; status %d, %d Newton steps)" % (
+        timeit(lambda: aa.qp_solve(s, h1, t1, hp1, T1 * 1.5, res=20, max_vel=4.0, max_acc=6.0, ctx=ctx), 100), s, N,
+        int(r["status"][0]), int(r["iters"][0])))
