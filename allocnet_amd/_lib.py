@@ -113,6 +113,7 @@ PROTOTYPES = {
     "anet_lbfgs_minco_bounded_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anet_set_cancel_flag": (c_int, [c_void_p, c_void_p]),
     "anet_lbfgs_minco_bounded": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),

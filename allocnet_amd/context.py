@@ -23,6 +23,17 @@ class Context:
     def synchronize(self):
         self.check(self.lib.anet_synchronize(self.handle))
 
+    def set_cancel_flag(self, flag):
+        """anet_set_cancel_flag: lbfgs_optimize's progress callback (lbfgs.hpp:580-587) as a cancel word.  `flag`: an int32
+        torch CUDA tensor of one element (kept alive here), a raw device-visible address, or None to clear.  While the word
+        is non-zero every problem of the one-launch MINCO L-BFGS calls on this context stops after the iteration it is in
+        with status LBFGS_CANCELED."""
+        addr = None
+        if flag is not None:
+            addr = int(flag.data_ptr()) if hasattr(flag, "data_ptr") else int(flag)
+        self._cancel_keepalive = flag
+        self.check(self.lib.anet_set_cancel_flag(self.handle, ctypes.c_void_p(addr) if addr else None))
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.anet_destroy(self.handle)

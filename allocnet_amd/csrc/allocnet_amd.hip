@@ -45,6 +45,8 @@ struct anet_ctx {
   // pinned host staging for single-trajectory calls (inputs are packed and sent with ONE copy)
   double *h_pack = nullptr;
   size_t h_pack_doubles = 0;
+  // cancel word of the one-launch L-BFGS (anet_set_cancel_flag), device-visible, owned by the caller
+  const int32_t *cancel_flag = nullptr;
   // RCCL communicator for the all-gather of costs
   ncclComm_t comm = nullptr;
   int comm_ranks = 0;
@@ -1447,6 +1449,12 @@ static int final_coeffs(anet_ctx *ctx, int s, int c, int N, int64_t batch, int64
   return anet_minco_solve_wide_spread_dev(ctx, s, c, N, batch, ld, head, tail, wps, T, kWideSpread, coeffs_out, nullptr, st);
 }
 
+int anet_set_cancel_flag(anet_ctx *ctx, const int32_t *flag) {
+  if (!ctx) return ANET_ERR_INVALID;
+  ctx->cancel_flag = flag;
+  return ANET_OK;
+}
+
 int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                          const double *head, const double *tail, double *wps, double *T,
                          const double *hpolys, const anet_penalty *pen, const anet_lbfgs_params *params,
@@ -1517,6 +1525,7 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
     pa.inv_mu = 1.0 / pa.pp.mu; pa.inv_res = 1.0 / (double)pa.pp.res;
     pa.p = to_kernel_params(*params);
     pa.step_bound = (min_duration > 0.0 && nt > 0) ? 1 : 0;  // (gcopter's backwardT, minco_core.h backward_T)
+    pa.cancel = (const int *)ctx->cancel_flag;
     pa.tau_min = min_duration > 1.0 ? sqrt(2.0 * min_duration - 1.0) - 1.0 : (min_duration > 0.0 ? 1.0 - sqrt(2.0 / min_duration - 1.0) : 0.0);
 #ifdef ANET_PERSIST_PROF
     static long long *d_prof = nullptr;

@@ -33,6 +33,8 @@ struct PersistArgs {
   LbfgsP p;
   int step_bound;  // 1: every line search is bounded so that the durations stay >= the minimum behind tau_min
   double tau_min;  // backward_T(minimum duration)
+  const int *cancel;  // optional device-visible word, polled once per evaluation: non-zero ends every problem with LBFGS_CANCELED
+                      // after its next completed iteration (lbfgs.hpp:580-587: what proc_progress returning non-zero does)
 #ifdef ANET_PERSIST_PROF
   long long *prof;  // [16] cycle counters of problem 0 (tools/persist_prof.py)
 #endif
@@ -203,7 +205,8 @@ struct LbfgsResident {
   }
   // consumes f = objective at x (gradient already in g); leaves the next point in x.  Returns the lbfgs.hpp
   // return code when the problem stops, 0x7fffffff while it runs.
-  __device__ __forceinline__ int update(const LbfgsP &P, const int lane, const double f, const StepBound sb = StepBound{0, 0, 0, 0.0}) {
+  __device__ __forceinline__ int update(const LbfgsP &P, const int lane, const double f, const StepBound sb = StepBound{0, 0, 0, 0.0},
+                                        const int cancel = 0) {
     const int m = P.mem_size;
     ++evals;
     bool start_ls = false;
@@ -266,7 +269,9 @@ struct LbfgsResident {
         x = __builtin_fma(step, d, xp);
       } else {
         fx = f;
-        if (conv_test(P)) {
+        if (cancel) {  // lbfgs.hpp:580-587: the progress report comes first after a line search; non-zero cancels
+          finish = LB_CANCELED;
+        } else if (conv_test(P)) {
           finish = LB_CONVERGENCE;
         } else {
           if (0 < P.past) {
@@ -1222,6 +1227,9 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
   __syncthreads();
 #pragma unroll 1
   for (int e = 0; e < a.max_evals; ++e) {
+    // (the cancel word is fetched now and looked at after the evaluation: its round trip costs nothing)
+    int cancel = 0;
+    if (a.cancel) cancel = __builtin_nontemporal_load(a.cancel);
     // publish the point to evaluate
     if (lane < a.nw) Lm.P[ax][na + 1] = st.x;
     else if (lane < n) Lm.T[lane - a.nw] = forward_T(st.x);
@@ -1231,7 +1239,7 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
     PERSIST_TICK_DECL;
     if (lane >= a.nw && lane < n) g *= dforward_T(st.x);
     st.g = (lane < n) ? g : 0.0;
-    finish = st.update(a.p, lane, f, StepBound{a.step_bound, a.nw, n, a.tau_min});
+    finish = st.update(a.p, lane, f, StepBound{a.step_bound, a.nw, n, a.tau_min}, __builtin_amdgcn_readfirstlane(cancel));
     finish = __builtin_amdgcn_readfirstlane(finish);
     PERSIST_TICK(9);
     if (finish != 0x7fffffff) break;

@@ -499,6 +499,15 @@ int anet_lbfgs_minco_bounded_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
                                  double *cost, double *coeffs_out, int32_t *status, int32_t *iters, int32_t *evals,
                                  void *stream);
 
+/* lbfgs_optimize's progress callback (lbfgs.hpp:226-246 lbfgs_progress_t, called at lbfgs.hpp:580-587 after every
+ * successful line search; a non-zero return ends the run with LBFGS_CANCELED) -- a host callback cannot run inside the
+ * kernels, so its one effect is offered as a word the caller owns: `flag` (device-visible int32 -- device memory written from
+ * another stream, or mapped pinned host memory; NULL: none) is read once per evaluation by every problem of the one-launch
+ * MINCO L-BFGS calls that follow on this context; while it is non-zero a problem stops after the iteration it is in, at
+ * the point lbfgs.hpp:583 would, with status LBFGS_CANCELED (2), its iterate, cost and counters as they stand.  Problems
+ * that stopped on their own keep their status.  The lockstep shape and the MVIE objective do not look at it.            */
+int anet_set_cancel_flag(anet_ctx *ctx, const int32_t *flag);
+
 /* launch_order for the call above from the evals[] of a previous solve of the same or a similar batch: longest first, in
  * buckets of 16 evaluations (device arrays; work: ANET_LAUNCH_ORDER_WORK_INTS int32 of scratch; asynchronous on `stream`). */
 #define ANET_LAUNCH_ORDER_WORK_INTS 4096

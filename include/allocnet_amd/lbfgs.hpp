@@ -106,7 +106,8 @@ inline std::vector<int> lbfgs_optimize_mvie(int batch, int M, const std::vector<
 // updated like the reference's, the return value is its return code.  Any other host callback is refused: there is no
 // CPU L-BFGS in this library (batched device objectives: lbfgs_optimize_mvie above, anet_lbfgs_minco).  The step-bound
 // mechanism itself (lbfgs.hpp:557-565) is there for the MINCO objective as a built-in bound, a minimum duration:
-// anet_lbfgs_minco_bounded[_dev](..., min_duration, ...).
+// anet_lbfgs_minco_bounded[_dev](..., min_duration, ...); the progress monitor's one effect (lbfgs.hpp:580-587: a non-zero
+// return cancels the run) as a word the caller owns: anet_set_cancel_flag.
 template <class V>
 inline int lbfgs_optimize(V &x, double &f, lbfgs_evaluate_t<V> proc_evaluate, lbfgs_stepbound_t<V> proc_stepbound,
                           lbfgs_progress_t<V> proc_progress, void *instance, const lbfgs_parameter_t &param) {

@@ -525,3 +525,49 @@ def test_minco_lbfgs_step_bound_keeps_a_minimum_duration(anet_ctx):
     with pytest.raises(aa.AnetError):
         aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=50, min_duration=Tmin,
                        opt=aa.lbfgs.OPT_WAYPOINTS | aa.lbfgs.OPT_TIMES | aa.lbfgs.OPT_LOCKSTEP, ctx=anet_ctx)
+
+
+def test_minco_lbfgs_cancel_word(anet_ctx):
+    """lbfgs_optimize's progress callback (lbfgs.hpp:580-587: called after every successful line search, a non-zero return
+    ends the run with LBFGS_CANCELED) as the cancel word of anet_set_cancel_flag.  With the word at zero the run is the
+    plain one bit for bit; with the word set from the start every problem is cancelled after its FIRST iteration -- at the
+    very point a run with max_iterations = 1 stops (the progress report comes before the convergence, stop and iteration
+    tests of the same iteration), so iterates, cost and counters must be those, only the return code differs."""
+    import torch
+    import allocnet_amd as aa
+    from allocnet_amd import lbfgs as L
+    rng = np.random.default_rng(32)
+    s, c, N, M, B = 3, 3, 6, 8, 96
+    head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
+    hp = make_corridors(rng, head, tail, wps, M, tight=2.0)
+    T = rng.uniform(1.2, 2.0, size=(B, N))
+    pen = aa.make_penalty(rho=50.0, w_corridor=1e3, w_vel=1.0, w_acc=1.0, smooth_mu=1e-2, max_vel=3.0, max_acc=4.0, res=8,
+                          poly_rows=M)
+    free = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
+    one = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx,
+                         param=aa.lbfgs_parameter_t(max_iterations=1))
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    anet_ctx.set_cancel_flag(flag)
+    try:
+        same = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
+        for k in ("cost", "evals", "iters", "status", "T"):
+            assert np.array_equal(same[k], free[k]), k
+        flag.fill_(1)
+        torch.cuda.synchronize()
+        can = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
+    finally:
+        anet_ctx.set_cancel_flag(None)
+    ran = one["status"] == L.LBFGSERR_MAXIMUMITERATION          # problems whose first iteration completed and went on
+    assert ran.mean() > 0.9
+    assert (can["status"][ran] == L.LBFGS_CANCELED).all()
+    for k in ("iters", "evals", "cost", "T", "wps"):
+        assert np.array_equal(can[k][ran], one[k][ran]), k
+    # the others: a failed first line search keeps its error code; a first iteration that would have ended the run on
+    # its own is reported as cancelled (the report comes first)
+    rest = ~ran
+    assert np.isin(can["status"][rest], (L.LBFGS_CANCELED,) + tuple(np.unique(one["status"][rest]))).all()
+    assert (can["status"][rest & (one["status"] < 0)] == one["status"][rest & (one["status"] < 0)]).all()
+    # cleared: the plain run again
+    again = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
+    assert np.array_equal(again["status"], free["status"]) and np.array_equal(again["evals"], free["evals"])
