@@ -15,6 +15,8 @@ SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liballocnet_amd.so")
 SOURCES = ["allocnet_amd.hip"]
+# translation units with flags of their own: (source, extra flags)
+UNITS = [("piece_grad_unit.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: the one MFMA of the library (the FP64 Schur update of k_qp_ipm) keeps its accumulator in VGPRs; in
 # AGPRs it pushes the jerk instantiation past 256 registers in total, i.e. from two workgroups per CU to one.
@@ -42,15 +44,38 @@ def build(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     extra = os.environ.get("ANET_BUILD_FLAGS", "").split()      # e.g. -DANET_PERSIST_PROF (tools/ only)
-    cmd = [HIPCC] + FLAGS + extra + [os.path.join(SRC_DIR, s) for s in SOURCES] + ["-o", LIB_PATH]
+    # the units compile while the main source does (-mllvm flags are per invocation), then everything is linked
+    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl")]
+    jobs, objs = [], []
+    for src, uflags in UNITS:
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        ucmd = [HIPCC] + cflags + uflags + extra + ["-c", os.path.join(SRC_DIR, src), "-o", obj]
+        if verbose:
+            print(" ".join(ucmd), flush=True)
+        jobs.append((ucmd, subprocess.Popen(ucmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    main_objs = []
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        main_objs.append(obj)
+        mcmd = [HIPCC] + cflags + extra + ["-c", os.path.join(SRC_DIR, src), "-o", obj]
+        if verbose:
+            print(" ".join(mcmd), flush=True)
+        jobs.append((mcmd, subprocess.Popen(mcmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for jcmd, pr in jobs:
+        out, err = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out + err)
+            raise RuntimeError("hipcc failed: " + " ".join(jcmd))
+        if verbose and err:
+            sys.stderr.write(err)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + main_objs + objs + ["-ldl", "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("hipcc failed building liballocnet_amd.so")
-    if verbose and res.stderr:
-        sys.stderr.write(res.stderr)
+        raise RuntimeError("hipcc failed linking liballocnet_amd.so")
     return LIB_PATH
 
 

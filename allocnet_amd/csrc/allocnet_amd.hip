@@ -234,26 +234,7 @@ int launch_prop(anet_ctx *ctx, const anet::PropArgs &a, hipStream_t st) {
   const dim3 block(anet::kSolveBlock);
   if (a.B <= axis_variant_max_batch()) {  // same small-batch split as launch_solve
     const dim3 g3((unsigned)((a.B + 20) / 21));
-    bool done = true;
-    if constexpr (S == 4) {
-      if (a.N == 8 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate_axis<4, 8, true, 2>), g3, block, 0, st, a);
-      else if (a.N == 8 && a.c == 4) hipLaunchKernelGGL((anet::k_minco_propagate_axis<4, 8, true, 3>), g3, block, 0, st, a);
-      else if (a.N == 5 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate_axis<4, 5, true, 2>), g3, block, 0, st, a);
-      else done = false;
-    } else if constexpr (S == 3) {
-      if (a.N == 16 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate_axis<3, 16, true, 2>), g3, block, 0, st, a);
-      else if (a.N == 5 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_propagate_axis<3, 5, true, 2>), g3, block, 0, st, a);
-      else done = false;
-    } else {
-      done = false;
-    }
-    if (done) {
-      ANET_HIP(ctx, hipGetLastError());
-      return ANET_OK;
-    }
-    if (a.N <= 4) hipLaunchKernelGGL((anet::k_minco_propagate_axis<S, 4>), g3, block, 0, st, a);
-    else if (a.N <= 8) hipLaunchKernelGGL((anet::k_minco_propagate_axis<S, 8>), g3, block, 0, st, a);
-    else hipLaunchKernelGGL((anet::k_minco_propagate_axis<S, 16>), g3, block, 0, st, a);
+    anet::launch_propagate_axis(S, a, g3, block, st);  // (piece_grad_unit.hip: scheduled for ILP)
     ANET_HIP(ctx, hipGetLastError());
     return ANET_OK;
   }
@@ -962,17 +943,13 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
   if (pen && batch <= axis_variant_max_batch() && batch * n_pieces <= sw_max_pairs) {
     // fewest waves: two lanes per (trajectory, piece) AND the samples spread over the four waves of a workgroup
     const dim3 g4((unsigned)((2 * batch + 63) / 64), (unsigned)n_pieces);
-    if (s == 2) hipLaunchKernelGGL((anet::k_piece_grad<2, true, 4>), g4, block, 0, st, a, tab);
-    else if (s == 3) hipLaunchKernelGGL((anet::k_piece_grad<3, true, 4>), g4, block, 0, st, a, tab);
-    else hipLaunchKernelGGL((anet::k_piece_grad<4, true, 4>), g4, block, 0, st, a, tab);
+    anet::launch_piece_grad(s, 2, g4, block, st, a, tab);
   } else if (pen && batch <= axis_variant_max_batch()) {  // small batches: two lanes per (trajectory, piece)
     const dim3 g2((unsigned)((2 * batch + 255) / 256), (unsigned)n_pieces);
-    if (s == 2) hipLaunchKernelGGL((anet::k_piece_grad<2, true>), g2, block, 0, st, a, tab);
-    else if (s == 3) hipLaunchKernelGGL((anet::k_piece_grad<3, true>), g2, block, 0, st, a, tab);
-    else hipLaunchKernelGGL((anet::k_piece_grad<4, true>), g2, block, 0, st, a, tab);
-  } else if (s == 2) hipLaunchKernelGGL((anet::k_piece_grad<2, false>), grid, block, 0, st, a, tab);
-  else if (s == 3) hipLaunchKernelGGL((anet::k_piece_grad<3, false>), grid, block, 0, st, a, tab);
-  else hipLaunchKernelGGL((anet::k_piece_grad<4, false>), grid, block, 0, st, a, tab);
+    anet::launch_piece_grad(s, 1, g2, block, st, a, tab);
+  } else {
+    anet::launch_piece_grad(s, 0, grid, block, st, a, tab);
+  }
   ANET_HIP(ctx, hipGetLastError());
   return ANET_OK;
 }

@@ -201,7 +201,7 @@ struct PieceGradArgs {
 // (order, res) into a small device buffer.  k_piece_grad reads it through a `const __restrict__` kernel argument with a
 // wave-uniform index, i.e. as SCALAR loads: the values arrive in SGPRs and feed the FMAs directly, no LDS traffic and
 // no vector registers for the table.
-__global__ void __launch_bounds__(256) k_build_basis_table(double *tab, int res, int D) {
+static __global__ void __launch_bounds__(256) k_build_basis_table(double *tab, int res, int D) {  // (static: this header is in two translation units)
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= res * 4 * D) return;
   const int j = e / (4 * D), d = (e / D) % 4, col = e % D, k = D - 1 - col;
@@ -492,6 +492,14 @@ __global__ void __launch_bounds__(256, SW > 1 ? ANET_PG_SW_MINB : ANET_PG_MINB) 
   a.gdT[(int64_t)i * ld + b] = gT;
   if (a.pcost) a.pcost[(int64_t)i * ld + b] = pc;
 }
+
+// k_piece_grad lives in a translation unit of its own (piece_grad_unit.hip), compiled with the max-ILP scheduling strategy:
+// its small-batch shapes are chains of dependent FP64 instructions on one or two waves per SIMD, and scheduled for ILP
+// rather than for occupancy BASELINE configs[2] (4096 x 8 pieces) takes 55 instead of 60 us per evaluation; the same
+// strategy costs k_minco_solve_axis a third (8.9 -> 12.2 us per launch of 1024) and the interior-point QP 3 %, so it is
+// not a flag of the whole library.  shape: 0 lane per (trajectory, piece); 1 two lanes per pair; 2 two lanes per pair and
+// the samples over the four waves of a workgroup.
+void launch_piece_grad(int s, int shape, dim3 grid, dim3 block, hipStream_t st, const PieceGradArgs &a, const double *tab);
 
 struct PropArgs {
   const double *T, *coeffs, *gdC, *gdT;
@@ -799,5 +807,8 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_propagate_axis(PropArgs a
     }
   if (a.cost && live && ax == 0) a.cost[bb] = (a.energy_in ? a.energy_in[bb] : 0.0) + a.rho * tsum + csum;
 }
+
+// the small-batch adjoint (lane = (trajectory, axis)), in the same translation unit as k_piece_grad and for the same reason
+void launch_propagate_axis(int s, const PropArgs &a, dim3 grid, dim3 block, hipStream_t st);
 
 }  // namespace anet

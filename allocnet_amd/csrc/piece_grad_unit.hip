@@ -1,0 +1,50 @@
+// The penalty / energy-gradient kernel k_piece_grad and the small-batch adjoint k_minco_propagate_axis (minco_kernels.h) as a
+// translation unit of their own: built with
+// -mllvm -amdgpu-sched-strategy=max-ilp (allocnet_amd/build.py; why: the comment at launch_piece_grad's declaration).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "minco_kernels.h"
+
+namespace anet {
+
+void launch_piece_grad(int s, int shape, dim3 grid, dim3 block, hipStream_t st, const PieceGradArgs &a, const double *tab) {
+  if (shape == 2) {
+    if (s == 2) hipLaunchKernelGGL((k_piece_grad<2, true, 4>), grid, block, 0, st, a, tab);
+    else if (s == 3) hipLaunchKernelGGL((k_piece_grad<3, true, 4>), grid, block, 0, st, a, tab);
+    else hipLaunchKernelGGL((k_piece_grad<4, true, 4>), grid, block, 0, st, a, tab);
+  } else if (shape == 1) {
+    if (s == 2) hipLaunchKernelGGL((k_piece_grad<2, true>), grid, block, 0, st, a, tab);
+    else if (s == 3) hipLaunchKernelGGL((k_piece_grad<3, true>), grid, block, 0, st, a, tab);
+    else hipLaunchKernelGGL((k_piece_grad<4, true>), grid, block, 0, st, a, tab);
+  } else {
+    if (s == 2) hipLaunchKernelGGL((k_piece_grad<2, false>), grid, block, 0, st, a, tab);
+    else if (s == 3) hipLaunchKernelGGL((k_piece_grad<3, false>), grid, block, 0, st, a, tab);
+    else hipLaunchKernelGGL((k_piece_grad<4, false>), grid, block, 0, st, a, tab);
+  }
+}
+
+template <int S>
+static void launch_propagate_axis_t(const PropArgs &a, dim3 g3, dim3 block, hipStream_t st) {
+  if constexpr (S == 4) {
+    if (a.N == 8 && a.c == 3) { hipLaunchKernelGGL((k_minco_propagate_axis<4, 8, true, 2>), g3, block, 0, st, a); return; }
+    if (a.N == 8 && a.c == 4) { hipLaunchKernelGGL((k_minco_propagate_axis<4, 8, true, 3>), g3, block, 0, st, a); return; }
+    if (a.N == 5 && a.c == 3) { hipLaunchKernelGGL((k_minco_propagate_axis<4, 5, true, 2>), g3, block, 0, st, a); return; }
+  } else if constexpr (S == 3) {
+    if (a.N == 16 && a.c == 3) { hipLaunchKernelGGL((k_minco_propagate_axis<3, 16, true, 2>), g3, block, 0, st, a); return; }
+    if (a.N == 5 && a.c == 3) { hipLaunchKernelGGL((k_minco_propagate_axis<3, 5, true, 2>), g3, block, 0, st, a); return; }
+  }
+  if (a.N <= 4) hipLaunchKernelGGL((k_minco_propagate_axis<S, 4>), g3, block, 0, st, a);
+  else if (a.N <= 8) hipLaunchKernelGGL((k_minco_propagate_axis<S, 8>), g3, block, 0, st, a);
+  else hipLaunchKernelGGL((k_minco_propagate_axis<S, 16>), g3, block, 0, st, a);
+}
+
+void launch_propagate_axis(int s, const PropArgs &a, dim3 grid, dim3 block, hipStream_t st) {
+  switch (s) {
+    case 2: return launch_propagate_axis_t<2>(a, grid, block, st);
+    case 3: return launch_propagate_axis_t<3>(a, grid, block, st);
+    default: return launch_propagate_axis_t<4>(a, grid, block, st);
+  }
+}
+
+}  // namespace anet

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Per-kernel VGPR / scratch / occupancy table from the compiler's own remarks (no GPU needed):
 #   bash tools/kernel_resources.sh [name-filter]
+#   ANET_RES_SOURCE=piece_grad_unit.hip ANET_RES_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp" bash tools/kernel_resources.sh   (the unit built for ILP)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I "$ROOT/include" -c "$ROOT/allocnet_amd/csrc/allocnet_amd.hip" \
+cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I "$ROOT/include" -c "$ROOT/allocnet_amd/csrc/${ANET_RES_SOURCE:-allocnet_amd.hip}" ${ANET_RES_FLAGS:-} \
   -o /tmp/anet_res.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import re, sys, subprocess
 flt = sys.argv[1] if len(sys.argv) > 1 else ''
