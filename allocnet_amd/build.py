@@ -16,7 +16,8 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liballocnet_amd.so")
 SOURCES = ["allocnet_amd.hip"]
 # translation units with flags of their own: (source, extra flags)
-UNITS = [("piece_grad_unit.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])]
+UNITS = [("piece_grad_unit.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+         ("qp_ipm_fuse_unit.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: the one MFMA of the library (the FP64 Schur update of k_qp_ipm) keeps its accumulator in VGPRs; in
 # AGPRs it pushes the jerk instantiation past 256 registers in total, i.e. from two workgroups per CU to one.

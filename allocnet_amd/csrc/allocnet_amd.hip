@@ -1826,8 +1826,11 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     // through the updating pass (registers: qp_ipm.h FUSE); a lone problem, a small batch or a problem whose LDS fills the
     // CU takes the fused form.  (jerk: the unbounded instantiation needs <= 256 registers as it is -- two workgroups per CU
     // -- and the compiler schedules it for latency; bounded to 256 it is 18 % slower per problem at the same occupancy)
-    if (s == 4) rc_l = two_per_cu ? launch_ipm(anet::k_qp_ipm<4, 2, false>) : launch_ipm(anet::k_qp_ipm<4, 1, true>);
-    else rc_l = two_per_cu ? launch_ipm(anet::k_qp_ipm<3, 1, false>) : launch_ipm(anet::k_qp_ipm<3, 1, true>);
+    if (!two_per_cu) {  // (qp_ipm_fuse_unit.hip: the FUSE instantiations, scheduled for ILP)
+      ANET_HIP(ctx, (hipError_t)anet::launch_qp_ipm_fuse(s, batch, ldsb, sti, ia));
+      rc_l = ANET_OK;
+    } else if (s == 4) rc_l = launch_ipm(anet::k_qp_ipm<4, 2, false>);
+    else rc_l = launch_ipm(anet::k_qp_ipm<3, 1, false>);
     if (rc_l != ANET_OK) return rc_l;
     ANET_HIP(ctx, hipGetLastError());
     return ANET_OK;

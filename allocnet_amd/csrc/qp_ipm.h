@@ -1186,4 +1186,9 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   }
 }
 
+// The FUSE instantiations (lone problems, small batches) live in qp_ipm_fuse_unit.hip, scheduled for ILP (2-3 % of their latency;
+// the throughput shapes lose 3 % under that strategy and stay in the main translation unit).  Returns the hipError_t of the
+// attribute call / launch as an int.
+int launch_qp_ipm_fuse(int s, int64_t batch, size_t lds_bytes, hipStream_t st, const IpmArgs &a);
+
 }  // namespace anet
