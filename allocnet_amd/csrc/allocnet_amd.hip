@@ -1813,7 +1813,10 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     // two workgroups per CU (registers bounded to 256) from this batch on, when two fit the LDS
     static const int64_t ipm_two_per_cu_min_batch = [] {
       const char *e = getenv("ANET_IPM_TWO_PER_CU_MIN_BATCH");
-      return e ? (int64_t)atoll(e) : (int64_t)1024;
+      // more than two rounds of one workgroup per CU (256 CUs): below that a batch lasts as long as its slowest problem and
+      // a problem alone on its CU is faster (measured: 512 problems are a draw -- 2.86 / 1.88 / 2.95 ms against 2.64 / 1.63 /
+      // 3.42 ms for 8 snap / 5 jerk / 5 snap pieces --, 768 problems gain 15-20 % from two per CU, 320 lose 15 %)
+      return e ? (int64_t)atoll(e) : (int64_t)513;
     }();
     const bool two_per_cu = batch >= ipm_two_per_cu_min_batch && 2 * ldsb <= 160 * 1024;
     auto launch_ipm = [&](auto kern) -> int {

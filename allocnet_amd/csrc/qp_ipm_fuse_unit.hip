@@ -1,4 +1,4 @@
-// The FUSE form of the interior-point QP kernel (qp_ipm.h: lone problems, batches below 1024, problems whose LDS fills a CU) as a
+// The FUSE form of the interior-point QP kernel (qp_ipm.h: lone problems, batches of up to 512, problems whose LDS fills a CU) as a
 // translation unit of its own, built with -mllvm -amdgpu-sched-strategy=max-ilp (allocnet_amd/build.py): one workgroup per CU,
 // nothing to gain from occupancy, every phase a dependent chain.
 #include <hip/hip_runtime.h>
