@@ -94,12 +94,20 @@ struct IpmBoxRow {
   __device__ __forceinline__ void weights(double w, double *A) const { A[3 + dsel * 3 + ax] += w; }
 };
 
+// LDS strides chosen for the banks (64 banks of 4 bytes; a double takes two): lanes of a row pass are SAMPLES, so they read the
+// basis table at 20 different j and write per-sample records at 64 different samples.  With the natural strides -- 3 D = 24
+// doubles = 192 B per table row (snap), 30 doubles = 240 B per record -- those addresses fall on 4 resp. 16 bank positions
+// (SQ_LDS_BANK_CONFLICT as large as SQ_ACTIVE_INST_LDS for the snap kernel, profiles/r03_qp_ipm_roofline.txt); one double of
+// padding each spreads them over 32.
+__host__ __device__ constexpr int ipm_ht_stride(int D) { return 3 * D + 1; }
+constexpr int kIpmRecord = 31;  // 30 sums per sample + 1 pad
+
 template <int S>
 inline size_t qp_ipm_lds_bytes(int N, int R, int M) {
   constexpr int D = 2 * S, NB = 3 * D, BK = 3 * S;
   const size_t NS = (size_t)N * R;
   return sizeof(double) * ((size_t)(N + 1) * BK * 5 + (size_t)(N + 1) * BK * BK + (size_t)N * BK * BK + 3 * (size_t)N * NB +
-                           (size_t)R * 3 * D + 2 * D * D + (size_t)N * D + NS * 30 + (size_t)N * M * 4 + 2 * N + 32);
+                           (size_t)R * ipm_ht_stride(D) + 2 * D * D + (size_t)N * D + NS * kIpmRecord + (size_t)N * M * 4 + 2 * N + 32);
 }
 
 // MINB: workgroups per CU the register allocation is bounded for.  The snap kernel needs more than 256 registers to run
@@ -110,6 +118,7 @@ inline size_t qp_ipm_lds_bytes(int N, int R, int M) {
 template <int S, int MINB = 1, bool FUSE = (MINB == 1)>
 __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   constexpr int D = 2 * S, NB = 3 * D, BK = 3 * S;
+  constexpr int HS = ipm_ht_stride(D), AS = kIpmRecord;  // padded strides of the basis table rows / per-sample records
   const int N = a.N, R = a.R, M = a.M;
   const int NS = N * R, RPS = M + 12;
   const int64_t mtot = (int64_t)NS * RPS;
@@ -128,11 +137,11 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   double *dua = uu + (size_t)N * NB;      // [N][NB] u_i of the affine direction
   double *duc = dua + (size_t)N * NB;     // [N][NB] u_i of the final direction
   double *ht = duc + (size_t)N * NB;      // [R][3][D] Hermite basis (derivative d) at tau_j
-  double *Hobj = ht + (size_t)R * 3 * D;  // [D][D] cost block in Hermite coordinates (per axis, T = 1)
+  double *Hobj = ht + (size_t)R * HS;  // [D][D] cost block in Hermite coordinates (per axis, T = 1)
   double *Hm = Hobj + D * D;              // [D][D] c~ = Hm u
   double *sc = Hm + D * D;                // [N][D] 1 for the start half, (T_i/T_i+1)^d for the end half
   double *acc = sc + (size_t)N * D;       // [NS][30]: 0-5 Wa (sym), 6-8 Wv, 9-11 Wacc, 12-20 gamma[d][ax], 21-29 gamma_lambda
-  double *hp_l = acc + (size_t)NS * 30;   // [N*M*4]
+  double *hp_l = acc + (size_t)NS * AS;   // [N*M*4]
   double *Tn = hp_l + (size_t)N * M * 4;  // [N]
   double *red = Tn + N;                   // [32]
   double *qsv = red + 32;                 // [N] T_i^(1-2s)
@@ -179,7 +188,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   }
   __syncthreads();
   for (int e = tid; e < R * 3 * D; e += nt) {
-    const int j = e / (3 * D), d = (e / D) % 3, m = e % D;
+    const int j = e / (3 * D), d = (e / D) % 3, m = e % D;  // stored at ht[j * HS + d * D + m]
     const double tau = (double)j / (double)R;
     double v = 0.0;
     for (int col = 0; col < D; ++col) {
@@ -190,7 +199,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         v += bv * Hm[col * D + m];
       }
     }
-    ht[e] = v;
+    ht[(size_t)j * HS + d * D + m] = v;
   }
   for (int e = tid; e < D * D; e += nt) {
     const int m = e / D, m2 = e % D;
@@ -249,7 +258,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
 
   // state rows (derivative d, axis ax) of a u-vector at sample (i, j)
   auto state_of = [&](const double *u, int i, int j, double (&s3)[3][3]) {
-    const double *hj = ht + (size_t)j * 3 * D, *ui = u + (size_t)i * NB;
+    const double *hj = ht + (size_t)j * HS, *ui = u + (size_t)i * NB;
 #pragma unroll
     for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -388,14 +397,14 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
           }
           if (goff2 < 0) {
             for (int j = 0; j < R; ++j) {
-              const double *ga = acc + (size_t)(i * R + j) * 30 + goff;
-              const double *hj = ht + (size_t)j * 3 * D;
+              const double *ga = acc + (size_t)(i * R + j) * AS + goff;
+              const double *hj = ht + (size_t)j * HS;
               g += ga[ax] * hj[m] + ga[3 + ax] * hj[D + m] + ga[6 + ax] * hj[2 * D + m];
             }
           } else {
             for (int j = 0; j < R; ++j) {
-              const double *ga = acc + (size_t)(i * R + j) * 30 + goff, *gb = acc + (size_t)(i * R + j) * 30 + goff2;
-              const double *hj = ht + (size_t)j * 3 * D;
+              const double *ga = acc + (size_t)(i * R + j) * AS + goff, *gb = acc + (size_t)(i * R + j) * AS + goff2;
+              const double *hj = ht + (size_t)j * HS;
               g += (ga[ax] + w2 * gb[ax]) * hj[m] + (ga[3 + ax] + w2 * gb[3 + ax]) * hj[D + m] +
                    (ga[6 + ax] + w2 * gb[6 + ax]) * hj[2 * D + m];
             }
@@ -427,8 +436,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         for (int m2 = 0; m2 < D; ++m2) g += qs * Hobj[m * D + m2] * ui[m2];
         double gr = g, ga = g;
         for (int j = 0; j < R; ++j) {
-          const double *ac = acc + (size_t)(i * R + j) * 30;
-          const double *hj = ht + (size_t)j * 3 * D;
+          const double *ac = acc + (size_t)(i * R + j) * AS;
+          const double *hj = ht + (size_t)j * HS;
           gr += ac[21 + ax] * hj[m] + ac[24 + ax] * hj[D + m] + ac[27 + ax] * hj[2 * D + m];
           ga += ac[12 + ax] * hj[m] + ac[15 + ax] * hj[D + m] + ac[18 + ax] * hj[2 * D + m];
         }
@@ -651,8 +660,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       if (m < S && m2 >= S) continue;  // upper off-diagonal block: the transpose of the stored one
       double Sa[6] = {0, 0, 0, 0, 0, 0}, Sd[3] = {0, 0, 0};
       for (int j = 0; j < R; ++j) {
-        const double *as = acc + (size_t)(i * R + j) * 30;
-        const double *hj = ht + (size_t)j * 3 * D;
+        const double *as = acc + (size_t)(i * R + j) * AS;
+        const double *hj = ht + (size_t)j * HS;
         const double p0 = hj[m] * hj[m2], p1 = hj[D + m] * hj[D + m2], p2 = hj[2 * D + m] * hj[2 * D + m2];
 #pragma unroll
         for (int q = 0; q < 6; ++q) Sa[q] += as[q] * p0;
@@ -718,7 +727,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
         row_A(row, hv, row.dot(s3[row.dsel]), sl, lm, A_, l_mu, l_pres, l_h);
       });
-      double *as = acc + (size_t)smp * 30;
+      double *as = acc + (size_t)smp * AS;
 #pragma unroll
       for (int q = 0; q < 30; ++q) as[q] = A_[q];
     }
@@ -755,7 +764,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
           row.axpy(t, A_ + 12 + row.dsel * 3);
           row.axpy(lm, A_ + 21 + row.dsel * 3);
         });
-        double *as = acc + (size_t)smp * 30;
+        double *as = acc + (size_t)smp * AS;
 #pragma unroll
         for (int q = 0; q < 30; ++q) as[q] = A_[q];
       }
@@ -847,7 +856,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
           row.axpy(t0, G0 + row.dsel * 3);
           row.axpy(isl, G1 + row.dsel * 3);
         });
-        double *as = acc + (size_t)smp * 30;
+        double *as = acc + (size_t)smp * AS;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
           as[12 + q] = G0[q];
@@ -954,7 +963,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
           lm += alpha * dl;
           row_A(row, hv, gy + alpha * ge, sl, lm, A_, l_mu, l_pres, l_h);
         });
-        double *as = acc + (size_t)smp * 30;
+        double *as = acc + (size_t)smp * AS;
 #pragma unroll
         for (int q = 0; q < 30; ++q) as[q] = A_[q];
       }
@@ -1001,7 +1010,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double, double sl, double lm) {
         row.weights((lm > sl) ? w_act : 0.0, A_);
       });
-      double *as = acc + (size_t)smp * 30;
+      double *as = acc + (size_t)smp * AS;
 #pragma unroll
       for (int q = 0; q < 12; ++q) as[q] = A_[q];
     }
@@ -1032,7 +1041,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     }
     for (int i = fresh_tid(); i < 3 * N; i += nt) rhs[i] = 0.0;
     for (int smp = fresh_tid(); smp < NS; smp += nt) {
-      double *as = acc + (size_t)smp * 30 + 12;
+      double *as = acc + (size_t)smp * AS + 12;
 #pragma unroll
       for (int q = 0; q < 9; ++q) as[q] = 0.0;
     }
@@ -1064,7 +1073,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
           if (row.dsel == 1) bsv += dl;
           if (row.dsel == 2) bsa += dl;
         });
-        double *as = acc + (size_t)smp * 30 + 12;
+        double *as = acc + (size_t)smp * AS + 12;
 #pragma unroll
         for (int q = 0; q < 9; ++q) as[q] += G_[q];
         atomicAdd(&rhs[N + i], bsv);
@@ -1091,8 +1100,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       if (d == 0) continue;
       double g = qsv[i] * hu, dg = qsv[i] * hv;
       for (int j = 0; j < R; ++j) {
-        const double *ga = acc + (size_t)(i * R + j) * 30;
-        const double *hj = ht + (size_t)j * 3 * D;
+        const double *ga = acc + (size_t)(i * R + j) * AS;
+        const double *hj = ht + (size_t)j * HS;
         g += ga[21 + ax] * hj[m] + ga[24 + ax] * hj[D + m] + ga[27 + ax] * hj[2 * D + m];
         dg += ga[12 + ax] * hj[m] + ga[15 + ax] * hj[D + m] + ga[18 + ax] * hj[2 * D + m];
       }
@@ -1130,8 +1139,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       if (d == 0) continue;
       double g = qsv[i] * hu;
       for (int j = 0; j < R; ++j) {
-        const double *ga = acc + (size_t)(i * R + j) * 30 + 21;
-        const double *hj = ht + (size_t)j * 3 * D;
+        const double *ga = acc + (size_t)(i * R + j) * AS + 21;
+        const double *hj = ht + (size_t)j * HS;
         g += ga[ax] * hj[m] + ga[3 + ax] * hj[D + m] + ga[6 + ax] * hj[2 * D + m];
       }
       const double c = g * ui[m] * (double)d;
