@@ -65,9 +65,11 @@ struct PersistLds {
   double Si[NB + 1][m][m];   // inverse Schur complements S_k^-1
   double H[NB][m][m];        // H_k = S_k^-1 Ko_k: y_k+1 = rhs_k+1 - H_k' y_k ;  x_k = z_k - H_k x_k+1
   double X[3][NB + 1][m];    // primal: right-hand side -> node derivatives; then adjoint: right-hand side -> multipliers
-  double co[NB][3][D];       // coefficients, highest power first; then the node-state adjoint contributions of a piece
+  // (rows of D + 1 doubles: lanes = (piece, axis) read and write these at a fixed column, and at 2 S doubles per row -- 48 or
+  //  64 bytes -- consecutive lanes fall on 16 resp. 4 bank positions)
+  double co[NB][3][D + 1];   // coefficients, highest power first; then the node-state adjoint contributions of a piece
                              // to its start node (first S entries) and its end node (last S), written by their reader
-  double gc[NB][3][D];       // penalty part of dJ/dc
+  double gc[NB][3][D + 1];   // penalty part of dJ/dc
   double gdT[NB], pc[NB];    // penalty part of dJ/dT, penalty cost per piece
   double wl[NB + 1][3], gTp[NB][3], ep[NB][3];
 };
