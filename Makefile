@@ -13,4 +13,4 @@ bench:
 profile:
 	bash tools/profile.sh r01
 clean:
-	rm -f allocnet_amd/lib/*.so oracle/liboracle.so tests/cpp/test_facade
+	rm -f allocnet_amd/lib/*.so allocnet_amd/lib/*.o oracle/liboracle.so tests/cpp/test_facade
