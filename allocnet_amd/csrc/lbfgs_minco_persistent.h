@@ -64,7 +64,16 @@ struct PersistLds {
   double Kp[NB][m][m];       // coupling block Ko_k of piece k
   double Si[NB + 1][m][m];   // inverse Schur complements S_k^-1
   double H[NB][m][m];        // H_k = S_k^-1 Ko_k: y_k+1 = rhs_k+1 - H_k' y_k ;  x_k = z_k - H_k x_k+1
-  double X[3][NB + 1][m];    // primal: right-hand side -> node derivatives; then adjoint: right-hand side -> multipliers
+  // X[axis][component][node], rows of XW doubles: the (node, axis) lanes and the 16-lane scan rows of chain_solve read one
+  // component of many nodes at a time -- node-minor keeps those on consecutive banks (node-major with 2 components per node put
+  // 51 lanes on 16 same-parity double-banks: four-way); XW makes the axes start 16 double-banks apart where a small pad can
+  static constexpr int xw_pad() {
+    for (int p = 0; p <= 8; ++p)
+      if ((m * (NB + 1 + p)) % 32 == 16) return p;
+    return 0;
+  }
+  static constexpr int XW = NB + 1 + xw_pad();
+  double X[3][m][XW];        // primal: right-hand side -> node derivatives; then adjoint: right-hand side -> multipliers
   // (rows of D + 1 doubles: lanes = (piece, axis) read and write these at a fixed column, and at 2 S doubles per row -- 48 or
   //  64 bytes -- consecutive lanes fall on 16 resp. 4 bank positions)
   double co[NB][3][D + 1];   // coefficients, highest power first; then the node-state adjoint contributions of a piece
@@ -486,7 +495,7 @@ __device__ __forceinline__ void scan_round(double (&M)[m][m], double (&v)[m], co
 }
 
 template <int S, int NB>
-__device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3][NB + 1][S - 1], const int N,
+__device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3][S - 1][PersistLds<S, NB>::XW], const int N,
                                             const int lane, const int, const int) {
   constexpr int m = S - 1;
   const int row = lane >> 4, j = lane & 15, ax = row < 3 ? row : 2;
@@ -495,8 +504,8 @@ __device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3
   double Hj[m][m], M[m][m], v[m], y0[m], z0[m], zf[m];
 #pragma unroll
   for (int a = 0; a < m; ++a) {
-    y0[a] = V[ax][0][a];
-    v[a] = valid ? V[ax][jc + 1][a] : 0.0;
+    y0[a] = V[ax][a][0];
+    v[a] = valid ? V[ax][a][jc + 1] : 0.0;
 #pragma unroll
     for (int b = 0; b < m; ++b) Hj[a][b] = valid ? Lm.H[jc][a][b] : 0.0;
   }
@@ -565,10 +574,10 @@ __device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3
   }
   if (valid && row < 3) {
 #pragma unroll
-    for (int a = 0; a < m; ++a) V[ax][j][a] = v[a];
+    for (int a = 0; a < m; ++a) V[ax][a][j] = v[a];
     if (j == N - 1) {
 #pragma unroll
-      for (int a = 0; a < m; ++a) V[ax][N][a] = zf[a];
+      for (int a = 0; a < m; ++a) V[ax][a][N] = zf[a];
     }
   }
   __syncthreads();
@@ -616,7 +625,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
     const double P0 = Lm.P[ax][k], Pm = Lm.P[ax][k > 0 ? k - 1 : 0], Pp = Lm.P[ax][k < N ? k + 1 : k];
     rhs_primal_node_rt<S>(k, N, np, rk, rkm, Pm, P0, Pp, hv, tv, y);
 #pragma unroll
-    for (int l = 0; l < m; ++l) Lm.X[ax][k][l] = y[l];
+    for (int l = 0; l < m; ++l) Lm.X[ax][l][k] = y[l];
     if (ax == 0 && refactor) {  // the blocks of the system (minco_core.h Factor::factorize, assembly part)
       double Ak[m][m];
 #pragma unroll
@@ -832,8 +841,8 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
     double x0[m], x1[m];
 #pragma unroll
     for (int l = 0; l < m; ++l) {
-      x0[l] = Lm.X[ax][i][l];
-      x1[l] = Lm.X[ax][i + 1][l];
+      x0[l] = Lm.X[ax][l][i];
+      x1[l] = Lm.X[ax][l][i + 1];
     }
     const double e = emit_piece<S>(i, p, Lm.P[ax][i], Lm.P[ax][i + 1], x0, x1,
                                    [&](int piece, int col, double v) { Lm.co[piece][ax][col] = v; });
@@ -1074,8 +1083,8 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
     x1s[0] = Lm.P[ax][i + 1];
 #pragma unroll
     for (int l = 0; l < m; ++l) {
-      x0s[l + 1] = Lm.X[ax][i][l];
-      x1s[l + 1] = Lm.X[ax][i + 1][l];
+      x0s[l + 1] = Lm.X[ax][l][i];
+      x1s[l + 1] = Lm.X[ax][l][i + 1];
     }
     double cA[S], cB[S];
     double fact = 1.0;
@@ -1124,7 +1133,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
       double v = 0.0;
       if (k > 0) v += Lm.co[k - 1][ax][S + l + 1];
       if (k < N) v += Lm.co[k < N ? k : 0][ax][l + 1];
-      Lm.X[ax][k][l] = ((k == 0 || k == N) && l < np) ? 0.0 : v;
+      Lm.X[ax][l][k] = ((k == 0 || k == N) && l < np) ? 0.0 : v;
     }
   }
   __syncthreads();
@@ -1139,8 +1148,8 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
     double la[m], lb[m];
 #pragma unroll
     for (int l = 0; l < m; ++l) {
-      la[l] = Lm.X[ax][k][l];
-      lb[l] = Lm.X[ax][k + 1][l];
+      la[l] = Lm.X[ax][l][k];
+      lb[l] = Lm.X[ax][l][k + 1];
     }
     double wl = 0.0;
 #pragma unroll
