@@ -21,8 +21,25 @@ UNITS = [("piece_grad_unit.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: the one MFMA of the library (the FP64 Schur update of k_qp_ipm) keeps its accumulator in VGPRs; in
 # AGPRs it pushes the jerk instantiation past 256 registers in total, i.e. from two workgroups per CU to one.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ldl", "-mllvm", "-amdgpu-mfma-vgpr-form",
-         "-I", os.path.join(ROOT, "include")]
+MFMA_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ldl", "-I", os.path.join(ROOT, "include")]
+
+
+def probe_flags(flags):
+    """`flags` if this hipcc accepts them (an LLVM without the option rejects an unknown -mllvm argument and the whole
+    library would fail to build), else [] with a warning: a trivial device compile decides."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "probe.hip")
+        with open(src, "w") as f:
+            f.write("__global__ void k(double *p) { p[0] = 1.0; }\n")
+        res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O1", "-c", src, "-o", os.path.join(td, "probe.o")] + flags,
+                             capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write("allocnet_amd.build: hipcc rejects " + " ".join(flags) + " -- building without it (the FP64 MFMA "
+                         "accumulator of k_qp_ipm goes to AGPRs: one workgroup per CU for the jerk instantiation)\n")
+        return []
+    return flags
 
 
 def _deps():
@@ -43,13 +60,16 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
+    import tempfile
     os.makedirs(LIB_DIR, exist_ok=True)
     extra = os.environ.get("ANET_BUILD_FLAGS", "").split()      # e.g. -DANET_PERSIST_PROF (tools/ only)
     # the units compile while the main source does (-mllvm flags are per invocation), then everything is linked
-    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl")]
+    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl")] + probe_flags(MFMA_VGPR_FORM)
     jobs, objs = [], []
+    tmp = tempfile.TemporaryDirectory(prefix="anet_build_")     # the objects do not stay in the tree
+    OBJ_DIR = tmp.name
     for src, uflags in UNITS:
-        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         ucmd = [HIPCC] + cflags + uflags + extra + ["-c", os.path.join(SRC_DIR, src), "-o", obj]
         if verbose:
@@ -57,7 +77,7 @@ def build(force=False, verbose=False):
         jobs.append((ucmd, subprocess.Popen(ucmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     main_objs = []
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
         main_objs.append(obj)
         mcmd = [HIPCC] + cflags + extra + ["-c", os.path.join(SRC_DIR, src), "-o", obj]
         if verbose:

@@ -444,7 +444,8 @@ __global__ void k_lbfgs_results(const int *is, const double *ds, int64_t B, int6
   if (status) status[b] = is[anet::IS_DONE * ld + b] ? is[anet::IS_RET * ld + b] : ANET_LBFGS_RUNNING;
   if (iters) iters[b] = is[anet::IS_K * ld + b];
   if (evals) evals[b] = is[anet::IS_EVALS * ld + b];
-  if (f) f[b] = ds[anet::DS_FX * ld + b];
+  // a problem no workgroup took (a launch order that skips it) has no cost: NaN, not whatever the workspace held
+  if (f) f[b] = (is[anet::IS_DONE * ld + b] == 0 && is[anet::IS_EVALS * ld + b] == 0) ? __builtin_nan("") : ds[anet::DS_FX * ld + b];
 }
 }  // namespace
 

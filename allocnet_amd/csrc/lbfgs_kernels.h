@@ -41,6 +41,15 @@ struct LbfgsArgs {
   double *map_T = nullptr;
   int map_nw = 0;
 };
+// x = xp + step * d as the reference computes it (lbfgs.hpp:308): the reference is built with -O3 and no -march
+// (src/planner/CMakeLists.txt:4-6), i.e. for baseline x86-64, where this is a multiply and an add -- two roundings.  The
+// trial point decides every later comparison of a line search, so the kernels round it the same way instead of fusing.
+__device__ __forceinline__ double trial_point(double step, double d, double xp) {
+#pragma clang fp contract(off)
+  const double p = step * d;
+  return xp + p;
+}
+
 __device__ __forceinline__ void store_x(const LbfgsArgs &a, int64_t b, int i, double v) {
   a.x[(int64_t)i * a.ld + b] = v;
   if (a.map_T && i >= a.map_nw) a.map_T[(int64_t)(i - a.map_nw) * a.ld + b] = forward_T(v);
@@ -144,7 +153,7 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
       fx = f;
       finish = err;
     } else if (!success) {
-      for (int i = 0; i < n; ++i) store_x(a, b, i, __builtin_fma(step, d[i * ld], xp[i * ld]));
+      for (int i = 0; i < n; ++i) store_x(a, b, i, trial_point(step, d[i * ld], xp[i * ld]));
       ds[DS_MU * ld] = mu;
       ds[DS_NU * ld] = nu;
       is[IS_COUNT * ld] = count;
@@ -237,7 +246,7 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
       is[IS_COUNT * ld] = 0;
       is[IS_BRACKT * ld] = 0;
       is[IS_TOUCHED * ld] = 0;
-      for (int i = 0; i < n; ++i) store_x(a, b, i, __builtin_fma(step, d[i * ld], xp[i * ld]));
+      for (int i = 0; i < n; ++i) store_x(a, b, i, trial_point(step, d[i * ld], xp[i * ld]));
     }
   }
   ds[DS_FX * ld] = fx;
@@ -535,7 +544,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
     } else if (!success) {
 #pragma unroll
       for (int q = 0; q < NV; ++q)
-        if (h[q]) store_x(a, b, (int)iv[q], __builtin_fma(step, dr[q], xpr[q]));
+        if (h[q]) store_x(a, b, (int)iv[q], trial_point(step, dr[q], xpr[q]));
     } else {
       fx = f;
       if (conv_test()) {
@@ -690,7 +699,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
       touched = 0;
 #pragma unroll
       for (int q = 0; q < NV; ++q)
-        if (h[q]) store_x(a, b, (int)iv[q], __builtin_fma(step, dr[q], xr[q]));
+        if (h[q]) store_x(a, b, (int)iv[q], trial_point(step, dr[q], xr[q]));
     }
   }
   if (lane == 0) {

@@ -277,7 +277,7 @@ struct LbfgsResident {
         fx = f;
         finish = err;
       } else if (!success) {
-        x = __builtin_fma(step, d, xp);
+        x = trial_point(step, d, xp);
       } else {
         fx = f;
         if (cancel) {  // lbfgs.hpp:580-587: the progress report comes first after a line search; non-zero cancels
@@ -366,7 +366,7 @@ struct LbfgsResident {
         count = 0;
         brackt = 0;
         touched = 0;
-        x = __builtin_fma(step, d, x);
+        x = trial_point(step, d, x);
       }
     }
     return finish;
@@ -1240,7 +1240,9 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
   for (int e = 0; e < a.max_evals; ++e) {
     // (the cancel word is fetched now and looked at after the evaluation: its round trip costs nothing)
     int cancel = 0;
-    if (a.cancel) cancel = __builtin_nontemporal_load(a.cancel);
+    // system-scope load (sc0 sc1): the word is written while the kernel runs -- by another stream or by the host through
+    // mapped pinned memory -- and a plain load could be served from this CU's vector L1 for the life of the kernel
+    if (a.cancel) cancel = __hip_atomic_load(a.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // publish the point to evaluate
     if (lane < a.nw) Lm.P[ax][na + 1] = st.x;
     else if (lane < n) Lm.T[lane - a.nw] = forward_T(st.x);

@@ -3,6 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_PER_GPU] [--pieces 8] [--order 4]
 
+`--gpus N` with N > 1 starts its own N ranks (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1);
+launched BY torch.distributed.run (WORLD_SIZE set) the process is one rank of the job, as the driver's multi-GPU form has it.
+
 One "step" = one pass of the hot path over one batch of synthetic input: for every trajectory of
 the batch the banded minimum-control-effort coefficient solve + energy (BASELINE.json configs[1]:
 8-segment min-snap, random waypoints, energy-only), inputs already resident in HBM in the library's
@@ -146,6 +149,66 @@ def _to_bm(torch, a, B, ld, device):
     return t
 
 
+def timed_reps(torch, fn, K, reps=3, warm_ms=10.0):
+    """[(host ms per call, stream ms per call)] of `reps` repetitions of K back-to-back calls of fn, each repetition bracketed
+    by one HIP-event pair on the current stream and a host clock, after at least `warm_ms` of GPU time of the same calls
+    (clocks, code objects, first-touch of the outputs: none of it in the timed repetitions)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    warmed, rounds = 0.0, 0
+    while warmed < warm_ms and rounds < 1000:
+        e0.record()
+        for _ in range(max(5, K // 8)):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        warmed += e0.elapsed_time(e1)
+        rounds += 1
+    out = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(K):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(((time.perf_counter() - t0) / K * 1e3, e0.elapsed_time(e1) / K))
+    return out
+
+
+def cost_grad_kernel_split(torch, aa, ctx, s, c, N, B, ld, th, tt, tw, tT, thp, pen, work, gP, gT, K=50):
+    """Device time of the three launches of one evaluation, each between its own HIP events (microseconds, mean of K; an
+    interval holds the launch gap in front of its kernel): anet_minco_solve_dev -> anet_minco_partial_grads_dev ->
+    anet_minco_propagate_grad_dev on the buffers the fused entry point uses."""
+    import ctypes
+    nco = N * 3 * 2 * s
+    w_co, w_gdC = work[:nco * ld], work[nco * ld:2 * nco * ld]
+    w_gdT = work[2 * nco * ld:(2 * nco + N) * ld]
+    w_pc = work[(2 * nco + N) * ld:(2 * nco + 2 * N) * ld]
+    w_en = work[(2 * nco + 2 * N) * ld:(2 * nco + 2 * N + 1) * ld]
+    q = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pp = ctypes.cast(ctypes.pointer(pen), ctypes.c_void_p)
+    lib, h = ctx.lib, ctx.handle
+
+    def three(ev):
+        ev[0].record()
+        ctx.check(lib.anet_minco_solve_dev(h, s, c, N, B, ld, q(th), q(tt), q(tw), q(tT), q(w_co), q(w_en), st))
+        ev[1].record()
+        ctx.check(lib.anet_minco_partial_grads_dev(h, s, N, B, ld, q(w_co), q(tT), q(thp), pp, 1, q(w_gdC), q(w_gdT), q(w_pc), st))
+        ev[2].record()
+        ctx.check(lib.anet_minco_propagate_grad_dev(h, s, c, N, B, ld, q(tT), q(w_co), q(w_gdC), q(w_gdT), q(gP), q(gT), st))
+        ev[3].record()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
+    for ev in evs[:5]:
+        three(ev)
+    torch.cuda.synchronize()
+    for ev in evs:
+        three(ev)
+    torch.cuda.synchronize()
+    names = ("k_minco_solve", "k_piece_grad", "k_minco_propagate")
+    return {n: 1e3 * sum(ev[i].elapsed_time(ev[i + 1]) for ev in evs) / K for i, n in enumerate(names)}
+
+
 def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
     """BASELINE configs[2] (SURVEY 8(d) "config 3"): B = 4096 x 8-segment min-snap, corridor (M = 16) + limit penalties,
     gradients w.r.t. waypoints and durations, seed 1.  One step = one cost + gradient evaluation of the whole batch
@@ -166,21 +229,19 @@ def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
         ld = aa.recommended_ld(B)
         th, tt, tw, tT, thp = (_to_bm(torch, x, B, ld, device) for x in (head, tail, wps, T, hp))
         cost, gP, gT, work = aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, ctx=ctx)
-        for _ in range(5):
+
+        def evaluate():
             aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, work=work, cost=cost, gradP=gP,
                                    gradT=gT, ctx=ctx)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(K):
-            aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, work=work, cost=cost, gradP=gP,
-                                   gradT=gT, ctx=ctx)
-        e1.record()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / K
-        kms = e0.elapsed_time(e1) / K
+        runs = timed_reps(torch, evaluate, K, reps=5, warm_ms=10.0)
+        host_ms = sorted(r[0] for r in runs)
+        st_ms = sorted(r[1] for r in runs)
+        dt, kms = host_ms[len(host_ms) // 2] * 1e-3, st_ms[len(st_ms) // 2]
         out[key] = {"batch": B, "ms_per_step": dt * 1e3, "stream_ms_per_step": kms, "value": B / dt,
+                    "stream_ms_min_median_max": [st_ms[0], kms, st_ms[-1]], "stream_ms_in_run_order": [r[1] for r in runs],
+                    "timing": f"{len(runs)} repetitions of {K} back-to-back evaluations after >= 10 ms of warm-up on the GPU, "
+                              f"one HIP-event pair per repetition; the median repetition is reported",
+                    "kernel_split_us": cost_grad_kernel_split(torch, aa, ctx, s, c, N, B, ld, th, tt, tw, tT, thp, pen, work, gP, gT),
                     "roofline": fp64_roofline(B * flops, kms * 1e-3, B * ab,
                                               "k_piece_grad (+ k_minco_solve, k_minco_propagate)")}
         if key == "b4096":
@@ -500,6 +561,59 @@ def synth_batch_minor(torch, B, ld, N, c, seed, device):
     return head.view(3 * c, ld), tail.view(3 * c, ld), wps, T
 
 
+def launch_plan(gpus, env, device_count):
+    """How `python bench.py --gpus N` becomes N ranks.  Returns (plan, n, message):
+      ("run", world, msg)   this process is a rank already (WORLD_SIZE is set: the driver's torch.distributed.run form) or the
+                            job has one rank;
+      ("spawn", n, msg)     --gpus N > 1 (or ANET_BENCH_SELF_LAUNCH=1) and no WORLD_SIZE: re-exec under torch.distributed.run
+                            with n = min(N, visible GPUs) ranks, one per GPU."""
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        msg = None if world == gpus else f"--gpus {gpus} but WORLD_SIZE={world}: running (and reporting) {world} ranks"
+        return "run", world, msg
+    n = max(1, int(gpus))
+    msg = None
+    if n > device_count:
+        msg = f"--gpus {gpus} but {device_count} GPU(s) visible: running (and reporting) {max(1, device_count)} rank(s)"
+        n = max(1, device_count)
+    if n > 1 or env.get("ANET_BENCH_SELF_LAUNCH") == "1":
+        return "spawn", n, msg
+    return "run", 1, msg
+
+
+def self_launch_cmd(n, argv, port):
+    """The torch.distributed.run command line of n ranks of this script: the caller's flags, `--gpus` replaced by the rank
+    count that really runs."""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+        elif a == "--gpus":
+            skip = True
+        elif not a.startswith("--gpus="):
+            out.append(a)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n)] + out
+
+
+def self_launch(n, argv):
+    """Start n ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free
+    port) and return its exit code.  Rank 0 prints the JSON line; the other ranks' stdout goes to /dev/null, so the line
+    stays the last line of this process's stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.pop("ANET_BENCH_SELF_LAUNCH", None)
+    env.pop("MASTER_PORT", None)                          # torch.distributed.run exports the port it was given
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    sys.stdout.flush()
+    return subprocess.run(self_launch_cmd(n, argv, port), env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -519,16 +633,19 @@ def main():
 
     import torch
     import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (allocnet_amd has no CPU fallback)")
+    plan, n, msg = launch_plan(args.gpus, os.environ, torch.cuda.device_count())
+    if msg:
+        print("bench.py: " + msg, file=sys.stderr, flush=True)
+    if plan == "spawn":
+        raise SystemExit(self_launch(n, sys.argv[1:]))
     import allocnet_amd as aa
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (allocnet_amd has no CPU fallback)")
     if rank != 0:
         # only rank 0 reports; keep other ranks' library banners (RCCL prints one) off the job's stdout
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
@@ -653,6 +770,8 @@ def main():
     }
 
     out["roofline"]["traffic"] = pmc_traffic_bytes(B, N, s)
+    out["roofline"]["traffic_source"] = ("committed rocprofv3 PMC pass of this launch shape (profiles/*_pmc.json: WRITE_SIZE + 2 x "
+                                         "FETCH_SIZE), a constant of the tree, not counted during this run")
     if c5 is not None:
         out["config5"] = c5
     if world == 1 and not args.main_only:

@@ -126,7 +126,12 @@ int anet_minco_spread_flags_dev(anet_ctx *ctx, int n_pieces, int64_t batch, int6
  * head / tail / wps are per PROBLEM (batch-minor with row stride ldp >= problems), T per SAMPLE (row stride ld); the only
  * output is cost[b] = int (p^(s))^2 + rho * sum T (rho = 0: the energy of MINCO_S*NU::getEnergy), 8 (N + 1) bytes of
  * traffic per sample instead of the 1920 of a full solve.  No counterpart in the reference (it solves one trajectory per
- * call, learning_planner.hpp:196); upstream's use is a loop over setParameters / getEnergy.                         */
+ * call, learning_planner.hpp:196); upstream's use is a loop over setParameters / getEnergy.
+ * ACCURACY ENVELOPE: the costs come from the reduced (block-tridiagonal) system only -- there is no pivoted re-solve
+ * here as anet_minco_solve_wide_spread_dev / anet_lbfgs_minco apply above a spread of 50.  Relative error of the energy:
+ * <= 1e-8 while max T / min T of a sample stays below ~100, degrading beyond it (order 1e-4 at 10^3 for snap).  A sampler
+ * that draws wider spreads should flag those samples with anet_minco_spread_flags_dev (same T layout) and re-evaluate
+ * them with anet_minco_solve_wide_spread_dev.                                                                        */
 int anet_minco_sample_costs_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t problems, int64_t samples_per_problem,
                                 int64_t ld, int64_t ldp, const double *head /* [3c][ldp] */, const double *tail,
                                 const double *wps /* [(N-1)*3][ldp] */, const double *T /* [N][ld] */, double rho,

@@ -4,8 +4,9 @@
 // solve(iniPVA, finPVA, hPolys, times, qp_solution) -> bool, getObjCost().
 //
 // The QP is the reference's own (same variables, equality rows, cost blocks, corridor and box rows
-// sampled at ConstRes points per piece); it is solved on the MI355X by the batched ADMM kernel behind
-// anet_qp_solve with OSQP's default settings instead of by OsqpEigen/OSQP on the CPU.  Acceptance rule
+// sampled at ConstRes points per piece); it is solved on the MI355X behind anet_qp_solve -- by the batched
+// interior-point kernel (k_qp_ipm, the default method; the OSQP-style ADMM kernel is opt-in through
+// anet_qp_settings.method) -- instead of by OsqpEigen/OSQP on the CPU.  Acceptance rule
 // as in the reference (:334-352): status Solved and -0.01 <= objective (read as float) <= 5000.
 // Matrix arguments are duck-typed ((r,c) / (i) access, rows(), resize(n)): Eigen types work unchanged.
 #pragma once

@@ -15,6 +15,10 @@
  * this path -> PARITY UNPINNED against reference outputs.  Pinned by known-answer problems
  * (quadratic, Rosenbrock: tests/test_lbfgs_cpu.py) and by finite differences of costMVIE.
  * Dot products are plain left-to-right sums (Eigen's vectorised order is not reproducible).
+ *
+ * ROUNDING CONVENTION: the reference is built with -O3 and no -march (src/planner/CMakeLists.txt:4-6): baseline x86-64
+ * has no fused multiply-add, so every a + b * c of lbfgs.hpp is a multiply and an add.  This file is therefore compiled
+ * with -ffp-contract=off (oracle/Makefile, oracle/cbind.py): no expression here is fused, whatever -march says.
  */
 #include <float.h>
 #include <math.h>
@@ -65,7 +69,7 @@ static int line_search(int n, double *x, double *f, double *g, double *stp, cons
   dgtest = param->f_dec_coeff * dginit;
   dstest = param->s_curv_coeff * dginit;
   for (;;) {
-    for (int i = 0; i < n; ++i) x[i] = fma(*stp, s[i], xp[i]); /* x = xp + stp * s (lbfgs.hpp:308), fused as the kernels do */
+    for (int i = 0; i < n; ++i) x[i] = xp[i] + *stp * s[i]; /* lbfgs.hpp:308; two roundings: this file is compiled with -ffp-contract=off */
     *f = eval(inst, x, g, n);
     ++count; ++*evals;
     if (isinf(*f) || isnan(*f)) return LBFGSERR_INVALID_FUNCVAL;

@@ -99,12 +99,25 @@ def test_config3_lbfgs_to_convergence_full_batch(anet_ctx):
     for b in range(0, B, 1024):          # ... also according to the numpy oracle (dense adjoint)
         cb, *_ = _oracle_cost_grad(s, head[b], tail[b], out["wps"][b], out["T"][b], hp[b])
         assert abs(cb - out["cost"][b]) <= 1e-8 * abs(cb), b
-    # ... and, 64 strided problems, according to the C restatement (classic banded LU with pivoting), whose gradient
-    # at the returned point must also be small where the optimiser said it stopped
+    # ... and, 64 strided problems, according to the C restatement (classic banded LU with pivoting).  Its gradient at the
+    # returned point, in the optimiser's variables (waypoints, tau): a problem that ended with LBFGS_CONVERGENCE meets the
+    # gradient test of lbfgs.hpp:590-597 there; one that ended with LBFGS_STOP (the past / delta test, :604-620) promises
+    # no gradient size, but the gradient has come down by orders of magnitude from the start's
     idx = np.arange(0, B, B // 64)
     cc, cgP, cgT = cbind.minco_cost_grad_batch(s, head[idx], tail[idx], out["wps"][idx], out["T"][idx], hp[idx], RHO,
                                                nthreads=4, **KW)
     assert np.abs(cc - out["cost"][idx]).max() <= 1e-8 * np.abs(cc).max()
+    _, sgP, sgT = cbind.minco_cost_grad_batch(s, head[idx], tail[idx], wps[idx], T[idx], hp[idx], RHO, nthreads=4, **KW)
+
+    def ginf(gP, gT, TT):
+        return np.maximum(np.abs(gP).reshape(len(idx), -1).max(axis=1), np.abs(gT * _dfwd(_bwd(TT))).max(axis=1))
+    g_end, g_start = ginf(cgP, cgT, out["T"][idx]), ginf(sgP, sgT, T[idx])
+    xinf = np.maximum(np.abs(out["wps"][idx]).reshape(len(idx), -1).max(axis=1), np.abs(_bwd(out["T"][idx])).max(axis=1))
+    conv = st[idx] == aa.lbfgs.LBFGS_CONVERGENCE
+    assert (g_end[conv] / np.maximum(1.0, xinf[conv]) < 1.01 * aa.lbfgs_parameter_t().g_epsilon).all()
+    print("configs[3] |g|_inf end / start: median %.2e max %.2e (%d of %d LBFGS_CONVERGENCE)"
+          % (np.median(g_end / g_start), (g_end / g_start).max(), int(conv.sum()), len(idx)))
+    assert np.median(g_end / g_start) < 1e-2 and (g_end < g_start).all()
     # the spread of the optimised durations this configuration ends with (recorded: the reduced system is accurate to
     # 1e-8 up to a spread of 100; beyond 50 the returned coefficients are re-solved with pivoting)
     spread = out["T"].max(axis=1) / out["T"].min(axis=1)
@@ -162,3 +175,35 @@ def test_config3_lbfgs_counters_match_the_c_driver_on_a_wide_sample(anet_ctx, ma
     rel = np.abs(out["cost"][idx] - ref["cost"]) / np.abs(ref["cost"])
     assert rel[same].max() <= 1e-7, rel[same].max()
     assert np.abs(out["T"][idx][same] - ref["T"][same]).max() <= 1e-6 * ref["T"].max()
+
+
+def test_config3_converged_costs_against_the_cpu_restatement(anet_ctx):
+    """configs[3] run to each problem's own stop on BOTH sides, 256 strided problems: the one-launch kernel against the C
+    restatement of lbfgs_optimize on the C objective (oracle_lbfgs_minco_batch).  ~2500 iterations of a non-convex problem
+    amplify the different rounding of the two objectives (reduced block-tridiagonal solve and wave reductions here, classic
+    banded LU and left-to-right sums there), so the END points differ -- counters are exact at small budgets (tests above) --
+    and what can be asked is statistical: the relative difference of the final costs has a median within +-2e-3, and the
+    GPU does not end systematically higher (sign test: at most 62 % of the sample, 3 sigma of a fair coin at n = 256).
+    The largest single difference is printed (recorded in DESIGN section 7), not bounded: a problem whose two runs part
+    ways early may settle in different local minima."""
+    import allocnet_amd as aa
+    B, s, c, N, M = 4096, 3, 3, 16, 16
+    rng = np.random.default_rng(2)
+    head, tail, wps, T, hp = corridor_problem(rng, B, N, c, M)
+    pen = _penalty(aa, M)
+    idx = np.arange(0, B, 16)
+    out = aa.lbfgs_minco(head[idx], tail[idx], wps[idx], T[idx], s, hpolys=hp[idx], penalty=pen, param=aa.lbfgs_parameter_t(),
+                         max_evals=40000, ctx=anet_ctx)
+    ref = cbind.lbfgs_minco_batch(s, head[idx], tail[idx], wps[idx], T[idx], hp[idx], RHO, nthreads=8,
+                                  param=cbind.lbfgs_default_param(), **KW)
+    ok = (aa.lbfgs.LBFGS_STOP, aa.lbfgs.LBFGS_CONVERGENCE)
+    assert np.isin(out["status"], ok).all() and np.isin(ref["status"], ok).all()
+    d = (out["cost"] - ref["cost"]) / ref["cost"]
+    worse = float((d > 0).mean())
+    print("configs[3] converged, GPU vs CPU restatement, 256 problems: median rel diff %.2e, |max| %.2e, GPU higher in "
+          "%.1f %%, evaluations GPU %.0f / CPU %.0f mean" % (np.median(d), np.abs(d).max(), 100 * worse, out["evals"].mean(),
+                                                           ref["evals"].mean()))
+    assert abs(np.median(d)) <= 2e-3
+    assert worse <= 0.62
+    # both ends are stationary to the same degree: the evaluation counts have the same scale
+    assert 0.8 < out["evals"].mean() / ref["evals"].mean() < 1.25

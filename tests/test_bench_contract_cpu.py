@@ -84,3 +84,27 @@ def test_qp_solve_bookkeeping():
     body = src[src.index("def run_qp"):]
     body = body[:body.index("\ndef ", 10)]
     assert body.index("from oracle import qp_np") > body.index("if cpu_baseline:")
+
+
+def test_launch_plan_and_self_launch_command():
+    """`python bench.py --gpus N`: N > 1 without WORLD_SIZE starts its own ranks (clamped to the visible GPUs, with a
+    message); under torch.distributed.run the process is a rank; one GPU runs in place unless the self-launch path is forced."""
+    import bench
+    assert bench.launch_plan(1, {}, 1) == ("run", 1, None)
+    assert bench.launch_plan(8, {}, 8) == ("spawn", 8, None)
+    plan, n, msg = bench.launch_plan(8, {}, 2)
+    assert (plan, n) == ("spawn", 2) and "2 GPU(s) visible" in msg
+    plan, n, msg = bench.launch_plan(8, {}, 1)
+    assert (plan, n) == ("run", 1) and msg
+    assert bench.launch_plan(1, {"ANET_BENCH_SELF_LAUNCH": "1"}, 1) == ("spawn", 1, None)
+    assert bench.launch_plan(4, {"WORLD_SIZE": "4", "RANK": "1"}, 8) == ("run", 4, None)
+    plan, n, msg = bench.launch_plan(8, {"WORLD_SIZE": "2"}, 8)
+    assert (plan, n) == ("run", 2) and "WORLD_SIZE=2" in msg
+    cmd = bench.self_launch_cmd(2, ["--gpus", "8", "--steps", "3", "--workload", "config5"], 12345)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in cmd
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--workload", "config5"]
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    assert bench.self_launch_cmd(4, ["--gpus=8", "--main-only"], 1)[-3:] == ["--gpus", "4", "--main-only"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "launch with: python -m torch.distributed.run" not in src

@@ -36,6 +36,26 @@ def test_rccl_path_single_rank(workload, port):
     assert 0 < out["roofline"]["frac"] < 1
 
 
+def test_self_launch_path():
+    """`python bench.py --gpus N` starts its own ranks: the same code path forced with one rank (ANET_BENCH_SELF_LAUNCH=1
+    re-executes under torch.distributed.run), RCCL group included; the JSON line stays the last line of stdout."""
+    for workload in ("solve", "config5"):
+        out = _bench(["--gpus", "1", "--main-only", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--workload", workload,
+                      "--batch", "65536"], env={"ANET_BENCH_SELF_LAUNCH": "1", "ANET_BENCH_FORCE_DIST": "1"})
+        for k in KEYS:
+            assert k in out, k
+        assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
+        assert "allgather(costs)" in out["config"]["parallelism"]
+
+
+def test_gpus_beyond_the_box_is_clamped_not_refused():
+    """--gpus 8 on a box with fewer GPUs runs the ranks there are and says so (n_gpus = what ran)."""
+    import torch
+    n = torch.cuda.device_count()
+    out = _bench(["--gpus", "8", "--main-only", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--batch", "65536"])
+    assert out["n_gpus"] == min(8, n) and out["value"] > 0
+
+
 def test_default_line_carries_the_north_star_loop():
     """configs[1] headline + config3 / config4 / config5 sub-objects, each with a roofline; CPU baselines off here (the
     driver's own bench run times them)."""

