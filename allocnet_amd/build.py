@@ -32,9 +32,11 @@ def probe_flags(flags):
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "probe.hip")
         with open(src, "w") as f:
-            f.write("__global__ void k(double *p) { p[0] = 1.0; }\n")
+            f.write("#include <hip/hip_runtime.h>\n__global__ void k(double *p) { p[0] = 1.0; }\n")
         res = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O1", "-c", src, "-o", os.path.join(td, "probe.o")] + flags,
                              capture_output=True, text=True)
+    if res.returncode != 0 and subprocess.run([a for a in res.args if a not in flags], capture_output=True).returncode != 0:
+        raise RuntimeError("hipcc cannot compile a trivial kernel for gfx950:\n" + res.stderr)
     if res.returncode != 0:
         sys.stderr.write("allocnet_amd.build: hipcc rejects " + " ".join(flags) + " -- building without it (the FP64 MFMA "
                          "accumulator of k_qp_ipm goes to AGPRs: one workgroup per CU for the jerk instantiation)\n")
@@ -45,7 +47,7 @@ def probe_flags(flags):
 def _deps():
     out = [os.path.join(ROOT, "include", "allocnet_amd.h")]
     for f in os.listdir(SRC_DIR):
-        if f.endswith((".hip", ".h", ".hpp")):
+        if f.endswith((".hip", ".h", ".hpp", ".inc")):
             out.append(os.path.join(SRC_DIR, f))
     return out
 

@@ -116,3 +116,49 @@ def test_random_shapes_against_both_oracles(anet_ctx):
                 assert np.abs(gP[b].T - gP0).max() <= 1e-6 * max(1.0, np.abs(gP0).max()), (s, c, N, B)
             assert np.abs(gT[b] - gT0).max() <= 1e-6 * max(1.0, np.abs(gT0).max()), (s, c, N, B)
     assert len(seen) >= 20
+
+
+@pytest.mark.parametrize("s,c,N,M", [(4, 3, 8, 16), (4, 4, 8, 9), (4, 3, 5, 16), (3, 3, 8, 12), (3, 3, 5, 7), (4, 3, 1, 6),
+                                     (4, 3, 2, 6), (3, 2, 3, 0)])
+def test_large_batch_shapes_agree_with_small_batch_shapes_and_oracle(anet_ctx, s, c, N, M):
+    """Batches above 16384 run the lane-per-trajectory solve / adjoint and the lane-per-piece penalty kernel, batches up to
+    16384 the lane-per-(trajectory, axis) and two-lanes-per-piece shapes: the same 16384 + 257 trajectories (a ragged last
+    workgroup) through both agree to rounding -- whole batch against chunks of 8192 -- and a strided sample agrees with the C
+    restatement (classic banded LU + adjoint) to the tolerance of the other parity tests."""
+    import allocnet_amd as aa
+    from oracle import cbind
+    from tests.util import corridor_problem
+    rng = np.random.default_rng(7000 + 100 * s + 10 * N + c)
+    B = 16384 + 257
+    if M:
+        head, tail, wps, T, hp = corridor_problem(rng, B, N, c, M)
+    else:
+        head, tail, wps, T = random_problem(rng, B, N, c)
+        hp = None
+    kw = dict(res=9, vmax=2.5, amax=3.5, wc=1e3, wv=40.0, wa=15.0, mu=0.03)
+    pen = aa.make_penalty(rho=3.0, w_corridor=kw["wc"], w_vel=kw["wv"], w_acc=kw["wa"], smooth_mu=kw["mu"], max_vel=kw["vmax"],
+                          max_acc=kw["amax"], res=kw["res"], poly_rows=M)
+    cost, gP, gT = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, ctx=anet_ctx)          # large-batch shapes
+    assert np.isfinite(cost).all() and np.isfinite(gP).all() and np.isfinite(gT).all()
+    # the small-batch shapes: chunks of at most 8192 trajectories (and, separately, the whole batch with coefficients asked for)
+    c2, gP2, gT2 = np.empty_like(cost), np.empty_like(gP), np.empty_like(gT)
+    for b0 in range(0, B, 8192):
+        sl = slice(b0, min(B, b0 + 8192))
+        c2[sl], gP2[sl], gT2[sl] = aa.minco_cost_grad(head[sl], tail[sl], wps[sl], T[sl], s, hpolys=None if hp is None else hp[sl],
+                                                      penalty=pen, ctx=anet_ctx)
+    c3, gP3, gT3, _ = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, want_coeffs=True, ctx=anet_ctx)
+    for other in ((c2, gP2, gT2), (c3, gP3, gT3)):
+        assert np.abs(cost - other[0]).max() <= 1e-11 * np.abs(other[0]).max()
+        sc = np.maximum(1.0, np.abs(other[2]).max(axis=1, keepdims=True))
+        assert (np.abs(gT - other[2]) <= 1e-9 * sc).all(), np.abs(gT - other[2]).max()
+        if N > 1:
+            sp = np.maximum(1.0, np.abs(other[1]).reshape(B, -1).max(axis=1))[:, None, None]
+            assert (np.abs(gP - other[1]) <= 1e-9 * sp).all(), np.abs(gP - other[1]).max()
+    idx = np.arange(0, B, B // 48)
+    cc, cgP, cgT = cbind.minco_cost_grad_batch(s, head[idx], tail[idx], wps[idx], T[idx], None if hp is None else hp[idx], 3.0,
+                                               nthreads=4, **kw)
+    assert np.abs(cost[idx] - cc).max() <= 1e-9 * np.abs(cc).max()
+    assert np.abs(gT[idx] - cgT).max() <= 1e-7 * max(1.0, np.abs(cgT).max())
+    if N > 1:
+        assert np.abs(gP[idx] - cgP).max() <= 1e-7 * max(1.0, np.abs(cgP).max())
+    assert (cost - 3.0 * T.sum(axis=1) > 0).all()

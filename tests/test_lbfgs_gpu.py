@@ -134,7 +134,7 @@ def test_mvie_register_resident_vs_state_in_memory_random_shapes(anet_ctx, monke
             assert (~agree).sum() <= max(1, int(0.15 * done.sum())), (tag, np.abs(f1 - f2)[done])
             long_runs[0] += int(done.sum())
             long_runs[1] += int(agree.sum())
-    assert long_runs[1] >= 0.97 * long_runs[0], long_runs
+    assert long_runs[0] - long_runs[1] <= max(1, int(0.03 * long_runs[0])), long_runs
 
 
 def test_mvie_error_codes_and_budget(anet_ctx):
