@@ -326,7 +326,8 @@ static int ensure_counter(anet_ctx *ctx) {
 // last problem stopped; they change nothing (finished problems ignore evaluations).
 template <class Eval>
 static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfgs_params &prm, int max_evals,
-                       hipStream_t st, Eval &&eval, double *map_T = nullptr, int map_nw = 0, bool reset = true) {
+                       hipStream_t st, Eval &&eval, double *map_T = nullptr, int map_nw = 0, bool reset = true,
+                       int sb_on = 0, double sb_xmin = 0.0, const int32_t *cancel = nullptr) {
   int rc = ensure_counter(ctx);
   if (rc) return rc;
   if (reset) {  // (a caller that pre-marks problems as finished resets the state itself)
@@ -337,7 +338,8 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
   // registers; otherwise one lane per problem (internal vectors batch-minor)
   const bool wave = B <= lbfgs_wave_max_batch() && L.n <= 128 && prm.mem_size <= 64;
   anet::LbfgsArgs a{L.n, B, L.ld, L.x, L.g, L.xp, L.gp, L.d, L.lm_s, L.lm_y, L.lm_ys, L.lm_alpha, L.pf, L.ds,
-                    L.feval, L.is, to_kernel_params(prm), nullptr, wave ? 1 : L.ld, wave ? L.n : 1, map_T, map_nw};
+                    L.feval, L.is, to_kernel_params(prm), nullptr, wave ? 1 : L.ld, wave ? L.n : 1, map_T, map_nw,
+                    sb_on, map_nw, sb_xmin, (const int *)cancel};
   const dim3 grid(wave ? (unsigned)B : (unsigned)((B + 63) / 64)), block(64);
   const int poll = 8;
   int group = 0;
@@ -1548,13 +1550,14 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
       return coeffs_out ? final_coeffs(ctx, s, c, N, batch, ld, head, tail, wps, T, coeffs_out, st) : ANET_OK;
     }
   }
-  if (min_duration > 0.0 && nt > 0)
-    return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_lbfgs_minco_bounded: the step bound is built into the one-launch shape only "
-                                            "(orders 3 / 4, <= 64 variables, mem_size <= 8, no ANET_OPT_LOCKSTEP)");
+  // the lockstep shape: the same minimum-duration bound (one maximum over the duration variables per iteration) and the
+  // same cancel word, looked at after every successful line search (lbfgs.hpp:557-565, 580-587)
+  const double tau_min = min_duration > 1.0 ? sqrt(2.0 * min_duration - 1.0) - 1.0
+                                            : (min_duration > 0.0 ? 1.0 - sqrt(2.0 / min_duration - 1.0) : 0.0);
   rc = lbfgs_drive(ctx, L, batch, *params, max_evals, st, [&]() -> int {
     return cost_grad_dev_impl(ctx, s, c, N, batch, ld, head, tail, wps_eval, T, hpolys, pen, w_cg, L.feval, gP_out,
                               gT_out, nullptr, st, tau);
-  }, nt ? T : nullptr, nw);
+  }, nt ? T : nullptr, nw, true, (min_duration > 0.0 && nt > 0) ? 1 : 0, tau_min, ctx->cancel_flag);
   if (rc) return rc;
   // final parameters (x may have been reverted by a failed line search) and outputs
   mp.mode = 1;

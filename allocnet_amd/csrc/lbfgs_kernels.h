@@ -18,7 +18,7 @@ struct LbfgsP {
   int max_iterations, max_linesearch;
   double min_step, max_step, f_dec_coeff, s_curv_coeff, cautious_factor, machine_prec;
 };
-enum { DS_FX = 0, DS_STEP, DS_FINIT, DS_DGTEST, DS_DSTEST, DS_MU, DS_NU, DS_COUNT_ };
+enum { DS_FX = 0, DS_STEP, DS_FINIT, DS_DGTEST, DS_DSTEST, DS_MU, DS_NU, DS_SMAX, DS_COUNT_ };  // DS_SMAX: stpmax of the running line search
 enum { IS_DONE = 0, IS_RET, IS_K, IS_END, IS_BOUND, IS_COUNT, IS_BRACKT, IS_TOUCHED, IS_EVALS, IS_PHASE, IS_COUNT_ };
 enum {  // lbfgs.hpp:135-184
   LB_CONVERGENCE = 0, LB_STOP = 1, LB_CANCELED = 2,
@@ -40,7 +40,16 @@ struct LbfgsArgs {
   // duration T = forward_T(tau) is written too (saves a launch per evaluation).  nullptr: no mapping.
   double *map_T = nullptr;
   int map_nw = 0;
+  // lbfgs_optimize's proc_stepbound (lbfgs.hpp:221-224, applied at :557-565) as the built-in bound of the MINCO objective:
+  // variables [sb_lo, n) (tau of the durations) may not fall below sb_xmin within one line search; 0: no bound
+  int sb_on = 0, sb_lo = 0;
+  double sb_xmin = 0.0;
+  // proc_progress's one effect (lbfgs.hpp:580-587): a device-visible word, non-zero cancels after the running iteration
+  const int *cancel = nullptr;
 };
+__device__ __forceinline__ int read_cancel_word(const int *w) {  // system scope: written while the kernels run
+  return w ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+}
 // x = xp + step * d as the reference computes it (lbfgs.hpp:308): the reference is built with -O3 and no -march
 // (src/planner/CMakeLists.txt:4-6), i.e. for baseline x86-64, where this is a multiply and an add -- two roundings.  The
 // trial point decides every later comparison of a line search, so the kernels round it the same way instead of fusing.
@@ -107,6 +116,7 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
     // ---- one trial of line_search_lewisoverton (lbfgs.hpp:307-383)
     const double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
     double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
+    const double smax = ds[DS_SMAX * ld];
     int count = is[IS_COUNT * ld] + 1, brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
     bool success = false;
     int err = 0;
@@ -133,12 +143,12 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
           step = brackt ? 0.5 * (mu + nu) : step * 2.0;
           if (step < P.min_step) {
             err = LBERR_MINIMUMSTEP;
-          } else if (step > P.max_step) {
+          } else if (step > smax) {
             if (touched) {
               err = LBERR_MAXIMUMSTEP;
             } else {
               touched = 1;
-              step = P.max_step;
+              step = smax;
             }
           }
         }
@@ -160,9 +170,11 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
       is[IS_BRACKT * ld] = brackt;
       is[IS_TOUCHED * ld] = touched;
     } else {
-      // ---- accepted step (lbfgs.hpp:579-709)
+      // ---- accepted step (lbfgs.hpp:579-709); the progress report (:580-587) comes first: non-zero cancels
       fx = f;
-      if (conv_test()) {
+      if (read_cancel_word(a.cancel)) {
+        finish = LB_CANCELED;
+      } else if (conv_test()) {
         finish = LB_CONVERGENCE;
       } else {
         if (0 < P.past) {
@@ -233,6 +245,18 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
       gp[i * ld] = gi;
       dginit = __builtin_fma(gi, d[i * ld], dginit);
     }
+    double smax = P.max_step;
+    if (a.sb_on) {  // lbfgs.hpp:557-565: step_max = min(proc_stepbound(xp, d), max_step); step = step < step_max ? step : step_max / 2
+      double worst = 0.0;
+      for (int i = a.sb_lo; i < n; ++i) {
+        const double di = d[i * ld], room = x[i * ld] - a.sb_xmin;
+        if (di < 0.0) worst = fmax(worst, -di / (room > 1e-300 ? room : 1e-300));
+      }
+      const double bnd = worst > 0.0 ? 1.0 / worst : INFINITY;
+      smax = bnd < P.max_step ? bnd : P.max_step;
+      step = step < smax ? step : 0.5 * smax;
+    }
+    ds[DS_SMAX * ld] = smax;
     if (!(step > 0.0)) {
       finish = LBERR_INVALIDPARAMETERS;
     } else if (0.0 < dginit) {
@@ -242,7 +266,7 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
       ds[DS_DGTEST * ld] = P.f_dec_coeff * dginit;
       ds[DS_DSTEST * ld] = P.s_curv_coeff * dginit;
       ds[DS_MU * ld] = 0.0;
-      ds[DS_NU * ld] = P.max_step;
+      ds[DS_NU * ld] = smax;
       is[IS_COUNT * ld] = 0;
       is[IS_BRACKT * ld] = 0;
       is[IS_TOUCHED * ld] = 0;
@@ -402,6 +426,8 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
   int count = is[IS_COUNT * ld], brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
   double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
   double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
+  double smax = ds[DS_SMAX * ld];
+  const int cancel = read_cancel_word(a.cancel);
   double xr[NV], gr[NV], dr[NV], xpr[NV], gpr[NV];
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
@@ -521,12 +547,12 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
           step = brackt ? 0.5 * (mu + nu) : step * 2.0;
           if (step < P.min_step) {
             err = LBERR_MINIMUMSTEP;
-          } else if (step > P.max_step) {
+          } else if (step > smax) {
             if (touched) {
               err = LBERR_MAXIMUMSTEP;
             } else {
               touched = 1;
-              step = P.max_step;
+              step = smax;
             }
           }
         }
@@ -547,7 +573,9 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
         if (h[q]) store_x(a, b, (int)iv[q], trial_point(step, dr[q], xpr[q]));
     } else {
       fx = f;
-      if (conv_test()) {
+      if (cancel) {  // lbfgs.hpp:580-587: the progress report comes first after a line search; non-zero cancels
+        finish = LB_CANCELED;
+      } else if (conv_test()) {
         finish = LB_CONVERGENCE;
       } else {
         if (0 < P.past) {
@@ -683,6 +711,21 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
         xp[iv[q] * vs] = xr[q];
         gp[iv[q] * vs] = gr[q];
       }
+    smax = P.max_step;
+    if (a.sb_on) {  // lbfgs.hpp:557-565 (see lbfgs_update_lane)
+      double q = 0.0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const double room = xr[v] - a.sb_xmin;
+        if (h[v] && iv[v] >= a.sb_lo && dr[v] < 0.0) q = fmax(q, -dr[v] / (room > 1e-300 ? room : 1e-300));
+      }
+      double worst;
+      if constexpr (HALF) worst = half_max_nonneg(q);
+      else worst = wave_max_nonneg<RL>(q);
+      const double bnd = worst > 0.0 ? 1.0 / worst : INFINITY;
+      smax = bnd < P.max_step ? bnd : P.max_step;
+      step = step < smax ? step : 0.5 * smax;
+    }
     const double dginit = dot(gr, dr);
     if (!(step > 0.0)) {
       finish = LBERR_INVALIDPARAMETERS;
@@ -693,7 +736,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
       dgtest = P.f_dec_coeff * dginit;
       dstest = P.s_curv_coeff * dginit;
       mu = 0.0;
-      nu = P.max_step;
+      nu = smax;
       count = 0;
       brackt = 0;
       touched = 0;
@@ -704,7 +747,7 @@ __device__ __forceinline__ void lbfgs_update_wave_body(const LbfgsArgs &a, const
   }
   if (lane == 0) {
     ds[DS_FX * ld] = fx; ds[DS_STEP * ld] = step; ds[DS_FINIT * ld] = finit; ds[DS_DGTEST * ld] = dgtest;
-    ds[DS_DSTEST * ld] = dstest; ds[DS_MU * ld] = mu; ds[DS_NU * ld] = nu;
+    ds[DS_DSTEST * ld] = dstest; ds[DS_MU * ld] = mu; ds[DS_NU * ld] = nu; ds[DS_SMAX * ld] = smax;
     is[IS_K * ld] = k; is[IS_END * ld] = end; is[IS_BOUND * ld] = bound; is[IS_PHASE * ld] = phase;
     is[IS_COUNT * ld] = count; is[IS_BRACKT * ld] = brackt; is[IS_TOUCHED * ld] = touched;
     is[IS_EVALS * ld] = evals;

@@ -489,9 +489,10 @@ int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
  * with that step_max) -- a host callback cannot run inside the kernels, so the one bound with a use is built in: a MINIMUM
  * DURATION.  min_duration > 0 bounds every line search to the largest step along the search direction that keeps every
  * duration variable tau_i >= backward_T(min_duration), i.e. T_i >= min_duration: 1 / max_i(-d_i / (tau_i - tau_min)) over the
- * duration variables that move down.  min_duration = 0: no bound (identical to the calls above).  One-launch shape only
- * (problems that fit a wave, no ANET_OPT_LOCKSTEP): ANET_ERR_UNSUPPORTED otherwise.  Start durations below the minimum make
- * the first bound 0 and the run end with LBFGSERR_INVALIDPARAMETERS, as the reference's loop would.                  */
+ * duration variables that move down.  min_duration = 0: no bound (identical to the calls above).  Both execution shapes
+ * apply it (the one-launch kernel and, with ANET_OPT_LOCKSTEP or problems that do not fit a wave, the per-evaluation
+ * update kernels).  Start durations below the minimum make the first bound 0 and the run end with
+ * LBFGSERR_INVALIDPARAMETERS, as the reference's loop would.                                                          */
 int anet_lbfgs_minco_bounded(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
                              const double *tail, double *wps, double *T, const double *hpolys,
                              const anet_penalty *pen, const anet_lbfgs_params *params, int opt_flags,
@@ -508,9 +509,10 @@ int anet_lbfgs_minco_bounded_dev(anet_ctx *ctx, int s, int c, int n_pieces, int6
  * successful line search; a non-zero return ends the run with LBFGS_CANCELED) -- a host callback cannot run inside the
  * kernels, so its one effect is offered as a word the caller owns: `flag` (device-visible int32 -- device memory written from
  * another stream, or mapped pinned host memory; NULL: none) is read once per evaluation by every problem of the one-launch
- * MINCO L-BFGS calls that follow on this context; while it is non-zero a problem stops after the iteration it is in, at
+ * MINCO L-BFGS calls (either execution shape) that follow on this context; while it is non-zero a problem stops after the iteration it is in, at
  * the point lbfgs.hpp:583 would, with status LBFGS_CANCELED (2), its iterate, cost and counters as they stand.  Problems
- * that stopped on their own keep their status.  The lockstep shape and the MVIE objective do not look at it.            */
+ * that stopped on their own keep their status.  Both shapes of the MINCO L-BFGS look at it (the lockstep update kernels
+ * read it once per problem and evaluation); the MVIE objective does not.                                               */
 int anet_set_cancel_flag(anet_ctx *ctx, const int32_t *flag);
 
 /* launch_order for the call above from the evals[] of a previous solve of the same or a similar batch: longest first, in

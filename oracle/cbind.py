@@ -13,7 +13,8 @@ _cpu_lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("minco_oracle.c", "lbfgs_oracle.c", "minco_costgrad.c", "minco_cpu_reduced.cpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("minco_oracle.c", "lbfgs_oracle.c", "minco_costgrad.c", "qp_ipm_port.c",
+                                             "minco_cpu_reduced.cpp")]
     srcs += [os.path.join(os.path.dirname(_HERE), "allocnet_amd", "csrc", f) for f in ("minco_core.h", "minco_tables.h")]
     outs = (_PATH, _CPU_PATH)
     if force or not all(os.path.exists(o) for o in outs) or any(os.path.getmtime(o) < os.path.getmtime(s) for o in outs for s in srcs):
@@ -69,8 +70,32 @@ def lib():
         L.oracle_lbfgs_minco_batch.restype = c_int
         L.oracle_lbfgs_minco_batch.argtypes = [c_int, c_int, c_int, c_int64] + [c_void_p] * 5 + \
             [ctypes.POINTER(Penalty), ctypes.POINTER(LbfgsParam)] + [c_void_p] * 4 + [c_int, c_double]
+        L.oracle_qp_ipm_batch.restype = c_int
+        L.oracle_qp_ipm_batch.argtypes = [c_int, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_double,
+                                          c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int]
         _lib = L
     return _lib
+
+
+def qp_ipm_batch(s, state, T, hpolys, res=20, vmax=4.0, amax=6.0, m34=1400.0, tol=1e-8, max_iter=80, want_coeffs=True,
+                 nthreads=1):
+    """CPU port of the structured interior point (oracle/qp_ipm_port.c): the reference's inequality QP
+    (qp_solver.hpp:119-358) in Hermite node coordinates, one problem per task.  state (B,2,3,3) [start/end][axis][p,v,a],
+    T (B,N), hpolys (B,N,M,4) rows a.x <= b (zero rows = padding).  Returns dict(coeffs (B,N,3,2s) or None, obj, status
+    (1 solved, -2 not converged / infeasible), iters)."""
+    state = np.ascontiguousarray(state, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    hpolys = np.ascontiguousarray(hpolys, dtype=np.float64)
+    B, N = T.shape
+    M = hpolys.shape[2]
+    assert state.shape == (B, 2, 3, 3) and hpolys.shape == (B, N, M, 4)
+    coeffs = np.zeros((B, N, 3, 2 * s)) if want_coeffs else None
+    obj = np.zeros(B); status = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32)
+    rc = lib().oracle_qp_ipm_batch(s, N, int(res), M, B, _p(state), _p(T), _p(hpolys), float(vmax), float(amax), float(m34),
+                                   float(tol), int(max_iter), _p(coeffs), _p(obj), _p(status), _p(iters), int(nthreads))
+    if rc:
+        raise RuntimeError(f"oracle_qp_ipm_batch failed: {rc}")
+    return dict(coeffs=coeffs, obj=obj, status=status, iters=iters)
 
 
 class Penalty(ctypes.Structure):

@@ -84,6 +84,9 @@ def test_qp_solve_bookkeeping():
     body = src[src.index("def run_qp"):]
     body = body[:body.index("\ndef ", 10)]
     assert body.index("from oracle import qp_np") > body.index("if cpu_baseline:")
+    assert body.index("from oracle import cbind") > body.index("if cpu_baseline:")
+    # the like-for-like CPU figure is the structured port; the dense numpy interior point is kept beside it
+    assert '"kind": "port"' in body and "qp_ipm_batch" in body and '"dense_numpy": dense_numpy' in body
 
 
 def test_launch_plan_and_self_launch_command():

@@ -487,12 +487,14 @@ def test_returned_coefficients_of_wide_spread_durations_come_from_the_pivoted_so
     assert np.abs(cd - out["coeffs"]).max() <= 1e-12 * np.abs(out["coeffs"]).max()
 
 
-def test_minco_lbfgs_step_bound_keeps_a_minimum_duration(anet_ctx):
+@pytest.mark.parametrize("lockstep", [False, True])
+def test_minco_lbfgs_step_bound_keeps_a_minimum_duration(anet_ctx, lockstep):
     """lbfgs_optimize's proc_stepbound (lbfgs.hpp:557-565) with the built-in minimum-duration bound
     (anet_lbfgs_minco_bounded): a cost that wants short durations (large rho) drives them below T_min without the bound and
     never with it; (status, iterations, evaluations) and iterates equal the C restatement of lbfgs_optimize WITH the same
-    bound as its proc_stepbound callback."""
+    bound as its proc_stepbound callback.  Both execution shapes: the one-launch kernel and the lockstep update kernels."""
     import allocnet_amd as aa
+    shape = aa.lbfgs.OPT_WAYPOINTS | aa.lbfgs.OPT_TIMES | (aa.lbfgs.OPT_LOCKSTEP if lockstep else 0)
     rng = np.random.default_rng(31)
     s, c, N, M, B = 3, 3, 6, 8, 96
     head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
@@ -503,12 +505,12 @@ def test_minco_lbfgs_step_bound_keeps_a_minimum_duration(anet_ctx):
     pen = aa.make_penalty(rho=rho, w_corridor=kw["wc"], w_vel=kw["wv"], w_acc=kw["wa"], smooth_mu=kw["mu"],
                           max_vel=kw["vmax"], max_acc=kw["amax"], res=kw["res"], poly_rows=M)
     Tmin = 0.9
-    free = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
+    free = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, opt=shape, ctx=anet_ctx)
     assert (free["T"].min(axis=1) < Tmin).sum() >= B // 4          # the bound has something to do
     for budget in (4, 15, 0):
         prm = aa.lbfgs_parameter_t(max_iterations=budget)
         out = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=prm, max_evals=3000, min_duration=Tmin,
-                             ctx=anet_ctx)
+                             opt=shape, ctx=anet_ctx)
         assert (out["T"] >= Tmin * (1 - 1e-12)).all(), out["T"].min()
         ref = cbind.lbfgs_minco_batch(s, head, tail, wps, T, hp, rho, nthreads=4, min_duration=Tmin,
                                       param=cbind.lbfgs_default_param(max_iterations=budget), **kw)
@@ -519,25 +521,63 @@ def test_minco_lbfgs_step_bound_keeps_a_minimum_duration(anet_ctx):
         # tried twice on the other, whichever way its last bit fell -- at the same point.  That pair of outcomes is one class.
         stuck = np.isin(out["status"], (-1011, -1010)) & np.isin(ref["status"], (-1011, -1010)) & (out["iters"] == ref["iters"])
         agree = same | stuck
-        assert same.mean() >= 0.85 and agree.mean() >= (0.97 if budget else 0.75), (budget, same.mean(), agree.mean())
         rel = np.abs(out["cost"] - ref["cost"]) / np.abs(ref["cost"])
+        print("step bound, lockstep=%s budget=%d: same %.3f agree %.3f; rel cost: agreeing max %.1e, others max %.1e median %.1e"
+              % (lockstep, budget, same.mean(), agree.mean(), rel[agree].max(), rel[~agree].max() if (~agree).any() else 0.0,
+                 np.median(rel[~agree]) if (~agree).any() else 0.0))
+        # (measured with the restatement built without contraction and the kernels' trial point unfused: same 0.92-0.93,
+        #  agree 0.99 at every budget, the run to each problem's own stop included)
+        assert same.mean() >= 0.9 and agree.mean() >= 0.98, (budget, same.mean(), agree.mean())
         assert rel[agree].max() <= 1e-6, (budget, rel[agree].max())
         if budget:
             assert np.abs(out["T"][agree] - ref["T"][agree]).max() <= 1e-6
+        # the problems whose counters differ are not excused: they ran to their own stop on both sides (budget 0: a flipped
+        # test at the bound sends the two runs along different iterates), they respect the bound, and they end at a cost
+        # within 2 % of the restatement's
+        assert (out["T"][~agree] >= Tmin * (1 - 1e-12)).all()
+        if (~agree).any():
+            assert rel[~agree].max() <= 2e-2, (budget, rel[~agree].max())
     # the bound is active, not decorative: some problem ends ON the minimum, and the bounded optimum costs more
     assert (np.abs(out["T"] - Tmin).min(axis=1) < 1e-6).sum() >= 1
     assert out["cost"].mean() > free["cost"].mean()
     # min_duration = 0 is the unbounded call, bit for bit
-    again = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, min_duration=0.0, ctx=anet_ctx)
+    again = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, min_duration=0.0, opt=shape,
+                           ctx=anet_ctx)
     assert np.array_equal(again["cost"], free["cost"]) and np.array_equal(again["evals"], free["evals"])
-    # refused where it is not built in
-    with pytest.raises(aa.AnetError):
-        aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=50, min_duration=Tmin,
-                       opt=aa.lbfgs.OPT_WAYPOINTS | aa.lbfgs.OPT_TIMES | aa.lbfgs.OPT_LOCKSTEP, ctx=anet_ctx)
 
 
-def test_minco_lbfgs_cancel_word(anet_ctx):
-    """lbfgs_optimize's progress callback (lbfgs.hpp:580-587: called after every successful line search, a non-zero return
+def test_minco_lbfgs_step_bound_shapes_agree(anet_ctx):
+    """The bounded run at fixed budgets: the one-launch kernel and the lockstep update kernels return the same counters and
+    iterates (as the unbounded shapes do, test_minco_lbfgs_one_launch_agrees_with_lockstep)."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(33)
+    s, c, N, M, B = 4, 3, 5, 8, 64
+    head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
+    hp = make_corridors(rng, head, tail, wps, M, tight=2.0)
+    T = rng.uniform(1.2, 2.0, size=(B, N))
+    pen = aa.make_penalty(rho=400.0, w_corridor=1e3, w_vel=1.0, w_acc=1.0, smooth_mu=1e-2, max_vel=3.0, max_acc=4.0, res=8,
+                          poly_rows=M)
+    both = aa.lbfgs.OPT_WAYPOINTS | aa.lbfgs.OPT_TIMES
+    for budget in (3, 10):
+        prm = aa.lbfgs_parameter_t(max_iterations=budget)
+        a = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=prm, max_evals=2000, min_duration=1.0, opt=both,
+                           ctx=anet_ctx)
+        b = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=prm, max_evals=2000, min_duration=1.0,
+                           opt=both | aa.lbfgs.OPT_LOCKSTEP, ctx=anet_ctx)
+        same = (a["status"] == b["status"]) & (a["iters"] == b["iters"]) & (a["evals"] == b["evals"])
+        # (a duration ON the bound: the next line search fails on both sides, by step_max tried twice or by a step below
+        # min_step as the last bit of tau - tau_min fell -- one class, as in the test against the restatement)
+        stuck = np.isin(a["status"], (-1011, -1010)) & np.isin(b["status"], (-1011, -1010)) & (a["iters"] == b["iters"])
+        agree = same | stuck
+        assert same.mean() >= 0.8 and agree.mean() >= 0.97, (budget, same.mean(), agree.mean())
+        assert (a["T"] >= 1.0 - 1e-12).all() and (b["T"] >= 1.0 - 1e-12).all()
+        assert np.abs(a["cost"] - b["cost"])[agree].max() <= 1e-7 * np.abs(b["cost"]).max()
+        assert np.abs(a["T"] - b["T"])[agree].max() <= 1e-6
+
+
+@pytest.mark.parametrize("lockstep", [False, True])
+def test_minco_lbfgs_cancel_word(anet_ctx, lockstep):
+    """(both execution shapes) lbfgs_optimize's progress callback (lbfgs.hpp:580-587: called after every successful line search, a non-zero return
     ends the run with LBFGS_CANCELED) as the cancel word of anet_set_cancel_flag.  With the word at zero the run is the
     plain one bit for bit; with the word set from the start every problem is cancelled after its FIRST iteration -- at the
     very point a run with max_iterations = 1 stops (the progress report comes before the convergence, stop and iteration
@@ -545,6 +585,7 @@ def test_minco_lbfgs_cancel_word(anet_ctx):
     import torch
     import allocnet_amd as aa
     from allocnet_amd import lbfgs as L
+    shape = aa.lbfgs.OPT_WAYPOINTS | aa.lbfgs.OPT_TIMES | (aa.lbfgs.OPT_LOCKSTEP if lockstep else 0)
     rng = np.random.default_rng(32)
     s, c, N, M, B = 3, 3, 6, 8, 96
     head, tail, wps, T = random_problem(rng, B, N, c, rest=True)
@@ -552,19 +593,19 @@ def test_minco_lbfgs_cancel_word(anet_ctx):
     T = rng.uniform(1.2, 2.0, size=(B, N))
     pen = aa.make_penalty(rho=50.0, w_corridor=1e3, w_vel=1.0, w_acc=1.0, smooth_mu=1e-2, max_vel=3.0, max_acc=4.0, res=8,
                           poly_rows=M)
-    free = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
-    one = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx,
+    free = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, opt=shape, ctx=anet_ctx)
+    one = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, opt=shape, ctx=anet_ctx,
                          param=aa.lbfgs_parameter_t(max_iterations=1))
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     anet_ctx.set_cancel_flag(flag)
     try:
-        same = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
+        same = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, opt=shape, ctx=anet_ctx)
         for k in ("cost", "evals", "iters", "status", "T"):
             assert np.array_equal(same[k], free[k]), k
         flag.fill_(1)
         torch.cuda.synchronize()
-        can = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
+        can = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, opt=shape, ctx=anet_ctx)
     finally:
         anet_ctx.set_cancel_flag(None)
     ran = one["status"] == L.LBFGSERR_MAXIMUMITERATION          # problems whose first iteration completed and went on
@@ -578,7 +619,7 @@ def test_minco_lbfgs_cancel_word(anet_ctx):
     assert np.isin(can["status"][rest], (L.LBFGS_CANCELED,) + tuple(np.unique(one["status"][rest]))).all()
     assert (can["status"][rest & (one["status"] < 0)] == one["status"][rest & (one["status"] < 0)]).all()
     # cleared: the plain run again
-    again = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, ctx=anet_ctx)
+    again = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, max_evals=3000, opt=shape, ctx=anet_ctx)
     assert np.array_equal(again["status"], free["status"]) and np.array_equal(again["evals"], free["evals"])
 
 
