@@ -575,74 +575,144 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         }
       }
     }
+    // ---- the diagonal factors are INVERTED in place, L_k -> L_k^-1 (lower triangle, zeros above): the substitutions of a
+    // step -- two solves, each forwards and backwards -- walk every knot four times, and with L_k each visit is a triangular
+    // solve of BK dependent steps (v_readlane -> scale -> update: ~21 k cycles per solve for nine 12 x 12 blocks); with
+    // L_k^-1 a visit is two small matrix-vector products without a dependent chain inside the block.  Nothing else reads
+    // the factors.  One wave per knot (knots dealt round the four waves), lane j = column j: y = L^-1 e_j by a right-looking
+    // forward substitution in registers (the entries of L arrive as LDS broadcasts: wave-uniform addresses), then column j
+    // is written back over L -- every read of the block precedes every write in the wave's instruction stream.
+    __syncthreads();
+#pragma nounroll
+    for (int k = wv; k <= N; k += 4) {
+      double *Dk = Dg + (size_t)k * BK * BK;
+      double pcol[BK];
+#pragma unroll
+      for (int c = 0; c < BK; ++c) pcol[c] = (c == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < BK; ++q) {
+        pcol[q] *= dinvd[k * BK + q];
+#pragma unroll
+        for (int c = q + 1; c < BK; ++c) pcol[c] -= Dk[c * BK + q] * pcol[q];
+      }
+      if (act) {
+#pragma unroll
+        for (int c = 0; c < BK; ++c) Dk[c * BK + lane] = pcol[c];  // (zero above the diagonal: c < lane)
+      }
+    }
   };
-  // x <- K^-1 x with the twisted factor: T z = x from both ends to the middle, T'x = z from the middle outwards
+  // x <- K^-1 x with the twisted factor (diagonal blocks inverted, see twisted_factor): T z = x from both ends to the
+  // middle, T'x = z from the middle outwards.  A chain keeps the vector it carries from knot to knot IN REGISTERS (lane r =
+  // component r; the other lanes' values arrive through v_readlane) and the rows of the two blocks a knot needs -- off the
+  // chain: they do not depend on the vector -- are requested one knot ahead, so what a knot costs is two products of a
+  // BK x BK block with a vector and nothing waits on LDS in between (the substitution with L_k itself was BK dependent
+  // readlane-scale-update steps per knot and an LDS round trip for the neighbour's result: 21 k cycles per solve at 8 pieces).
   auto twisted_solve = [&](double *x) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, in an SGPR
     int lane = tid & 63;
     asm volatile("" : "+v"(lane));  // (keeps the per-lane LDS addresses of this phase from being hoisted out of the Newton loop)
     const bool act = lane < BK;
+    const int lr = act ? lane : 0;  // (idle lanes read row / column 0 and store nothing)
     const int dir = wv == 0 ? 1 : -1, kfrom = wv == 0 ? 0 : N;
-    // ---- forward: phase 0 the chains, phase 1 (behind a barrier) wave 0 on the middle knot
-#pragma nounroll
-    for (int ph = 0; ph < 2; ++ph) {
-      if (ph == 1) __syncthreads();
-      if (wv >= 2 || (ph == 1 && wv == 1)) continue;
-      const int kbeg = ph == 0 ? kfrom : PT, kend = ph == 0 ? PT : PT + 1, stepk = ph == 0 ? dir : 1;
-#pragma nounroll
-      for (int k = kbeg; k != kend; k += stepk) {
-        double xr = act ? x[k * BK + lane] : 0.0;
-        const int src0 = ph == 0 ? (k == kfrom ? -1 : (dir > 0 ? k - 1 : k)) : (PT > 0 ? PT - 1 : -1);
-        const int src1 = ph == 0 ? -1 : (PT < N ? PT : -1);
-        const int nb0 = ph == 0 ? k - dir : PT - 1, nb1 = PT + 1;
-#pragma nounroll
-        for (int u = 0; u < 2; ++u) {
-          const int src = u == 0 ? src0 : src1;
-          if (src < 0) continue;
-          const double *X = Of + (size_t)src * BK * BK, *v = x + (u == 0 ? nb0 : nb1) * BK;
-          double sdot = 0.0;
+    auto matvec = [&](const double (&Mrow)[BK], const double v) {  // sum_c Mrow[c] v_c, v_c = lane c's v
+      double acc = 0.0;
 #pragma unroll
-          for (int q = 0; q < BK; ++q) sdot += (act ? X[lane * BK + q] : 0.0) * v[q];
-          xr -= sdot;
+      for (int c = 0; c < BK; ++c) acc = __builtin_fma(Mrow[c], rl(v, c), acc);
+      return acc;
+    };
+    // row lr of block `blk` (st = BK) or column lr (st = 1 -> element [c][lr] at c * BK + lr)
+    auto load_row = [&](const double *blk, double (&dst)[BK]) {
+#pragma unroll
+      for (int c = 0; c < BK; ++c) dst[c] = blk[lr * BK + c];
+    };
+    auto load_col = [&](const double *blk, double (&dst)[BK]) {
+#pragma unroll
+      for (int c = 0; c < BK; ++c) dst[c] = blk[c * BK + lr];
+    };
+    double zmid = 0.0;  // wave 0: the middle knot's value, carried from the forward to the backward phase
+    // ---- forward, phase 0: the two chains; z_k = L_k^-1 (x_k - X z_prev), X = L_{k,k-1} (wave 0: rows of Of[k-1]) or M_k (wave 1: rows of Of[k])
+    double zprev = 0.0;
+    if (wv < 2 && kfrom != PT) {
+      double Lr[BK], Xr[BK], Ln[BK], Xn[BK];
+      load_row(Dg + (size_t)kfrom * BK * BK, Lr);
+#pragma unroll
+      for (int c = 0; c < BK; ++c) Xr[c] = 0.0;
+      double xin = act ? x[kfrom * BK + lane] : 0.0;
+#pragma nounroll
+      for (int k = kfrom; k != PT; k += dir) {
+        const int kn = k + dir;
+        const bool more = kn != PT;
+        double xnext = 0.0;
+        if (more) {  // the next knot's blocks and right-hand side: in flight during this knot's arithmetic
+          load_row(Dg + (size_t)kn * BK * BK, Ln);
+          load_row(Of + (size_t)(dir > 0 ? kn - 1 : kn) * BK * BK, Xn);
+          xnext = act ? x[kn * BK + lane] : 0.0;
         }
-        const double *Dk = Dg + (size_t)k * BK * BK;
-        double Dr[BK];
+        const double xr = xin - matvec(Xr, zprev);
+        const double z = matvec(Lr, xr);
+        if (act) x[k * BK + lane] = z;
+        zprev = z;
+        if (more) {
 #pragma unroll
-        for (int c = 0; c < BK; ++c) Dr[c] = act ? Dk[lane * BK + c] : (c == 0 ? 1.0 : 0.0);
-#pragma unroll
-        for (int c = 0; c < BK; ++c) {
-          const double zc = rl(xr, c) * dinvd[k * BK + c];
-          xr = (lane == c) ? zc : (lane > c ? xr - Dr[c] * zc : xr);
+          for (int c = 0; c < BK; ++c) {
+            Lr[c] = Ln[c];
+            Xr[c] = Xn[c];
+          }
+          xin = xnext;
         }
-        if (act) x[k * BK + lane] = xr;
       }
     }
-    // ---- backward: phase 0 wave 0 on the middle knot (its own forward result: no barrier needed), phase 1 the chains
+    __syncthreads();
+    // ---- forward, phase 1 and backward, phase 0: wave 0 on the middle knot (Schur terms from both neighbours)
+    if (wv == 0) {
+      double Lr[BK], Xr[BK];
+      double xr = act ? x[PT * BK + lane] : 0.0;
+      if (PT > 0) {  // own chain: z_{PT-1} is in registers
+        load_row(Of + (size_t)(PT - 1) * BK * BK, Xr);
+        xr -= matvec(Xr, zprev);
+      }
+      if (PT < N) {  // the other chain's last knot: through LDS (behind the barrier)
+        load_row(Of + (size_t)PT * BK * BK, Xr);
+        const double zo = act ? x[(PT + 1) * BK + lane] : 0.0;
+        xr -= matvec(Xr, zo);
+      }
+      load_row(Dg + (size_t)PT * BK * BK, Lr);
+      const double z = matvec(Lr, xr);
+      load_col(Dg + (size_t)PT * BK * BK, Lr);
+      zmid = matvec(Lr, z);  // x_PT = L^-T z
+      if (act) x[PT * BK + lane] = zmid;
+    }
+    __syncthreads();
+    // ---- backward, phase 1: the chains outwards; x_k = L_k^-T (z_k - X' x_next), X' = columns of Of[k] (wave 0) / Of[k-1] (wave 1)
+    if (wv < 2 && kfrom != PT) {
+      double Lc[BK], Xc[BK], Ln[BK], Xn[BK];
+      const int k0 = PT - dir;
+      double xnb = wv == 0 ? zmid : (act ? x[PT * BK + lane] : 0.0);  // the inner neighbour's value
+      load_col(Dg + (size_t)k0 * BK * BK, Lc);
+      load_col(Of + (size_t)(dir > 0 ? k0 : k0 - 1) * BK * BK, Xc);
+      double zin = act ? x[k0 * BK + lane] : 0.0;
 #pragma nounroll
-    for (int ph = 0; ph < 2; ++ph) {
-      if (ph == 1) __syncthreads();
-      if (wv >= 2 || (ph == 0 && wv == 1)) continue;
-      const int kbeg = ph == 0 ? PT : PT - dir, kend = ph == 0 ? PT - 1 : kfrom - dir, stepk = ph == 0 ? -1 : -dir;
-#pragma nounroll
-      for (int k = kbeg; k != kend; k += stepk) {
-        double xr = act ? x[k * BK + lane] : 0.0;
-        if (ph == 1) {
-          const double *X = Of + (size_t)(dir > 0 ? k : k - 1) * BK * BK, *v = x + (k + dir) * BK;
-          double sdot = 0.0;
-#pragma unroll
-          for (int q = 0; q < BK; ++q) sdot += (act ? X[q * BK + lane] : 0.0) * v[q];
-          xr -= sdot;
+      for (int k = k0; k != kfrom - dir; k -= dir) {
+        const int kn = k - dir;
+        const bool more = kn != kfrom - dir;
+        double znext = 0.0;
+        if (more) {
+          load_col(Dg + (size_t)kn * BK * BK, Ln);
+          load_col(Of + (size_t)(dir > 0 ? kn : kn - 1) * BK * BK, Xn);
+          znext = act ? x[kn * BK + lane] : 0.0;
         }
-        const double *Dk = Dg + (size_t)k * BK * BK;
-        double Dc[BK];  // column `lane` of L_k: Dc[c] = L_k[c][lane]
+        const double xr = zin - matvec(Xc, xnb);
+        const double xo = matvec(Lc, xr);
+        if (act) x[k * BK + lane] = xo;
+        xnb = xo;
+        if (more) {
 #pragma unroll
-        for (int c = 0; c < BK; ++c) Dc[c] = act ? Dk[c * BK + lane] : (c == 0 ? 1.0 : 0.0);
-#pragma unroll
-        for (int c = BK - 1; c >= 0; --c) {
-          const double xc = rl(xr, c) * dinvd[k * BK + c];
-          xr = (lane == c) ? xc : (lane < c ? xr - Dc[c] * xc : xr);
+          for (int c = 0; c < BK; ++c) {
+            Lc[c] = Ln[c];
+            Xc[c] = Xn[c];
+          }
+          zin = znext;
         }
-        if (act) x[k * BK + lane] = xr;
       }
     }
   };
