@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
 #pragma nounroll
       for (int k = kbeg; k != kend; k += stepk) {
         double *Dk = Dg + (size_t)k * BK * BK;
-        double Dr[BK], dinv[BK], Lp[BK];
+        double Dr[BK], dinv[BK];
         // Schur updates: from the knot eliminated before this one in its chain; the middle knot from both sides
         const int src0 = ph == 0 ? (k == kfrom ? -1 : (dir > 0 ? k - 1 : k)) : (PT > 0 ? PT - 1 : -1);
         const int src1 = ph == 0 ? -1 : (PT < N ? PT : -1);
@@ -547,57 +547,48 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
 #pragma unroll
         for (int c = 0; c < BK; ++c) Dr[c] = act ? Dk[lane * BK + c] : (c == 0 ? 1.0 : 0.0);
         chol_rows(lane, Dr, dinv);
+        // ---- L_k -> L_k^-1 right here, in registers: lane j = column j of the inverse by a right-looking forward
+        // substitution on e_j; the entries of L (lane c holds row c) arrive as wave-uniform scalars through v_readlane.
+        // The substitutions of a step walk every knot four times and with L_k each visit is a triangular solve of BK
+        // dependent steps; with L_k^-1 it is a block-vector product (twisted_solve).  The inverse also gives the block
+        // towards the next knot as a PRODUCT instead of a second substitution (below).  Nothing else reads the factors.
+        double pcol[BK];
+#pragma unroll
+        for (int c = 0; c < BK; ++c) pcol[c] = (c == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < BK; ++q) {
+          pcol[q] *= dinv[q];
+#pragma unroll
+          for (int c = q + 1; c < BK; ++c) pcol[c] -= rl(Dr[q], c) * pcol[q];  // L[c][q] = lane c's Dr[q]
+        }
         if (act) {
 #pragma unroll
-          for (int c = 0; c < BK; ++c) Dk[lane * BK + c] = Dr[c];
-        }
-        if (lane == 0) {
-#pragma unroll
-          for (int c = 0; c < BK; ++c) dinvd[k * BK + c] = dinv[c];
+          for (int c = 0; c < BK; ++c) Dk[c * BK + lane] = pcol[c];  // column `lane` of L_k^-1 (zero above the diagonal)
         }
         if (ph == 1) continue;
-        // the block towards the next knot of the chain: L_{k+1,k} = A_{k+1,k} L_k^-T (rows of A), or
-        // M_{k-1} = A_{k,k-1}' L_k^-T (columns of A), row by row: forward substitution over the columns
+        // the block towards the next knot of the chain: L_{k+1,k} = A_{k+1,k} L_k^-T, or M_{k-1} = A_{k,k-1}' L_k^-T for
+        // the chain that walks down -- out[r][q] = sum_c A[r][c] (or A[c][r]) Linv[q][c]: one 16x16x4 FP64 MFMA per four
+        // values of c (operands straight from LDS, A[i = lane & 15][k = lane >> 4], B[k][j = lane & 15] = Linv[j][k]), where
+        // the substitution over the columns of L_k was BK (BK - 1) / 2 dependent LDS-broadcast FMAs per knot.
         double *Lo = Of + (size_t)(dir > 0 ? k : k - 1) * BK * BK;
         const int st_c = dir > 0 ? 1 : BK, st_l = dir > 0 ? BK : 1;
+        {
+          const int li = lane & 15, lk = lane >> 4;
+          d4_t c4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int c = 0; c < BK; ++c) Lp[c] = act ? Lo[lane * st_l + c * st_c] : 0.0;
+          for (int ks = 0; ks < (BK + 3) / 4; ++ks) {
+            const int kk = 4 * ks + lk;
+            const bool in = li < BK && kk < BK;
+            const double av = in ? Lo[li * st_l + kk * st_c] : 0.0;
+            const double bv = in ? Dk[li * BK + kk] : 0.0;
+            c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c4, 0, 0, 0);
+          }
 #pragma unroll
-        for (int c = 0; c < BK; ++c) {
-          double v = Lp[c];
-#pragma unroll
-          for (int q = 0; q < c; ++q) v -= Lp[q] * Dk[c * BK + q];  // L_k[c][q], just stored: LDS broadcast read
-          Lp[c] = v * dinv[c];
+          for (int r = 0; r < 4; ++r) {
+            const int row = lk + 4 * r;
+            if (row < BK && li < BK) Lo[row * BK + li] = c4[r];
+          }
         }
-        if (act) {
-#pragma unroll
-          for (int c = 0; c < BK; ++c) Lo[lane * BK + c] = Lp[c];
-        }
-      }
-    }
-    // ---- the diagonal factors are INVERTED in place, L_k -> L_k^-1 (lower triangle, zeros above): the substitutions of a
-    // step -- two solves, each forwards and backwards -- walk every knot four times, and with L_k each visit is a triangular
-    // solve of BK dependent steps (v_readlane -> scale -> update: ~21 k cycles per solve for nine 12 x 12 blocks); with
-    // L_k^-1 a visit is two small matrix-vector products without a dependent chain inside the block.  Nothing else reads
-    // the factors.  One wave per knot (knots dealt round the four waves), lane j = column j: y = L^-1 e_j by a right-looking
-    // forward substitution in registers (the entries of L arrive as LDS broadcasts: wave-uniform addresses), then column j
-    // is written back over L -- every read of the block precedes every write in the wave's instruction stream.
-    __syncthreads();
-#pragma nounroll
-    for (int k = wv; k <= N; k += 4) {
-      double *Dk = Dg + (size_t)k * BK * BK;
-      double pcol[BK];
-#pragma unroll
-      for (int c = 0; c < BK; ++c) pcol[c] = (c == lane) ? 1.0 : 0.0;
-#pragma unroll
-      for (int q = 0; q < BK; ++q) {
-        pcol[q] *= dinvd[k * BK + q];
-#pragma unroll
-        for (int c = q + 1; c < BK; ++c) pcol[c] -= Dk[c * BK + q] * pcol[q];
-      }
-      if (act) {
-#pragma unroll
-        for (int c = 0; c < BK; ++c) Dk[c * BK + lane] = pcol[c];  // (zero above the diagonal: c < lane)
       }
     }
   };
