@@ -81,7 +81,13 @@ struct PersistLds {
   double gc[NB][3][D + 1];   // penalty part of dJ/dc
   double gdT[NB], pc[NB];    // penalty part of dJ/dT, penalty cost per piece
   double wl[NB + 1][3], gTp[NB][3], ep[NB][3];
+  double mid[3][2][m];       // twisted sweeps: what the last node of either chain contributes to the middle node's right-hand side
 };
+// The block-tridiagonal system is eliminated from BOTH ends towards the middle node (1) or from node 0 to node N (0: the
+// one-ended walk, kept for A/B runs: tools/ab_build.sh "-DANET_PERSIST_TWISTED=0").
+#ifndef ANET_PERSIST_TWISTED
+#define ANET_PERSIST_TWISTED 1
+#endif
 
 template <int S, int NB>
 constexpr size_t persist_lds_fixed_bytes() { return (sizeof(PersistLds<S, NB>) + 15) / 16 * 16; }
@@ -583,6 +589,113 @@ __device__ __forceinline__ void chain_solve(PersistLds<S, NB> &Lm, double (&V)[3
   __syncthreads();
 }
 
+// The same solve with the TWISTED factor of E2: nodes 0 .. pm-1 were eliminated upwards (S_k), nodes N .. pm+1 downwards (R_k),
+// the middle node pm = N / 2 last.  Lm.Si[k] holds S_k^-1 (k < pm), R_k^-1 (k > pm) or the inverse of the middle block;
+// Lm.H[i] (piece i, between nodes i and i+1) holds S_i^-1 Ko_i for i < pm and R_{i+1}^-1 Ko_i' for i >= pm -- in either chain
+// "the inverse of the node FARTHER from the middle times the coupling towards the nearer one".  A row of 16 lanes per axis
+// carries BOTH chains: lanes 0..7 the lower one (lane jj = node jj), lanes 8..15 the upper one reversed (lane jj = node N - jj);
+// in both, towards the middle is towards higher lanes, so one row_shr scan runs both forward sweeps
+//   y_node = rhs_node - H[piece behind]' y_prev
+// and one row_shl scan both backward sweeps x_node = z_node - H[piece ahead] x_next (z = inverse block times y); a zero matrix
+// at the head of a chain stops anything from crossing between lanes 7 and 8.  Chains of at most 8 nodes: three scan rounds
+// where the one-ended sweep over 16 pieces took four, and the factor's chain (E2) is walked by two lanes at once.  The middle
+// node's right-hand side takes one term from the last node of either chain (through Lm.mid: the source lanes depend on N).
+template <int S, int NB>
+__device__ __forceinline__ void chain_solve_twisted(PersistLds<S, NB> &Lm, double (&V)[3][S - 1][PersistLds<S, NB>::XW], const int N,
+                                                    const int lane) {
+  constexpr int m = S - 1;
+  const int row = lane >> 4, j = lane & 15, ax = row < 3 ? row : 2;
+  const int half = j >> 3, jj = j & 7;
+  const int pm = N >> 1;
+  const int cnt = half == 0 ? pm : N - pm;  // nodes of this lane's chain
+  const int L = N - pm;                     // the longer chain (wave-uniform): how many scan rounds
+  const bool valid = jj < cnt;
+  const bool last = valid && jj == cnt - 1;
+  const int k = valid ? (half == 0 ? jj : N - jj) : 0;                  // this lane's node
+  const int pb = valid ? (half == 0 ? jj : N - jj - 1) : 0;             // piece between it and the next node towards the middle
+  const int pf = (valid && jj > 0) ? (half == 0 ? jj - 1 : N - jj) : 0;  // piece between it and the previous node of its chain
+  double Hf[m][m], Hb[m][m], M[m][m], v[m], Sk[m][m];
+#pragma unroll
+  for (int a = 0; a < m; ++a) {
+    v[a] = valid ? V[ax][a][k] : 0.0;
+#pragma unroll
+    for (int b = 0; b < m; ++b) {
+      Hf[a][b] = (valid && jj > 0) ? Lm.H[pf][a][b] : 0.0;
+      Hb[a][b] = valid ? Lm.H[pb][a][b] : 0.0;
+      Sk[a][b] = Lm.Si[k][a][b];
+    }
+  }
+  if (row < 3 && jj == 0) {  // (an empty lower chain -- N = 1 -- contributes nothing)
+#pragma unroll
+    for (int a = 0; a < m; ++a) Lm.mid[ax][half][a] = 0.0;
+  }
+  // ---- forwards, both chains: y = rhs - Hf' y_prev
+#pragma unroll
+  for (int a = 0; a < m; ++a)
+#pragma unroll
+    for (int b = 0; b < m; ++b) M[a][b] = -Hf[b][a];
+  if (L > 1) scan_round<0x111, m>(M, v, L > 2);
+  if (L > 2) scan_round<0x112, m>(M, v, L > 4);
+  if (L > 4) scan_round<0x114, m>(M, v, false);
+  // ---- the middle node: rhs - Hb' y of the last node of either chain, then its inverse block
+  if (last && row < 3) {
+#pragma unroll
+    for (int a = 0; a < m; ++a) {
+      double t = 0.0;
+#pragma unroll
+      for (int b = 0; b < m; ++b) t = __builtin_fma(Hb[b][a], v[b], t);
+      Lm.mid[ax][half][a] = t;
+    }
+  }
+  double ym[m], xm[m], z[m];
+#pragma unroll
+  for (int a = 0; a < m; ++a) ym[a] = V[ax][a][pm] - Lm.mid[ax][0][a] - Lm.mid[ax][1][a];
+#pragma unroll
+  for (int a = 0; a < m; ++a) {
+    double acc = 0.0, accz = 0.0;
+#pragma unroll
+    for (int b = 0; b < m; ++b) {
+      acc = __builtin_fma(Lm.Si[pm][a][b], ym[b], acc);
+      accz = __builtin_fma(Sk[a][b], v[b], accz);
+    }
+    xm[a] = acc;
+    z[a] = valid ? accz : 0.0;
+  }
+  // ---- backwards, both chains: x = z - Hb x_next; the last node of a chain takes the middle node's value in
+#pragma unroll
+  for (int a = 0; a < m; ++a) {
+    v[a] = z[a];
+#pragma unroll
+    for (int b = 0; b < m; ++b) M[a][b] = -Hb[a][b];
+  }
+  if (last) {
+#pragma unroll
+    for (int a = 0; a < m; ++a)
+#pragma unroll
+      for (int b = 0; b < m; ++b) v[a] = __builtin_fma(M[a][b], xm[b], v[a]);
+  }
+  if (last || !valid) {
+#pragma unroll
+    for (int a = 0; a < m; ++a)
+#pragma unroll
+      for (int b = 0; b < m; ++b) M[a][b] = 0.0;
+  }
+  if (L > 1) scan_round<0x101, m>(M, v, L > 2);
+  if (L > 2) scan_round<0x102, m>(M, v, L > 4);
+  if (L > 4) scan_round<0x104, m>(M, v, false);
+  if (row < 3) {
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < m; ++a) V[ax][a][k] = v[a];
+    }
+    if (j == 0) {
+#pragma unroll
+      for (int a = 0; a < m; ++a) V[ax][a][pm] = xm[a];
+    }
+  }
+  __syncthreads();
+}
+
 // ---- one objective evaluation of one problem by one wave ---------------------------------------------------------
 // in: Lm.P (node positions), Lm.T (durations), Lm.hv / tv, rows; out: f (wave-uniform) and this lane's gradient
 // component (lane < nw: waypoint coordinate lane = 3 (k-1) + axis; lane in [nw, nw+nt): dJ/dT of piece lane - nw,
@@ -675,6 +788,212 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   //      the sweeps are bare m x m recurrences (chain_solve) and the products with S_k^-1 run on lanes = (node, axis).
   // The system depends on the durations only: with the durations fixed (waypoints-only optimisation) it is factorised
   // by the first evaluation and S_k^-1, H_k stay in LDS for the rest of the run.
+#if ANET_PERSIST_TWISTED
+  // TWISTED: lane 0 walks nodes 0 .. pm-1 upwards, lane 1 walks nodes N .. pm+1 downwards -- the same instructions on
+  // two lanes, so half the chain costs nothing extra -- and lane 0 finishes with the middle node pm = N / 2, whose block takes a
+  // Schur term from either side.  The downward chain is the upward one with every coupling block transposed.  (Measured by
+  // walking half the chain a second time: 3.7 k of the 9.6 k cycles of this phase per half chain at 16 jerk pieces.)
+  if (lane < 2 && refactor) {
+    const int pm = N >> 1;
+    const int cnt = lane == 0 ? pm : N - pm;
+    const int steps = N - pm;  // (the longer of the two chains: wave-uniform)
+    double Dk[m][m];
+#pragma unroll
+    for (int j = 0; j < m; ++j)
+#pragma unroll
+      for (int l = 0; l < m; ++l) Dk[j][l] = 0.0;
+    // operands of step t of this lane's chain: diagonal block of node kk, coupling block of piece kp (transposed downwards)
+    auto load = [&](int t, double (&BA)[m][m], double (&BK)[m][m]) {
+      const int tt = (t < cnt) ? t : (cnt > 0 ? cnt - 1 : 0);
+      const int kk = lane == 0 ? tt : N - tt;
+      const int kp = lane == 0 ? (tt < N ? tt : N - 1) : N - tt - 1;
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+#pragma unroll
+        for (int l = 0; l < m; ++l) {
+          BA[j][l] = (l <= j) ? Lm.Ad[kk][j][l] : 0.0;
+          BK[j][l] = lane == 0 ? Lm.Kp[kp][j][l] : Lm.Kp[kp][l][j];
+        }
+    };
+    // one node: S = Dk + A; inverse (2 x 2) or LDL^T factor (3 x 3) stored for the sweeps; W = S^-1 K stored as H of the piece
+    // towards the middle; the Schur seed -K' W for the next node stays in Dk.  `on`: this lane's chain still has a node here.
+    auto step = [&](const bool on, const int kk, const int kp, const double (&Ak)[m][m], const double (&Kk)[m][m]) {
+      double Sd[m][m];
+#pragma unroll
+      for (int j = 0; j < m; ++j)
+#pragma unroll
+        for (int l = 0; l <= j; ++l) Sd[j][l] = Dk[j][l] + Ak[j][l];
+      if constexpr (m == 2) {
+        const double r = fast_rcp(__builtin_fma(Sd[0][0], Sd[1][1], -Sd[1][0] * Sd[1][0]));
+        const double s00 = Sd[1][1] * r, s11 = Sd[0][0] * r, s10 = -Sd[1][0] * r;
+        double W[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          W[0][b] = __builtin_fma(s00, Kk[0][b], s10 * Kk[1][b]);
+          W[1][b] = __builtin_fma(s10, Kk[0][b], s11 * Kk[1][b]);
+        }
+        if (on) {
+          Lm.Si[kk][0][0] = s00; Lm.Si[kk][0][1] = s10; Lm.Si[kk][1][0] = s10; Lm.Si[kk][1][1] = s11;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            Lm.H[kp][0][b] = W[0][b];
+            Lm.H[kp][1][b] = W[1][b];
+          }
+#pragma unroll
+          for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+            for (int bb = 0; bb <= aa; ++bb) Dk[aa][bb] = -__builtin_fma(Kk[0][aa], W[0][bb], Kk[1][aa] * W[1][bb]);
+        }
+      } else {
+        double Lk[NLA] = {}, dd[m], dik[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+          double dj = Sd[j][j];
+          double ld_[m];
+#pragma unroll
+          for (int q = 0; q < j; ++q) {
+            ld_[q] = Lk[BlkOps<S>::li(j, q)] * dd[q];
+            dj = __builtin_fma(-ld_[q], Lk[BlkOps<S>::li(j, q)], dj);
+          }
+          dd[j] = dj;
+          dik[j] = fast_rcp(dj);
+#pragma unroll
+          for (int i = j + 1; i < m; ++i) {
+            double v = Sd[i][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) v = __builtin_fma(-Lk[BlkOps<S>::li(i, q)], ld_[q], v);
+            Lk[BlkOps<S>::li(i, j)] = v * dik[j];
+          }
+        }
+        double Y[m][m], Z[m][m];
+#pragma unroll
+        for (int l = 0; l < m; ++l) {
+          double col[m];
+#pragma unroll
+          for (int j = 0; j < m; ++j) col[j] = Kk[j][l];
+          BlkOps<S>::solve_L(Lk, col);
+#pragma unroll
+          for (int j = 0; j < m; ++j) {
+            Y[j][l] = col[j];
+            Z[j][l] = col[j] * dik[j];
+          }
+        }
+        if (on) {
+#pragma unroll
+          for (int aa = 0; aa < m; ++aa)
+#pragma unroll
+            for (int bb = 0; bb <= aa; ++bb) {
+              double acc = 0.0;
+#pragma unroll
+              for (int j = 0; j < m; ++j) acc = __builtin_fma(-Y[j][aa], Z[j][bb], acc);
+              Dk[aa][bb] = acc;
+            }
+          // the factor of the node, for the lanes that turn it into the inverse block and H below: [1/d | L] in the slot
+          double *slot = &Lm.Si[kk][0][0];
+#pragma unroll
+          for (int j = 0; j < m; ++j) slot[j] = dik[j];
+#pragma unroll
+          for (int q = 0; q < BlkOps<S>::nl; ++q) slot[m + q] = Lk[q];
+        }
+      }
+    };
+    auto node_of = [&](int t) { return lane == 0 ? t : N - t; };
+    auto piece_of = [&](int t) { return lane == 0 ? t : N - t - 1; };
+    double A1[m][m], K1[m][m], A2[m][m], K2[m][m];
+    load(0, A1, K1);
+#pragma unroll 1
+    for (int t = 0; t < steps; t += 2) {
+      load(t + 1, A2, K2);
+      step(t < cnt, node_of(t), piece_of(t), A1, K1);
+      load(t + 2, A1, K1);
+      if (t + 1 < steps) step(t + 1 < cnt, node_of(t + 1), piece_of(t + 1), A2, K2);
+    }
+    // ---- the middle node: Schur terms of both chains (lane 1's arrive by a DPP swap), then its inverse block
+    double Sd[m][m];
+#pragma unroll
+    for (int j = 0; j < m; ++j)
+#pragma unroll
+      for (int l = 0; l <= j; ++l) Sd[j][l] = Dk[j][l] + dpp_f64<0xB1>(Dk[j][l]) + Lm.Ad[pm][j][l];
+    if (lane == 0) {
+      if constexpr (m == 2) {
+        const double r = fast_rcp(__builtin_fma(Sd[0][0], Sd[1][1], -Sd[1][0] * Sd[1][0]));
+        const double s10 = -Sd[1][0] * r;
+        Lm.Si[pm][0][0] = Sd[1][1] * r; Lm.Si[pm][0][1] = s10; Lm.Si[pm][1][0] = s10; Lm.Si[pm][1][1] = Sd[0][0] * r;
+      } else {
+        double Lk[NLA] = {}, dd[m], dik[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+          double dj = Sd[j][j];
+          double ld_[m];
+#pragma unroll
+          for (int q = 0; q < j; ++q) {
+            ld_[q] = Lk[BlkOps<S>::li(j, q)] * dd[q];
+            dj = __builtin_fma(-ld_[q], Lk[BlkOps<S>::li(j, q)], dj);
+          }
+          dd[j] = dj;
+          dik[j] = fast_rcp(dj);
+#pragma unroll
+          for (int i = j + 1; i < m; ++i) {
+            double v = Sd[i][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) v = __builtin_fma(-Lk[BlkOps<S>::li(i, q)], ld_[q], v);
+            Lk[BlkOps<S>::li(i, j)] = v * dik[j];
+          }
+        }
+        double *slot = &Lm.Si[pm][0][0];
+#pragma unroll
+        for (int j = 0; j < m; ++j) slot[j] = dik[j];
+#pragma unroll
+        for (int q = 0; q < BlkOps<S>::nl; ++q) slot[m + q] = Lk[q];
+      }
+    }
+  }
+  __syncthreads();
+  // inverse blocks and H = (inverse block) (coupling towards the middle) are off the chain: every node on its own lane (3 x 3)
+  if (m > 2 && refactor && lane <= N) {
+    const int k = lane, pm = N >> 1;
+    double Lk[NLA] = {}, dik[m];
+    const double *slot = &Lm.Si[k][0][0];
+#pragma unroll
+    for (int j = 0; j < m; ++j) dik[j] = slot[j];
+#pragma unroll
+    for (int q = 0; q < BlkOps<S>::nl; ++q) Lk[q] = slot[m + q];
+    if (k != pm) {
+      const int kp = k < pm ? k : k - 1;  // the piece towards the middle
+#pragma unroll
+      for (int l = 0; l < m; ++l) {
+        double col[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) col[j] = k < pm ? Lm.Kp[kp][j][l] : Lm.Kp[kp][l][j];
+        BlkOps<S>::solve_L(Lk, col);
+#pragma unroll
+        for (int j = 0; j < m; ++j) col[j] *= dik[j];
+        BlkOps<S>::solve_LT(Lk, col);
+#pragma unroll
+        for (int j = 0; j < m; ++j) Lm.H[kp][j][l] = col[j];
+      }
+    }
+    double Sk[m][m];
+#pragma unroll
+    for (int cc = 0; cc < m; ++cc) {
+      double col[m];
+#pragma unroll
+      for (int j = 0; j < m; ++j) col[j] = (j == cc) ? 1.0 : 0.0;
+      BlkOps<S>::solve_L(Lk, col);
+#pragma unroll
+      for (int j = 0; j < m; ++j) col[j] *= dik[j];
+      BlkOps<S>::solve_LT(Lk, col);
+#pragma unroll
+      for (int j = 0; j < m; ++j) Sk[j][cc] = col[j];
+    }
+#pragma unroll
+    for (int j = 0; j < m; ++j)
+#pragma unroll
+      for (int cc = 0; cc < m; ++cc) Lm.Si[k][j][cc] = Sk[j][cc];
+  }
+  if constexpr (m > 2) __syncthreads();
+  chain_solve_twisted<S, NB>(Lm, Lm.X, N, lane);
+#else
   if (lane == 0 && refactor) {
     constexpr int CH = (m <= 2) ? 4 : 2;
     double Dk[m][m];
@@ -831,6 +1150,7 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
   }
   if constexpr (m > 2) __syncthreads();
   chain_solve<S, NB>(Lm, Lm.X, N, lane, na, ax);
+#endif
 
   PERSIST_TICK(2);
   PERSIST_PHASE();
@@ -1137,7 +1457,11 @@ __device__ __forceinline__ void persist_eval(PersistLds<S, NB> &Lm, const double
     }
   }
   __syncthreads();
+#if ANET_PERSIST_TWISTED
+  chain_solve_twisted<S, NB>(Lm, Lm.X, N, lane);
+#else
   chain_solve<S, NB>(Lm, Lm.X, N, lane, na, ax);
+#endif
 
   PERSIST_TICK(6);
   PERSIST_PHASE();
