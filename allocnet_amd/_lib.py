@@ -99,6 +99,9 @@ PROTOTYPES = {
     "anet_lbfgs_strerror": (c_char_p, [c_int]),
     "anet_lbfgs_mvie": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_double, c_double, c_void_p, c_void_p,
                                 c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "anet_lbfgs_workspace": (c_int64, [c_int, c_int64, c_void_p]),
+    "anet_lbfgs_optimize_dev": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "anet_lbfgs_minco": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),

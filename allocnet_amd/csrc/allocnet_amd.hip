@@ -1179,6 +1179,40 @@ int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A, double
   return st.download(L.x, n, x);
 }
 
+int64_t anet_lbfgs_workspace(int n, int64_t ld, const anet_lbfgs_params *params) {
+  if (!params || n < 1 || ld < 1) return 0;
+  return LbfgsLayout::doubles(n, params->mem_size, params->past > 1 ? params->past : 1, ld);
+}
+
+int anet_lbfgs_optimize_dev(anet_ctx *ctx, int n, int64_t batch, int64_t ld, double *x, double *f, double *g,
+                            anet_lbfgs_evaluate_t proc_evaluate, void *instance, const anet_lbfgs_params *params,
+                            int max_evals, int bound_from, double bound_min, double *work, int32_t *status,
+                            int32_t *iters, int32_t *evals, void *stream) {
+  ANET_ON_DEVICE(ctx);
+  int rc = check_lbfgs(ctx, n, params, max_evals);
+  if (rc) return rc;
+  if (batch < 0 || ld < batch) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_optimize_dev: batch < 0 or ld < batch");
+  if (batch == 0) return ANET_OK;
+  if (!x || !f || !g || !proc_evaluate || !work) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_optimize_dev: NULL pointer");
+  const int m = params->mem_size, npf = params->past > 1 ? params->past : 1;
+  LbfgsLayout L{n, m, npf, ld};
+  L.carve(work);
+  L.x = x;      // the caller's buffers: what its callback reads and fills
+  L.g = g;
+  L.feval = f;
+  hipStream_t st = (hipStream_t)stream;
+  int cb_rc = 0;
+  rc = lbfgs_drive(ctx, L, batch, *params, max_evals, st, [&]() -> int {
+    cb_rc = proc_evaluate(instance, L.x, L.feval, L.g, batch, ld, n, stream);
+    return cb_rc ? fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_optimize_dev: proc_evaluate returned non-zero") : ANET_OK;
+  }, nullptr, bound_from < n ? (bound_from > 0 ? bound_from : 0) : n, true, bound_from < n ? 1 : 0, bound_min, ctx->cancel_flag);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_lbfgs_results, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, L.is, L.ds, batch, ld, status,
+                     iters, evals, f);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
 // ---- batched FIRI -------------------------------------------------------------------------------
 void anet_firi_default_params(anet_firi_params *p) {
   if (!p) return;

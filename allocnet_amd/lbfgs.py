@@ -169,3 +169,52 @@ def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, p
     wide = torch.empty(ld, device=dev, dtype=torch.int32)
     ctx.check(ctx.lib.anet_minco_spread_flags_dev(ctx.handle, N, B, ld, p(T), 0.0, p(wide), ctypes.c_void_p(stream)))
     return dict(cost=cost[:B], status=status[:B], iters=iters[:B], evals=evals[:B], wide_spread=wide[:B])
+
+
+_EVAL_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                           ctypes.c_int64, ctypes.c_int, ctypes.c_void_p)
+
+
+def lbfgs_optimize_dev(x, evaluate, batch=None, param=None, max_evals=2000, bound_from=None, bound_min=0.0, ctx=None):
+    """lbfgs::lbfgs_optimize (lbfgs.hpp:434-717) for an objective the caller evaluates on the device -> anet_lbfgs_optimize_dev.
+
+    x: torch CUDA float64 tensor (n, ld), batch-minor (variable i of problem b at x[i, b]), start point in, result out.
+    evaluate(x, f, g): called once per evaluation step of the batch; must fill f (ld,) and g (n, ld) -- torch tensors owned by
+    this call -- with the objective and its gradient at x for every problem, using torch operations on the CURRENT stream
+    (values of problems that have stopped are ignored).  bound_from / bound_min: lbfgs_optimize's step bound as the built-in
+    lower bound on the variables i >= bound_from (None: no bound).  Returns dict(f, status, iters, evals) of device tensors."""
+    import torch
+    ctx = ctx or default_context(x.device.index or 0)
+    param = param or lbfgs_parameter_t()
+    if not (x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.stride(1) == 1):
+        raise ValueError("x: CUDA float64 tensor (n, ld), batch-minor")
+    n, ld = x.shape[0], x.stride(0)
+    B = int(batch) if batch is not None else x.shape[1]
+    dev = x.device
+    f = torch.zeros(ld, device=dev, dtype=torch.float64)
+    g = torch.zeros(n, ld, device=dev, dtype=torch.float64)
+    work = torch.empty(ctx.lib.anet_lbfgs_workspace(n, ld, ctypes.cast(ctypes.pointer(param), ctypes.c_void_p)), device=dev,
+                       dtype=torch.float64)
+    status = torch.empty(ld, device=dev, dtype=torch.int32)
+    iters = torch.empty(ld, device=dev, dtype=torch.int32)
+    evals = torch.empty(ld, device=dev, dtype=torch.int32)
+    err = []
+
+    def _cb(_inst, _x, _f, _g, _b, _ld, _n, _stream):
+        try:
+            evaluate(x, f, g)
+            return 0
+        except Exception as exc:          # (an exception must not unwind through the C frames)
+            err.append(exc)
+            return 1
+    cb = _EVAL_T(_cb)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = ctx.lib.anet_lbfgs_optimize_dev(ctx.handle, n, B, ld, p(x), p(f), p(g), ctypes.cast(cb, ctypes.c_void_p), None,
+                                         ctypes.cast(ctypes.pointer(param), ctypes.c_void_p), int(max_evals),
+                                         n if bound_from is None else int(bound_from), float(bound_min), p(work), p(status),
+                                         p(iters), p(evals), ctypes.c_void_p(stream))
+    if err:
+        raise err[0]
+    ctx.check(rc)
+    return dict(f=f[:B], status=status[:B], iters=iters[:B], evals=evals[:B])

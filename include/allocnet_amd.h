@@ -437,6 +437,24 @@ int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A /* [bat
                     double *f /* [batch] */, const anet_lbfgs_params *params, int max_evals,
                     int32_t *status, int32_t *iters, int32_t *evals);
 
+/* lbfgs::lbfgs_optimize for an objective the CALLER evaluates on the device (lbfgs.hpp:434-440: x, f, proc_evaluate,
+ * proc_stepbound, proc_progress, instance, param).  proc_evaluate (lbfgs.hpp:186-219) becomes a host function that ENQUEUES
+ * the evaluation of the whole batch on `stream`: given x ([n][ld] device, batch-minor: variable i of problem b at x[i*ld + b])
+ * it must leave f[b] and g[i*ld + b] for every problem b < batch (the values of problems that have stopped are ignored) and
+ * return 0; anything else aborts the run with ANET_ERR_INVALID.  It is called once per evaluation step of the batch (the
+ * lockstep shape: every running problem consumes one evaluation per call; a completion flag is polled every eight steps, so
+ * up to eight calls may follow the last problem's stop).  x is the start point in, the result out; f and g are the caller's
+ * buffers the callback fills ([batch] and [n][ld]); on return f[b] is lbfgs_optimize's fx.  proc_stepbound: the one bound
+ * with a use is built in -- bound_from < n keeps the variables i >= bound_from at or above bound_min within every line search
+ * (lbfgs.hpp:557-565; bound_from >= n: none); proc_progress: anet_set_cancel_flag.  work: anet_lbfgs_workspace() doubles.  */
+typedef int (*anet_lbfgs_evaluate_t)(void *instance, const double *x, double *f, double *g, int64_t batch, int64_t ld, int n,
+                                     void *stream);
+int64_t anet_lbfgs_workspace(int n, int64_t ld, const anet_lbfgs_params *params);
+int anet_lbfgs_optimize_dev(anet_ctx *ctx, int n, int64_t batch, int64_t ld, double *x, double *f, double *g,
+                            anet_lbfgs_evaluate_t proc_evaluate, void *instance, const anet_lbfgs_params *params,
+                            int max_evals, int bound_from, double bound_min, double *work, int32_t *status,
+                            int32_t *iters, int32_t *evals, void *stream);
+
 /* Objective = the MINCO cost  int (p^(s))^2 + rho*sum(T) + J_pen  (anet_minco_cost_grad) over the
  * interior waypoints (opt_flags bit 0) and/or the durations (bit 1), the durations through the
  * smooth bijection T(tau) so the problem is unconstrained.  wps and T are in/out.

@@ -103,8 +103,9 @@ inline std::vector<int> lbfgs_optimize_mvie(int batch, int M, const std::vector<
 // lbfgs::lbfgs_optimize (lbfgs.hpp:434-440) for the reference's own call (firi.hpp:221-227): objective
 // &firi::costMVIE, no step bound, no progress monitor, `instance` = firi's optData blob {int M; double smoothEps,
 // penaltyWt; double A[3 M] column-major} (firi.hpp:186-200).  Runs anet_lbfgs_mvie with a batch of one; x and f are
-// updated like the reference's, the return value is its return code.  Any other host callback is refused: there is no
-// CPU L-BFGS in this library (batched device objectives: lbfgs_optimize_mvie above, anet_lbfgs_minco).  The step-bound
+// updated like the reference's, the return value is its return code.  Any other HOST-evaluated objective is refused: there
+// is no CPU L-BFGS in this library.  Batched device objectives: lbfgs_optimize_mvie above, anet_lbfgs_minco, and -- any
+// objective the caller can evaluate on the device -- lbfgs_optimize_batched below (anet_lbfgs_optimize_dev).  The step-bound
 // mechanism itself (lbfgs.hpp:557-565) is there for the MINCO objective as a built-in bound, a minimum duration:
 // anet_lbfgs_minco_bounded[_dev](..., min_duration, ...); the progress monitor's one effect (lbfgs.hpp:580-587: a non-zero
 // return cancels the run) as a word the caller owns: anet_set_cancel_flag.
@@ -129,6 +130,30 @@ inline int lbfgs_optimize(V &x, double &f, lbfgs_evaluate_t<V> proc_evaluate, lb
   for (int i = 0; i < 9; ++i) x(i) = xs[i];
   f = cost[0];
   return ret[0];
+}
+
+// lbfgs_optimize for a batch of problems whose objective the caller evaluates ON THE DEVICE: proc_evaluate (the C signature
+// anet_lbfgs_evaluate_t: instance, x [n][ld], f [batch], g [n][ld], batch, ld, n, stream) enqueues one evaluation of the whole
+// batch on `stream`.  x (device, batch-minor) is the start point in and the result out, f / g are device buffers of the
+// caller's; returns lbfgs_optimize's return code per problem (anet_lbfgs_optimize_dev).
+inline std::vector<int> lbfgs_optimize_batched(int n, int64_t batch, int64_t ld, double *x_dev, double *f_dev, double *g_dev,
+                                               anet_lbfgs_evaluate_t proc_evaluate, void *instance,
+                                               const lbfgs_parameter_t &param, int max_evals = 20000, void *stream = nullptr) {
+  anet_lbfgs_params q = to_c(param);
+  anet::Context &ctx = anet::Context::thread_default();
+  const int64_t nwork = anet_lbfgs_workspace(n, ld, &q);
+  double *work = nullptr, *st3 = nullptr;  // st3: the int32 status row in a buffer of doubles
+  ctx.check(anet_dev_alloc(ctx.get(), (size_t)nwork, &work));
+  ctx.check(anet_dev_alloc(ctx.get(), (size_t)(ld + 1) / 2, &st3));
+  std::vector<int32_t> status32((size_t)(ld + 2));
+  const int rc = anet_lbfgs_optimize_dev(ctx.get(), n, batch, ld, x_dev, f_dev, g_dev, proc_evaluate, instance, &q, max_evals, n,
+                                         0.0, work, (int32_t *)st3, nullptr, nullptr, stream ? stream : anet_stream(ctx.get()));
+  if (rc == ANET_OK) anet_dev_download(ctx.get(), (double *)status32.data(), st3, (size_t)(ld + 1) / 2);
+  anet_dev_free(work);
+  anet_dev_free(st3);
+  std::vector<int> status(status32.begin(), status32.begin() + batch);
+  ctx.check(rc);
+  return status;
 }
 
 }  // namespace lbfgs
