@@ -556,6 +556,15 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         // The substitutions of a step walk every knot four times and with L_k each visit is a triangular solve of BK
         // dependent steps; with L_k^-1 it is a block-vector product (twisted_solve).  The inverse also gives the block
         // towards the next knot as a PRODUCT instead of a second substitution (below).  Nothing else reads the factors.
+#ifndef ANET_IPM_INV_FROM_LDS
+#define ANET_IPM_INV_FROM_LDS 1
+#endif
+        if constexpr (ANET_IPM_INV_FROM_LDS != 0) {  // L through LDS: the rows are stored, its entries come back as broadcasts
+          if (act) {
+#pragma unroll
+            for (int c = 0; c < BK; ++c) Dk[lane * BK + c] = Dr[c];
+          }
+        }
         double pcol[BK];
 #pragma unroll
         for (int c = 0; c < BK; ++c) pcol[c] = (c == lane) ? 1.0 : 0.0;
@@ -563,7 +572,10 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         for (int q = 0; q < BK; ++q) {
           pcol[q] *= dinv[q];
 #pragma unroll
-          for (int c = q + 1; c < BK; ++c) pcol[c] -= rl(Dr[q], c) * pcol[q];  // L[c][q] = lane c's Dr[q]
+          for (int c = q + 1; c < BK; ++c) {
+            if constexpr (ANET_IPM_INV_FROM_LDS != 0) pcol[c] -= Dk[c * BK + q] * pcol[q];
+            else pcol[c] -= rl(Dr[q], c) * pcol[q];  // L[c][q] = lane c's Dr[q]
+          }
         }
         if (act) {
 #pragma unroll
