@@ -31,6 +31,7 @@
 
 #include "minco_core.h"  // fast_rcp
 #include "minco_kernels.h"  // pair_sum
+#include "wave_ops.h"  // wave_sum, wave_min_f64
 #include "qp_admm.h"    // qblk1, fallf
 
 namespace anet {
@@ -343,11 +344,10 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   };
   using RowsLoad = std::integral_constant<bool, false>;
   using RowsUpdate = std::integral_constant<bool, true>;
+  // (wave part on the DPP path -- in-row scans and row broadcasts, ~20 VALU instructions -- where the __shfl_xor butterfly was
+  //  twelve dependent ds_bpermute round trips per reduction, ten reductions per Newton step)
   auto block_reduce = [&](double v, int slot, bool is_min) {  // red[slot] must have been initialised before a barrier
-    for (int o = 32; o > 0; o >>= 1) {
-      const double w = __shfl_xor(v, o);
-      v = is_min ? fmin(v, w) : v + w;
-    }
+    v = is_min ? wave_min_f64(v) : wave_sum<63>(v);
     if ((tid & 63) == 0) {
       if (is_min) atomic_max_pos(&red[slot], 1.0 / fmax(v, 1e-300));  // min of positives via max of reciprocals
       else atomicAdd(&red[slot], v);
