@@ -154,6 +154,14 @@ def timed_reps(torch, fn, K, reps=3, warm_ms=10.0):
     by one HIP-event pair on the current stream and a host clock, after at least `warm_ms` of GPU time of the same calls
     (clocks, code objects, first-touch of the outputs: none of it in the timed repetitions)."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if K >= 100:
+        # The HIP runtime stalls a stream ONCE per process, for 20-60 ms, when the host first gets ~10^3 launches ahead of
+        # the GPU (tools/stall_probe.py, profiles/r04_launch_backlog_stall.txt: always in the launches 900-1050 of a
+        # back-to-back loop of small kernels, never again).  A loop of 200 three-launch evaluations can be where that
+        # happens -- round 3's driver run: 11 ms of kernels + 28 ms = "0.196 ms per step" -- so it is made to happen here.
+        for _ in range(450):
+            fn()
+        torch.cuda.synchronize()
     warmed, rounds = 0.0, 0
     while warmed < warm_ms and rounds < 1000:
         e0.record()
@@ -239,8 +247,9 @@ def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
         dt, kms = host_ms[len(host_ms) // 2] * 1e-3, st_ms[len(st_ms) // 2]
         out[key] = {"batch": B, "ms_per_step": dt * 1e3, "stream_ms_per_step": kms, "value": B / dt,
                     "stream_ms_min_median_max": [st_ms[0], kms, st_ms[-1]], "stream_ms_in_run_order": [r[1] for r in runs],
-                    "timing": f"{len(runs)} repetitions of {K} back-to-back evaluations after >= 10 ms of warm-up on the GPU, "
-                              f"one HIP-event pair per repetition; the median repetition is reported",
+                    "timing": f"{len(runs)} repetitions of {K} back-to-back evaluations after >= 10 ms of warm-up on the GPU (and, for "
+                              f"the small batch, an un-synchronised burst of 450 evaluations that takes the runtime's one-off "
+                              f"launch-backlog stall), one HIP-event pair per repetition; the median repetition is reported",
                     "kernel_split_us": cost_grad_kernel_split(torch, aa, ctx, s, c, N, B, ld, th, tt, tw, tT, thp, pen, work, gP, gT),
                     "roofline": fp64_roofline(B * flops, kms * 1e-3, B * ab,
                                               "k_piece_grad (+ k_minco_solve, k_minco_propagate)")}
