@@ -25,6 +25,13 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return x;
 }
 
+// 1/d to ~1e-14: v_rcp_f64 + ONE Newton step -- for quantities that only steer an iteration (interior-point weights and
+// step directions: the iteration tests its true residuals), not for results.
+__device__ __forceinline__ double fast_rcp1(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  return __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
+}
+
 // Optimisation barrier.  The sweeps below deliberately RECOMPUTE the cheap per-piece quantities
 // (powers of r, the coupling block Y = L^-1 Ko) instead of keeping them: left alone the compiler
 // would CSE/hoist them across the sweeps and hold ~150 doubles live, which spills.  Laundering

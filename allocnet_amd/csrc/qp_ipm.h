@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   IPM_TICK(0);
   // ---- pass A: residuals, weights, right-hand-side pieces per sample.  A row of the iterate (gy = its value, sl, lm):
   auto row_A = [&](auto row, double hv, double gy, double sl, double lm, double *A_, double &l_mu, double &l_pres, double &l_h) {
-    const double rg = gy + sl - hv, w = lm * fast_rcp(sl), t = lm + w * (gy - hv);
+    const double rg = gy + sl - hv, w = lm * fast_rcp1(sl), t = lm + w * (gy - hv);
     l_mu += sl * lm;
     l_pres = fmax(l_pres, fabs(rg));
     l_h = fmax(l_h, fabs(hv));
@@ -833,7 +833,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         for (int q = 0; q < 30; ++q) A_[q] = 0.0;
         for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
           const double gy = row.dot(s3[row.dsel]);
-          const double rg = gy + sl - hv, w = lm * fast_rcp(sl), t = lm + w * (gy - hv);
+          const double rg = gy + sl - hv, w = lm * fast_rcp1(sl), t = lm + w * (gy - hv);
           l_mu += sl * lm;
           l_pres = fmax(l_pres, fabs(rg));
           l_h = fmax(l_h, fabs(hv));
@@ -923,7 +923,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         for_rows_sl(i, smp, RowsLoad{}, [&](int q, auto row, double hv, double sl, double lm) {
           const double rg = row.dot(s3[row.dsel]) + sl - hv;
           const double ds = -rg - row.dot(d3[row.dsel]);
-          const double isl = fast_rcp(sl);
+          const double isl = fast_rcp1(sl);
           const double dl = -lm - (lm * isl) * ds;
           // step to the boundary: the largest of -ds/s, -dl/lambda over the rows is 1/alpha (no division per row)
           l_ap = fmax(l_ap, fmax(-ds * isl, -dl * __builtin_amdgcn_rcp(lm)));  // (a step length: the raw reciprocal does, 1e-7)
@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
                          const double (&e3)[3][3], double sl, double lm, double &ds, double &dl) {
       const double rg = row.dot(s3[row.dsel]) + sl - hv;
       const double dsa = -rg - row.dot(d3[row.dsel]);
-      const double isl = fast_rcp(sl);
+      const double isl = fast_rcp1(sl);
       const double dla = -lm - (lm * isl) * dsa;
       const double rc = sl * lm + dsa * dla - mu_target;
       ds = -rg - row.dot(e3[row.dsel]);
@@ -1031,7 +1031,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
           const double gy = row.dot(s3[row.dsel]), ge = row.dot(e3[row.dsel]);
           const double rg = gy + sl - hv;
           const double dsa = -rg - row.dot(d3[row.dsel]);
-          const double isl = fast_rcp(sl);
+          const double isl = fast_rcp1(sl);
           const double dla = -lm - (lm * isl) * dsa;
           const double rc = sl * lm + dsa * dla - mu_target;
           const double ds = -rg - ge;
