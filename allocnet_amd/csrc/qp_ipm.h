@@ -161,7 +161,10 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   }
   // ---- Hermite matrix: E[row][col] = value of derivative d of the monomial col at tau = 0 / 1; Hm = E^-1
   if (tid == 0) {
-    double *E = acc;  // [D][2D] scratch in LDS (acc is not in use yet)
+    // [D][2D] scratch in LDS: the diagonal blocks, first written by the first assembly -- (N + 1) BK^2 >= 2 D^2 doubles for every
+    // piece count (the per-sample records, NS x 31 doubles, are SHORTER than that for one piece with <= 4 samples)
+    double *E = Dg;
+    static_assert(2 * BK * BK >= 2 * D * D, "Hermite scratch must fit the two diagonal blocks of a one-piece problem");
     constexpr int W = 2 * D;
     for (int r = 0; r < D; ++r)
       for (int col = 0; col < D; ++col) {

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Randomised soak of the cost + gradient path against the C restatement (oracle/minco_costgrad.c): orders, boundary counts,
+piece counts, corridor row counts, sample counts and batch sizes around every launch-shape threshold.
+    gpurun -- 'python tools/soak_cost_grad.py 300'"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import allocnet_amd as aa
+from oracle import cbind
+from allocnet_amd.synth import corridor_problem, random_problem
+
+def run(n_cases, seed=12345, ctx=None, verbose=True):
+    """Returns the worst relative errors (cost, gradT, gradP) over n_cases random configurations; raises AssertionError on the
+    first configuration beyond 1e-9 / 1e-7 / 1e-7."""
+    ctx = ctx or aa.Context(0)
+    rng = np.random.default_rng(seed)
+    worst = dict(cost=0.0, gT=0.0, gP=0.0)
+    for case in range(n_cases):
+        s = int(rng.choice([3, 4]))
+        c = int(rng.integers(2, s + 1))
+        N = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16]))
+        M = int(rng.choice([0, 6, 7, 9, 12, 16]))
+        res = int(rng.choice([1, 3, 8, 20, 33]))
+        B = int(rng.choice([1, 2, 63, 64, 65, 100, 511, 2047, 2048, 2049, 4096, 16384, 16385, 20000]))
+        if N >= 12 and B > 4096:
+            B = 4096
+        if M:
+            head, tail, wps, T, hp = corridor_problem(rng, B, N, c, M)
+        else:
+            head, tail, wps, T = random_problem(rng, B, N, c)
+            hp = None
+        T = T * rng.uniform(0.6, 2.0)
+        kw = dict(res=res, vmax=float(rng.uniform(1.0, 5.0)), amax=float(rng.uniform(1.5, 8.0)), wc=float(10 ** rng.uniform(0, 4)),
+                  wv=float(10 ** rng.uniform(0, 3)), wa=float(10 ** rng.uniform(0, 3)), mu=float(10 ** rng.uniform(-3, -1)))
+        rho = float(rng.uniform(0.0, 100.0))
+        pen = aa.make_penalty(rho=rho, w_corridor=kw["wc"], w_vel=kw["wv"], w_acc=kw["wa"], smooth_mu=kw["mu"], max_vel=kw["vmax"],
+                              max_acc=kw["amax"], res=res, poly_rows=M)
+        cost, gP, gT = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, ctx=ctx)
+        idx = np.unique(np.r_[0, B - 1, rng.integers(0, B, size=min(B, 24))])
+        cc, cgP, cgT = cbind.minco_cost_grad_batch(s, head[idx], tail[idx], wps[idx], T[idx], None if hp is None else hp[idx], rho,
+                                                   nthreads=4, **kw)
+        e_c = np.abs(cost[idx] - cc).max() / np.abs(cc).max()
+        e_t = np.abs(gT[idx] - cgT).max() / max(1.0, np.abs(cgT).max())
+        e_p = np.abs(gP[idx] - cgP).max() / max(1.0, np.abs(cgP).max()) if N > 1 else 0.0
+        worst = dict(cost=max(worst["cost"], e_c), gT=max(worst["gT"], e_t), gP=max(worst["gP"], e_p))
+        tag = f"case {case}: s={s} c={c} N={N} M={M} res={res} B={B} rel err cost {e_c:.1e} gT {e_t:.1e} gP {e_p:.1e}"
+        if verbose and case % 25 == 0:
+            print("ok   " + tag, flush=True)
+        assert np.isfinite(cost).all() and e_c <= 1e-9 and e_t <= 1e-7 and e_p <= 1e-7, tag
+    return worst
+
+
+if __name__ == "__main__":
+    t0 = time.time()
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    w = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    print(f"{n} cases in {time.time() - t0:.0f} s; worst relative errors: {w}")
