@@ -1,7 +1,7 @@
 """Where the interior-point kernel and its C port (oracle/qp_ipm_port.c) disagree on the verdict, who is right: the dense
 interior point of oracle/qp_np.py on the reference-assembled problem decides (objective, worst row violation of either
 answer).  Durations scaled to 0.7 of the generator's -- close to infeasibly short, optimal costs up to 1e9.
-   gpurun -- 'python tools/qp_disagree.py'"""
+   gpurun -- 'python tests/soak/qp_disagree.py'"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

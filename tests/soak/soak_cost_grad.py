@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of the cost + gradient path against the C restatement (oracle/minco_costgrad.c): orders, boundary counts,
 piece counts, corridor row counts, sample counts and batch sizes around every launch-shape threshold.
-    gpurun -- 'python tools/soak_cost_grad.py 300'"""
+    gpurun -- 'python tests/soak/soak_cost_grad.py 300'"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))

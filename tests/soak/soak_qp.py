@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of the interior-point QP kernel against the C port of the structured interior point (oracle/qp_ipm_port.c,
 itself pinned to the dense oracle on the reference-assembled fixtures): orders, piece counts, corridor rows, samples per piece,
-duration scales from infeasibly short to slack.   gpurun -- 'python tools/soak_qp.py 60'"""
+duration scales from infeasibly short to slack.   gpurun -- 'python tests/soak/soak_qp.py 60'"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -13,7 +13,7 @@ from allocnet_amd.synth import corridor_problem
 def run(n_cases, seed=777, ctx=None, verbose=True):
     """Returns (problems solved by both, worst relative objective difference, solved by the port only, solved by the GPU only,
     problems).  (The port gives up on some badly scaled problems -- optimal cost 1e7 and more, durations close to infeasibly
-    short -- that the kernel and the dense oracle both solve: tools/qp_disagree.py prints them with the dense verdict.)"""
+    short -- that the kernel and the dense oracle both solve: tests/soak/qp_disagree.py prints them with the dense verdict.)"""
     ctx = ctx or aa.Context(0)
     rng = np.random.default_rng(seed)
     worst, compared, port_only, gpu_only, total = 0.0, 0, 0, 0, 0

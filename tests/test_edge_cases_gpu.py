@@ -268,10 +268,10 @@ def test_one_launch_lbfgs_captures_into_a_hip_graph(anet_ctx):
 
 
 def test_randomised_soak_of_cost_and_gradients(anet_ctx):
-    """tools/soak_cost_grad.py: 80 random configurations -- orders 3 / 4, 2..s boundary derivatives, 1..16 pieces, 0..16 corridor
+    """tests/soak/soak_cost_grad.py: 80 random configurations -- orders 3 / 4, 2..s boundary derivatives, 1..16 pieces, 0..16 corridor
     rows, 1..33 samples per piece, batch sizes on both sides of every launch-shape threshold (63 / 64 / 65, 2047 / 2048 / 2049,
     16384 / 16385), random weights, limits and smoothing -- each against the C restatement (classic banded LU + adjoint) on a
     random sample of its trajectories: cost 1e-9, gradients 1e-7."""
-    from tools.soak_cost_grad import run
+    from tests.soak.soak_cost_grad import run
     worst = run(80, seed=2024, ctx=anet_ctx, verbose=False)
     assert worst["cost"] <= 1e-10 and worst["gT"] <= 1e-9 and worst["gP"] <= 1e-9, worst

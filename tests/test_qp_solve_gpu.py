@@ -635,7 +635,7 @@ def test_twisted_and_classic_elimination_orders_agree():
 def test_few_samples_per_problem(anet_ctx, s, N, res):
     """Problems with fewer than five samples in all (one piece at a resolution of 1..4, two pieces at 1..2).  The per-sample
     records of such a problem are shorter than the 2s x 4s scratch of the Hermite-matrix inversion, which once lived there and
-    ran over the corridor rows and durations behind it (found by tools/soak_qp.py: s = 4, N = 1, res = 3 returned wrong optima
+    ran over the corridor rows and durations behind it (found by tests/soak/soak_qp.py: s = 4, N = 1, res = 3 returned wrong optima
     or 'not solved'; res = 4 silently lost the first corridor row).  Verdicts and optima against the C port of the method."""
     import allocnet_amd as aa
     from allocnet_amd.synth import corridor_problem
@@ -655,12 +655,12 @@ def test_few_samples_per_problem(anet_ctx, s, N, res):
 
 
 def test_randomised_soak_against_the_c_port(anet_ctx):
-    """tools/soak_qp.py: 60 random shapes (orders 3 / 4, 1..16 pieces, 6..16 corridor rows, 3 / 8 / 20 samples per piece, lone
+    """tests/soak/soak_qp.py: 60 random shapes (orders 3 / 4, 1..16 pieces, 6..16 corridor rows, 3 / 8 / 20 samples per piece, lone
     problems and small batches, durations from infeasibly short to slack) against oracle/qp_ipm_port.c."""
-    from tools.soak_qp import run
+    from tests.soak.soak_qp import run
     compared, worst, port_only, gpu_only, total = run(60, seed=777, ctx=anet_ctx, verbose=False)
     assert compared > 0.5 * total
     assert worst <= 2e-5
-    # the port gives up on some badly scaled problems the kernel (and the dense oracle: tools/qp_disagree.py) solves; the other
+    # the port gives up on some badly scaled problems the kernel (and the dense oracle: tests/soak/qp_disagree.py) solves; the other
     # direction -- a problem the CPU solves and the kernel does not -- is the one that must not happen
     assert port_only <= 0.005 * total and gpu_only <= 0.05 * total, (port_only, gpu_only, total)
