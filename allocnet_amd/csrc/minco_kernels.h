@@ -226,6 +226,26 @@ __device__ __forceinline__ double pair_sum(double v) {  // v + the value of the 
   return v + __hiloint2double(hi, lo);
 }
 
+// A row of the basis table (D <= 8 doubles, wave-uniform address) through a scalar load the COMPILER does not track: request()
+// issues it, await() is the s_waitcnt the values may be read behind.  (Six-column rows load eight: the table's rows are 4 D apart.)
+template <int D>
+struct TabRow {
+  static_assert(D == 4 || D == 6 || D == 8, "orders 2..4");
+  static constexpr int W = D == 4 ? 4 : 8;
+  typedef double vec_t __attribute__((ext_vector_type(W)));
+  vec_t v;
+  __device__ __forceinline__ void request(const double *row_) {
+    // (the address in scalar registers whatever the compiler proved about it: the sample index of the sample-split shape
+    // comes from threadIdx.x >> 6)
+    const unsigned long long pa = (unsigned long long)row_;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pa), hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+    const double *row = (const double *)(((unsigned long long)hi << 32) | lo);
+    if constexpr (W == 8) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(v) : "s"(row));
+    else asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(v) : "s"(row));
+  }
+  __device__ __forceinline__ void await() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); }
+};
+
 // SW = 4 (smaller batches still, with SPLIT): the four WAVES of a workgroup take every fourth sample of the SAME 32
 // (trajectory, piece) pairs -- the sample index stays wave-uniform, so the basis table is still read with scalar
 // loads -- and their partial gradients are summed through LDS by wave 0.  A quarter of the dependent chain per lane
@@ -323,14 +343,32 @@ __global__ void __launch_bounds__(256, SW > 1 ? ANET_PG_SW_MINB : ANET_PG_MINB) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) hr[r][q] *= inv_mu;
       const bool first = SPLIT ? (half == 1 && pass == 0) : (ch == 0);  // the pass that also evaluates the box rows
+      // The table rows are scalar loads, a wave waited for each where it was used (~10^2 cycles, five times per sample, the
+      // two waves of a SIMD in phase) and the compiler keeps such a load next to its use: the position row of the NEXT sample
+      // is requested by hand at the top of the sample (tab_row_request: the compiler does not know it is in flight; it is
+      // awaited at the bottom, tab_row_await), the velocity / acceleration rows of THIS sample right behind it -- scalar
+      // loads return out of order, so a wait for any is a wait for all, and the first one stands behind the eight corridor
+      // rows' worth of arithmetic.
+      TabRow<D> nx, r1, r2;
+      nx.request(tab + (size_t)wv * 4 * D);
+      nx.await();
       for (int j = wv; j < pp.res; j += SW) {
         const double *tb = tab + (size_t)j * 4 * D;
+        double t0[D];
+#pragma unroll
+        for (int col = 0; col < D; ++col) t0[col] = nx.v[col];
+        nx.request(tab + (size_t)(j + SW < pp.res ? j + SW : j) * 4 * D);
+        // (by hand as well: behind an asm statement the compiler takes the table for clobbered and loads it per lane; and in
+        // every pass: a request under a condition leaves the registers undefined on the other path, which the register
+        // allocator answers with vector registers)
+        r1.request(tb + D);
+        r2.request(tb + 2 * D);
         double pos[3];
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
           double acc = 0.0;
 #pragma unroll
-          for (int col = 0; col < D; ++col) acc = __builtin_fma(ct[ax][col], tb[col], acc);
+          for (int col = 0; col < D; ++col) acc = __builtin_fma(ct[ax][col], t0[col], acc);
           pos[ax] = acc;
         }
         double Fs = 0.0, G[3] = {0.0, 0.0, 0.0};  // sum of F(u) and of F'(u) a/mu over the rows
@@ -352,13 +390,21 @@ __global__ void __launch_bounds__(256, SW > 1 ? ANET_PG_SW_MINB : ANET_PG_MINB) 
           // velocity / acceleration limits in units of mu, straight from the normalised-time sums a1 = sum c~ tab',
           // a2 = sum c~ tab'':  u = (|a1| / T - vmax) / mu = |a1| kv - cv  (one FMA, |.| is an operand modifier)
           double a1[3], a2[3], worst = 0.0;
+          r1.await();
+          r2.await();
+          double t1[D], t2[D];
+#pragma unroll
+          for (int col = 0; col < D; ++col) {
+            t1[col] = r1.v[col];
+            t2[col] = r2.v[col];
+          }
 #pragma unroll
           for (int ax = 0; ax < 3; ++ax) {
             double x1 = 0.0, x2 = 0.0;
 #pragma unroll
             for (int col = 0; col < D; ++col) {
-              x1 = __builtin_fma(ct[ax][col], tb[D + col], x1);
-              x2 = __builtin_fma(ct[ax][col], tb[2 * D + col], x2);
+              x1 = __builtin_fma(ct[ax][col], t1[col], x1);
+              x2 = __builtin_fma(ct[ax][col], t2[col], x2);
             }
             a1[ax] = x1;
             a2[ax] = x2;
@@ -379,7 +425,7 @@ __global__ void __launch_bounds__(256, SW > 1 ? ANET_PG_SW_MINB : ANET_PG_MINB) 
               // (the gradient of the limit rows goes into gN here, while s1 and s2 are at hand)
 #pragma unroll
               for (int col = 0; col < D; ++col)
-                gN[ax][col] = __builtin_fma(s2, tb[2 * D + col], __builtin_fma(s1, tb[D + col], gN[ax][col]));
+                gN[ax][col] = __builtin_fma(s2, t2[col], __builtin_fma(s1, t1[col], gN[ax][col]));
             }
           }
         }
@@ -389,9 +435,10 @@ __global__ void __launch_bounds__(256, SW > 1 ? ANET_PG_SW_MINB : ANET_PG_MINB) 
           for (int ax = 0; ax < 3; ++ax) {
             const double s0 = step * wcm * G[ax];
 #pragma unroll
-            for (int col = 0; col < D; ++col) gN[ax][col] = __builtin_fma(s0, tb[col], gN[ax][col]);
+            for (int col = 0; col < D; ++col) gN[ax][col] = __builtin_fma(s0, t0[col], gN[ax][col]);
           }
         }
+        nx.await();
       }
     }
     pc = step * csum;
