@@ -16,7 +16,7 @@ def main():
     from tools.bench_configs import synth, to_bm
     dev = torch.device("cuda", 0)
     ctx = aa.Context(0)
-    B, s, c, N, M = 1 << 17, 4, 3, 8, 16
+    B, s, c, N, M = int(os.environ.get("ANET_RUN_BATCH", str(1 << 17))), 4, 3, 8, 16   # ANET_RUN_BATCH: another batch size
     ld = aa.recommended_ld(B)
     head, tail, wps, T, hp = synth(np.random.default_rng(1), B, N, c, M)
     pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0,
