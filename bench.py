@@ -418,8 +418,9 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
                                          f"interior point in Hermite node coordinates (the algorithm of k_qp_ipm: per-sample weights, "
                                          f"banded Cholesky, Mehrotra) in scalar C, one problem per task, {nthreads} threads, "
                                          f"{pdt:.1f} s (oracle/qp_ipm_port.c)",
-                               "newton_steps_mean": float(po["iters"].mean()), "solved_frac": float((po["status"] == 1).mean()),
-                               "same_verdict_as_gpu_frac": float(((po["status"] == 1) == (gpu_status[idx] == 1)).mean()),
+                               "newton_steps_mean": float(po["iters"].mean()), "solved_frac": float((po["status"] >= 1).mean()),
+                               "solved_to_1e-7_only_frac": float((po["status"] == 2).mean()),
+                               "same_verdict_as_gpu_frac": float(((po["status"] >= 1) == (gpu_status[idx] == 1)).mean()),
                                "gpu_vs_cpu_max_rel_obj_err": float(prel.max()) if prel.size else None, "compared": int(both.sum()),
                                "dense_numpy": dense_numpy}
     return out

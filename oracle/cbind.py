@@ -82,7 +82,7 @@ def qp_ipm_batch(s, state, T, hpolys, res=20, vmax=4.0, amax=6.0, m34=1400.0, to
     """CPU port of the structured interior point (oracle/qp_ipm_port.c): the reference's inequality QP
     (qp_solver.hpp:119-358) in Hermite node coordinates, one problem per task.  state (B,2,3,3) [start/end][axis][p,v,a],
     T (B,N), hpolys (B,N,M,4) rows a.x <= b (zero rows = padding).  Returns dict(coeffs (B,N,3,2s) or None, obj, status
-    (1 solved, -2 not converged / infeasible), iters)."""
+    (1 solved to tol, 2 solved to 1e-7 only -- stalled at its rounding floor --, -2 not converged / infeasible), iters)."""
     state = np.ascontiguousarray(state, dtype=np.float64)
     T = np.ascontiguousarray(T, dtype=np.float64)
     hpolys = np.ascontiguousarray(hpolys, dtype=np.float64)

@@ -137,7 +137,9 @@ typedef struct {
 } qp_cfg;
 
 /* One problem.  state [2][3][3] (start / end, axis, p v a), T [N], hp [N][M][4] (rows a.x <= b, zero rows = padding).
- * coeffs (may be NULL) [N][3][D] highest power first.  Returns 1 solved, -2 iteration cap (infeasible or not converged), -1 failure. */
+ * coeffs (may be NULL) [N][3][D] highest power first.  Returns 1 solved to tol, 2 solved to 1e-7 only (stalled at the rounding floor of
+ * its Newton solve: a checker comparing optima to better than that must leave these out), -2 iteration cap (infeasible or not
+ * converged), -1 failure. */
 static int qp_ipm_one(const qp_cfg *cf, const double *state, const double *T, const double *hp, double *coeffs, double *obj_out,
                       int *iters_out) {
   const int s = cf->s, D = 2 * s, N = cf->N, R = cf->R, M = cf->M, BK = 3 * s, nv = (N + 1) * BK, bw = 2 * BK - 1;
@@ -401,7 +403,7 @@ static int qp_ipm_one(const qp_cfg *cf, const double *state, const double *T, co
       }
     }
   }
-  if (status == -2 && best <= 1e-7) status = 1; /* stalled at its rounding floor (oracle/qp_np.py accepts the same) */
+  if (status == -2 && best <= 1e-7) status = 2; /* stalled at its rounding floor above tol: solved, to 1e-7 only (oracle/qp_np.py accepts the same) */
   *obj_out = obj;
   *iters_out = it;
   free(X);
@@ -430,7 +432,7 @@ static void *qp_worker(void *arg) {
 }
 
 /* Batch driver, one problem per task, contiguous ranges per thread.  state [B][2][3][3], T [B][N], hpolys [B][N][M][4];
- * coeffs [B][N][3][2s] or NULL, obj [B], status [B] (1 solved, -2 not converged / infeasible, -1 failure), iters [B]. */
+ * coeffs [B][N][3][2s] or NULL, obj [B], status [B] (1 solved, 2 solved to 1e-7 only, -2 not converged / infeasible, -1 failure), iters [B]. */
 int oracle_qp_ipm_batch(int s, int N, int R, int M, int64_t B, const double *state, const double *T, const double *hpolys,
                         double vmax, double amax, double m34, double tol, int max_iter, double *coeffs, double *obj,
                         int *status, int *iters, int nthreads) {
