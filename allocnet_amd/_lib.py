@@ -74,6 +74,8 @@ PROTOTYPES = {
     "anet_qp_solve_workspace": (c_int64, [c_int, c_int, c_int64, c_int, c_int]),
     "anet_qp_solve_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double]
                           + [c_void_p] * 11),
+    "anet_qp_solve_ordered_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double]
+                                  + [c_void_p] * 12),
     "anet_qp_solve_time_grad": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double, c_double]
                                 + [c_void_p] * 10),
     "anet_qp_solve_time_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_double, c_double,
@@ -110,6 +112,7 @@ PROTOTYPES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "anet_launch_order_from_counts_dev": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anet_launch_order_from_steps_dev": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "anet_lbfgs_minco_ordered_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

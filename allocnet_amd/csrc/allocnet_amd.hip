@@ -397,13 +397,15 @@ static int lbfgs_drive(anet_ctx *ctx, LbfgsLayout &L, int64_t B, const anet_lbfg
 // Launch order for anet_lbfgs_minco_ordered_dev from the evaluation counts of a previous solve: a counting sort into 4096
 // buckets of 16 evaluations, longest first (the order inside a bucket is whatever the atomics make it: irrelevant here).
 constexpr int kOrderBuckets = 4096;
-__device__ __forceinline__ int order_bucket(int v) {
-  v = v < 0 ? 0 : (v > 65535 ? 65535 : v);
-  return kOrderBuckets - 1 - (v >> 4);  // descending
+// (shift 4: evaluation counts of an L-BFGS run, up to 65535; shift 0: Newton-step counts of the interior point, up to 4095)
+__device__ __forceinline__ int order_bucket(int v, int shift) {
+  const int top = (kOrderBuckets << shift) - 1;
+  v = v < 0 ? 0 : (v > top ? top : v);
+  return kOrderBuckets - 1 - (v >> shift);  // descending
 }
-__global__ void k_order_hist(const int *counts, int64_t B, int *hist) {
+__global__ void k_order_hist(const int *counts, int64_t B, int *hist, int shift) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b < B) atomicAdd(&hist[order_bucket(counts[b])], 1);
+  if (b < B) atomicAdd(&hist[order_bucket(counts[b], shift)], 1);
 }
 __global__ void __launch_bounds__(1024) k_order_scan(int *hist) {  // exclusive scan of the 4096 bucket sizes, one workgroup
   __shared__ int part[1024];
@@ -421,9 +423,9 @@ __global__ void __launch_bounds__(1024) k_order_scan(int *hist) {  // exclusive 
   int run = part[t] - sum;
   for (int q = 0; q < 4; ++q) { hist[4 * t + q] = run; run += v[q]; }
 }
-__global__ void k_order_scatter(const int *counts, int64_t B, int *hist, int *order) {
+__global__ void k_order_scatter(const int *counts, int64_t B, int *hist, int *order, int shift) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b < B) order[atomicAdd(&hist[order_bucket(counts[b])], 1)] = (int)b;
+  if (b < B) order[atomicAdd(&hist[order_bucket(counts[b], shift)], 1)] = (int)b;
 }
 
 // 1 where the durations of a trajectory spread over more than min_spread (max T > min_spread min T)
@@ -1425,8 +1427,8 @@ int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_l
          (int64_t)n * ld;
 }
 
-int anet_launch_order_from_counts_dev(anet_ctx *ctx, int64_t batch, const int32_t *counts, int32_t *launch_order,
-                                      int32_t *work, void *stream) {
+static int launch_order_impl(anet_ctx *ctx, int64_t batch, const int32_t *counts, int32_t *launch_order, int32_t *work,
+                             void *stream, int shift) {
   ANET_ON_DEVICE(ctx);
   if (batch < 0 || batch > 0x7fffffff) return fail(ctx, ANET_ERR_INVALID, "anet_launch_order_from_counts: bad batch");
   if (batch == 0) return ANET_OK;
@@ -1434,11 +1436,21 @@ int anet_launch_order_from_counts_dev(anet_ctx *ctx, int64_t batch, const int32_
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)((batch + 255) / 256)), block(256);
   ANET_HIP(ctx, hipMemsetAsync(work, 0, sizeof(int) * kOrderBuckets, st));
-  hipLaunchKernelGGL(k_order_hist, grid, block, 0, st, counts, batch, work);
+  hipLaunchKernelGGL(k_order_hist, grid, block, 0, st, counts, batch, work, shift);
   hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, st, work);
-  hipLaunchKernelGGL(k_order_scatter, grid, block, 0, st, counts, batch, work, launch_order);
+  hipLaunchKernelGGL(k_order_scatter, grid, block, 0, st, counts, batch, work, launch_order, shift);
   ANET_HIP(ctx, hipGetLastError());
   return ANET_OK;
+}
+
+int anet_launch_order_from_counts_dev(anet_ctx *ctx, int64_t batch, const int32_t *counts, int32_t *launch_order,
+                                      int32_t *work, void *stream) {
+  return launch_order_impl(ctx, batch, counts, launch_order, work, stream, 4);
+}
+
+int anet_launch_order_from_steps_dev(anet_ctx *ctx, int64_t batch, const int32_t *steps, int32_t *launch_order,
+                                     int32_t *work, void *stream) {
+  return launch_order_impl(ctx, batch, steps, launch_order, work, stream, 0);
 }
 
 int anet_minco_spread_flags_dev(anet_ctx *ctx, int n_pieces, int64_t batch, int64_t ld, const double *T, double min_spread,
@@ -1797,7 +1809,8 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
                              double max_acc, double m34, const double *state, const double *T,
                              const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
                              double *obj, int32_t *status, int32_t *iters, double *residuals, double *grad_T,
-                             void *stream, const double *grad_z = nullptr, double *vjp_T = nullptr) {
+                             void *stream, const double *grad_z = nullptr, double *vjp_T = nullptr,
+                             const int32_t *launch_order = nullptr) {
   ANET_ON_DEVICE(ctx);
   if (s != 3 && s != 4) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: order must be 3 (jerk) or 4 (snap)");
   if (n_pieces < 1 || batch < 0 || res < 1 || M < 0) return fail(ctx, ANET_ERR_INVALID, "anet_qp_solve: bad argument");
@@ -1826,7 +1839,7 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     if (grad_z && tol > 1e-9) tol = 1e-9;
     anet::IpmArgs ia{state, T, hpolys, work, work + mi * batch, coeffs, obj, status, iters,
                      residuals ? residuals : work + 2 * mi * batch, grad_T, grad_z, vjp_T, batch, n_pieces, res, M, max_vel,
-                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200, tol_plain > tol ? tol_plain : 0.0, 0.1 * tol, 0};
+                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200, tol_plain > tol ? tol_plain : 0.0, 0.1 * tol, 0, launch_order};
     static const int ipm_twist_min_pieces = [] {
       const char *e = getenv("ANET_IPM_TWIST_MIN_PIECES");
       return e ? atoi(e) : 2;
@@ -1911,6 +1924,14 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
                       double *obj, int32_t *status, int32_t *iters, double *residuals, void *stream) {
   return qp_solve_dev_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, state, T, hpolys, settings, work,
                            coeffs, obj, status, iters, residuals, nullptr, stream);
+}
+
+int anet_qp_solve_ordered_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                              double max_acc, double m34, const double *state, const double *T, const double *hpolys,
+                              const anet_qp_settings *settings, const int32_t *launch_order, double *work, double *coeffs,
+                              double *obj, int32_t *status, int32_t *iters, double *residuals, void *stream) {
+  return qp_solve_dev_impl(ctx, s, n_pieces, batch, res, M, max_vel, max_acc, m34, state, T, hpolys, settings, work,
+                           coeffs, obj, status, iters, residuals, nullptr, stream, nullptr, nullptr, launch_order);
 }
 
 int anet_qp_solve_time_grad_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,

@@ -55,6 +55,7 @@ struct IpmArgs {
   double tol_accept;  // >= tol: once met, at most 8 more Newton steps are spent on reaching tol (0: same as tol)
   double tol_tenth;      // 0.1 tol (a kernel argument: computed in the kernel it is a loop invariant parked in registers)
   int twist_min_pieces;  // chains of at least this many pieces are factored from both ends (two waves), shorter ones from one
+  const int *order;      // optional [B]: workgroup w takes problem order[w] (a permutation; longest-first from a previous solve)
 #ifdef ANET_IPM_PROF
   long long *prof;  // [16] cycle counters of problem 0 (tools: ANET_BUILD_FLAGS=-DANET_IPM_PROF)
 #endif
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   const int N = a.N, R = a.R, M = a.M;
   const int NS = N * R, RPS = M + 12;
   const int64_t mtot = (int64_t)NS * RPS;
-  const int64_t b = blockIdx.x;
+  const int64_t b = a.order ? (int64_t)a.order[blockIdx.x] : (int64_t)blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int NY = (N + 1) * BK;
 
@@ -349,12 +350,21 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   using RowsUpdate = std::integral_constant<bool, true>;
   // (wave part on the DPP path -- in-row scans and row broadcasts, ~20 VALU instructions -- where the __shfl_xor butterfly was
   //  twelve dependent ds_bpermute round trips per reduction, ten reductions per Newton step)
-  auto block_reduce = [&](double v, int slot, bool is_min) {  // red[slot] must have been initialised before a barrier
+  // Sums are DETERMINISTIC: each wave stores its partial sum in a slot of its own (red[16 + 4 k + wave] for the four sums of a
+  // step, k = sum_index(slot)) and red_sum() adds the four in a fixed order -- with atomicAdd the order of the waves' additions,
+  // i.e. the last bit of mu, changed from launch to launch (and with the order in which workgroups are started).  A maximum is
+  // exact in any order.
+  auto sum_index = [](int slot) { return slot == 0 ? 0 : (slot == 4 ? 1 : (slot == 5 ? 2 : 3)); };  // slots 0, 4, 5, 10
+  auto block_reduce = [&](double v, int slot, bool is_min) {  // red[] must have been zeroed before a barrier
     v = is_min ? wave_min_f64(v) : wave_sum<63>(v);
     if ((tid & 63) == 0) {
       if (is_min) atomic_max_pos(&red[slot], 1.0 / fmax(v, 1e-300));  // min of positives via max of reciprocals
-      else atomicAdd(&red[slot], v);
+      else red[16 + 4 * sum_index(slot) + (tid >> 6)] = v;
     }
+  };
+  auto red_sum = [&](int slot) {
+    const double *p4 = red + 16 + 4 * sum_index(slot);
+    return (p4[0] + p4[1]) + (p4[2] + p4[3]);
   };
 
   // ---- initial slacks / multipliers.  The multipliers start at the scale of the cost gradient of the first iterate, lambda_0 =
@@ -410,7 +420,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   __syncthreads();
   block_reduce((double)nrows_local, 0, false);
   __syncthreads();
-  const double mrows = uni(fmax(red[0], 1.0));
+  const double mrows = uni(fmax(red_sum(0), 1.0));
   __syncthreads();
 
   // assemble the node-space vector  out_k = sum over the pieces touching knot k of sc * (qs Hobj u + sum_j gamma_j h_j)
@@ -886,7 +896,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       __syncthreads();
     }
     IPM_TICK(1);
-    mu = uni(red[0] / mrows);
+    mu = uni(red_sum(0) / mrows);
     if (it == 0) mu0 = mu;
     pres = uni(red[1] / fmax(1.0, red[2]));
     __syncthreads();
@@ -900,7 +910,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     IPM_TICK(5);
     dres = uni(red[8] / fmax(1.0, red[9]));
-    const double objn = uni(red[10]);
+    const double objn = uni(red_sum(10));
     // (the duality gap is mu * rows: that, not mu, is what bounds the distance of the objective from the optimum)
     if (pres < a.tol && dres < a.tol && mu * mrows < a.tol * fmax(1.0, 0.5 * fabs(objn))) { status = 1; break; }
     // The backward pass asks for three digits more than a plain solve; a few percent of the problems stall above that
@@ -989,7 +999,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     __syncthreads();
     IPM_TICK(7);
     const double a_aff = fmin(1.0, red[3] > 0.0 ? 1.0 / red[3] : 1.0);
-    const double mu_aff = uni((mu * mrows + a_aff * red[4] + a_aff * a_aff * red[5]) / mrows);
+    const double mu_aff = uni((mu * mrows + a_aff * red_sum(4) + a_aff * a_aff * red_sum(5)) / mrows);
     double sigma = mu_aff / mu;
     sigma = sigma * sigma * sigma;
     // Centring target sigma mu, but never below a tenth of the complementarity the stopping test asks for: a problem that

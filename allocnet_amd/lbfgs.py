@@ -119,9 +119,10 @@ def launch_order_from_counts(evals):
     return torch.argsort(evals, descending=True, stable=True).to(torch.int32).contiguous()
 
 
-def launch_order_from_counts_dev(evals, stream=None, ctx=None):
+def launch_order_from_counts_dev(evals, stream=None, ctx=None, fine=False):
     """The same through the library's own counting sort (anet_launch_order_from_counts_dev: what a C / C++ caller uses;
-    buckets of 16 evaluations, order inside a bucket unspecified)."""
+    buckets of 16 evaluations, order inside a bucket unspecified).  fine=True: buckets of one (anet_launch_order_from_steps_dev),
+    for the Newton-step counts of `qp_solve_dev`."""
     import torch
     ctx = ctx or default_context(evals.device.index or 0)
     if not (evals.is_cuda and evals.dtype == torch.int32 and evals.is_contiguous() and evals.dim() == 1):
@@ -129,7 +130,8 @@ def launch_order_from_counts_dev(evals, stream=None, ctx=None):
     order = torch.empty_like(evals)
     work = torch.empty(4096, device=evals.device, dtype=torch.int32)
     st = stream if stream is not None else torch.cuda.current_stream(evals.device).cuda_stream
-    ctx.check(ctx.lib.anet_launch_order_from_counts_dev(ctx.handle, evals.numel(), ctypes.c_void_p(evals.data_ptr()),
+    fn = ctx.lib.anet_launch_order_from_steps_dev if fine else ctx.lib.anet_launch_order_from_counts_dev
+    ctx.check(fn(ctx.handle, evals.numel(), ctypes.c_void_p(evals.data_ptr()),
                                                         ctypes.c_void_p(order.data_ptr()), ctypes.c_void_p(work.data_ptr()),
                                                         ctypes.c_void_p(st)))
     return order

@@ -165,11 +165,14 @@ def _qp_dev_common(order, state, times, hPolys, res, ctx):
 
 
 def qp_solve_dev(order, state, times, hPolys, res=20, max_vel=4.0, max_acc=6.0, m34=1400.0, settings=None, time_grad=False,
-                 stream=None, ctx=None):
+                 stream=None, ctx=None, launch_order=None):
     """anet_qp_solve[_time_grad]_dev: the batched QPSolver::solve with torch CUDA tensors in and out, nothing through the
     host, asynchronous on `stream` (default: torch's current stream).  state (B,2,3,3) = [start PVA, end PVA] (row = axis,
     columns p, v, a), times (B,N), hPolys (B,N,M,4) rows a.x <= b with zero rows as padding.  Returns the dict of
-    `qp_solve` as device tensors (grad_T (B,N) with time_grad=True)."""
+    `qp_solve` as device tensors (grad_T (B,N) with time_grad=True).
+    launch_order: optional int32 CUDA tensor (B,), a permutation -- the problem each successive workgroup of the interior-point
+    kernel takes (`launch_order_from_counts(previous["iters"])` when re-solving a similar batch: anet_qp_solve_ordered_dev);
+    results do not depend on it."""
     import torch
     ctx = ctx or default_context(times.device.index or 0)
     B, N, M, work, out = _qp_dev_common(order, state, times, hPolys, res, ctx)
@@ -178,7 +181,14 @@ def qp_solve_dev(order, state, times, hPolys, res=20, max_vel=4.0, max_acc=6.0, 
     q = lambda t: ctypes.c_void_p(t.data_ptr())
     args = (ctx.handle, int(order), N, B, int(res), M, float(max_vel), float(max_acc), float(m34), q(state), q(times), q(hPolys),
             sp, q(work), q(out["coeffs"]), q(out["obj"]), q(out["status"]), q(out["iters"]), q(out["residuals"]))
-    if time_grad:
+    if launch_order is not None:
+        if time_grad:
+            raise ValueError("launch_order: the plain solve only")
+        if not (launch_order.is_cuda and launch_order.dtype == torch.int32 and launch_order.is_contiguous() and
+                launch_order.shape == (B,)):
+            raise ValueError("launch_order: contiguous int32 CUDA tensor of shape (B,)")
+        ctx.check(ctx.lib.anet_qp_solve_ordered_dev(*args[:13], q(launch_order), *args[13:], ctypes.c_void_p(st)))
+    elif time_grad:
         out["grad_T"] = torch.empty((B, N), device=times.device, dtype=torch.float64)
         ctx.check(ctx.lib.anet_qp_solve_time_grad_dev(*args, q(out["grad_T"]), ctypes.c_void_p(st)))
     else:

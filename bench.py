@@ -335,6 +335,24 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
                                  "flops_counted": "analytic per Newton step (bench.qp_newton_step_flops) x the steps taken",
                                  "note": "latency-bound: block-Cholesky chains and row passes of one 256-thread workgroup per "
                                          "problem, two problems per CU (LDS); nowhere near a throughput roofline"}}
+        # the same batch with a launch order (anet_qp_solve_ordered_dev: a re-solve of the same / a similar batch): longest first by
+        # this batch's own step counts, and by the counts of a PERTURBED copy (durations x U(0.97, 1.03)) -- what a receding-horizon
+        # re-solve has.  Beside the as-given number, never instead of it.
+        def timed_order(order):
+            aa.qp_solve_dev(s, st, tT, thp, ctx=ctx, launch_order=order)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(K):
+                aa.qp_solve_dev(s, st, tT, thp, ctx=ctx, launch_order=order)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / K
+        own = aa.launch_order_from_counts(r["iters"])
+        tTp = tT * torch.from_numpy(np.random.default_rng(9).uniform(0.97, 1.03, size=T.shape)).to(device)
+        rp = aa.qp_solve_dev(s, st, tTp, thp, ctx=ctx)
+        out[key]["with_launch_order"] = {"own_counts_ms": timed_order(own),
+                                         "perturbed_copy_counts_ms": timed_order(aa.launch_order_from_counts(rp["iters"])),
+                                         "note": "longest first (anet_qp_solve_ordered_dev); results bit-identical; the re-solve case"}
         if key == "snap8":
             out[key]["gpu_obj"] = r["obj"].cpu().numpy()
             out[key]["gpu_status"] = r["status"].cpu().numpy()

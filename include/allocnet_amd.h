@@ -342,6 +342,17 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
                       const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
                       double *obj, int32_t *status, int32_t *iters, double *residuals, void *stream);
 
+/* The same with a launch order for the interior-point method (one workgroup per problem, 512 resident at a time: a batch ends
+ * with whichever long problem started late -- 27 % above its balanced figure for 4096 problems): launch_order
+ * (device, int32 [batch], a permutation of 0..batch-1) is the problem each successive workgroup takes; longest first from the
+ * iters[] of a previous solve of the same or a similar batch (anet_launch_order_from_steps_dev) -- the re-solve of a receding-
+ * horizon planner or a sampler.  Results are bit-identical for any order; NULL = as given; the ADMM method ignores it.
+ * No reference counterpart (QPSolver::solve takes one problem: qp_solver.hpp:119).                                        */
+int anet_qp_solve_ordered_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
+                              double max_acc, double m34, const double *state, const double *T, const double *hpolys,
+                              const anet_qp_settings *settings, const int32_t *launch_order, double *work, double *coeffs,
+                              double *obj, int32_t *status, int32_t *iters, double *residuals, void *stream);
+
 /* The same solve plus grad_T [batch][N] = d(obj)/dT_i, the derivative of the OPTIMAL cost 1/2 z*'Q z*
  * with respect to the segment durations -- the "time-allocation gradient" the reference's training loop
  * is after (network/layers.py:120-147 installs a -J^-1 grad KKT hook for it, a dense (n+m)^2 solve per
@@ -538,6 +549,9 @@ int anet_set_cancel_flag(anet_ctx *ctx, const int32_t *flag);
 #define ANET_LAUNCH_ORDER_WORK_INTS 4096
 int anet_launch_order_from_counts_dev(anet_ctx *ctx, int64_t batch, const int32_t *counts, int32_t *launch_order,
                                       int32_t *work, void *stream);
+/* The same in buckets of ONE: for the Newton-step counts iters[] of anet_qp_solve_dev (-> anet_qp_solve_ordered_dev). */
+int anet_launch_order_from_steps_dev(anet_ctx *ctx, int64_t batch, const int32_t *steps, int32_t *launch_order,
+                                     int32_t *work, void *stream);
 
 /* ---- corridor generation: batched FIRI ------------------------------------ */
 /* firi::firi + firi::maxVolInsEllipsoid (gcopter/firi.hpp:159-416), the inner step of

@@ -671,3 +671,34 @@ def test_randomised_soak_against_the_c_port(anet_ctx):
     # the port gives up on some badly scaled problems the kernel (and the dense oracle: tests/soak/qp_disagree.py) solves; the other
     # direction -- a problem the CPU solves and the kernel does not -- is the one that must not happen
     assert port_only <= 0.001 * total and gpu_only <= 0.05 * total, (port_only, gpu_only, total)
+
+
+def test_launch_order_changes_nothing_but_the_schedule(anet_ctx):
+    """anet_qp_solve_ordered_dev: workgroup w takes problem order[w].  Any permutation -- longest first from the step counts of a
+    previous solve (torch's sort and the library's own counting sort in buckets of one step), reversed, random -- returns the
+    bit-identical solution, verdict and step count of every problem; the library's order is a permutation, longest first."""
+    import torch
+    import allocnet_amd as aa
+    from allocnet_amd.synth import corridor_problem
+    dev = torch.device("cuda", 0)
+    for (s, N, B) in ((4, 8, 1500), (3, 5, 700), (4, 1, 64)):
+        head, tail, wps, T, hp = corridor_problem(np.random.default_rng(3), B, N, 3, 16)
+        state = np.ascontiguousarray(np.stack([head, tail], axis=1)[..., :3])
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        st, tT, thp = t(state), t(T * 1.5), t(hp)
+        ref = aa.qp_solve_dev(s, st, tT, thp, ctx=anet_ctx)
+        torch.cuda.synchronize()
+        lib_order = aa.lbfgs.launch_order_from_counts_dev(ref["iters"], ctx=anet_ctx, fine=True)
+        lo = lib_order.cpu().numpy()
+        assert np.array_equal(np.sort(lo), np.arange(B))
+        it = ref["iters"].cpu().numpy()
+        assert (np.diff(it[lo]) <= 0).all()
+        orders = [aa.launch_order_from_counts(ref["iters"]), lib_order, torch.flip(lib_order, dims=[0]).contiguous(),
+                  torch.from_numpy(np.random.default_rng(5).permutation(B).astype(np.int32)).to(dev)]
+        for order in orders:
+            out = aa.qp_solve_dev(s, st, tT, thp, ctx=anet_ctx, launch_order=order)
+            torch.cuda.synchronize()
+            for k in ("coeffs", "obj", "status", "iters"):
+                assert torch.equal(out[k], ref[k]), (s, N, k)
+    with pytest.raises(ValueError):
+        aa.qp_solve_dev(4, st, tT, thp, ctx=anet_ctx, launch_order=torch.zeros(3, dtype=torch.int32, device=dev))
