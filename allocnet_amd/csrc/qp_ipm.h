@@ -1177,11 +1177,15 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       }
       dyc[e] = v;
     }
+    // (sums over samples and pieces below: every term is stored where its thread owns the slot and added up in index order by one
+    //  thread per piece -- no atomics, the gradient is the same bit for bit from launch to launch)
     for (int i = fresh_tid(); i < 3 * N; i += nt) rhs[i] = 0.0;
     for (int smp = fresh_tid(); smp < NS; smp += nt) {
       double *as = acc + (size_t)smp * AS + 12;
 #pragma unroll
       for (int q = 0; q < 9; ++q) as[q] = 0.0;
+      as[-12] = 0.0;  // slots 0 / 1 of the record (weights, consumed by the assembly above): this sample's sums of d_lambda
+      as[-11] = 0.0;  //   over its velocity / acceleration rows
     }
     __syncthreads();
     // Method of multipliers on  min 1/2 d'P d + g_y.d  s.t.  g_r.d = 0 (touched rows):  (P + w Ga'Ga) d_k = -g_y - Ga'nu_k,
@@ -1214,11 +1218,21 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         double *as = acc + (size_t)smp * AS + 12;
 #pragma unroll
         for (int q = 0; q < 9; ++q) as[q] += G_[q];
-        atomicAdd(&rhs[N + i], bsv);
-        atomicAdd(&rhs[2 * N + i], bsa);
+        as[-12] += bsv;
+        as[-11] += bsa;
       }
       __syncthreads();
     }
+    for (int i = fresh_tid(); i < N; i += nt) {
+      double sv = 0.0, sa = 0.0;
+      for (int j = 0; j < R; ++j) {
+        sv += acc[(size_t)(i * R + j) * AS];
+        sa += acc[(size_t)(i * R + j) * AS + 1];
+      }
+      rhs[N + i] = sv;
+      rhs[2 * N + i] = sa;
+    }
+    double *cA = Dg, *cB = Dg + (size_t)N * NB;  // per-entry terms of piece i / of its right neighbour (the factors are done with)
     for (int e = fresh_tid(); e < N * NB; e += nt) {
       const int i = e / NB, ax = (e % NB) / D, m = e % D, d = m % S;
       const double *ui = uu + (size_t)i * NB + ax * D, *vi = dua + (size_t)i * NB + ax * D;
@@ -1234,7 +1248,8 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         for (int m2 = 0; m2 < D; ++m2) cc += Hm[col * D + m2] * ui[m2];
         t -= (double)k * cc * pow(Tn[i], (double)(-k)) * gz[(size_t)i * NB + ax * D + col] / Tn[i];
       }
-      atomicAdd(&rhs[i], t);
+      cA[e] = t;
+      cB[e] = 0.0;
       if (d == 0) continue;
       double g = qsv[i] * hu, dg = qsv[i] * hv;
       for (int j = 0; j < R; ++j) {
@@ -1246,18 +1261,23 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       const double c = (dg * ui[m] + g * vi[m] + duc[e] * ui[m]) * (double)d;
       if (m >= S) {
         if (i < N - 1) {
-          atomicAdd(&rhs[i], c / Tn[i]);
-          atomicAdd(&rhs[i + 1], -c / Tn[i + 1]);
+          cA[e] = t + c / Tn[i];
+          cB[e] = -c / Tn[i + 1];
         } else if (d < 3) {
-          atomicAdd(&rhs[i], c / Tn[i]);
+          cA[e] = t + c / Tn[i];
         }
       } else if (i == 0 && d < 3) {
-        atomicAdd(&rhs[0], c / Tn[0]);
+        cA[e] = t + c / Tn[0];
       }
     }
     __syncthreads();
-    for (int i = fresh_tid(); i < N; i += nt)
-      a.vjpT[b * N + i] = rhs[i] - (a.vmax * rhs[N + i] + 2.0 * a.amax * Tn[i] * rhs[2 * N + i]);
+    for (int i = fresh_tid(); i < N; i += nt) {
+      double r = 0.0;
+      for (int q = 0; q < NB; ++q) r += cA[i * NB + q];
+      if (i > 0)
+        for (int q = 0; q < NB; ++q) r += cB[(i - 1) * NB + q];
+      a.vjpT[b * N + i] = r - (a.vmax * rhs[N + i] + 2.0 * a.amax * Tn[i] * rhs[2 * N + i]);
+    }
     __syncthreads();
   }
   // ---- time gradient of the optimal cost (anet_qp_solve_time_grad): envelope theorem in these coordinates ----
@@ -1266,14 +1286,15 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   // y_N[d] = fin_d T_N-1^d, and the box bounds vmax T_i, amax T_i^2.  (acc[21..29] holds G'lambda per sample
   // for the iterate the loop stopped at.)
   if (a.gradT) {
-    for (int i = fresh_tid(); i < N; i += nt) rhs[i] = 0.0;
-    __syncthreads();
+    double *cA = Dg, *cB = Dg + (size_t)N * NB;  // as in the backward pass: terms stored per entry, added up in index order
     for (int e = fresh_tid(); e < N * NB; e += nt) {
       const int i = e / NB, ax = (e % NB) / D, m = e % D, d = m % S;
       const double *ui = uu + (size_t)i * NB + ax * D;
       double hu = 0.0;
       for (int m2 = 0; m2 < D; ++m2) hu += Hobj[m * D + m2] * ui[m2];
-      atomicAdd(&rhs[i], (double)(1 - 2 * S) * 0.5 * qsv[i] * ui[m] * hu / Tn[i]);  // (1-2s) J_i / T_i
+      const double t = (double)(1 - 2 * S) * 0.5 * qsv[i] * ui[m] * hu / Tn[i];  // (1-2s) J_i / T_i
+      cA[e] = t;
+      cB[e] = 0.0;
       if (d == 0) continue;
       double g = qsv[i] * hu;
       for (int j = 0; j < R; ++j) {
@@ -1284,13 +1305,13 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       const double c = g * ui[m] * (double)d;
       if (m >= S) {
         if (i < N - 1) {
-          atomicAdd(&rhs[i], c / Tn[i]);
-          atomicAdd(&rhs[i + 1], -c / Tn[i + 1]);
+          cA[e] = t + c / Tn[i];
+          cB[e] = -c / Tn[i + 1];
         } else if (d < 3) {
-          atomicAdd(&rhs[i], c / Tn[i]);
+          cA[e] = t + c / Tn[i];
         }
       } else if (i == 0 && d < 3) {
-        atomicAdd(&rhs[0], c / Tn[0]);
+        cA[e] = t + c / Tn[0];
       }
     }
     for (int smp = fresh_tid(); smp < NS; smp += nt) {
@@ -1301,10 +1322,17 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
         if ((qq % 4) & 1) sa += lm;
         else sv += lm;
       }
-      atomicAdd(&rhs[i], -(a.vmax * sv + 2.0 * a.amax * Tn[i] * sa));
+      acc[(size_t)smp * AS + 30] = -(a.vmax * sv + 2.0 * a.amax * Tn[i] * sa);  // (the record's spare slot)
     }
     __syncthreads();
-    for (int i = fresh_tid(); i < N; i += nt) a.gradT[b * N + i] = rhs[i];
+    for (int i = fresh_tid(); i < N; i += nt) {
+      double r = 0.0;
+      for (int q = 0; q < NB; ++q) r += cA[i * NB + q];
+      if (i > 0)
+        for (int q = 0; q < NB; ++q) r += cB[(i - 1) * NB + q];
+      for (int j = 0; j < R; ++j) r += acc[(size_t)(i * R + j) * AS + 30];
+      a.gradT[b * N + i] = r;
+    }
     __syncthreads();
   }
   // ---- report: coefficients c = Hm u / T^k, objective in original units ---------------------------------
