@@ -59,6 +59,15 @@ struct anet_ctx {
     hipEvent_t ready;
   };
   std::vector<BasisTable> tabs;
+  // tables of k_qp_ipm, one per (order, res, m34) ever used (csrc/qp_ipm.h k_qp_ipm_tables): same lifetime rules
+  struct IpmTable {
+    int s, res;
+    double m34;
+    double *d;
+    hipStream_t built_on;
+    hipEvent_t ready;
+  };
+  std::vector<IpmTable> ipm_tabs;
 };
 
 namespace {
@@ -493,6 +502,10 @@ void anet_destroy(anet_ctx *ctx) {
   if (ctx->comm) (void)anet_comm_destroy(ctx);
   if (ctx->d_counter) (void)hipFree(ctx->d_counter);
   for (auto &t : ctx->tabs) {
+    if (t.d) (void)hipFree(t.d);
+    if (t.ready) (void)hipEventDestroy(t.ready);
+  }
+  for (auto &t : ctx->ipm_tabs) {
     if (t.d) (void)hipFree(t.d);
     if (t.ready) (void)hipEventDestroy(t.ready);
   }
@@ -1802,7 +1815,32 @@ void anet_qp_default_settings(anet_qp_settings *s) {
 
 int64_t anet_qp_solve_workspace(int s, int n_pieces, int64_t batch, int res, int M) {
   const int64_t m = 3 * (6 + (int64_t)s * (n_pieces - 1)) + (int64_t)n_pieces * res * (M + 12);
-  return 2 * m * batch + 2 * batch;  // z, y, residuals
+  // z, y, residuals; then (interior point, two-launch form) the parked state of every problem, its score and the launch order of
+  // the second part (int32 each) and the 4096 bins of the counting sort
+  const int64_t cont = (int64_t)3 * s * (n_pieces + 1) + anet::kIpmContScalars;
+  return 2 * m * batch + 2 * batch + cont * batch + batch + 4096 / 2 + 8;
+}
+
+// Second part of a two-launch interior-point solve: what order its workgroups take the problems in.  Score of a parked problem,
+// larger = expected to take longer (tools/qp_split_features.py: the parked scalars of 3 x 4096 problems against the steps they still
+// needed).  The problems a batch waits for -- the infeasible ones, told at step 30..50, and the hard feasible ones -- stand out
+// after four steps already: their PRIMAL residual is still above 2e-4 (1e-3..4e-2 against <= 5e-5 for the rest) and their steps
+// are short; they go first, by residual.  Behind them the rest by the decades their complementarity stands above the tolerance
+// (Spearman 0.75..0.94 with the steps left: an interior point gains a fixed number of digits per step at the end).  Problems
+// decided in the first part score 0 and come last (their workgroups leave at once).
+__global__ void k_qp_resume_score(const int *status, const double *cont, int64_t B, int ny, double tol, int *score) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  int sc = 0;
+  if (status[b] == 0) {
+    const double *c = cont + b * (int64_t)(ny + anet::kIpmContScalars) + ny;
+    const double pres = c[8], gap = c[10];
+    double v = 200.0 + 100.0 * log10(fmax(gap / tol, 1.0));
+    if (!(pres <= 2e-4)) v = 2000.0 + 100.0 * log10(fmax(pres / 2e-4, 1.0));
+    if (!(v == v)) v = 4000.0;
+    sc = (int)fmin(fmax(v, 1.0), 4000.0);
+  }
+  score[b] = sc;
 }
 
 static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
@@ -1839,13 +1877,35 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     if (grad_z && tol > 1e-9) tol = 1e-9;
     anet::IpmArgs ia{state, T, hpolys, work, work + mi * batch, coeffs, obj, status, iters,
                      residuals ? residuals : work + 2 * mi * batch, grad_T, grad_z, vjp_T, batch, n_pieces, res, M, max_vel,
-                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200, tol_plain > tol ? tol_plain : 0.0, 0.1 * tol, 0, launch_order};
+                     max_acc, m34, tol, st_.max_iter < 200 ? st_.max_iter : 200, tol_plain > tol ? tol_plain : 0.0, 0.1 * tol, 0, launch_order, 0, 0, nullptr, nullptr};
     static const int ipm_twist_min_pieces = [] {
       const char *e = getenv("ANET_IPM_TWIST_MIN_PIECES");
       return e ? atoi(e) : 2;
     }();
     ia.twist_min_pieces = ipm_twist_min_pieces;
     hipStream_t sti = (hipStream_t)stream;
+    {  // the tables of (order, res, m34): built once, on the stream that first needs them
+      const double *tab = nullptr;
+      for (auto &tb : ctx->ipm_tabs)
+        if (tb.s == s && tb.res == res && tb.m34 == m34) {
+          if (tb.built_on != sti) ANET_HIP(ctx, hipStreamWaitEvent(sti, tb.ready, 0));
+          tab = tb.d;
+        }
+      if (!tab) {
+        anet_ctx::IpmTable tb{s, res, m34, nullptr, sti, nullptr};
+        const size_t need = (size_t)2 * (2 * s) * (2 * s) + (size_t)res * anet::ipm_ht_stride(2 * s);
+        ANET_HIP(ctx, hipMalloc((void **)&tb.d, sizeof(double) * need));
+        ANET_HIP(ctx, hipMemsetAsync(tb.d, 0, sizeof(double) * need, sti));
+        ANET_HIP(ctx, hipEventCreateWithFlags(&tb.ready, hipEventDisableTiming));
+        if (s == 4) hipLaunchKernelGGL(anet::k_qp_ipm_tables<4>, dim3(1), dim3(256), 0, sti, tb.d, res, m34);
+        else hipLaunchKernelGGL(anet::k_qp_ipm_tables<3>, dim3(1), dim3(256), 0, sti, tb.d, res, m34);
+        ANET_HIP(ctx, hipGetLastError());
+        ANET_HIP(ctx, hipEventRecord(tb.ready, sti));
+        ctx->ipm_tabs.push_back(tb);
+        tab = tb.d;
+      }
+      ia.tab = tab;
+    }
 #ifdef ANET_IPM_PROF
     static long long *d_iprof = nullptr;
     if (!d_iprof) ANET_HIP(ctx, hipMalloc((void **)&d_iprof, 16 * sizeof(long long)));
@@ -1856,8 +1916,8 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
       ~ProfDump() {
         long long h[16];
         if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
-        fprintf(stderr, "ipm_prof cycles (problem 0): setup %lld | passA %lld resid %lld assemble %lld rhs %lld factor %lld solve1 %lld passB %lld passC %lld rhs2 %lld solve2 %lld passD %lld passE %lld\n",
-                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12]);
+        fprintf(stderr, "ipm_prof cycles (problem 0): setup %lld | passA %lld resid %lld assemble %lld rhs %lld factor %lld solve1 %lld passB %lld passC %lld rhs2 %lld solve2 %lld passD %lld passE %lld | before the loop (tables, first iterate) %lld\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12], h[13]);
       }
     } prof_dump{ctx, d_iprof, sti};
 #endif
@@ -1876,6 +1936,33 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
       return ANET_OK;
     };
     int rc_l;
+    // Large batches in TWO launches (qp_ipm.h, IpmArgs::it_stop): the first takes every problem through the same number of Newton
+    // steps -- no tail: all workgroups are equally long --, the second resumes the unfinished ones longest-expected first.  A batch
+    // of 4096 in one launch ends 27 % above its balanced figure because its 30..50-step problems start whenever their turn comes.
+    static const int ipm_split_steps = [] { const char *e = getenv("ANET_IPM_SPLIT_STEPS"); return e ? atoi(e) : 4; }();
+    static const int64_t ipm_split_min_batch = [] { const char *e = getenv("ANET_IPM_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)1536; }();
+    if (two_per_cu && ipm_split_steps > 0 && batch >= ipm_split_min_batch && !grad_z && !launch_order && ia.max_iter > ipm_split_steps) {
+      const int ny = 3 * s * (n_pieces + 1);
+      const int64_t m_adm = 3 * (6 + (int64_t)s * (n_pieces - 1)) + mi;
+      double *cont = work + 2 * m_adm * batch + 2 * batch;
+      int32_t *score = (int32_t *)(cont + (int64_t)(ny + anet::kIpmContScalars) * batch);
+      int32_t *order2 = score + batch + (batch & 1);
+      int32_t *bins = order2 + batch + (batch & 1);
+      ia.cont = cont;
+      ia.it_stop = ipm_split_steps;
+      rc_l = s == 4 ? launch_ipm(anet::k_qp_ipm<4, 2, false>) : launch_ipm(anet::k_qp_ipm<3, 1, false>);
+      if (rc_l != ANET_OK) return rc_l;
+      hipLaunchKernelGGL(k_qp_resume_score, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, sti, status, cont, batch, ny, tol, score);
+      rc_l = launch_order_impl(ctx, batch, score, order2, bins, sti, 0);
+      if (rc_l != ANET_OK) return rc_l;
+      ia.it_stop = 0;
+      ia.resume = 1;
+      ia.order = order2;
+      rc_l = s == 4 ? launch_ipm(anet::k_qp_ipm<4, 2, false>) : launch_ipm(anet::k_qp_ipm<3, 1, false>);
+      if (rc_l != ANET_OK) return rc_l;
+      ANET_HIP(ctx, hipGetLastError());
+      return ANET_OK;
+    }
     // Shapes that put two workgroups on a CU visit the rows once more per step instead of carrying the next step's sums
     // through the updating pass (registers: qp_ipm.h FUSE); a lone problem, a small batch or a problem whose LDS fills the
     // CU takes the fused form.  (jerk: the unbounded instantiation needs <= 256 registers as it is -- two workgroups per CU

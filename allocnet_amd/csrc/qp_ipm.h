@@ -56,6 +56,14 @@ struct IpmArgs {
   double tol_tenth;      // 0.1 tol (a kernel argument: computed in the kernel it is a loop invariant parked in registers)
   int twist_min_pieces;  // chains of at least this many pieces are factored from both ends (two waves), shorter ones from one
   const int *order;      // optional [B]: workgroup w takes problem order[w] (a permutation; longest-first from a previous solve)
+  // A solve in TWO launches (large batches; qp_solve_dev_impl): the first stops every problem after it_stop Newton steps and
+  // parks what the iteration carries -- node states and a dozen scalars; slacks and multipliers are in global memory anyway --
+  // in cont [B][NY + kIpmContScalars]; the second (resume = 1) picks the unfinished ones up, LONGEST EXPECTED FIRST (order from
+  // the parked residuals).  The first launch is perfectly balanced (every problem takes the same number of steps), the second
+  // starts its long problems early: the batch no longer ends with a long problem that happened to start late.
+  int it_stop, resume;
+  double *cont;
+  const double *tab;     // k_qp_ipm_tables' output for (order, R, m34)
 #ifdef ANET_IPM_PROF
   long long *prof;  // [16] cycle counters of problem 0 (tools: ANET_BUILD_FLAGS=-DANET_IPM_PROF)
 #endif
@@ -104,6 +112,7 @@ struct IpmBoxRow {
 // padding each spreads them over 32.
 __host__ __device__ constexpr int ipm_ht_stride(int D) { return 3 * D + 1; }
 constexpr int kIpmRecord = 31;  // 30 sums per sample + 1 pad
+constexpr int kIpmContScalars = 16;  // scalars parked behind the node states of a stopped problem (IpmArgs::cont)
 
 template <int S>
 inline size_t qp_ipm_lds_bytes(int N, int R, int M) {
@@ -113,59 +122,18 @@ inline size_t qp_ipm_lds_bytes(int N, int R, int M) {
                            (size_t)R * ipm_ht_stride(D) + 2 * D * D + (size_t)N * D + NS * kIpmRecord + (size_t)N * M * 4 + 2 * N + 32);
 }
 
-// MINB: workgroups per CU the register allocation is bounded for.  The snap kernel needs more than 256 registers to run
-// without spills (one workgroup per CU); bounded to 256 (92 B of scratch) two share a CU, which pays for large batches
-// (4096 x 8 pieces 24.7 -> 18.8 ms) and costs a single problem a quarter of its latency (0.82 -> 1.02 ms): the host picks.
-// FUSE: the updating pass of a step also forms the per-sample sums of the NEXT step (one row pass fewer, 6 % of a lone
-// problem's latency) -- at the price of registers: with two workgroups per CU it spills, so the throughput shapes visit the rows again.
-template <int S, int MINB = 1, bool FUSE = (MINB == 1)>
-__global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
-  constexpr int D = 2 * S, NB = 3 * D, BK = 3 * S;
-  constexpr int HS = ipm_ht_stride(D), AS = kIpmRecord;  // padded strides of the basis table rows / per-sample records
-  const int N = a.N, R = a.R, M = a.M;
-  const int NS = N * R, RPS = M + 12;
-  const int64_t mtot = (int64_t)NS * RPS;
-  const int64_t b = a.order ? (int64_t)a.order[blockIdx.x] : (int64_t)blockIdx.x;
+// The tables of k_qp_ipm that depend on (order, samples per piece, m34) only -- Hm = inverse of the Hermite collocation matrix
+// (Gauss-Jordan on ONE thread), the basis rows ht at tau_j, the cost block Hobj in Hermite coordinates -- built ONCE per context
+// and (order, res, m34) by this one-workgroup kernel and copied into LDS by every solve (0.7 of a Newton step of every workgroup
+// went into rebuilding them: 98 k of the lone 8-piece problem's 1.55 M cycles).  Layout: Hm [D][D] | Hobj [D][D] | ht [R][3 D + 1].
+template <int S>
+__global__ void __launch_bounds__(256) k_qp_ipm_tables(double *out, int R, double m34) {
+  constexpr int D = 2 * S, HS = ipm_ht_stride(D);
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int NY = (N + 1) * BK;
-
-  extern __shared__ double lds[];
-  double *yv = lds;                       // [NY] node states (scaled by T^d of the piece to their right)
-  double *dya = yv + NY;                  // [NY] affine direction
-  double *dyc = dya + NY;                 // [NY] final direction
-  double *rhs = dyc + NY;                 // [NY]
-  double *Dg = rhs + NY;                  // [(N+1)][BK*BK] diagonal blocks -> their Cholesky factors
-  double *Of = Dg + (size_t)(N + 1) * BK * BK;  // [N][BK*BK] block (k+1,k) -> L_{k+1,k}
-  double *uu = Of + (size_t)N * BK * BK;  // [N][NB] u_i of y
-  double *dua = uu + (size_t)N * NB;      // [N][NB] u_i of the affine direction
-  double *duc = dua + (size_t)N * NB;     // [N][NB] u_i of the final direction
-  double *ht = duc + (size_t)N * NB;      // [R][3][D] Hermite basis (derivative d) at tau_j
-  double *Hobj = ht + (size_t)R * HS;  // [D][D] cost block in Hermite coordinates (per axis, T = 1)
-  double *Hm = Hobj + D * D;              // [D][D] c~ = Hm u
-  double *sc = Hm + D * D;                // [N][D] 1 for the start half, (T_i/T_i+1)^d for the end half
-  double *acc = sc + (size_t)N * D;       // [NS][30]: 0-5 Wa (sym), 6-8 Wv, 9-11 Wacc, 12-20 gamma[d][ax], 21-29 gamma_lambda
-  double *hp_l = acc + (size_t)NS * AS;   // [N*M*4]
-  double *Tn = hp_l + (size_t)N * M * 4;  // [N]
-  double *red = Tn + N;                   // [32]
-  double *qsv = red + 32;                 // [N] T_i^(1-2s)
-  double *dinvd = qsv + N;                // [NY] reciprocals of the diagonal of the block Cholesky factor
-
-  const double *Tg = a.T + b * N;
-  const double *hp = a.hpolys + b * (int64_t)N * M * 4;
-  const double *st = a.state + b * 18;
-  double *slg = a.sl + b * mtot, *lmg = a.lam + b * mtot;
-
-  for (int e = tid; e < N * M * 4; e += nt) hp_l[e] = hp[e];
-  for (int i = tid; i < N; i += nt) {
-    Tn[i] = Tg[i];
-    qsv[i] = pow(Tg[i], (double)(1 - 2 * S));
-  }
+  __shared__ double E[2 * D * D], Hm[D * D];
+  double *Hobj = out + D * D, *ht = out + 2 * D * D;
   // ---- Hermite matrix: E[row][col] = value of derivative d of the monomial col at tau = 0 / 1; Hm = E^-1
   if (tid == 0) {
-    // [D][2D] scratch in LDS: the diagonal blocks, first written by the first assembly -- (N + 1) BK^2 >= 2 D^2 doubles for every
-    // piece count (the per-sample records, NS x 31 doubles, are SHORTER than that for one piece with <= 4 samples)
-    double *E = Dg;
-    static_assert(2 * BK * BK >= 2 * D * D, "Hermite scratch must fit the two diagonal blocks of a one-piece problem");
     constexpr int W = 2 * D;
     for (int r = 0; r < D; ++r)
       for (int col = 0; col < D; ++col) {
@@ -211,9 +179,75 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     const int m = e / D, m2 = e % D;
     double v = 0.0;
     for (int c1 = 0; c1 < S; ++c1)
-      for (int c2 = 0; c2 < S; ++c2) v += Hm[c1 * D + m] * qblk1<S>(c1, c2, a.m34) * Hm[c2 * D + m2];
+      for (int c2 = 0; c2 < S; ++c2) v += Hm[c1 * D + m] * qblk1<S>(c1, c2, m34) * Hm[c2 * D + m2];
     Hobj[e] = v;
   }
+  for (int e = tid; e < D * D; e += nt) out[e] = Hm[e];
+}
+
+// MINB: workgroups per CU the register allocation is bounded for.  The snap kernel needs more than 256 registers to run
+// without spills (one workgroup per CU); bounded to 256 (92 B of scratch) two share a CU, which pays for large batches
+// (4096 x 8 pieces 24.7 -> 18.8 ms) and costs a single problem a quarter of its latency (0.82 -> 1.02 ms): the host picks.
+// FUSE: the updating pass of a step also forms the per-sample sums of the NEXT step (one row pass fewer, 6 % of a lone
+// problem's latency) -- at the price of registers: with two workgroups per CU it spills, so the throughput shapes visit the rows again.
+template <int S, int MINB = 1, bool FUSE = (MINB == 1)>
+__global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
+  constexpr int D = 2 * S, NB = 3 * D, BK = 3 * S;
+  constexpr int HS = ipm_ht_stride(D), AS = kIpmRecord;  // padded strides of the basis table rows / per-sample records
+  const int N = a.N, R = a.R, M = a.M;
+  const int NS = N * R, RPS = M + 12;
+  const int64_t mtot = (int64_t)NS * RPS;
+  const int64_t b = a.order ? (int64_t)a.order[blockIdx.x] : (int64_t)blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int NY = (N + 1) * BK;
+  const bool resume = a.resume != 0;
+  if (resume && a.status[b] != 0) return;  // decided in the first launch (wave-uniform: the whole workgroup leaves)
+  double *ct = a.cont ? a.cont + b * (int64_t)(NY + kIpmContScalars) : nullptr;
+
+#ifdef ANET_IPM_PROF
+  const long long prof_start_ = __builtin_readcyclecounter();
+#endif
+  extern __shared__ double lds[];
+  double *yv = lds;                       // [NY] node states (scaled by T^d of the piece to their right)
+  double *dya = yv + NY;                  // [NY] affine direction
+  double *dyc = dya + NY;                 // [NY] final direction
+  double *rhs = dyc + NY;                 // [NY]
+  double *Dg = rhs + NY;                  // [(N+1)][BK*BK] diagonal blocks -> their Cholesky factors
+  double *Of = Dg + (size_t)(N + 1) * BK * BK;  // [N][BK*BK] block (k+1,k) -> L_{k+1,k}
+  double *uu = Of + (size_t)N * BK * BK;  // [N][NB] u_i of y
+  double *dua = uu + (size_t)N * NB;      // [N][NB] u_i of the affine direction
+  double *duc = dua + (size_t)N * NB;     // [N][NB] u_i of the final direction
+  double *ht = duc + (size_t)N * NB;      // [R][3][D] Hermite basis (derivative d) at tau_j
+  double *Hobj = ht + (size_t)R * HS;  // [D][D] cost block in Hermite coordinates (per axis, T = 1)
+  double *Hm = Hobj + D * D;              // [D][D] c~ = Hm u
+  double *sc = Hm + D * D;                // [N][D] 1 for the start half, (T_i/T_i+1)^d for the end half
+  double *acc = sc + (size_t)N * D;       // [NS][30]: 0-5 Wa (sym), 6-8 Wv, 9-11 Wacc, 12-20 gamma[d][ax], 21-29 gamma_lambda
+  double *hp_l = acc + (size_t)NS * AS;   // [N*M*4]
+  double *Tn = hp_l + (size_t)N * M * 4;  // [N]
+  double *red = Tn + N;                   // [32]
+  double *qsv = red + 32;                 // [N] T_i^(1-2s)
+  double *dinvd = qsv + N;                // [NY] reciprocals of the diagonal of the block Cholesky factor
+
+  const double *Tg = a.T + b * N;
+  const double *hp = a.hpolys + b * (int64_t)N * M * 4;
+  const double *st = a.state + b * 18;
+  double *slg = a.sl + b * mtot, *lmg = a.lam + b * mtot;
+
+  for (int e = tid; e < N * M * 4; e += nt) hp_l[e] = hp[e];
+  for (int i = tid; i < N; i += nt) {
+    Tn[i] = Tg[i];
+    qsv[i] = pow(Tg[i], (double)(1 - 2 * S));
+  }
+  // ---- tables of (order, res, m34): built once per context (k_qp_ipm_tables), copied here
+  {
+    const double *tb = a.tab;
+    for (int e = tid; e < D * D; e += nt) {
+      Hm[e] = tb[e];
+      Hobj[e] = tb[D * D + e];
+    }
+    for (int e = tid; e < R * HS; e += nt) ht[e] = tb[2 * D * D + e];
+  }
+  __syncthreads();  // (Tn, qsv, the corridor rows and the tables: read by other threads from here on)
   for (int e = tid; e < N * D; e += nt) {
     const int i = e / D, m = e % D;
     double v = 1.0;
@@ -232,7 +266,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
       const double f = tk / tsum;
       v = (1.0 - f) * st[ax * 3] + f * st[9 + ax * 3];
     }
-    yv[e] = v;
+    yv[e] = resume ? ct[e] : v;
     dya[e] = 0.0;
     dyc[e] = 0.0;
   }
@@ -376,6 +410,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
 #ifndef ANET_IPM_LAM0_SCALE
 #define ANET_IPM_LAM0_SCALE 1e-6
 #endif
+  auto first_iterate = [&]() -> double {  // slacks and multipliers of the first iterate; returns the number of live rows
   if (tid < 32) red[tid] = 0.0;
   __syncthreads();
   {
@@ -420,8 +455,11 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   __syncthreads();
   block_reduce((double)nrows_local, 0, false);
   __syncthreads();
-  const double mrows = uni(fmax(red_sum(0), 1.0));
+  const double mr = uni(fmax(red_sum(0), 1.0));
   __syncthreads();
+  return mr;
+  };
+  const double mrows = resume ? uni(ct[NY]) : first_iterate();  // (a resumed problem: parked with the rest of its state)
 
   // assemble the node-space vector  out_k = sum over the pieces touching knot k of sc * (qs Hobj u + sum_j gamma_j h_j)
   // (gamma at acc offset `goff`; with_obj adds the cost gradient); pinned components are zeroed
@@ -818,8 +856,22 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   int it = 0, status = -2, accepted_steps = 0;  // OSQP_MAX_ITER_REACHED unless decided below
   double pres = 0.0, dres = 0.0, mu = 0.0, mu0 = 0.0, pres_mark = INFINITY, mu_mark = INFINITY, alpha_win = 0.0;
   int stalled_windows = 0;
+  double objn_last = 0.0, alpha_last = 1.0;
+  bool stopped = false;
+  if (resume) {  // what the first launch parked (below, at its it_stop-th step)
+    it = (int)ct[NY + 1];
+    accepted_steps = (int)ct[NY + 2];
+    stalled_windows = (int)ct[NY + 3];
+    mu0 = ct[NY + 4];
+    pres_mark = ct[NY + 5];
+    mu_mark = ct[NY + 6];
+    alpha_win = ct[NY + 7];
+    it = __builtin_amdgcn_readfirstlane(it);
+  }
+  const int it_first = it;
 #ifdef ANET_IPM_PROF
   long long prof_t_ = __builtin_readcyclecounter();
+  if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[13] = prof_t_ - prof_start_;  // tables, first iterate
 #endif
   IPM_TICK(0);
   // ---- pass A: residuals, weights, right-hand-side pieces per sample.  A row of the iterate (gy = its value, sl, lm):
@@ -863,7 +915,11 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     pass_A();
     __syncthreads();
   }
-  for (it = 0; it < a.max_iter; ++it) {
+  for (it = it_first; it < a.max_iter; ++it) {
+    if (a.it_stop > 0 && it == a.it_stop && !resume) {  // park the iterate: node states here, slacks / multipliers where they are
+      stopped = true;
+      break;
+    }
     if constexpr (!FUSE) {
       // ---- pass A: residuals, weights, right-hand-side pieces per sample
       if (tid < 32) red[tid] = 0.0;
@@ -911,6 +967,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     IPM_TICK(5);
     dres = uni(red[8] / fmax(1.0, red[9]));
     const double objn = uni(red_sum(10));
+    objn_last = objn;
     // (the duality gap is mu * rows: that, not mu, is what bounds the distance of the objective from the optimum)
     if (pres < a.tol && dres < a.tol && mu * mrows < a.tol * fmax(1.0, 0.5 * fabs(objn))) { status = 1; break; }
     // The backward pass asks for three digits more than a plain solve; a few percent of the problems stall above that
@@ -1058,6 +1115,7 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     constexpr double step_fraction = ANET_IPM_STEP_FRACTION;
     const double alpha = uni(fmin(1.0, step_fraction * (red[6] > 0.0 ? 1.0 / red[6] : 1e300)));
     alpha_win = uni(fmax(alpha_win, alpha));
+    alpha_last = alpha;
     __syncthreads();
     if constexpr (!FUSE) {
       // ---- pass E: update
@@ -1117,6 +1175,27 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
     IPM_TICK(12);
   }
   __syncthreads();
+  if (stopped) {
+    for (int e = fresh_tid(); e < NY; e += nt) ct[e] = yv[e];
+    if (tid == 0) {
+      ct[NY] = mrows;
+      ct[NY + 1] = (double)it;
+      ct[NY + 2] = (double)accepted_steps;
+      ct[NY + 3] = (double)stalled_windows;
+      ct[NY + 4] = mu0;
+      ct[NY + 5] = pres_mark;
+      ct[NY + 6] = mu_mark;
+      ct[NY + 7] = alpha_win;
+      // what the order of the second launch is made from: the residuals of the last tested iterate and its step
+      ct[NY + 8] = pres;
+      ct[NY + 9] = dres;
+      ct[NY + 10] = mu * mrows / fmax(1.0, 0.5 * fabs(objn_last));
+      ct[NY + 11] = alpha_last;
+      a.status[b] = 0;  // still running
+      a.iters[b] = it;
+    }
+    return;
+  }
   // ---- backward pass through the optimum (anet_qp_solve_vjp) ---------------------------------------------------
   // The reference's hook solves the dense KKT system  J [d_z; d_lambda; d_nu] = -grad  (layers.py:129-141) and stops
   // there: its z is a detached leaf.  Here the same adjoint is taken in Hermite coordinates and carried through to the

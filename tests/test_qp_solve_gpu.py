@@ -702,3 +702,32 @@ def test_launch_order_changes_nothing_but_the_schedule(anet_ctx):
                 assert torch.equal(out[k], ref[k]), (s, N, k)
     with pytest.raises(ValueError):
         aa.qp_solve_dev(4, st, tT, thp, ctx=anet_ctx, launch_order=torch.zeros(3, dtype=torch.int32, device=dev))
+
+
+def test_two_launch_form_returns_the_same_bits():
+    """Batches of 1536 problems and more run in TWO launches (csrc/qp_ipm.h IpmArgs::it_stop): four Newton steps of every problem,
+    then the unfinished ones resumed longest-expected first.  Parking and resuming an iterate changes no arithmetic: against one
+    launch (ANET_IPM_SPLIT_STEPS=0, read once per process: two child processes) the coefficients, objectives, verdicts, step counts
+    and time gradients are bit-identical."""
+    import hashlib, json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, hashlib, numpy as np; sys.path.insert(0, %r); import allocnet_amd as aa\n"
+            "from allocnet_amd.synth import corridor_problem\n"
+            "out = {}\n"
+            "for (s, N, B, tsc) in ((4, 8, 2048, 1.5), (3, 5, 1600, 1.5), (4, 3, 1536, 0.7)):\n"
+            "    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(31), B, N, 3, 16)\n"
+            "    r = aa.qp_solve(s, head, tail, hp, T * tsc, res=20, max_vel=4.0, max_acc=6.0, time_grad=True)\n"
+            "    h = hashlib.sha256()\n"
+            "    for k in ('coeffs', 'obj', 'status', 'iters', 'grad_T'): h.update(np.ascontiguousarray(r[k]).tobytes())\n"
+            "    out['%%d_%%d' %% (s, N)] = dict(sha=h.hexdigest(), solved=int((r['status'] == 1).sum()), steps=int(r['iters'].sum()),\n"
+            "                                 longest=int(r['iters'].max()))\n"
+            "print(json.dumps(out))\n") % root
+    res = {}
+    for name, val in (("two", "4"), ("one", "0")):
+        env = dict(os.environ, ANET_IPM_SPLIT_STEPS=val)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[name] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["two"] == res["one"], res
+    for key, v in res["two"].items():
+        assert v["solved"] > 0 and v["longest"] > 4, (key, v)
