@@ -331,7 +331,8 @@ void anet_qp_default_settings(anet_qp_settings *s);
  * coeffs [batch][N][3][2s] (the flatten order callModel unpacks, learning_planner.hpp:212,227),
  * obj [batch] = 1/2 z'Qz (QPSolver::getObjCost), status/iters [batch], residuals [batch][2] (primal, dual;
  * may be NULL).  All HOST pointers; the _dev variant takes DEVICE pointers (same trajectory-major
- * layout) plus a device workspace of anet_qp_solve_workspace() doubles.                            */
+ * layout) plus a device workspace of anet_qp_solve_workspace() doubles (the slacks and multipliers of every row, and for the
+ * two-launch form of large batches the parked iterates and the order of the second launch: always ask, never compute it). */
 int anet_qp_solve(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
                   double max_acc, double m34, const double *state, const double *T, const double *hpolys,
                   const anet_qp_settings *settings, double *coeffs, double *obj, int32_t *status,
