@@ -10,7 +10,7 @@ from oracle import cbind
 from allocnet_amd.synth import corridor_problem
 
 
-def run(n_cases, seed=777, ctx=None, verbose=True):
+def run(n_cases, seed=777, ctx=None, verbose=True, batches=(1, 7, 64)):
     """Returns (problems solved by both, worst relative objective difference, solved by the port only, solved by the GPU only,
     problems).  (The port gives up on some badly scaled problems -- optimal cost 1e7 and more, durations close to infeasibly
     short -- that the kernel and the dense oracle both solve: tests/soak/qp_disagree.py prints them with the dense verdict.)"""
@@ -22,7 +22,7 @@ def run(n_cases, seed=777, ctx=None, verbose=True):
         N = int(rng.choice([1, 2, 3, 5, 8, 11, 16] if s == 3 else [1, 2, 3, 5, 8]))
         M = int(rng.choice([6, 8, 12, 16]))
         res = int(rng.choice([3, 8, 20]))
-        B = int(rng.choice([1, 7, 64]))
+        B = int(rng.choice(list(batches)))
         head, tail, wps, T, hp = corridor_problem(rng, B, N, 3, M)
         T = T * float(rng.choice([0.3, 0.7, 1.5, 4.0]))
         vmax, amax = float(rng.uniform(2.0, 6.0)), float(rng.uniform(3.0, 9.0))
@@ -47,6 +47,7 @@ def run(n_cases, seed=777, ctx=None, verbose=True):
 if __name__ == "__main__":
     t0 = time.time()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    c, w, po, go, t = run(n)
+    batches = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 7, 64)   # e.g. 1600: the two-launch form
+    c, w, po, go, t = run(n, batches=batches)
     print(f"{n} cases, {t} problems in {time.time() - t0:.0f} s: {c} solved by both, worst relative objective difference {w:.2e}, "
           f"{po} solved by the port only, {go} by the kernel only")

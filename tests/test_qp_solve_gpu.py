@@ -671,6 +671,10 @@ def test_randomised_soak_against_the_c_port(anet_ctx):
     # the port gives up on some badly scaled problems the kernel (and the dense oracle: tests/soak/qp_disagree.py) solves; the other
     # direction -- a problem the CPU solves and the kernel does not -- is the one that must not happen
     assert port_only <= 0.001 * total and gpu_only <= 0.05 * total, (port_only, gpu_only, total)
+    # batches large enough for two workgroups per CU and the two-launch form
+    compared, worst, port_only, gpu_only, total = run(8, seed=4242, ctx=anet_ctx, verbose=False, batches=(600, 1600))
+    assert compared > 0.4 * total and worst <= 2e-5
+    assert port_only <= 0.001 * total and gpu_only <= 0.06 * total, (port_only, gpu_only, total)
 
 
 def test_launch_order_changes_nothing_but_the_schedule(anet_ctx):
