@@ -23,6 +23,12 @@
 //        twelve box rows of a sample multiply no zeros;
 //      - every phase starts from an opaque thread index and the scalars of the iteration live in SGPRs: what is the
 //        same in every Newton step is not hoisted out of the loop into registers the phases need.
+//  * Round 4: the diagonal factors are inverted in the chain and the substitutions are block-vector products carried in registers;
+//    the multipliers start at the scale of the first iterate's cost gradient; every sum of a step is added in a fixed order
+//    (results are the same bit for bit from launch to launch and for any launch order); the tables of (order, res, m34) are
+//    built once per context (k_qp_ipm_tables); a large batch runs in TWO launches -- four steps of every problem, then the
+//    unfinished ones longest-expected first (IpmArgs::it_stop / resume / cont) -- because what a batch of thousands costs beyond
+//    its Newton steps is the problem that takes 40 of them and happens to start last.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
