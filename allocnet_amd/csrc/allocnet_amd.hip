@@ -1435,9 +1435,29 @@ int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_l
   if (!params || params->mem_size <= 0) return -1;
   const int n = 3 * (n_pieces - 1) + n_pieces;
   const int npf = params->past > 1 ? params->past : 1;
-  // L-BFGS state + cost/grad workspace + gradP + gradT
+  // L-BFGS state + cost/grad workspace + gradP + gradT; then, for the two-launch form of the one-launch shape, the parked
+  // optimisers, their scores and the order of the second launch (int32 each) and the bins of the counting sort
   return LbfgsLayout::doubles(n, params->mem_size, npf, ld) + anet_minco_cost_grad_workspace(s, n_pieces, ld) +
-         (int64_t)n * ld;
+         (int64_t)n * ld + (int64_t)anet::kPersistContDoubles * ld + ld + 2 + kOrderBuckets / 2;
+}
+
+// Order of the second launch of a two-launch L-BFGS run (lbfgs_minco_persistent.h PersistArgs::park): larger = expected to need more
+// evaluations.  What predicts it at the split point (4096 problems of BASELINE configs[3], parked after 1000 evaluations;
+// Spearman 0.61 with the evaluations left, and the order it gives simulates to the longest-first makespan): the gradient norm
+// relative to the cost and the relative decrease of the cost over the last half of the first part, in decades.  Problems that
+// ended in the first part score 0 and come last (their waves leave at once).
+__global__ void k_lbfgs_resume_score(const int *is, const double *cont, int64_t B, int64_t ld, int *score) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  int sc = 0;
+  if (is[(int64_t)anet::IS_DONE * ld + b] == 0) {
+    const double *u = cont + b * (int64_t)anet::kPersistContDoubles + 22 * 64;
+    const double fx = fabs(u[8]) + 1e-300, dec = fmax((u[23] - u[8]) / fx, 1e-16), gn = sqrt(fmax(u[24], 0.0)) / fx;
+    double v = 4000.0 + 150.0 * (log10(fmax(gn, 1e-16)) + log10(dec));
+    if (!(v == v)) v = 4000.0;
+    sc = (int)fmin(fmax(v, 1.0), 4000.0);
+  }
+  score[b] = sc;
 }
 
 static int launch_order_impl(anet_ctx *ctx, int64_t batch, const int32_t *counts, int32_t *launch_order, int32_t *work,
@@ -1575,7 +1595,33 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
     // a caller-supplied launch order is not checked: a problem it skips (out-of-range or repeated entries) must report
     // ANET_LBFGS_RUNNING with zero counters, not whatever the workspace held
     if (launch_order) ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_ * ld, st));
+    // Batches well beyond the 2048 resident waves in TWO launches: the first takes every problem through the same number of
+    // evaluations (equally long waves: no late starters), the second resumes the unfinished ones longest-expected first.  The
+    // batch of BASELINE configs[3] (4096 problems, 300..7400 evaluations) otherwise ends with whichever long problem happened to
+    // start in the second round: 0.160 s against 0.117 s with the problems longest first by their true counts.
+    static const int split_evals = [] { const char *e = getenv("ANET_LBFGS_SPLIT_EVALS"); return e ? atoi(e) : 1000; }();
+    static const int64_t split_min_batch = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)3072; }();
+    const bool two_launches = split_evals > 1 && batch >= split_min_batch && !launch_order && max_evals > split_evals;
+    double *cont = w_gP + (int64_t)n * ld;
+    int32_t *score = (int32_t *)(cont + (int64_t)anet::kPersistContDoubles * ld);
+    int32_t *order2 = score + ld + (ld & 1);
+    int32_t *bins = order2 + ld + (ld & 1);
     auto launch = [&](auto kernel, size_t fixed_bytes) {
+      if (!two_launches) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
+        return;
+      }
+      pa.cont = cont;
+      pa.park = 1;
+      pa.half_mark = split_evals / 2;
+      pa.max_evals = split_evals;
+      hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
+      hipLaunchKernelGGL(k_lbfgs_resume_score, g256, b256, 0, st, L.is, cont, batch, ld, score);
+      (void)launch_order_impl(ctx, batch, score, order2, bins, st, 0);
+      pa.park = 0;
+      pa.resume = 1;
+      pa.max_evals = max_evals;
+      pa.order = order2;
       hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
     };
     const size_t lds_cap = 64 * 1024;

@@ -35,6 +35,13 @@ struct PersistArgs {
   double tau_min;  // backward_T(minimum duration)
   const int *cancel;  // optional device-visible word, polled once per evaluation: non-zero ends every problem with LBFGS_CANCELED
                       // after its next completed iteration (lbfgs.hpp:580-587: what proc_progress returning non-zero does)
+  // A run in TWO launches (batches well beyond the 2048 resident waves: lbfgs_minco_dev_impl).  The first launch takes every
+  // problem through max_evals (= the split point) evaluations and, park = 1, parks the optimiser of those still running in
+  // `cont` ([B][kPersistContDoubles]: 22 per-lane values x 64 lanes, then 64 wave-uniform ones); the second, resume = 1, loads
+  // it and goes on -- longest-expected first (`order` from the parked gradient norm and the decrease of the cost over the last
+  // half of the first part).  half_mark: the evaluation count at which the cost is noted for that decrease.
+  int park, resume, half_mark;
+  double *cont;
 #ifdef ANET_PERSIST_PROF
   long long *prof;  // [16] cycle counters of problem 0 (tools/persist_prof.py)
 #endif
@@ -53,6 +60,8 @@ struct PersistArgs {
 #define PERSIST_TICK(slot) do {} while (0)
 #define PERSIST_TICK_DECL do {} while (0)
 #endif
+
+constexpr int kPersistContLaneFields = 22, kPersistContDoubles = (kPersistContLaneFields + 1) * 64;
 
 template <int S, int NB>
 struct PersistLds {
@@ -212,6 +221,44 @@ struct LbfgsResident {
     }
     fx = step = finit = dgtest = dstest = mu = nu = pf = smax = 0.0;
     k = bound = count = brackt = touched = evals = phase = 0;
+  }
+  // the whole state to / from global memory ([field][lane], then 64 wave-uniform values): what a second launch needs to go on
+  // exactly where this one stopped (PersistArgs::park / resume)
+  __device__ __forceinline__ void park(double *c, const int lane, const double f_half) const {
+    static_assert(MR <= 8, "layout of the parked state");
+    double *pl = c + lane;
+    pl[0 * 64] = x; pl[1 * 64] = g; pl[2 * 64] = d; pl[3 * 64] = xp; pl[4 * 64] = gp; pl[5 * 64] = pf;
+#pragma unroll
+    for (int it = 0; it < MR; ++it) {
+      pl[(6 + it) * 64] = hs[it];
+      pl[(14 + it) * 64] = hy[it];
+    }
+    const double gn2 = dot(gp, gp);
+    if (lane == 0) {
+      double *u = c + 22 * 64;
+#pragma unroll
+      for (int it = 0; it < MR; ++it) u[it] = hys[it];
+      u[8] = fx; u[9] = step; u[10] = finit; u[11] = dgtest; u[12] = dstest; u[13] = mu; u[14] = nu; u[15] = smax;
+      u[16] = (double)k; u[17] = (double)bound; u[18] = (double)count; u[19] = (double)brackt; u[20] = (double)touched;
+      u[21] = (double)evals; u[22] = (double)phase;
+      u[23] = f_half;  // (for the order of the second launch only)
+      u[24] = gn2;
+    }
+  }
+  __device__ __forceinline__ void unpark(const double *c, const int lane) {
+    const double *pl = c + lane;
+    x = pl[0 * 64]; g = pl[1 * 64]; d = pl[2 * 64]; xp = pl[3 * 64]; gp = pl[4 * 64]; pf = pl[5 * 64];
+#pragma unroll
+    for (int it = 0; it < MR; ++it) {
+      hs[it] = pl[(6 + it) * 64];
+      hy[it] = pl[(14 + it) * 64];
+    }
+    const double *u = c + 22 * 64;
+#pragma unroll
+    for (int it = 0; it < MR; ++it) hys[it] = u[it];
+    fx = u[8]; step = u[9]; finit = u[10]; dgtest = u[11]; dstest = u[12]; mu = u[13]; nu = u[14]; smax = u[15];
+    k = (int)u[16]; bound = (int)u[17]; count = (int)u[18]; brackt = (int)u[19]; touched = (int)u[20];
+    evals = (int)u[21]; phase = (int)u[22];
   }
   __device__ __forceinline__ static double dot(double u, double v) { return wave_sum<LAST>(u * v); }
   // |g|_inf / max(1, |x|_inf) < g_epsilon (lbfgs.hpp:520-524, 592-596), the quotient cleared
@@ -1531,6 +1578,7 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
   const int lane = threadIdx.x;
   const int64_t b = a.order ? (int64_t)a.order[blockIdx.x] : (int64_t)blockIdx.x, ld = a.ld;
   if ((uint64_t)b >= (uint64_t)a.B) return;  // (an out-of-range entry of a caller's order: leave it, touch nothing)
+  if (a.resume && a.is[(int64_t)IS_DONE * ld + b] != 0) return;  // decided in the first launch
   const int N = a.N, np = a.c - 1, n = a.nw + a.nt;
 
   // ---- problem data -> LDS (batch-minor global: strided, once per problem)
@@ -1557,11 +1605,18 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
   }
   LbfgsResident<MR> st;
   st.init(lane < n ? a.x[(int64_t)lane * ld + b] : 0.0);
+  double *cont = a.cont ? a.cont + b * (int64_t)kPersistContDoubles : nullptr;
+  int e_first = 0;
+  double f_half = 0.0;
+  if (a.resume) {
+    st.unpark(cont, lane);
+    e_first = __builtin_amdgcn_readfirstlane(st.evals);
+  }
   const int na = lane / 3, ax = lane - 3 * na;
   int finish = 0x7fffffff;
   __syncthreads();
 #pragma unroll 1
-  for (int e = 0; e < a.max_evals; ++e) {
+  for (int e = e_first; e < a.max_evals; ++e) {
     // (the cancel word is fetched now and looked at after the evaluation: its round trip costs nothing)
     int cancel = 0;
     // system-scope load (sc0 sc1): the word is written while the kernel runs -- by another stream or by the host through
@@ -1572,7 +1627,7 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
     else if (lane < n) Lm.T[lane - a.nw] = forward_T(st.x);
     __syncthreads();
     double f, g;
-    persist_eval<S, NB>(Lm, rows, a, lane, e == 0 || a.nt > 0, f, g);
+    persist_eval<S, NB>(Lm, rows, a, lane, e == e_first || a.nt > 0, f, g);
     PERSIST_TICK_DECL;
     if (lane >= a.nw && lane < n) g *= dforward_T(st.x);
     st.g = (lane < n) ? g : 0.0;
@@ -1580,7 +1635,9 @@ __global__ void __launch_bounds__(64, 2) k_lbfgs_minco_persistent(PersistArgs a)
     finish = __builtin_amdgcn_readfirstlane(finish);
     PERSIST_TICK(9);
     if (finish != 0x7fffffff) break;
+    if (a.park && e + 1 == a.half_mark) f_half = st.fx;
   }
+  if (a.park && finish == 0x7fffffff) st.park(cont, lane, f_half);
   if (lane < n) a.x[(int64_t)lane * ld + b] = st.x;
   if (lane == 0) {
     a.is[(int64_t)IS_DONE * ld + b] = finish != 0x7fffffff;

@@ -735,3 +735,34 @@ def test_generic_device_objective_matches_the_restatement(anet_ctx, n, B):
     # an exception in the objective comes back as the exception, not as a crash
     with pytest.raises(ZeroDivisionError):
         aa.lbfgs_optimize_dev(start(), lambda x, f, g: 1 / 0, batch=B, ctx=anet_ctx)
+
+
+def test_minco_lbfgs_two_launch_form_returns_the_same_bits():
+    """Batches of 3072 problems and more run the one-launch shape in TWO launches (lbfgs_minco_persistent.h PersistArgs::park):
+    1000 evaluations of every problem, the optimisers of the unfinished ones parked, then resumed longest-expected first.
+    Parking changes no arithmetic: against a single launch (ANET_LBFGS_SPLIT_EVALS=0, read once per process: two child
+    processes) waypoints, durations, costs, return codes and both counters are bit-identical -- with and without the
+    minimum-duration bound, problems that stop before the split point and after it."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, hashlib, numpy as np; sys.path.insert(0, %r); import allocnet_amd as aa\n"
+            "from allocnet_amd.synth import corridor_problem\n"
+            "out = {}\n"
+            "for (s, N, B, mind) in ((3, 16, 3200, 0.0), (4, 8, 3100, 0.0), (3, 5, 3072, 0.4)):\n"
+            "    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(41), B, N, 3, 16)\n"
+            "    pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20, poly_rows=16)\n"
+            "    kw = dict(min_duration=mind) if mind else {}\n"
+            "    r = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=aa.lbfgs_parameter_t(), max_evals=20000, **kw)\n"
+            "    h = hashlib.sha256()\n"
+            "    for k in ('wps', 'T', 'cost', 'status', 'iters', 'evals'): h.update(np.ascontiguousarray(r[k]).tobytes())\n"
+            "    ev = r['evals']\n"
+            "    out['%%d_%%d' %% (s, N)] = dict(sha=h.hexdigest(), below=int((ev < 1000).sum()), above=int((ev > 1000).sum()), longest=int(ev.max()))\n"
+            "print(json.dumps(out))\n") % root
+    res = {}
+    for name, val in (("two", "1000"), ("one", "0")):
+        env = dict(os.environ, ANET_LBFGS_SPLIT_EVALS=val)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[name] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["two"] == res["one"], res
+    assert sum(v["below"] for v in res["two"].values()) > 100 and sum(v["above"] for v in res["two"].values()) > 1000, res
