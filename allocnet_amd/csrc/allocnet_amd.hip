@@ -1600,8 +1600,14 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
     // batch of BASELINE configs[3] (4096 problems, 300..7400 evaluations) otherwise ends with whichever long problem happened to
     // start in the second round: 0.160 s against 0.117 s with the problems longest first by their true counts.
     static const int split_evals = [] { const char *e = getenv("ANET_LBFGS_SPLIT_EVALS"); return e ? atoi(e) : 1000; }();
-    static const int64_t split_min_batch = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)3072; }();
-    const bool two_launches = split_evals > 1 && batch >= split_min_batch && !launch_order && max_evals > split_evals;
+    static const int64_t split_min_batch = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+    // ... where it was measured to pay (tools/time_lbfgs_batch.py, 4096 problems unless noted, one launch -> two): 16 jerk pieces
+    // 165 -> 140 ms (bench: 0.169 -> 0.133 s), 16 snap pieces 424 -> 389, 12 jerk pieces 107 -> 98, 10 jerk pieces 79 -> 77, 16 jerk
+    // pieces x 8192 235 -> 216, x 16384 415 -> 403, x 3072 no change; 8 snap pieces 102 -> 100..109, 5 jerk pieces 23.5 -> 25, 5
+    // snap pieces 37 -> 39 (their runs are a few hundred evaluations long: the split point lies behind most of them, and at 250..700
+    // evaluations the parked state does not tell the long problems yet).  Hence: problems of at least 36 variables (ten pieces).
+    static const int split_min_vars = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_VARS"); return e ? atoi(e) : 36; }();
+    const bool two_launches = split_evals > 1 && batch >= split_min_batch && n >= split_min_vars && !launch_order && max_evals > split_evals;
     double *cont = w_gP + (int64_t)n * ld;
     int32_t *score = (int32_t *)(cont + (int64_t)anet::kPersistContDoubles * ld);
     int32_t *order2 = score + ld + (ld & 1);

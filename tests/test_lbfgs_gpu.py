@@ -738,7 +738,8 @@ def test_generic_device_objective_matches_the_restatement(anet_ctx, n, B):
 
 
 def test_minco_lbfgs_two_launch_form_returns_the_same_bits():
-    """Batches of 3072 problems and more run the one-launch shape in TWO launches (lbfgs_minco_persistent.h PersistArgs::park):
+    """Batches of 4096 problems and more with ten pieces or more run the one-launch shape in TWO launches (lbfgs_minco_persistent.h
+    PersistArgs::park; the thresholds are lowered here through the environment so that smaller shapes take the path too):
     1000 evaluations of every problem, the optimisers of the unfinished ones parked, then resumed longest-expected first.
     Parking changes no arithmetic: against a single launch (ANET_LBFGS_SPLIT_EVALS=0, read once per process: two child
     processes) waypoints, durations, costs, return codes and both counters are bit-identical -- with and without the
@@ -760,7 +761,7 @@ def test_minco_lbfgs_two_launch_form_returns_the_same_bits():
             "print(json.dumps(out))\n") % root
     res = {}
     for name, val in (("two", "1000"), ("one", "0")):
-        env = dict(os.environ, ANET_LBFGS_SPLIT_EVALS=val)
+        env = dict(os.environ, ANET_LBFGS_SPLIT_EVALS=val, ANET_LBFGS_SPLIT_MIN_BATCH="3000", ANET_LBFGS_SPLIT_MIN_VARS="1")
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
         assert p.returncode == 0, p.stderr[-2000:]
         res[name] = json.loads(p.stdout.strip().splitlines()[-1])
