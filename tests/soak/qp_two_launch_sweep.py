@@ -1,0 +1,37 @@
+"""The interior point in one launch against two (csrc/qp_ipm.h IpmArgs::it_stop) over shapes the -m gpu test leaves out: orders,
+1..16 pieces, 6..16 rows, 3 / 8 / 20 samples, lone problems and small batches (the non-fused instantiation and the split forced
+through the environment), split points 1..9, with and without the time gradient -- hashes of every output must be equal.
+   gpurun -- 'python tests/soak/qp_two_launch_sweep.py'        (runs itself with different environments)"""
+import hashlib, json, os, subprocess, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import allocnet_amd as aa
+    from allocnet_amd.synth import corridor_problem
+    rng = np.random.default_rng(99)
+    out = []
+    for trial in range(40):
+        s = int(rng.choice([3, 4])); N = int(rng.choice([1, 2, 3, 5, 8, 11] if s == 3 else [1, 2, 3, 5, 8]))
+        M = int(rng.choice([6, 12, 16])); res = int(rng.choice([3, 8, 20])); B = int(rng.choice([1, 37, 600]))
+        head, tail, wps, T, hp = corridor_problem(rng, B, N, 3, M)
+        T = T * float(rng.choice([0.5, 1.5, 4.0]))
+        r = aa.qp_solve(s, head, tail, hp, T, res=res, max_vel=4.0, max_acc=6.0, time_grad=bool(trial & 1))
+        h = hashlib.sha256()
+        for k in ("coeffs", "obj", "status", "iters") + (("grad_T",) if trial & 1 else ()): h.update(np.ascontiguousarray(r[k]).tobytes())
+        out.append(dict(trial=trial, s=s, N=N, M=M, res=res, B=B, sha=h.hexdigest(), solved=int((r["status"] == 1).sum()), steps_max=int(r["iters"].max())))
+    print(json.dumps(out))
+    sys.exit(0)
+res = {}
+for name, k in (("one", "0"), ("two@1", "1"), ("two@3", "3"), ("two@9", "9")):
+    env = dict(os.environ, ANET_IPM_SPLIT_STEPS=k, ANET_IPM_SPLIT_MIN_BATCH="1", ANET_IPM_TWO_PER_CU_MIN_BATCH="1")
+    p = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res[name] = json.loads(p.stdout.strip().splitlines()[-1])
+bad = 0
+for rows in zip(*res.values()):
+    same = len({r["sha"] for r in rows}) == 1
+    bad += not same
+    print(("ok  " if same else "DIFF"), {k: rows[0][k] for k in ("trial", "s", "N", "M", "res", "B", "solved", "steps_max")})
+print("different:", bad)
+sys.exit(1 if bad else 0)
