@@ -709,7 +709,7 @@ def test_launch_order_changes_nothing_but_the_schedule(anet_ctx):
 
 
 def test_two_launch_form_returns_the_same_bits():
-    """Batches of 1536 problems and more run in TWO launches (csrc/qp_ipm.h IpmArgs::it_stop): four Newton steps of every problem,
+    """Batches of 576 problems and more run in TWO launches (csrc/qp_ipm.h IpmArgs::it_stop): four Newton steps of every problem,
     then the unfinished ones resumed longest-expected first.  Parking and resuming an iterate changes no arithmetic: against one
     launch (ANET_IPM_SPLIT_STEPS=0, read once per process: two child processes) the coefficients, objectives, verdicts, step counts
     and time gradients are bit-identical."""
