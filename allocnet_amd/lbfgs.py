@@ -170,7 +170,7 @@ def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, p
         p(coeffs), p(status), p(iters), p(evals), ctypes.c_void_p(stream)))
     wide = torch.empty(ld, device=dev, dtype=torch.int32)
     ctx.check(ctx.lib.anet_minco_spread_flags_dev(ctx.handle, N, B, ld, p(T), 0.0, p(wide), ctypes.c_void_p(stream)))
-    return dict(cost=cost[:B], status=status[:B], iters=iters[:B], evals=evals[:B], wide_spread=wide[:B])
+    return dict(cost=cost[:B], status=status[:B], iters=iters[:B], evals=evals[:B], wide_spread=wide[:B], _work=work)
 
 
 _EVAL_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
