@@ -482,7 +482,9 @@ int anet_lbfgs_optimize_dev(anet_ctx *ctx, int n, int64_t batch, int64_t ld, dou
  * 64 variables, mem_size <= 8, past <= 64) run as ONE launch, one wave per problem, each until its
  * own stop (lbfgs.hpp:551-709 is one loop per problem); this bit forces the launch-per-evaluation kernels instead,
  * which advance the whole batch in lockstep (up to twice the throughput per evaluation step at batches of 10^5, so the
- * better shape for a small FIXED evaluation budget there; a run to convergence is faster in one launch at any batch). */
+ * better shape for a small FIXED evaluation budget there; a run to convergence is faster in one launch at any batch).
+ * Batches of >= 4096 problems with >= 36 variables take the wave-per-problem shape in TWO launches -- 1000 evaluations of
+ * every problem, then the unfinished ones resumed longest-expected first -- with bit-identical results.   */
 #define ANET_OPT_LOCKSTEP 4
 int anet_lbfgs_minco(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const double *head,
                      const double *tail, double *wps, double *T, const double *hpolys,
