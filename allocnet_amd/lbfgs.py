@@ -139,7 +139,7 @@ def launch_order_from_counts_dev(evals, stream=None, ctx=None, fine=False):
 
 def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, param=None,
                     opt=OPT_WAYPOINTS | OPT_TIMES, max_evals=2000, coeffs=None, stream=None, ctx=None, launch_order=None,
-                    min_duration=0.0):
+                    min_duration=0.0, return_work=False):
     """Device entry point -> anet_lbfgs_minco_[ordered_]dev.  torch CUDA float64 tensors, batch-minor, common row
     stride; wps and T are updated in place.  Returns dict(cost, status, iters, evals) of device tensors.
     launch_order: optional int32 CUDA tensor (B,), a permutation -- the problem each successive workgroup of the
@@ -170,7 +170,10 @@ def lbfgs_minco_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, p
         p(coeffs), p(status), p(iters), p(evals), ctypes.c_void_p(stream)))
     wide = torch.empty(ld, device=dev, dtype=torch.int32)
     ctx.check(ctx.lib.anet_minco_spread_flags_dev(ctx.handle, N, B, ld, p(T), 0.0, p(wide), ctypes.c_void_p(stream)))
-    return dict(cost=cost[:B], status=status[:B], iters=iters[:B], evals=evals[:B], wide_spread=wide[:B], _work=work)
+    out = dict(cost=cost[:B], status=status[:B], iters=iters[:B], evals=evals[:B], wide_spread=wide[:B])
+    if return_work:  # (the workspace, for probes of what the two-launch form parks: tools/lbfgs_split_features.py)
+        out["_work"] = work
+    return out
 
 
 _EVAL_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,

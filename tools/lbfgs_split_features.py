@@ -18,7 +18,7 @@ for arg in sys.argv[1:]:
     data = corridor_problem(np.random.default_rng(2), B, N, 3, M)
     pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20, poly_rows=M)
     th, tt, tw, tT, thp = (to_bm(torch, x, B, ld, dev) for x in data)
-    r = aa.lbfgs_minco_dev(th, tt, tw, tT, s, 3, N, B, hpolys=thp, penalty=pen, param=aa.lbfgs_parameter_t(), max_evals=40000, opt=3, ctx=ctx)
+    r = aa.lbfgs_minco_dev(th, tt, tw, tT, s, 3, N, B, hpolys=thp, penalty=pen, param=aa.lbfgs_parameter_t(), max_evals=40000, opt=3, ctx=ctx, return_work=True)
     torch.cuda.synchronize()
     w = r["_work"]
     tail_len = 1472 * ld + ld + 2 + 2048
