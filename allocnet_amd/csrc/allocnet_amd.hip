@@ -1993,7 +1993,7 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     // of 4096 in one launch ends 27 % above its balanced figure because its 30..50-step problems start whenever their turn comes.
     static const int ipm_split_steps = [] { const char *e = getenv("ANET_IPM_SPLIT_STEPS"); return e ? atoi(e) : 4; }();
     static const int64_t ipm_split_min_batch = [] { const char *e = getenv("ANET_IPM_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)576; }();  // (measured: 520..560 problems lose 7-10 %, 600..1280 gain 10-19 %)
-    if (two_per_cu && ipm_split_steps > 0 && batch >= ipm_split_min_batch && !grad_z && !launch_order && ia.max_iter > ipm_split_steps) {
+    if (two_per_cu && ipm_split_steps > 0 && batch >= ipm_split_min_batch && !launch_order && ia.max_iter > ipm_split_steps) {
       const int ny = 3 * s * (n_pieces + 1);
       const int64_t m_adm = 3 * (6 + (int64_t)s * (n_pieces - 1)) + mi;
       double *cont = work + 2 * m_adm * batch + 2 * batch;

@@ -16,9 +16,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         M = int(rng.choice([6, 12, 16])); res = int(rng.choice([3, 8, 20])); B = int(rng.choice([1, 37, 600]))
         head, tail, wps, T, hp = corridor_problem(rng, B, N, 3, M)
         T = T * float(rng.choice([0.5, 1.5, 4.0]))
-        r = aa.qp_solve(s, head, tail, hp, T, res=res, max_vel=4.0, max_acc=6.0, time_grad=bool(trial & 1))
+        if trial % 3 == 2:   # the backward pass (anet_qp_solve_vjp)
+            gz = rng.normal(size=(B, N, 3, 2 * s))
+            r = aa.qp_solve_vjp(s, head, tail, hp, T, gz, res=res, max_vel=4.0, max_acc=6.0)
+            keys = ("coeffs", "obj", "status", "iters", "grad_T")
+        else:
+            r = aa.qp_solve(s, head, tail, hp, T, res=res, max_vel=4.0, max_acc=6.0, time_grad=bool(trial & 1))
+            keys = ("coeffs", "obj", "status", "iters") + (("grad_T",) if trial & 1 else ())
         h = hashlib.sha256()
-        for k in ("coeffs", "obj", "status", "iters") + (("grad_T",) if trial & 1 else ()): h.update(np.ascontiguousarray(r[k]).tobytes())
+        for k in keys: h.update(np.ascontiguousarray(r[k]).tobytes())
         out.append(dict(trial=trial, s=s, N=N, M=M, res=res, B=B, sha=h.hexdigest(), solved=int((r["status"] == 1).sum()), steps_max=int(r["iters"].max())))
     print(json.dumps(out))
     sys.exit(0)
