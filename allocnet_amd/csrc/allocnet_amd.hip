@@ -1612,6 +1612,7 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
     int32_t *score = (int32_t *)(cont + (int64_t)anet::kPersistContDoubles * ld);
     int32_t *order2 = score + ld + (ld & 1);
     int32_t *bins = order2 + ld + (ld & 1);
+    bool order_failed = false;
     auto launch = [&](auto kernel, size_t fixed_bytes) {
       if (!two_launches) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
@@ -1623,7 +1624,10 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
       pa.max_evals = split_evals;
       hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
       hipLaunchKernelGGL(k_lbfgs_resume_score, g256, b256, 0, st, L.is, cont, batch, ld, score);
-      (void)launch_order_impl(ctx, batch, score, order2, bins, st, 0);
+      if (launch_order_impl(ctx, batch, score, order2, bins, st, 0) != ANET_OK) {  // (cannot fail with these arguments; if it ever does:
+        order_failed = true;                                                       //  the error is the caller's return code)
+        return;
+      }
       pa.park = 0;
       pa.resume = 1;
       pa.max_evals = max_evals;
@@ -1642,6 +1646,7 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
       launch(anet::k_lbfgs_minco_persistent<4, 16, 8>, anet::persist_lds_fixed_bytes<4, 16>());
     else
       launched = false;
+    if (order_failed) return ANET_ERR_INVALID;
     if (launched) {
       ANET_HIP(ctx, hipGetLastError());
 #ifdef ANET_PERSIST_PROF
