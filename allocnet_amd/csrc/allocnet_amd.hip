@@ -1949,6 +1949,10 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
           tab = tb.d;
         }
       if (!tab) {
+        // (never freed before anet_destroy -- a launch on another stream may still read one: a caller that sweeps m34 or res over
+        //  hundreds of values is told so instead of growing the context without bound)
+        if (ctx->ipm_tabs.size() >= 256)
+          return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_qp_solve: more than 256 distinct (order, res, m34) on one context");
         anet_ctx::IpmTable tb{s, res, m34, nullptr, sti, nullptr};
         const size_t need = (size_t)2 * (2 * s) * (2 * s) + (size_t)res * anet::ipm_ht_stride(2 * s);
         ANET_HIP(ctx, hipMalloc((void **)&tb.d, sizeof(double) * need));
