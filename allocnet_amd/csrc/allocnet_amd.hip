@@ -129,6 +129,31 @@ int ensure_scratch(anet_ctx *ctx, size_t bytes) {
 
 inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// Per-context tables (basis rows of k_piece_grad per (order, res); tables of k_qp_ipm per (order, res, m34)) live until
+// anet_destroy; their number is bounded, and a table whose build fails half-way is released, not leaked.
+constexpr size_t kMaxTablesPerContext = 256;
+int new_table(anet_ctx *ctx, size_t bytes, double **d, hipEvent_t *ready) {
+  *d = nullptr;
+  *ready = nullptr;
+  hipError_t e = hipMalloc((void **)d, bytes);
+  if (e != hipSuccess) {
+    *d = nullptr;
+    return fail(ctx, ANET_ERR_NOMEM, std::string("hipMalloc(table): ") + hipGetErrorString(e));
+  }
+  e = hipEventCreateWithFlags(ready, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    (void)hipFree(*d);
+    *d = nullptr;
+    *ready = nullptr;
+    return hip_fail(ctx, e, "hipEventCreateWithFlags(table)");
+  }
+  return ANET_OK;
+}
+void drop_table(double *d, hipEvent_t ready) {
+  if (d) (void)hipFree(d);
+  if (ready) (void)hipEventDestroy(ready);
+}
+
 // max T / min T inside one trajectory above which the host entry point of the coefficient solve switches to the pivoted
 // collocation solve (minco_dense_kernels.h)
 constexpr double kWideSpread = 50.0;
@@ -945,13 +970,20 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
         tab = t.d;
       }
     if (!tab) {
+      // (never freed before anet_destroy -- a launch on another stream may still read one: a caller that sweeps res over
+      //  hundreds of values is told so instead of growing the context without bound, as for the tables of k_qp_ipm)
+      if (ctx->tabs.size() >= kMaxTablesPerContext)
+        return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_minco_partial_grads: more than 256 distinct (order, res) on one context");
       anet_ctx::BasisTable t{s, pen->res, nullptr, st, nullptr};
       const int need = pen->res * 4 * 2 * s;
-      ANET_HIP(ctx, hipMalloc((void **)&t.d, sizeof(double) * need));
-      ANET_HIP(ctx, hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+      if ((rc = new_table(ctx, sizeof(double) * need, &t.d, &t.ready))) return rc;
       hipLaunchKernelGGL(anet::k_build_basis_table, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, t.d, pen->res, 2 * s);
-      ANET_HIP(ctx, hipGetLastError());
-      ANET_HIP(ctx, hipEventRecord(t.ready, st));
+      hipError_t e1 = hipGetLastError();
+      if (e1 == hipSuccess) e1 = hipEventRecord(t.ready, st);
+      if (e1 != hipSuccess) {
+        drop_table(t.d, t.ready);
+        return hip_fail(ctx, e1, "k_build_basis_table");
+      }
       ctx->tabs.push_back(t);
       tab = t.d;
     }
@@ -1225,6 +1257,9 @@ int anet_lbfgs_optimize_dev(anet_ctx *ctx, int n, int64_t batch, int64_t ld, dou
   hipLaunchKernelGGL(k_lbfgs_results, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, L.is, L.ds, batch, ld, status,
                      iters, evals, f);
   ANET_HIP(ctx, hipGetLastError());
+  // the run synchronises `stream` as it goes (completion polls); so does its end: status / iters / evals / f are complete
+  // when this returns, whatever stream the caller reads them on
+  ANET_HIP(ctx, hipStreamSynchronize(st));
   return ANET_OK;
 }
 
@@ -1431,14 +1466,23 @@ int anet_polytope_depth(anet_ctx *ctx, int64_t batch, int max_rows, const double
   return ANET_OK;
 }
 
+// Thresholds of the two-launch form of the one-launch L-BFGS (lbfgs_minco_dev_impl; the environment overrides are for A/B runs)
+static int lbfgs_split_evals() { static const int v = [] { const char *e = getenv("ANET_LBFGS_SPLIT_EVALS"); return e ? atoi(e) : 1000; }(); return v; }
+static int64_t lbfgs_split_min_batch() { static const int64_t v = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)4096; }(); return v; }
+static int lbfgs_split_min_vars() { static const int v = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_VARS"); return e ? atoi(e) : 36; }(); return v; }
+
 int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_lbfgs_params *params) {
   if (!params || params->mem_size <= 0) return -1;
   const int n = 3 * (n_pieces - 1) + n_pieces;
   const int npf = params->past > 1 ? params->past : 1;
-  // L-BFGS state + cost/grad workspace + gradP + gradT; then, for the two-launch form of the one-launch shape, the parked
-  // optimisers, their scores and the order of the second launch (int32 each) and the bins of the counting sort
-  return LbfgsLayout::doubles(n, params->mem_size, npf, ld) + anet_minco_cost_grad_workspace(s, n_pieces, ld) +
-         (int64_t)n * ld + (int64_t)anet::kPersistContDoubles * ld + ld + 2 + kOrderBuckets / 2;
+  // L-BFGS state + cost/grad workspace + gradP + gradT ...
+  int64_t w = LbfgsLayout::doubles(n, params->mem_size, npf, ld) + anet_minco_cost_grad_workspace(s, n_pieces, ld) + (int64_t)n * ld;
+  // ... then, only where the two-launch form of the one-launch shape can run (ld >= batch >= its minimum batch, enough
+  // variables: 12 KB per problem otherwise reserved for nothing), the parked optimisers, their scores and the order of the
+  // second launch (int32 each) and the bins of the counting sort
+  if (lbfgs_split_evals() > 1 && ld >= lbfgs_split_min_batch() && n >= lbfgs_split_min_vars())
+    w += (int64_t)anet::kPersistContDoubles * ld + ld + 2 + kOrderBuckets / 2;
+  return w;
 }
 
 // Order of the second launch of a two-launch L-BFGS run (lbfgs_minco_persistent.h PersistArgs::park): larger = expected to need more
@@ -1599,14 +1643,14 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
     // evaluations (equally long waves: no late starters), the second resumes the unfinished ones longest-expected first.  The
     // batch of BASELINE configs[3] (4096 problems, 300..7400 evaluations) otherwise ends with whichever long problem happened to
     // start in the second round: 0.160 s against 0.117 s with the problems longest first by their true counts.
-    static const int split_evals = [] { const char *e = getenv("ANET_LBFGS_SPLIT_EVALS"); return e ? atoi(e) : 1000; }();
-    static const int64_t split_min_batch = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+    const int split_evals = lbfgs_split_evals();
+    const int64_t split_min_batch = lbfgs_split_min_batch();
     // ... where it was measured to pay (tools/time_lbfgs_batch.py, 4096 problems unless noted, one launch -> two): 16 jerk pieces
     // 165 -> 140 ms (bench: 0.169 -> 0.133 s), 16 snap pieces 424 -> 389, 12 jerk pieces 107 -> 98, 10 jerk pieces 79 -> 77, 16 jerk
     // pieces x 8192 235 -> 216, x 16384 415 -> 403, x 3072 no change; 8 snap pieces 102 -> 100..109, 5 jerk pieces 23.5 -> 25, 5
     // snap pieces 37 -> 39 (their runs are a few hundred evaluations long: the split point lies behind most of them, and at 250..700
     // evaluations the parked state does not tell the long problems yet).  Hence: problems of at least 36 variables (ten pieces).
-    static const int split_min_vars = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_VARS"); return e ? atoi(e) : 36; }();
+    const int split_min_vars = lbfgs_split_min_vars();
     const bool two_launches = split_evals > 1 && batch >= split_min_batch && n >= split_min_vars && !launch_order && max_evals > split_evals;
     double *cont = w_gP + (int64_t)n * ld;
     int32_t *score = (int32_t *)(cont + (int64_t)anet::kPersistContDoubles * ld);
@@ -1719,8 +1763,11 @@ static int lbfgs_minco_host_impl(anet_ctx *ctx, int s, int c, int n_pieces, int6
   const int64_t nco = (int64_t)N * 3 * 2 * s;
   const int64_t M = (pen && hpolys) ? pen->poly_rows : 0;
   const int64_t nhp = (int64_t)N * M * 4;
-  const int64_t wdoubles = anet_lbfgs_minco_workspace(s, N, 1, params);
-  if (wdoubles < 0) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_minco: bad lbfgs parameters");
+  // (the workspace has terms that do not scale with ld: asked for with the stager's own row stride, reserved in rows of it)
+  const int64_t ld_h = batch == 1 ? 1 : anet_recommended_ld(batch);
+  const int64_t wtotal = anet_lbfgs_minco_workspace(s, N, ld_h, params);
+  if (wtotal < 0) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_minco: bad lbfgs parameters");
+  const int64_t wdoubles = (wtotal + ld_h - 1) / ld_h;
   int64_t mx = nco > nhp ? nco : nhp;
   if (mx < 3 * (int64_t)c) mx = 3 * c;
   Stager st;
@@ -1900,6 +1947,15 @@ __global__ void k_qp_resume_score(const int *status, const double *cont, int64_t
   score[b] = sc;
 }
 
+// A caller's launch order is not checked (device memory): whatever it skips -- out-of-range or repeated entries -- must say so
+__global__ void k_qp_mark_not_run(int64_t B, int *status, int *iters, double *obj) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  status[b] = ANET_QP_UNSOLVED;
+  iters[b] = 0;
+  obj[b] = __builtin_nan("");
+}
+
 static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
                              double max_acc, double m34, const double *state, const double *T,
                              const double *hpolys, const anet_qp_settings *settings, double *work, double *coeffs,
@@ -1941,6 +1997,10 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     }();
     ia.twist_min_pieces = ipm_twist_min_pieces;
     hipStream_t sti = (hipStream_t)stream;
+    if (launch_order) {
+      hipLaunchKernelGGL(k_qp_mark_not_run, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, sti, batch, status, iters, obj);
+      ANET_HIP(ctx, hipGetLastError());
+    }
     {  // the tables of (order, res, m34): built once, on the stream that first needs them
       const double *tab = nullptr;
       for (auto &tb : ctx->ipm_tabs)
@@ -1951,17 +2011,23 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
       if (!tab) {
         // (never freed before anet_destroy -- a launch on another stream may still read one: a caller that sweeps m34 or res over
         //  hundreds of values is told so instead of growing the context without bound)
-        if (ctx->ipm_tabs.size() >= 256)
+        if (ctx->ipm_tabs.size() >= kMaxTablesPerContext)
           return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_qp_solve: more than 256 distinct (order, res, m34) on one context");
         anet_ctx::IpmTable tb{s, res, m34, nullptr, sti, nullptr};
         const size_t need = (size_t)2 * (2 * s) * (2 * s) + (size_t)res * anet::ipm_ht_stride(2 * s);
-        ANET_HIP(ctx, hipMalloc((void **)&tb.d, sizeof(double) * need));
-        ANET_HIP(ctx, hipMemsetAsync(tb.d, 0, sizeof(double) * need, sti));
-        ANET_HIP(ctx, hipEventCreateWithFlags(&tb.ready, hipEventDisableTiming));
-        if (s == 4) hipLaunchKernelGGL(anet::k_qp_ipm_tables<4>, dim3(1), dim3(256), 0, sti, tb.d, res, m34);
-        else hipLaunchKernelGGL(anet::k_qp_ipm_tables<3>, dim3(1), dim3(256), 0, sti, tb.d, res, m34);
-        ANET_HIP(ctx, hipGetLastError());
-        ANET_HIP(ctx, hipEventRecord(tb.ready, sti));
+        int rc_t = new_table(ctx, sizeof(double) * need, &tb.d, &tb.ready);
+        if (rc_t) return rc_t;
+        hipError_t e1 = hipMemsetAsync(tb.d, 0, sizeof(double) * need, sti);
+        if (e1 == hipSuccess) {
+          if (s == 4) hipLaunchKernelGGL(anet::k_qp_ipm_tables<4>, dim3(1), dim3(256), 0, sti, tb.d, res, m34);
+          else hipLaunchKernelGGL(anet::k_qp_ipm_tables<3>, dim3(1), dim3(256), 0, sti, tb.d, res, m34);
+          e1 = hipGetLastError();
+        }
+        if (e1 == hipSuccess) e1 = hipEventRecord(tb.ready, sti);
+        if (e1 != hipSuccess) {  // nothing half-built stays behind
+          drop_table(tb.d, tb.ready);
+          return hip_fail(ctx, e1, "k_qp_ipm_tables");
+        }
         ctx->ipm_tabs.push_back(tb);
         tab = tb.d;
       }

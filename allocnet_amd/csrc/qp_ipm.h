@@ -207,6 +207,9 @@ __global__ void __launch_bounds__(256, MINB) k_qp_ipm(IpmArgs a) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int NY = (N + 1) * BK;
   const bool resume = a.resume != 0;
+  // a caller's launch order is not checked on the host: an entry outside [0, B) is skipped (the host pre-sets the status of
+  // every problem to "not run" whenever an order is given, so a problem no workgroup took says so)
+  if ((uint64_t)b >= (uint64_t)a.B) return;
   if (resume && a.status[b] != 0) return;  // decided in the first launch (wave-uniform: the whole workgroup leaves)
   double *ct = a.cont ? a.cont + b * (int64_t)(NY + kIpmContScalars) : nullptr;
 

@@ -78,3 +78,49 @@ class NativeComm:
 
     def close(self):
         self.ctx.check(self.ctx.lib.anet_comm_destroy(self.ctx.handle))
+
+
+class OverlappedCostGather:
+    """The all-gather of step k runs on the collective's stream while step k + 1 computes: two send / receive slots, and a slot
+    is handed back to the solve only after the collective that last read it has completed (`work.wait()` orders the current
+    stream behind it; with gloo it blocks the host).  bench.py's `step()` and the world-size-2 gloo test drive this very class.
+
+        j = g.acquire(i)          # slot of step i: waits for the gather issued from it two steps ago
+        ... write this step's costs into g.send[j][:count] ...
+        g.submit(i)               # issues the gather of slot j (only every `every`-th step)
+        g.drain()                 # waits for what is in flight
+
+    `every` > 1 skips the collective on the other steps (bench.py --allgather-every k: lets a lost scaling factor be attributed)."""
+
+    def __init__(self, count, world, device, dtype=None, alloc=None, every=1, group=None, enabled=True):
+        import torch
+        dtype = dtype or torch.float64
+        self.count, self.world, self.every, self.group, self.enabled = int(count), int(world), max(1, int(every)), group, enabled
+        self.send = [torch.zeros(int(alloc or count), device=device, dtype=dtype) for _ in range(2)]
+        self.recv = [torch.empty(self.world * self.count, device=device, dtype=dtype) for _ in range(2)] if enabled else None
+        self.works = [None, None]
+        self.issued = 0
+        self.last = None            # slot of the last gather issued
+
+    def acquire(self, i):
+        j = i & 1
+        if self.works[j] is not None:
+            self.works[j].wait()
+            self.works[j] = None
+        return j
+
+    def submit(self, i):
+        if not self.enabled or (i + 1) % self.every:
+            return None
+        import torch.distributed as dist
+        j = i & 1
+        self.works[j] = dist.all_gather_into_tensor(self.recv[j], self.send[j][:self.count], group=self.group, async_op=True)
+        self.issued += 1
+        self.last = j
+        return self.works[j]
+
+    def drain(self):
+        for j in range(2):
+            if self.works[j] is not None:
+                self.works[j].wait()
+                self.works[j] = None

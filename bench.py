@@ -131,10 +131,10 @@ def lbfgs_update_flops(n, m):
 def fp64_roofline(flops_per_launch, seconds, hbm_bytes_per_launch, kernel):
     ach = flops_per_launch / seconds / 1e12
     hb = hbm_bytes_per_launch / seconds / 1e9
+    # (FLOPs: analytic, data-independent -- cost_grad_flops; "hbm": SURVEY 8(d)'s compulsory bytes over the same time)
     return {"bound": "fp64", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-            "traffic": None, "kernel": kernel, "flops_counted": "analytic, data-independent (bench.cost_grad_flops)",
-            "hbm": {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS,
-                    "note": "compulsory bytes (SURVEY 8(d)) over the same time: not the binding limit"}}
+            "traffic": None, "kernel": kernel,
+            "hbm": {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS}}
 
 
 PEN = dict(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20)
@@ -245,20 +245,23 @@ def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
         host_ms = sorted(r[0] for r in runs)
         st_ms = sorted(r[1] for r in runs)
         dt, kms = host_ms[len(host_ms) // 2] * 1e-3, st_ms[len(st_ms) // 2]
+        # results of the FUSED entry point, taken before the per-kernel split below runs: the split's third launch is the
+        # plain anet_minco_propagate_grad_dev (no rho * sum T term, allocnet_amd.hip) and has output buffers of its own
+        if key == "b4096":
+            torch.cuda.synchronize()
+            snap = (cost[:B].cpu().numpy(), gT[:, :B].cpu().numpy().T.copy(), gP[:, :B].cpu().numpy().T.copy())
+        gP2, gT2 = torch.empty_like(gP), torch.empty_like(gT)
+        # (timing: 5 repetitions of K back-to-back evaluations after >= 10 ms of warm-up and, for the small batch, a burst of 450
+        #  evaluations that takes the runtime's one-off launch-backlog stall; median repetition: DESIGN.md section 7)
         out[key] = {"batch": B, "ms_per_step": dt * 1e3, "stream_ms_per_step": kms, "value": B / dt,
-                    "stream_ms_min_median_max": [st_ms[0], kms, st_ms[-1]], "stream_ms_in_run_order": [r[1] for r in runs],
-                    "timing": f"{len(runs)} repetitions of {K} back-to-back evaluations after >= 10 ms of warm-up on the GPU (and, for "
-                              f"the small batch, an un-synchronised burst of 450 evaluations that takes the runtime's one-off "
-                              f"launch-backlog stall), one HIP-event pair per repetition; the median repetition is reported",
-                    "kernel_split_us": cost_grad_kernel_split(torch, aa, ctx, s, c, N, B, ld, th, tt, tw, tT, thp, pen, work, gP, gT),
+                    "stream_ms_min_median_max": [st_ms[0], kms, st_ms[-1]],
+                    "kernel_split_us": cost_grad_kernel_split(torch, aa, ctx, s, c, N, B, ld, th, tt, tw, tT, thp, pen, work, gP2, gT2),
                     "roofline": fp64_roofline(B * flops, kms * 1e-3, B * ab,
                                               "k_piece_grad (+ k_minco_solve, k_minco_propagate)")}
-        if key == "b4096":
-            out[key]["gpu_cost"] = cost[:B].cpu().numpy()
-            out[key]["gpu_gT"] = gT[:, :B].cpu().numpy().T
+        del gP2, gT2
     out["flops_per_evaluation"] = flops
     out["algorithmic_bytes_per_trajectory"] = ab
-    gpu_cost, gpu_gT = out["b4096"].pop("gpu_cost"), out["b4096"].pop("gpu_gT")
+    gpu_cost, gpu_gT, gpu_gP = snap
     if cpu_baseline:
         from oracle import cbind
         nthreads = host_cores()
@@ -272,12 +275,13 @@ def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
         for _ in range(reps):
             cbind.minco_cost_grad_batch(s, head, tail, wps, T, hp, nthreads=nthreads, **PEN_ORACLE)
         rate = 4096 * reps / (time.perf_counter() - t0)
+        # (classic banded-LU MINCO + adjoint through the same factors + penalty partials in scalar C: oracle/minco_costgrad.c)
         out["cpu_baseline"] = {"value": rate, "unit": out["unit"], "cores": nthreads, "kind": "port",
-                               "sample": f"the same 4096 trajectories, {reps} passes, classic banded-LU MINCO + adjoint through "
-                                         f"the same factors + penalty partials in scalar C (oracle/minco_costgrad.c), "
-                                         f"{nthreads} threads",
+                               "sample": f"the same 4096 trajectories x {reps} passes, oracle/minco_costgrad.c",
                                "gpu_vs_cpu_max_rel_cost_err": float(np.abs(gpu_cost - cc).max() / np.abs(cc).max()),
-                               "gpu_vs_cpu_max_rel_gradT_err": float(np.abs(gpu_gT - cgT).max() / np.abs(cgT).max())}
+                               "gpu_vs_cpu_max_rel_gradT_err": float(np.abs(gpu_gT - cgT).max() / np.abs(cgT).max()),
+                               "gpu_vs_cpu_max_rel_gradP_err": float(np.abs(gpu_gP - cgP.reshape(gpu_gP.shape)).max()
+                                                                     / np.abs(cgP).max())}
     return out
 
 
@@ -302,8 +306,8 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
     (learning_planner.hpp:179), SURVEY 8(d) corridor generator, seed 1, durations x 1.5."""
     import numpy as np
     from allocnet_amd.synth import corridor_problem
-    out = {"unit": "QP solves/s", "seed": 1, "res": 20, "poly_rows": 16, "max_vel": 4.0, "max_acc": 6.0, "method": "interior point",
-           "note": "a batch lasts as long as its slowest problem; ~1.5 % of the generator's problems are infeasible (status -3)"}
+    # (a batch lasts as long as its slowest problem; ~1.5 % of the generator's problems are infeasible, status -3)
+    out = {"unit": "QP solves/s", "seed": 1, "res": 20, "poly_rows": 16, "max_vel": 4.0, "max_acc": 6.0, "method": "interior point"}
     host = None
     for key, s, N, B in (("snap8", 4, 8, 4096), ("jerk5", 3, 5, 4096)):
         M = 16
@@ -318,23 +322,26 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
         torch.cuda.synchronize()
         K = 5
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(K):
-            r = aa.qp_solve_dev(s, st, tT, thp, ctx=ctx)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / K
+        reps_ms = []
+        for _ in range(3):                          # median of three repetitions of K batches
+            e0.record()
+            for _ in range(K):
+                r = aa.qp_solve_dev(s, st, tT, thp, ctx=ctx)
+            e1.record()
+            torch.cuda.synchronize()
+            reps_ms.append(e0.elapsed_time(e1) / K)
+        ms = sorted(reps_ms)[1]
         iters = r["iters"].double()
         solved = float((r["status"] == 1).double().mean())
         flops = float(iters.sum()) * qp_newton_step_flops(s, N, M, 20)
         ach = flops / (ms * 1e-3) / 1e12
         out[key] = {"order": s, "pieces": N, "batch": B, "ms_per_batch": ms, "value": B / (ms * 1e-3), "solved_frac": solved,
                     "newton_steps_mean": float(iters.mean()), "newton_steps_max": int(iters.max()),
+                    # (FLOPs: analytic per Newton step, qp_newton_step_flops, x the steps taken; the kernel is latency-bound --
+                    #  block-Cholesky chains and row passes of one 256-thread workgroup per problem: DESIGN.md 8b)
+                    "ms_reps": reps_ms, "infeasible_frac": float((r["status"] == -3).double().mean()),
                     "roofline": {"bound": "fp64", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": ach / FP64_PEAK_TFLOPS, "traffic": None, "kernel": "k_qp_ipm",
-                                 "flops_counted": "analytic per Newton step (bench.qp_newton_step_flops) x the steps taken",
-                                 "note": "latency-bound: block-Cholesky chains and row passes of one 256-thread workgroup per "
-                                         "problem, two problems per CU (LDS); nowhere near a throughput roofline"}}
+                                 "frac": ach / FP64_PEAK_TFLOPS, "traffic": None, "kernel": "k_qp_ipm"}}
         # the same batch with a launch order (anet_qp_solve_ordered_dev: a re-solve of the same / a similar batch): longest first by
         # this batch's own step counts, and by the counts of a PERTURBED copy (durations x U(0.97, 1.03)) -- what a receding-horizon
         # re-solve has.  Beside the as-given number, never instead of it.
@@ -351,8 +358,7 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
         tTp = tT * torch.from_numpy(np.random.default_rng(9).uniform(0.97, 1.03, size=T.shape)).to(device)
         rp = aa.qp_solve_dev(s, st, tTp, thp, ctx=ctx)
         out[key]["with_launch_order"] = {"own_counts_ms": timed_order(own),
-                                         "perturbed_copy_counts_ms": timed_order(aa.launch_order_from_counts(rp["iters"])),
-                                         "note": "longest first (anet_qp_solve_ordered_dev); results bit-identical; the re-solve case"}
+                                         "perturbed_copy_counts_ms": timed_order(aa.launch_order_from_counts(rp["iters"]))}
         if key == "snap8":
             out[key]["gpu_obj"] = r["obj"].cpu().numpy()
             out[key]["gpu_status"] = r["status"].cpu().numpy()
@@ -410,11 +416,9 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
                 rel.append(abs(gpu_obj[b] - fo) / max(1.0, abs(fo)))
             if time.perf_counter() - t_all > 0.5 * cpu_seconds and done >= 3:
                 break
-        dense_numpy = {"value": done / t_sol, "unit": "QP solves/s", "cores": nthreads,
-                       "sample": f"{done} of the 4096 8-segment snap problems (every 64th): dense Mehrotra interior point "
-                                 f"in numpy / LAPACK with {nthreads} threads, one problem at a time (oracle/qp_np.py) on the matrices of qp_solver.hpp:119-296 restated "
-                                 f"(oracle/minco_np.qp_assemble), solve time only ({t_sol:.1f} s; assembly {t_asm:.1f} s "
-                                 f"not counted); OSQP itself is not in the image",
+        # (dense Mehrotra interior point in numpy / LAPACK, one problem at a time, on the matrices of qp_solver.hpp:119-296
+        #  restated by oracle/minco_np.qp_assemble; solve time only; OSQP itself is not in the image)
+        dense_numpy = {"value": done / t_sol, "cores": nthreads, "sample": f"{done} problems (every 64th), oracle/qp_np.py",
                        "gpu_vs_cpu_max_rel_obj_err": float(max(rel)) if rel else None, "compared": len(rel)}
         # like for like: the structured algorithm of k_qp_ipm (block-tridiagonal interior point in Hermite node coordinates,
         # Mehrotra) in scalar C, one problem per task on the host cores (oracle/qp_ipm_port.c)
@@ -432,10 +436,7 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
         both = (po["status"] == 1) & (gpu_status[idx] == 1)
         prel = np.abs(po["obj"] - gpu_obj[idx])[both] / np.maximum(1.0, np.abs(po["obj"][both]))
         out["cpu_baseline"] = {"value": ns / pdt, "unit": "QP solves/s", "cores": nthreads, "kind": "port",
-                               "sample": f"{ns} of the 4096 8-segment snap problems (strided), each to tol 1e-8: block-tridiagonal "
-                                         f"interior point in Hermite node coordinates (the algorithm of k_qp_ipm: per-sample weights, "
-                                         f"banded Cholesky, Mehrotra) in scalar C, one problem per task, {nthreads} threads, "
-                                         f"{pdt:.1f} s (oracle/qp_ipm_port.c)",
+                               "sample": f"{ns} of the 4096 snap8 problems (strided) to 1e-8, oracle/qp_ipm_port.c, {pdt:.1f} s",
                                "newton_steps_mean": float(po["iters"].mean()), "solved_frac": float((po["status"] >= 1).mean()),
                                "solved_to_1e-7_only_frac": float((po["status"] == 2).mean()),
                                "same_verdict_as_gpu_frac": float(((po["status"] >= 1) == (gpu_status[idx] == 1)).mean()),
@@ -477,17 +478,14 @@ def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
     ab = B * (config5_bytes(s, c, N, M) + 8)        # compulsory: problem data in, optimised waypoints / durations / cost out
     out = {"batch": B, "pieces": N, "order": s, "poly_rows": M, "res": PEN["res"], "seed": 2,
            "seconds": dt, "stream_seconds": kdt, "value": B / dt, "unit": "trajectories optimised to convergence/s",
-           "lbfgs_params": {k: getattr(prm, k) for k in ("mem_size", "g_epsilon", "past", "delta", "max_iterations",
-                                                         "max_linesearch", "min_step", "max_step", "f_dec_coeff",
-                                                         "s_curv_coeff", "cautious_factor", "machine_prec")},
+           "lbfgs_params": "lbfgs_parameter_t defaults (lbfgs.hpp:25-128): mem 8, g_eps 1e-5, past 3, delta 1e-6",
            "max_evals_cap": cap, "iters_mean": float(it.mean()), "iters_max": int(it.max()),
            "evals_mean": float(ev.mean()), "evals_p50_p90_p99": [float(v) for v in np.percentile(ev, [50, 90, 99])],
            "evals_max": int(ev.max()), "evaluations_per_s": float(ev.sum()) / dt,
            "status_hist": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
            "cost_final_mean": float(cf.mean()), "flops_per_evaluation": cost_grad_flops(s, N, M, PEN["res"]),
            "roofline": fp64_roofline(flops, kdt, ab, "k_lbfgs_minco_persistent")}
-    out["roofline"]["note"] = ("one launch; run time = the LAST problem to stop (tail), so the fraction mixes kernel quality with "
-                               "the spread of the evaluation counts")
+    # (run time = the LAST problem to stop, so the fraction mixes kernel quality with the spread of the evaluation counts)
     if cpu_baseline:
         from oracle import cbind
         nthreads = host_cores()
@@ -500,9 +498,8 @@ def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
         cdt = time.perf_counter() - t0
         rel = np.abs(o["cost"] - cf[idx]) / np.abs(o["cost"])
         out["cpu_baseline"] = {"value": ns / cdt, "unit": out["unit"], "cores": nthreads, "kind": "port",
-                               "sample": f"{ns} of the 4096 problems (strided), each to its own stop: oracle_lbfgs_optimize "
-                                         f"(lbfgs.hpp:434-717 restated) on the classic banded-LU cost + gradient in scalar C "
-                                         f"(oracle/minco_costgrad.c), one problem per task, {nthreads} threads, {cdt:.1f} s",
+                               # (oracle_lbfgs_optimize = lbfgs.hpp:434-717 restated, on oracle/minco_costgrad.c, one problem per task)
+                               "sample": f"{ns} of the 4096 problems (strided), each to its own stop, {cdt:.1f} s",
                                "evals_mean": float(o["evals"].mean()), "evals_max": int(o["evals"].max()),
                                "evaluations_per_s": float(o["evals"].sum()) / cdt,
                                "status_hist": {str(k): int(v) for k, v in zip(*np.unique(o["status"], return_counts=True))},
@@ -512,7 +509,29 @@ def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
     return out
 
 
-def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warmup, total=32768):
+def allgather_probe(torch, dist, og, device, use_dist, reps=10):
+    """What the first real multi-GPU run needs to describe itself: how many ranks the RCCL group really has (an all-reduce of
+    ones), the collective alone (not overlapped: `reps` blocking all-gathers of the step's payload between one event pair on
+    the current stream, which waits for RCCL's stream), its payload, and how many were issued in the timed loop."""
+    if not use_dist:
+        return {"ranks_seen": 1, "allgather_ms": None, "allgather_bytes_per_rank": 0, "every": og.every, "issued": 0}
+    one = torch.ones(1, device=device, dtype=torch.float64)
+    dist.all_reduce(one)
+    j = 0
+    for _ in range(3):
+        dist.all_gather_into_tensor(og.recv[j], og.send[j][:og.count])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dist.all_gather_into_tensor(og.recv[j], og.send[j][:og.count])
+    e1.record()
+    torch.cuda.synchronize()
+    return {"ranks_seen": int(round(float(one.item()))), "allgather_ms": e0.elapsed_time(e1) / reps,
+            "allgather_bytes_per_rank": 8 * og.count, "every": og.every, "issued": og.issued}
+
+
+def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warmup, total=32768, every=1):
     """BASELINE configs[4]: `total` x 8-segment min-snap, corridor + velocity / acceleration limit penalties (seed 3),
     contiguous shards over the ranks (remainder to the low ranks), one cost + gradient evaluation of the shard per step
     (k_minco_solve -> k_piece_grad -> k_minco_propagate) and the all-gather of the costs."""
@@ -536,11 +555,10 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
     cost, gP, gT, work = aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, ctx=ctx)
     m = -(-total // world)                      # padded shard length of the gather (ragged shards)
     # The all-gather of a step (8 B per trajectory: latency-bound) runs on RCCL's stream while the next
-    # step's evaluation runs on the compute stream: two send / receive buffers, a buffer is reused only after its
-    # collective has completed (work.wait() orders the compute stream behind it on the device, not the host).
-    send = [torch.zeros(m, device=device, dtype=torch.float64) for _ in range(2)]
-    gathered = [torch.empty(world * m, device=device, dtype=torch.float64) for _ in range(2)] if use_dist else None
-    works = [None, None]
+    # step's evaluation runs on the compute stream: two send / receive slots, a slot is reused only after its
+    # collective has completed (allocnet_amd.distributed.OverlappedCostGather).
+    from allocnet_amd.distributed import OverlappedCostGather
+    og = OverlappedCostGather(m, world, device, every=every, enabled=use_dist)
     count = [0]
 
     def step(ev=None):
@@ -551,18 +569,14 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
         if ev is not None:
             ev[1].record()
         if use_dist:
-            b = count[0] & 1
+            j = og.acquire(count[0])
+            og.send[j][:B].copy_(cost[:B])
+            og.submit(count[0])
             count[0] += 1
-            if works[b] is not None:
-                works[b].wait()
-            send[b][:B].copy_(cost[:B])
-            works[b] = dist.all_gather_into_tensor(gathered[b], send[b], async_op=True)
 
     def sync():
         if use_dist:
-            for w in works:
-                if w is not None:
-                    w.wait()
+            og.drain()
             dist.barrier()
         torch.cuda.synchronize()
     for _ in range(warmup):
@@ -578,9 +592,9 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        last = gathered[(count[0] - 1) & 1]
-        if not torch.equal(last[rank * m:rank * m + B], cost[:B]):
-            raise SystemExit("config5: all-gather of costs returned wrong data")
+        if og.last is not None and every == 1:
+            if not torch.equal(og.recv[og.last][rank * m:rank * m + B], cost[:B]):
+                raise SystemExit("config5: all-gather of costs returned wrong data")
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
     ab = config5_bytes(s, c, N, M)
     roof = fp64_roofline(B * cost_grad_flops(s, N, M, 20), kernel_ms * 1e-3, B * ab,
@@ -590,7 +604,7 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
             "batch_this_rank": B, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kernel_ms, "steps": steps,
             "scaling": "strong", "pieces": N, "order": s, "poly_rows": M, "res": 20,
             "penalty_active_frac": float((cost[:B] > 0).double().mean().item()),
-            "roofline": roof}
+            "allgather": allgather_probe(torch, dist, og, device, use_dist), "roofline": roof}
 
 
 def synth_batch_minor(torch, B, ld, N, c, seed, device):
@@ -611,6 +625,46 @@ def synth_batch_minor(torch, B, ld, N, c, seed, device):
     wps = pts[1:N].contiguous().view((N - 1) * 3, ld)
     T = 0.5 + 1.5 * torch.rand(N, ld, generator=g, device=device, dtype=f64)
     return head.view(3 * c, ld), tail.view(3 * c, ld), wps, T
+
+
+LINE_BUDGET = 7000      # the driver keeps a ~8 KB tail of stdout: a longer line loses its head (round 4: config3.b4096, config5)
+# what goes first if a line is still over budget after rounding (least important first); each entry a key path
+DROP_ORDER = (("host_api",), ("config1_b1024", "sampler"), ("qp_solve", "cpu_baseline", "dense_numpy"),
+              ("config1_b1024", "streams8"), ("config1_b1024", "graph64x8"), ("config4", "cpu_baseline"),
+              ("qp_solve", "jerk5", "with_launch_order"), ("qp_solve", "snap8", "with_launch_order"),
+              ("config3", "saturating", "kernel_split_us"), ("qp_solve", "cpu_baseline"), ("config4", "status_hist"))
+
+
+def _rounded(o):
+    """floats to five significant digits (a bench line is read, not recomputed from)"""
+    if isinstance(o, float):
+        return float(f"{o:.5g}") if o == o and abs(o) != float("inf") else None
+    if isinstance(o, dict):
+        return {k: _rounded(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_rounded(v) for v in o]
+    return o
+
+
+def finalize_line(out, budget=LINE_BUDGET):
+    """The ONE JSON line: numbers rounded, compact separators, and -- should it still exceed the driver's tail -- the least
+    important sub-objects dropped in DROP_ORDER, their names listed under "dropped" (prose lives in DESIGN.md section 7)."""
+    out = _rounded(out)
+    enc = lambda: json.dumps(out, separators=(",", ":"))
+    line = enc()
+    for path in DROP_ORDER:
+        if len(line) <= budget:
+            break
+        d = out
+        for k in path[:-1]:
+            d = d.get(k) if isinstance(d, dict) else None
+            if d is None:
+                break
+        if isinstance(d, dict) and path[-1] in d:
+            del d[path[-1]]
+            out.setdefault("dropped", []).append(".".join(path))
+            line = enc()
+    return line
 
 
 def launch_plan(gpus, env, device_count):
@@ -679,6 +733,8 @@ def main():
     ap.add_argument("--main-only", action="store_true",
                     help="only the timed main workload (used under rocprofv3 so kernel stats are not mixed)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--allgather-every", type=int, default=1,
+                    help="issue the all-gather of the costs every k-th step only (N > 1; default 1 = every step, the north star)")
     ap.add_argument("--workload", choices=("solve", "config5"), default="solve",
                     help="solve: the headline (configs[1] problem at a saturating batch); config5: BASELINE configs[4]")
     args = ap.parse_args()
@@ -715,7 +771,7 @@ def main():
     ld = aa.recommended_ld(B)      # non-power-of-two row stride (HBM channel/bank spread)
     ctx = aa.Context(local_rank)
     if args.workload == "config5":
-        c5 = run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, args.steps, args.warmup)
+        c5 = run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, args.steps, args.warmup, every=args.allgather_every)
         if use_dist:
             dist.destroy_process_group()
         if rank != 0:
@@ -729,42 +785,34 @@ def main():
                           "global_batch": c5["total_batch"], "batch_this_rank": c5["batch_this_rank"],
                           "parallelism": f"dp{world}" + ("+allgather(costs)" if use_dist else "")},
                "roofline": dict(c5["roofline"], traffic=None), "config5": c5}
+        out["config"].update(ranks_seen=c5["allgather"]["ranks_seen"], allgather_ms=c5["allgather"]["allgather_ms"],
+                             allgather_bytes_per_rank=c5["allgather"]["allgather_bytes_per_rank"],
+                             allgather_every=c5["allgather"]["every"])
         try:
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        print(finalize_line(out), flush=True)
         return
     head, tail, wps, T = synth_batch_minor(torch, B, ld, N, c, seed=rank, device=device)
     coeffs = torch.empty(N * 3 * D, ld, device=device, dtype=torch.float64)
     # two cost buffers: the all-gather of step k (RCCL stream) overlaps the solve of step k+1
-    energies = [torch.empty(ld, device=device, dtype=torch.float64) for _ in range(2)]
-    gathered = [torch.empty(world * B, device=device, dtype=torch.float64) for _ in range(2)] if use_dist else None
-    works = [None, None]
-    energy = energies[0]
+    from allocnet_amd.distributed import OverlappedCostGather
+    og = OverlappedCostGather(B, world, device, alloc=ld, every=args.allgather_every, enabled=use_dist)
+    energy = og.send[0]
 
     def step(i, ev=None):
-        j = i % 2
-        if works[j] is not None:
-            works[j].wait()                       # the collective that read energies[j] two steps ago
-            works[j] = None
+        j = og.acquire(i)                         # waits for the collective that read this slot two steps ago
         if ev is not None:
             ev[0].record()
-        aa.minco_solve_dev(head, tail, wps, T, s, c, N, B, coeffs=coeffs, energy=energies[j], ctx=ctx)
+        aa.minco_solve_dev(head, tail, wps, T, s, c, N, B, coeffs=coeffs, energy=og.send[j], ctx=ctx)
         if ev is not None:
             ev[1].record()
-        if use_dist:
-            works[j] = dist.all_gather_into_tensor(gathered[j], energies[j][:B], async_op=True)
-
-    def drain():
-        for j in range(2):
-            if works[j] is not None:
-                works[j].wait()
-                works[j] = None
+        og.submit(i)
 
     def sync():
-        drain()
+        og.drain()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -783,17 +831,17 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the gathered costs of the last step must be every rank's costs in rank order
-        chk = gathered[(args.steps - 1) % 2][rank * B:(rank + 1) * B]
-        if not torch.equal(chk, energies[(args.steps - 1) % 2][:B]):
+        # the gathered costs of the last gather issued must be every rank's costs in rank order
+        if og.last is not None and not torch.equal(og.recv[og.last][rank * B:(rank + 1) * B], og.send[og.last][:B]):
             raise SystemExit("all-gather of costs returned wrong data")
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    ag = allgather_probe(torch, dist, og, device, use_dist)
 
     # every rank takes part in the sharded cost + gradient evaluation (BASELINE configs[4])
     c5 = None
     if not args.main_only:
         del coeffs
-        c5 = run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps=50, warmup=5)
+        c5 = run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps=50, warmup=5, every=args.allgather_every)
         coeffs = torch.empty(N * 3 * D, ld, device=device, dtype=torch.float64)
     if rank != 0:
         if use_dist:
@@ -813,7 +861,10 @@ def main():
         "config": {"workload": f"configs[1] problem ({N}-segment order-{s} MINCO, random-walk waypoints, "
                                f"energy-only, PVA boundary c={c}) at saturating batch {B}/GPU",
                    "batch_per_gpu": B, "row_stride_ld": ld, "pieces": N, "order": s, "global_batch": world * B,
-                   "parallelism": f"dp{world}" + ("+allgather(costs)" if use_dist else "")},
+                   "parallelism": f"dp{world}" + ("+allgather(costs)" if use_dist else ""),
+                   "ranks_seen": ag["ranks_seen"], "allgather_ms": ag["allgather_ms"],
+                   "allgather_bytes_per_rank": ag["allgather_bytes_per_rank"], "allgather_every": ag["every"],
+                   "allgathers_in_timed_loop_and_warmup": ag["issued"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_minco_solve", "kernel_ms": kernel_ms,
@@ -822,8 +873,9 @@ def main():
     }
 
     out["roofline"]["traffic"] = pmc_traffic_bytes(B, N, s)
-    out["roofline"]["traffic_source"] = ("committed rocprofv3 PMC pass of this launch shape (profiles/*_pmc.json: WRITE_SIZE + 2 x "
-                                         "FETCH_SIZE), a constant of the tree, not counted during this run")
+    # (the committed rocprofv3 PMC pass of this launch shape, WRITE_SIZE + 2 x FETCH_SIZE: a constant of the tree, not counted
+    #  during this run)
+    out["roofline"]["traffic_source"] = "profiles/*_pmc.json (committed PMC pass, not this run)"
     if c5 is not None:
         out["config5"] = c5
     if world == 1 and not args.main_only:
@@ -836,21 +888,15 @@ def main():
         # literal configs[1]: B = 1024 (launch-latency bound; reported, not the headline)
         b2 = 1024
         K2 = 200
-        for _ in range(20):
+
+        def solve_b1024():
             aa.minco_solve_dev(head, tail, wps, T, s, c, N, b2, coeffs=coeffs, energy=energy, ctx=ctx)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(K2):
-            aa.minco_solve_dev(head, tail, wps, T, s, c, N, b2, coeffs=coeffs, energy=energy, ctx=ctx)
-        e1.record()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out["config1_b1024"] = {"batch": b2, "value": b2 * K2 / dt, "ms_per_step": dt / K2 * 1e3,
-                                "stream_ms_per_step": e0.elapsed_time(e1) / K2,
-                                "hbm_frac": b2 * abytes / (e0.elapsed_time(e1) / K2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "note": "launch-latency bound: 2 MB per launch"}
+        # (the GPU has idled through seconds of CPU-baseline work: >= 10 ms of warm-up, five repetitions, median -- as the config3 leg)
+        runs = timed_reps(torch, solve_b1024, K2, reps=5, warm_ms=10.0)
+        h_ms, s_ms = sorted(r[0] for r in runs), sorted(r[1] for r in runs)
+        out["config1_b1024"] = {"batch": b2, "value": b2 / (h_ms[2] * 1e-3), "ms_per_step": h_ms[2],
+                                "stream_ms_per_step": s_ms[2], "stream_ms_min_median_max": [s_ms[0], s_ms[2], s_ms[-1]],
+                                "hbm_frac": b2 * abytes / (s_ms[2] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # The same 1024-trajectory launches from EIGHT streams (a sampler of time allocations issues many independent
         # batches): a launch is 49 waves on 1024 SIMDs, so independent batches overlap until the chip fills.
         ns = 8
@@ -860,14 +906,20 @@ def main():
                 for _ in range(ns)]
         ins = [x[:, :ld2].contiguous() for x in (head, tail, wps, T)]
         torch.cuda.synchronize()
-        for rep in range(2):                      # first pass = warm-up
-            t0 = time.perf_counter()
-            for k in range(K2 * ns if rep else ns * 4):
-                j = k % ns
+
+        def round_robin():
+            for j in range(ns):
                 aa.minco_solve_dev(ins[0], ins[1], ins[2], ins[3], s, c, N, b2, coeffs=outs[j][0], energy=outs[j][1],
                                    stream=streams[j].cuda_stream, ctx=ctx)
+        dt8s = []
+        for rep in range(6):                      # first pass = warm-up; then five repetitions, median (host clock: 8 streams)
+            t0 = time.perf_counter()
+            for k in range(K2 if rep else 25):
+                round_robin()
             torch.cuda.synchronize()
-            dt8 = time.perf_counter() - t0
+            if rep:
+                dt8s.append(time.perf_counter() - t0)
+        dt8 = sorted(dt8s)[2]
         # ... and as ONE hipGraph of 64 such launches on 8 parallel chains, replayed: what is left of the launch side
         try:
             cap = torch.cuda.Stream(device=device)
@@ -883,23 +935,16 @@ def main():
                                        stream=streams[j].cuda_stream, ctx=ctx)
                 for st in streams:
                     cur.wait_stream(st)
-            for _ in range(5):
-                graph.replay()
-            torch.cuda.synchronize()
             reps = 50
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                graph.replay()
-            torch.cuda.synchronize()
-            dtg = time.perf_counter() - t0
+            # (64 launches of 1024 trajectories on 8 parallel chains captured in one hipGraph, replayed)
+            gr = timed_reps(torch, graph.replay, reps, reps=5, warm_ms=10.0)
+            dtg = sorted(r[0] for r in gr)[2] * 1e-3 * reps
             out["config1_b1024"]["graph64x8"] = {"value": b2 * NG * reps / dtg, "ms_per_launch": dtg / (NG * reps) * 1e3,
-                                                 "hbm_frac": b2 * abytes / (dtg / (NG * reps)) / 1e9 / HBM_PEAK_GBS,
-                                                 "note": "64 launches of 1024 trajectories on 8 parallel chains captured in one hipGraph"}
+                                                 "hbm_frac": b2 * abytes / (dtg / (NG * reps)) / 1e9 / HBM_PEAK_GBS}
         except Exception as exc:      # (graph capture is an extra, never the headline)
             out["config1_b1024"]["graph64x8"] = {"error": str(exc)[:200]}
         out["config1_b1024"]["streams8"] = {"value": b2 * K2 * ns / dt8, "ms_per_launch": dt8 / (K2 * ns) * 1e3,
-                                            "hbm_frac": b2 * abytes / (dt8 / (K2 * ns)) / 1e9 / HBM_PEAK_GBS,
-                                            "note": "1024-trajectory launches round-robin on 8 streams"}
+                                            "hbm_frac": b2 * abytes / (dt8 / (K2 * ns)) / 1e9 / HBM_PEAK_GBS}
         # ... and what a sampler of time allocations should call instead of K launches of 1024 replicated problems: ONE
         # launch over K candidate duration vectors of few problems (anet_minco_sample_costs_dev: problem data per problem,
         # durations per sample, only the cost comes back)
@@ -923,8 +968,7 @@ def main():
                 smp[label] = {"samples": Ks, "ms_per_launch": ms, "value": Ks / (ms * 1e-3),
                               "hbm_frac": Ks * 8 * (N + 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "fp64_frac_at_4.1_kflop_per_sample": Ks * 4100.0 / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
-            smp["note"] = ("time-allocation samples/s in one launch; 8 (N + 1) bytes per sample, so the launch is bound by its "
-                           "FP64 work (~4.1 kFLOP per 8-segment snap sample in the reduced form)")
+            # (time-allocation samples/s in one launch; 8 (N + 1) bytes per sample: bound by its FP64 work, ~4.1 kFLOP per sample)
             out["config1_b1024"]["sampler"] = smp
         except Exception as exc:
             out["config1_b1024"]["sampler"] = {"error": str(exc)[:200]}
@@ -938,8 +982,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(3):
             aa.minco_solve(h_head, h_tail, h_wps, h_T, s, ctx=ctx)
-        out["host_api"] = {"batch": bh, "value": 3 * bh / (time.perf_counter() - t0),
-                           "note": "host pointers in/out, PCIe + layout transposes included"}
+        out["host_api"] = {"batch": bh, "value": 3 * bh / (time.perf_counter() - t0)}     # PCIe + layout transposes included
 
         if not args.no_cpu_baseline:
             from oracle import cbind
@@ -974,11 +1017,9 @@ def main():
             # (2) like for like: the kernels' own reduced algorithm compiled for the host cores
             rate_red, n_red, _ = time_cpu(cbind.cpu_reduced_solve_batch, 0.5 * args.cpu_seconds)
             out["cpu_baseline"] = {"value": rate_red, "unit": "trajectories/s", "cores": nthreads, "kind": "port",
-                                   "sample": f"{n_red} trajectories of the same workload, the kernels' own reduced (Hermite / "
-                                             f"block-tridiagonal) algorithm compiled for the host (oracle/minco_cpu_reduced.cpp), "
-                                             f"scalar FP64, {nthreads} threads",
-                                   "classic_banded_lu": {"value": rate_lu, "sample": f"{n_lu} trajectories, oracle/minco_oracle.c, "
-                                                                                      f"{nthreads} threads"},
+                                   # (port = the kernels' own reduced Hermite / block-tridiagonal algorithm compiled for the host)
+                                   "sample": f"{n_red} trajectories of the same workload, oracle/minco_cpu_reduced.cpp, scalar FP64",
+                                   "classic_banded_lu": {"value": rate_lu, "sample": f"{n_lu} trajectories, oracle/minco_oracle.c"},
                                    "gpu_vs_cpu_max_rel_coeff_err": err}
     if use_dist:
         dist.destroy_process_group()
@@ -990,7 +1031,7 @@ def main():
     except Exception:
         pass
     sys.stderr.flush()
-    print(json.dumps(out), flush=True)
+    print(finalize_line(out), flush=True)
 
 
 if __name__ == "__main__":

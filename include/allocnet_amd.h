@@ -327,6 +327,7 @@ void anet_qp_default_settings(anet_qp_settings *s);
 #define ANET_QP_SOLVED 1          /* OSQP_SOLVED                 */
 #define ANET_QP_MAX_ITER_REACHED (-2) /* OSQP_MAX_ITER_REACHED; the reference treats anything but Solved as failure (qp_solver.hpp:346-350) */
 #define ANET_QP_PRIMAL_INFEASIBLE (-3) /* OSQP_PRIMAL_INFEASIBLE: OSQP's certificate test on y(k+1)-y(k), eps_prim_inf 1e-4 */
+#define ANET_QP_UNSOLVED (-10)    /* OSQP_UNSOLVED: a problem no workgroup took (a launch_order that skips it); obj = NaN, iters = 0 */
 /* hpolys [batch][N][M][4] rows a.x <= b with all-zero rows as inert padding.
  * coeffs [batch][N][3][2s] (the flatten order callModel unpacks, learning_planner.hpp:212,227),
  * obj [batch] = 1/2 z'Qz (QPSolver::getObjCost), status/iters [batch], residuals [batch][2] (primal, dual;
@@ -348,6 +349,8 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
  * (device, int32 [batch], a permutation of 0..batch-1) is the problem each successive workgroup takes; longest first from the
  * iters[] of a previous solve of the same or a similar batch (anet_launch_order_from_steps_dev) -- the re-solve of a receding-
  * horizon planner or a sampler.  Results are bit-identical for any order; NULL = as given; the ADMM method ignores it.
+ * Entries are not checked on the host (device memory): an entry outside [0, batch) is skipped, a repeated one solves its problem
+ * twice, and a problem no entry names reports status ANET_QP_UNSOLVED, iters 0 and obj NaN (its coeffs are left untouched).
  * No reference counterpart (QPSolver::solve takes one problem: qp_solver.hpp:119).                                        */
 int anet_qp_solve_ordered_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
                               double max_acc, double m34, const double *state, const double *T, const double *hpolys,
@@ -453,7 +456,8 @@ int anet_lbfgs_mvie(anet_ctx *ctx, int64_t batch, int M, const double *A /* [bat
  * proc_stepbound, proc_progress, instance, param).  proc_evaluate (lbfgs.hpp:186-219) becomes a host function that ENQUEUES
  * the evaluation of the whole batch on `stream`: given x ([n][ld] device, batch-minor: variable i of problem b at x[i*ld + b])
  * it must leave f[b] and g[i*ld + b] for every problem b < batch (the values of problems that have stopped are ignored) and
- * return 0; anything else aborts the run with ANET_ERR_INVALID.  It is called once per evaluation step of the batch (the
+ * return 0; anything else aborts the run with ANET_ERR_INVALID.  The call synchronises `stream` as it goes (completion polls) and at
+ * its end: x, f, status, iters and evals are complete on return, on whatever stream the caller reads them.  It is called once per evaluation step of the batch (the
  * lockstep shape: every running problem consumes one evaluation per call; a completion flag is polled every eight steps, so
  * up to eight calls may follow the last problem's stop).  x is the start point in, the result out; f and g are the caller's
  * buffers the callback fills ([batch] and [n][ld]); on return f[b] is lbfgs_optimize's fx.  proc_stepbound: the one bound

@@ -67,3 +67,60 @@ def test_allgather_costs_gloo_world2(total):
     mp.spawn(_worker, args=(2, port, total, ret), nprocs=2, join=True)
     assert ret["n"] == total
     assert ret["err"] == 0.0
+
+
+def _overlap_worker(rank, world, port, steps, every, ret):
+    """bench.py's step(): slot j = i & 1 is overwritten by the (fake) solve of step i only after the gather issued from it at
+    step i - 2 has completed; every gather must deliver the costs of ITS step from every rank."""
+    import torch
+    import torch.distributed as dist
+    from allocnet_amd.distributed import OverlappedCostGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 257
+        og = OverlappedCostGather(n, world, "cpu", alloc=n + 63, every=every)
+        bad, seen = 0, 0
+        pending = {}                                   # slot -> step whose gather is in flight
+        for i in range(steps):
+            j = og.acquire(i)
+            if j in pending:                           # acquire() waited: that gather is complete and must hold step pending[j]
+                st = pending.pop(j)
+                for r in range(world):
+                    exp = torch.arange(n, dtype=torch.float64) + 1000.0 * st + 1e6 * r
+                    bad += int(not torch.equal(og.recv[j][r * n:(r + 1) * n], exp))
+                seen += 1
+            og.send[j][:n] = torch.arange(n, dtype=torch.float64) + 1000.0 * i + 1e6 * rank      # the "solve" of step i
+            if og.submit(i) is not None:
+                pending[j] = i
+        og.drain()
+        for j, st in pending.items():
+            for r in range(world):
+                exp = torch.arange(n, dtype=torch.float64) + 1000.0 * st + 1e6 * r
+                bad += int(not torch.equal(og.recv[j][r * n:(r + 1) * n], exp))
+            seen += 1
+        if rank == 0:
+            ret["bad"], ret["seen"], ret["issued"] = bad, seen, og.issued
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("every", [1, 3])
+def test_overlapped_cost_gather_double_buffer_order_gloo_world2(every):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    steps = 13
+    mp.spawn(_overlap_worker, args=(2, _free_port(), steps, every, ret), nprocs=2, join=True)
+    assert ret["bad"] == 0
+    assert ret["issued"] == steps // every and ret["seen"] == ret["issued"]
+
+
+def test_overlapped_cost_gather_disabled_is_a_plain_double_buffer():
+    from allocnet_amd.distributed import OverlappedCostGather
+    og = OverlappedCostGather(8, 1, "cpu", enabled=False)
+    assert [og.acquire(i) for i in range(4)] == [0, 1, 0, 1]
+    assert og.submit(0) is None and og.issued == 0 and og.recv is None
+    og.drain()

@@ -708,6 +708,37 @@ def test_launch_order_changes_nothing_but_the_schedule(anet_ctx):
         aa.qp_solve_dev(4, st, tT, thp, ctx=anet_ctx, launch_order=torch.zeros(3, dtype=torch.int32, device=dev))
 
 
+def test_a_bad_launch_order_cannot_write_out_of_bounds_and_says_what_it_skipped(anet_ctx):
+    """The launch order is device memory the host cannot check: an entry outside [0, batch) is skipped by the kernel (it used to
+    index sl / lam / coeffs / status with it), a repeated entry solves its problem twice, and a problem no entry names reports
+    ANET_QP_UNSOLVED (-10) with iters 0 and a NaN objective instead of whatever the buffers held."""
+    import torch
+    import allocnet_amd as aa
+    from allocnet_amd.synth import corridor_problem
+    dev = torch.device("cuda", 0)
+    s, N, B = 3, 5, 96
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(8), B, N, 3, 16)
+    state = np.ascontiguousarray(np.stack([head, tail], axis=1)[..., :3])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    st, tT, thp = t(state), t(T * 1.5), t(hp)
+    ref = aa.qp_solve_dev(s, st, tT, thp, ctx=anet_ctx)
+    order = np.arange(B, dtype=np.int32)
+    order[5] = 10 ** 9          # far outside
+    order[6] = -3               # negative
+    order[7] = B                # one past the end
+    order[8] = 9                # repeated: problem 8 is never taken
+    guard = torch.full((4096,), 7.25, device=dev, dtype=torch.float64)     # a neighbouring allocation must stay untouched
+    out = aa.qp_solve_dev(s, st, tT, thp, ctx=anet_ctx, launch_order=torch.from_numpy(order).to(dev))
+    torch.cuda.synchronize()
+    skipped = np.array([5, 6, 7, 8])
+    taken = np.setdiff1d(np.arange(B), skipped)
+    stt, it, ob = out["status"].cpu().numpy(), out["iters"].cpu().numpy(), out["obj"].cpu().numpy()
+    assert (stt[skipped] == -10).all() and (it[skipped] == 0).all() and np.isnan(ob[skipped]).all()
+    for k in ("coeffs", "obj", "status", "iters"):
+        assert torch.equal(out[k][torch.from_numpy(taken).to(dev)], ref[k][torch.from_numpy(taken).to(dev)]), k
+    assert bool((guard == 7.25).all())
+
+
 def test_two_launch_form_returns_the_same_bits():
     """Batches of 576 problems and more run in TWO launches (csrc/qp_ipm.h IpmArgs::it_stop): four Newton steps of every problem,
     then the unfinished ones resumed longest-expected first.  Parking and resuming an iterate changes no arithmetic: against one
