@@ -16,6 +16,7 @@
 #include "../../include/allocnet_amd.h"
 #include "minco_core.h"
 #include "minco_kernels.h"
+#include "minco_fused_kernel.h"
 #include "minco_sample_kernel.h"
 #include "minco_dense_kernels.h"
 #include "traj_kernels.h"
@@ -941,6 +942,39 @@ static int check_penalty(anet_ctx *ctx, const anet_penalty *pen) {
   return ANET_OK;
 }
 
+// The basis table of k_piece_grad for (order, res): built once per context on the stream that first needs it; other streams are
+// ordered behind the build by its event.
+static int basis_table(anet_ctx *ctx, int s, int res, hipStream_t st, const double **out) {
+  int rc = ANET_OK;
+  *out = nullptr;
+  if (res > 4096) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_penalty.res too large for the basis table");
+  for (auto &t : ctx->tabs)
+    if (t.s == s && t.res == res) {
+      // built on another stream: order this stream behind the build (no host or device-wide synchronisation)
+      if (t.built_on != st) ANET_HIP(ctx, hipStreamWaitEvent(st, t.ready, 0));
+      *out = t.d;
+    }
+  if (!*out) {
+    // (never freed before anet_destroy -- a launch on another stream may still read one: a caller that sweeps res over
+    //  hundreds of values is told so instead of growing the context without bound, as for the tables of k_qp_ipm)
+    if (ctx->tabs.size() >= kMaxTablesPerContext)
+      return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_minco_partial_grads: more than 256 distinct (order, res) on one context");
+    anet_ctx::BasisTable t{s, res, nullptr, st, nullptr};
+    const int need = res * 4 * 2 * s;
+    if ((rc = new_table(ctx, sizeof(double) * need, &t.d, &t.ready))) return rc;
+    hipLaunchKernelGGL(anet::k_build_basis_table, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, t.d, res, 2 * s);
+    hipError_t e1 = hipGetLastError();
+    if (e1 == hipSuccess) e1 = hipEventRecord(t.ready, st);
+    if (e1 != hipSuccess) {
+      drop_table(t.d, t.ready);
+      return hip_fail(ctx, e1, "k_build_basis_table");
+    }
+    ctx->tabs.push_back(t);
+    *out = t.d;
+  }
+  return rc;
+}
+
 int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
                                  const double *coeffs, const double *T, const double *hpolys,
                                  const anet_penalty *pen, int with_energy, double *gdC, double *gdT,
@@ -960,34 +994,8 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
                                pen->max_vel, pen->max_acc, pen->res, pen->poly_rows};
   const dim3 grid((unsigned)((batch + 255) / 256), (unsigned)n_pieces), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (pen && pen->res > 4096) return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_penalty.res too large for the basis table");
   const double *tab = nullptr;
-  if (pen) {
-    for (auto &t : ctx->tabs)
-      if (t.s == s && t.res == pen->res) {
-        // built on another stream: order this stream behind the build (no host or device-wide synchronisation)
-        if (t.built_on != st) ANET_HIP(ctx, hipStreamWaitEvent(st, t.ready, 0));
-        tab = t.d;
-      }
-    if (!tab) {
-      // (never freed before anet_destroy -- a launch on another stream may still read one: a caller that sweeps res over
-      //  hundreds of values is told so instead of growing the context without bound, as for the tables of k_qp_ipm)
-      if (ctx->tabs.size() >= kMaxTablesPerContext)
-        return fail(ctx, ANET_ERR_UNSUPPORTED, "anet_minco_partial_grads: more than 256 distinct (order, res) on one context");
-      anet_ctx::BasisTable t{s, pen->res, nullptr, st, nullptr};
-      const int need = pen->res * 4 * 2 * s;
-      if ((rc = new_table(ctx, sizeof(double) * need, &t.d, &t.ready))) return rc;
-      hipLaunchKernelGGL(anet::k_build_basis_table, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, st, t.d, pen->res, 2 * s);
-      hipError_t e1 = hipGetLastError();
-      if (e1 == hipSuccess) e1 = hipEventRecord(t.ready, st);
-      if (e1 != hipSuccess) {
-        drop_table(t.d, t.ready);
-        return hip_fail(ctx, e1, "k_build_basis_table");
-      }
-      ctx->tabs.push_back(t);
-      tab = t.d;
-    }
-  }
+  if (pen && (rc = basis_table(ctx, s, pen->res, st, &tab))) return rc;
   // ANET_PIECE_SW_MAX_PAIRS overrides (tuning / A-B runs)
   static const int64_t sw_max_pairs = [] { const char *e = getenv("ANET_PIECE_SW_MAX_PAIRS"); return e ? (int64_t)atoll(e) : kPieceSampleSplitMaxPairs; }();
   if (pen && batch <= axis_variant_max_batch() && batch * n_pieces <= sw_max_pairs) {
@@ -1036,6 +1044,40 @@ static int cost_grad_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t
   if (batch == 0) return ANET_OK;
   if (!work || !cost || !gradT || (n_pieces > 1 && !gradP))
     return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad_dev: NULL output or workspace");
+  // Small batches in ONE launch (minco_fused_kernel.h): up to one workgroup per CU -- beyond that the three streaming kernels
+  // have the chip full anyway and are the better shape (ANET_FUSED_MAX_GROUPS overrides the 256; 0 disables).
+  static const int64_t fused_max_groups = [] { const char *e = getenv("ANET_FUSED_MAX_GROUPS"); return e ? (int64_t)atoll(e) : (int64_t)256; }();
+  const int fg = pen ? anet::cost_grad_fused_group(s, n_pieces) : 0;
+  if (fg > 0 && (batch + fg - 1) / fg <= fused_max_groups && pen->res <= anet::kFusedMaxRes) {
+    if (!head || !tail || !T || (n_pieces > 1 && !wps) || ld < batch)
+      return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad_dev: NULL input or ld < batch");
+    const double *tab = nullptr;
+    if ((rc = basis_table(ctx, s, pen->res, (hipStream_t)stream, &tab))) return rc;
+    anet::FusedArgs fa{head, tail, wps, T, pen->poly_rows > 0 ? hpolys : nullptr, cost, gradP, gradT, coeffs_out, tau, batch, ld,
+                       n_pieces, c, anet::Penalty{pen->rho, pen->w_corridor, pen->w_vel, pen->w_acc, pen->smooth_mu, pen->max_vel,
+                                                  pen->max_acc, pen->res, pen->poly_rows}, 0};
+#ifdef ANET_FUSED_PROF
+    static long long *d_fprof = nullptr;
+    if (!d_fprof) ANET_HIP(ctx, hipMalloc((void **)&d_fprof, 16 * sizeof(long long)));
+    fa.prof = d_fprof;
+#endif
+    if (anet::launch_cost_grad_fused(s, fa, tab, (hipStream_t)stream, fused_max_groups)) {
+      ANET_HIP(ctx, hipGetLastError());
+#ifdef ANET_FUSED_PROF
+      if (getenv("ANET_FUSED_PROF_PRINT")) {
+        long long h[16];
+        ANET_HIP(ctx, hipMemcpyAsync(h, d_fprof, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        ANET_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+        static const char *nm[13] = {"loads1", "factor", "solve", "stash", "barrier1", "lds-in", "penalty", "energy+pairsum+reduce", "nodeform",
+                                     "barrier2", "lds-in3", "fwd", "bwd"};
+        fprintf(stderr, "fused_prof cycles (workgroup 0, thread 0):");
+        for (int k = 0; k < 13; ++k) fprintf(stderr, " %s %lld", nm[k], h[k + 1] - h[k]);
+        fprintf(stderr, " | total %lld\n", h[13] - h[0]);
+      }
+#endif
+      return ANET_OK;
+    }
+  }
   const int64_t nco = (int64_t)n_pieces * 3 * 2 * s;
   double *w_co = coeffs_out ? coeffs_out : work;
   double *w_gdC = work + nco * ld;

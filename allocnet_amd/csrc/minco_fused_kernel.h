@@ -1,0 +1,406 @@
+// One cost + gradient evaluation of a SMALL batch in ONE launch: solve -> penalty / energy partial gradients -> adjoint.
+//
+// Why (profiles/r05_cost_grad_small_batch.txt): at BASELINE configs[2]'s literal batch (4096 x 8 pieces) the three launches of
+// anet_minco_cost_grad_dev take 8.6 + 26.5 + 13.2 us of kernel time back to back, and ~9 us of each are the same whatever the
+// arithmetic (k_piece_grad with ONE sample per piece instead of 20: 10.1 us): a kernel boundary makes every wave of the next
+// kernel start with cold loads from beyond the L2 (what the previous kernel wrote is written back at its end), the adjoint
+// re-factorises the system the solve factorised and re-reads the node states it had in registers.  Here a workgroup owns G
+// trajectories from their waypoints to their gradients:
+//   phase 1  wave 0, lane = (trajectory, axis): k_minco_solve_axis' chain; the coefficients go to LDS (and to coeffs_out if
+//            asked for), the factor, the node states and the energy STAY IN REGISTERS for phase 3;
+//   phase 2  all 256 lanes, at least two per (trajectory, piece): k_piece_grad's penalty / energy code on the coefficients
+//            from LDS; the pair's partial gradient w.r.t. the piece's coefficients is turned into its adjoint
+//            w.r.t. the piece's two node states right there (what the adjoint kernel's first loop does piece after piece on
+//            one lane) and handed over through LDS;
+//   phase 3  wave 0 again: the two sweeps of the adjoint with the factor and the node states of phase 1.
+// No global round trip between the phases, one launch, no second factorisation.
+// The group size G is a run-time value (a power of two, at most FusedShape<NB>::G): a batch too small to give every CU a
+// workgroup of G trajectories takes a smaller G, and the lanes that frees split the SAMPLES of a piece further: Q = 128 / (G NB)
+// lane pairs per (trajectory, piece), 2 Q lanes taking every 2 Q-th sample each (the basis table from a copy in LDS, since the
+// sample index differs from lane to lane); their partial gradients are added in a fixed order through LDS.  For batches that fill the chip the three
+// streaming kernels remain the better shape (the host picks: allocnet_amd.hip cost_grad_dev_impl).
+#pragma once
+#include "minco_kernels.h"
+
+namespace anet {
+
+struct FusedArgs {
+  const double *head, *tail, *wps, *T, *hpolys;
+  double *cost, *gradP, *gradT, *coeffs_out;
+  const double *tau;  // optional: durations parametrised as T = forward_T(tau), gradT returned as dJ/dtau (L-BFGS driver)
+  int64_t B, ld;
+  int N, c;
+  Penalty pp;
+  int G;   // trajectories per workgroup: a power of two <= FusedShape<NB>::G
+#ifdef ANET_FUSED_PROF
+  long long *prof;  // [16] cycle stamps of thread 0 of workgroup 0 (tools: ANET_BUILD_FLAGS=-DANET_FUSED_PROF)
+#endif
+};
+#ifdef ANET_FUSED_PROF
+// (sched_barrier: nothing is scheduled across a stamp, or max-ILP scheduling moves the arithmetic of a phase past its stamp)
+#define ANET_FP(k) do { __builtin_amdgcn_sched_barrier(0); if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[k] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ANET_FP(k) do { } while (0)
+#endif
+
+constexpr int kFusedMaxRes = 64;  // samples per piece the LDS copy of the basis table holds (more: the three-launch path)
+
+template <int NB>
+struct FusedShape {
+  static constexpr int G = (128 / NB) < 16 ? (128 / NB) : 16;  // trajectories per workgroup: at most 128 (trajectory, piece) pairs
+  static constexpr int PST = 130;                              // row stride of the LDS arrays (pairs, padded)
+};
+
+template <int S, int NB, bool NEXACT = false, int NPC = -1>
+__global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, const double *__restrict__ tab) {
+  constexpr int m = S - 1, D = 2 * S, GM = FusedShape<NB>::G, PST = FusedShape<NB>::PST;
+  constexpr int ROW_T = 3 * D, ROW_GX = ROW_T + 1, ROW_GTD = ROW_GX + 3 * D, ROW_GDT = ROW_GTD + 3, ROW_PC = ROW_GDT + 1;
+  constexpr int NRED = 3 * D + 2;  // values a lane pair hands to the pair that adds up a piece: gC, gT, pc
+  __shared__ double lds[(ROW_PC + 1) * PST];
+  __shared__ double lred[NRED * 128];
+  __shared__ double ltab[kFusedMaxRes * 3 * D];
+  // What phase 3 needs of phase 1 (factor, node states, durations, energy: ~100 doubles per chain lane) waits in LDS, not in
+  // registers across phase 2: with them the sample loop (whose table rows are per-lane values) goes into scratch
+  constexpr int nl = Factor<S, NB>::nl > 0 ? Factor<S, NB>::nl : 1;
+  constexpr int NST = (NB + 1) * (nl + 2 * m + 1) + 2 * NB + 1, SST = 3 * GM;
+  __shared__ double lst[NST * SST];
+  const int G = a.G;                              // trajectories of this workgroup
+  const int LPQ = 2 * G * NB;                     // lanes of one sample subset (a power of two <= 256)
+  const int Q = 256 / LPQ;                        // lane pairs per (trajectory, piece)
+  const int N = NEXACT ? NB : a.N;
+  const int np = NPC >= 0 ? NPC : a.c - 1;
+  const int c = np + 1;
+  const int64_t ld = a.ld;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int64_t b0 = (int64_t)blockIdx.x * G;
+  ANET_FP(0);
+  {
+    // the rows of position, velocity and acceleration of every sample (read by other threads behind the barrier); by the waves
+    // that have no chain to start: a load-to-store round trip in front of wave 0's chain would be in front of everything
+    if (wave != 0)
+      for (int e = tid - 64; e < a.pp.res * 3 * D; e += 192) ltab[e] = tab[(size_t)(e / (3 * D)) * 4 * D + e % (3 * D)];
+  }
+
+  // phase 2's lane mapping
+  const int q2 = tid / LPQ;                      // which lane pair of its (trajectory, piece)
+  const int pair = (tid % LPQ) >> 1, half = tid & 1;
+  const int piece = pair / G, t2 = pair % G;
+  // (pairs beyond N * G idle -- the two lanes of a pair always agree; GM * NB < 128: the lanes beyond the last subset too)
+  const bool pair_ok = piece < N && q2 < Q;
+  const int64_t bb2 = (pair_ok && b0 + t2 < a.B) ? b0 + t2 : (a.B - 1);
+
+  // ---- phase 1 (wave 0): the coefficient solve, one lane per (trajectory, axis) ---------------------------------------------
+  Factor<S, NB> F;
+  double P[NB + 1], X[NB + 1][m], tt[NB];
+  double e_axis = 0.0;
+  const int t1 = tid / 3, ax1 = tid % 3;
+  const bool chain_lane = wave == 0 && tid < 3 * G;
+  const bool live1 = chain_lane && b0 + t1 < a.B;
+  const int64_t bb1 = live1 ? b0 + t1 : (a.B - 1);
+  double hv[m], tv[m];
+  if (wave == 0) {
+    const double *hp = a.head + (int64_t)(ax1 * c) * ld + bb1;
+    const double *tp = a.tail + (int64_t)(ax1 * c) * ld + bb1;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) tt[i] = a.T[(int64_t)(i < N ? i : 0) * ld + bb1];
+#pragma unroll
+    for (int k = 0; k <= NB; ++k) {
+      const double *src = (k == 0) ? hp : (k < N) ? a.wps + (int64_t)((k - 1) * 3 + ax1) * ld + bb1 : tp;
+      const double v = *src;
+      P[k] = (k <= N) ? v : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      const int64_t row = (j < np) ? 1 + j : 0;
+      const double h = hp[row * ld], t = tp[row * ld];
+      hv[j] = (j < np) ? h : 0.0;
+      tv[j] = (j < np) ? t : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (i < N) F.r[i] = fast_rcp(tt[i]);
+    ANET_FP(1);
+    F.factorize(N, np);
+    ANET_FP(2);
+    double *cp = (a.coeffs_out && live1) ? a.coeffs_out + (int64_t)(ax1 * D) * ld + bb1 : nullptr;
+    e_axis = solve_axis<S, NB>(F, N, np, P, hv, tv, X, [&](int piece, int col, double v) {
+      if (chain_lane) lds[(ax1 * D + col) * PST + piece * G + t1] = v;
+      if (cp) cp[(int64_t)(piece * 3 * D + col) * ld] = v;
+    });
+    ANET_FP(3);
+    if (chain_lane && ax1 == 0) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (i < N) lds[ROW_T * PST + i * G + t1] = tt[i];
+    }
+    {
+      if (chain_lane) {
+        int v = 0;
+        auto put = [&](double x) { lst[(v++) * SST + tid] = x; };
+#pragma unroll
+        for (int k = 0; k <= NB; ++k) {
+#pragma unroll
+          for (int j = 0; j < nl; ++j) put(F.L[k][j]);
+#pragma unroll
+          for (int j = 0; j < m; ++j) put(F.dinv[k][j]);
+#pragma unroll
+          for (int j = 0; j < m; ++j) put(X[k][j]);
+          put(P[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          put(F.r[i]);
+          put(tt[i]);
+        }
+        put(e_axis);
+      }
+    }
+  }
+  __syncthreads();
+  ANET_FP(4);
+
+  // ---- phase 2 (all waves): two lanes per (trajectory, piece) ------------------------------------------------------------------
+  {
+    const int q = q2;
+    double gC[3][D], cf[3][D];
+    double gT = 0.0, pc = 0.0, Ti = 1.0;
+    if (pair_ok) {
+      Ti = lds[ROW_T * PST + pair];
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+        for (int col = 0; col < D; ++col) {
+          cf[ax][col] = lds[(ax * D + col) * PST + pair];
+          gC[ax][col] = 0.0;
+        }
+      ANET_FP(5);
+      // The 2 Q lanes of a (trajectory, piece) split its SAMPLES (lane h of pair q takes j = 2q + h, 2q + h + 2Q, ...) and each
+      // visits every corridor row: the position is evaluated once per sample and pass, the limit rows once per sample.  (With
+      // the rows split between the two lanes of a pair, as k_piece_grad<S, true> has it, both lanes evaluate every position and
+      // the limit block runs for the whole wave on behalf of half its lanes: 18.3 us of sample loop against 14.3 at 4096 x 8.)
+      piece_penalty_part<S, false, 1, true>(a.pp, a.hpolys, ld, bb2, piece, 0, 2 * q + half, Ti, cf, ltab, gC, gT, pc, 2 * Q);
+      ANET_FP(6);
+      if (half == 0 && q == 0) {
+        double ch[3][S];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+          for (int col = 0; col < S; ++col) ch[ax][col] = cf[ax][col];
+        piece_energy_compute<S>(ch, Ti, gC, gT);
+      }
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+        for (int col = 0; col < D; ++col) gC[ax][col] = pair_sum(gC[ax][col]);
+      gT = pair_sum(gT);
+      pc = pair_sum(pc);
+    }
+    {  // the lane pairs of a piece, added by pair 0 in the order of q (deterministic)
+      const int PPQ = G * NB;  // pairs per subset; (Q - 1) PPQ < 128 slots
+      if (pair_ok && q > 0 && half == 0) {
+        const int slot = (q - 1) * PPQ + pair;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+          for (int col = 0; col < D; ++col) lred[(ax * D + col) * 128 + slot] = gC[ax][col];
+        lred[(3 * D) * 128 + slot] = gT;
+        lred[(3 * D + 1) * 128 + slot] = pc;
+      }
+      __syncthreads();
+      if (pair_ok && q == 0 && half == 0) {
+        for (int qq = 1; qq < Q; ++qq) {
+          const int slot = (qq - 1) * PPQ + pair;
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+            for (int col = 0; col < D; ++col) gC[ax][col] += lred[(ax * D + col) * 128 + slot];
+          gT += lred[(3 * D) * 128 + slot];
+          pc += lred[(3 * D + 1) * 128 + slot];
+        }
+      }
+    }
+    ANET_FP(7);
+    if (pair_ok) {
+      if (half == 0 && q == 0) {
+        // The adjoint's first step, per piece and in parallel: g_x = Phi' gC for the piece's two node states and the direct
+        // dPhi/dT term (k_minco_propagate's loop over the pieces, minco_kernels.h propagate_axis), from the piece's own
+        // coefficients: x0[j] = j! c_j, x1 = the piece's derivatives at its end.
+        const Pw<S> p(fast_rcp(Ti));
+        double tp[D];
+        tp[0] = 1.0;
+#pragma unroll
+        for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          double x0[S], x1[S], gs[S], ge[S], h[S];
+          double fact = 1.0;
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            if (j > 0) fact *= (double)j;
+            x0[j] = fact * cf[ax][D - 1 - j];
+            double acc = 0.0;
+#pragma unroll
+            for (int q = j; q < D; ++q) {
+              double f = 1.0;
+#pragma unroll
+              for (int e = 0; e < j; ++e) f *= (double)(q - e);
+              acc = __builtin_fma(f * tp[q - j], cf[ax][D - 1 - q], acc);
+            }
+            x1[j] = acc;
+            gs[j] = gC[ax][D - 1 - j] * (1.0 / fact);
+            ge[j] = 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < S; ++q) h[q] = gC[ax][S - 1 - q] * p[q];
+          double dsum = 0.0;
+#pragma unroll
+          for (int bb = 0; bb < 2 * S; ++bb) {
+            const int dg = bb % S;
+            double u = 0.0, qd = 0.0;
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+              u = __builtin_fma(Tab<S>::BHI[q][bb], h[q], u);
+              qd = __builtin_fma((double)(S + q - dg) * Tab<S>::BHI[q][bb], h[q], qd);
+            }
+            const double sc = p[S - dg];
+            const double xb = (bb < S) ? x0[dg] : x1[dg];
+            if (bb < S) gs[dg] = __builtin_fma(u, sc, gs[dg]);
+            else ge[dg] = u * sc;
+            dsum = __builtin_fma(xb * sc, qd, dsum);
+          }
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            lds[(ROW_GX + ax * D + j) * PST + pair] = gs[j];
+            lds[(ROW_GX + ax * D + S + j) * PST + pair] = ge[j];
+          }
+          lds[(ROW_GTD + ax) * PST + pair] = -p[1] * dsum;
+        }
+        lds[ROW_GDT * PST + pair] = gT;
+        lds[ROW_PC * PST + pair] = pc;
+      }
+    }
+  }
+  ANET_FP(8);
+  __syncthreads();
+  ANET_FP(9);
+
+  // ---- phase 3 (wave 0): the adjoint sweeps with the factor and the node states of phase 1 -----------------------------------------
+  if (wave != 0) return;
+  {
+    const int lane = chain_lane ? tid : 0;
+    int v = 0;
+    auto get = [&]() { return lst[(v++) * SST + lane]; };
+#pragma unroll
+    for (int k = 0; k <= NB; ++k) {
+#pragma unroll
+      for (int j = 0; j < nl; ++j) F.L[k][j] = get();
+#pragma unroll
+      for (int j = 0; j < m; ++j) F.dinv[k][j] = get();
+#pragma unroll
+      for (int j = 0; j < m; ++j) X[k][j] = get();
+      P[k] = get();
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      F.r[i] = get();
+      tt[i] = get();
+    }
+    e_axis = get();
+  }
+  {
+    double GP[NB + 1], XA[NB + 1][m], gTl[NB], rr[NB];
+#pragma unroll
+    for (int k = 0; k <= NB; ++k) {
+      GP[k] = 0.0;
+#pragma unroll
+      for (int l = 0; l < m; ++l) XA[k][l] = 0.0;
+      if (k <= N && chain_lane) {
+        if (k < N) {
+          GP[k] = lds[(ROW_GX + ax1 * D) * PST + k * G + t1];
+#pragma unroll
+          for (int l = 0; l < m; ++l) XA[k][l] = lds[(ROW_GX + ax1 * D + 1 + l) * PST + k * G + t1];
+        }
+        if (k > 0) {
+          GP[k] += lds[(ROW_GX + ax1 * D + S) * PST + (k - 1) * G + t1];
+#pragma unroll
+          for (int l = 0; l < m; ++l) XA[k][l] += lds[(ROW_GX + ax1 * D + S + 1 + l) * PST + (k - 1) * G + t1];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      gTl[i] = (i < N && chain_lane) ? lds[(ROW_GTD + ax1) * PST + i * G + t1] : 0.0;
+      rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
+    }
+    ANET_FP(10);
+    // adjoint solve K lam = g_x|free (pinned rows 0)
+    sweep_forward<S, NB>(F, N, np, rr, XA, [&](int k, double (&y)[m]) {
+#pragma unroll
+      for (int l = 0; l < m; ++l) y[l] = ((k == 0 || k == N) && l < np) ? 0.0 : XA[k][l];
+    });
+    ANET_FP(11);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
+    sweep_backward<S, NB>(F, N, np, rr, XA, [&](int k, const Pw<S> &p) {
+      // (W_k lam^)[position row of node k]; the row of node k+1 is its negative
+      double wl = 0.0;
+#pragma unroll
+      for (int l = 0; l < m; ++l) {
+        wl = __builtin_fma(Tab<S>::M[0][1 + l] * p[2 * S - 2 - l], XA[k][l], wl);
+        wl = __builtin_fma(Tab<S>::M[0][S + 1 + l] * p[2 * S - 2 - l], XA[k + 1][l], wl);
+      }
+      GP[k] -= wl;
+      GP[k + 1] += wl;
+      // - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b; x^ from phase 1's registers
+      double xs[2 * S];
+#pragma unroll
+      for (int bb = 0; bb < 2 * S; ++bb) {
+        const int dg = bb % S;
+        const double xv = dg == 0 ? P[bb < S ? k : k + 1] : X[bb < S ? k : k + 1][dg - 1];
+        xs[bb] = xv * p[S - dg];
+      }
+      double acc = 0.0;
+#pragma unroll
+      for (int aa = 0; aa < 2 * S; ++aa) {
+        const int da = aa % S;
+        if (da == 0) continue;
+        double row = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < 2 * S; ++bb)
+          row = __builtin_fma(Tab<S>::M[aa][bb] * (double)(2 * S - 1 - da - bb % S), xs[bb], row);
+        const double ls = ((aa < S) ? XA[k][da - 1] : XA[k + 1][da - 1]) * p[S - da];
+        acc = __builtin_fma(ls, row, acc);
+      }
+      gTl[k] += acc;
+    });
+    ANET_FP(12);
+    if (live1 && a.gradP) {
+      double *gp = a.gradP + (int64_t)ax1 * ld + bb1;
+#pragma unroll
+      for (int k = 1; k < NB; ++k)
+        if (k < N) gp[(int64_t)((k - 1) * 3) * ld] = GP[k];
+    }
+    // per trajectory: the three axes' shares (adjacent lanes), the partial dJ/dT of phase 2, rho, the chain rule of tau
+    const double e_tot = e_axis + __shfl_down(e_axis, 1) + __shfl_down(e_axis, 2);
+    double csum = 0.0, tsum = 0.0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (i < N) {
+        const double tot = gTl[i] + __shfl_down(gTl[i], 1) + __shfl_down(gTl[i], 2);
+        if (live1 && ax1 == 0) {
+          const double gt = lds[ROW_GDT * PST + i * G + t1] + tot + a.pp.rho;
+          a.gradT[(int64_t)i * ld + bb1] = a.tau ? gt * dforward_T(a.tau[(int64_t)i * ld + bb1]) : gt;
+          csum += lds[ROW_PC * PST + i * G + t1];
+          tsum += tt[i];
+        }
+      }
+    if (a.cost && live1 && ax1 == 0) a.cost[bb1] = e_tot + a.pp.rho * tsum + csum;
+    ANET_FP(13);
+  }
+}
+
+// false: no instantiation for this shape (the caller takes the three-launch path)
+bool launch_cost_grad_fused(int s, const FusedArgs &a, const double *tab, hipStream_t st, int64_t max_groups);
+int cost_grad_fused_group(int s, int n_pieces);  // trajectories per workgroup of the instantiation that would run (0: none)
+
+}  // namespace anet

@@ -246,6 +246,266 @@ struct TabRow {
   __device__ __forceinline__ void await() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); }
 };
 
+// The penalty part of one (trajectory, piece) on one lane (of a pair: SPLIT; of a pair and a sample subset: SW > 1): adds the
+// gradient of J_pen w.r.t. the piece's coefficients to gC and w.r.t. its duration to gT, sets pc = this lane's share of the
+// piece's J_pen.  Shared by k_piece_grad and the one-launch small-batch evaluation (minco_fused_kernel.h): same code, same bits.
+// LTAB = false: the samples j = wv, wv + SW, ... -- the same for every lane of the wave -- with the basis table read through
+// scalar loads; LTAB = true: this LANE's samples j = wv, wv + jstep, ... (wv, jstep run-time values that may differ from lane to
+// lane) with `tab` a copy of the table in LDS, rows [j][3][D] (position, velocity, acceleration).
+template <int S, bool SPLIT, int SW, bool LTAB = false>
+__device__ __forceinline__ void piece_penalty_part(const Penalty &pp_in, const double *hpolys, const int64_t ld, const int64_t b,
+                                                   const int i, const int half, const int wv, const double Ti,
+                                                   const double (&c)[3][2 * S], const double *__restrict__ tab,
+                                                   double (&gC)[3][2 * S], double &gT, double &pc, const int jstep = SW) {
+  constexpr int D = 2 * S;
+  // Normalised time: with c~_k = c_k T^k the state rows at sample j depend on tau_j = j/res only,
+  //   d^d p/dt^d (t_j) = T^-d sum_col c~[col] tab[j][d][col],  tab[j][d][col] = k!/(k-d)! tau_j^(k-d)
+  // (table read with a wave-uniform index: scalar loads).
+  //
+  // Instruction diet (the kernel is bound by FP64 issue, tools/micro/fp64_peak.hip):
+  //  * smoothed L1 in normalised form: with u = x/mu, F(u) = uc^3 (1 - uc/2) + max(u-1, 0), F'(u) = uc^2 (3 - 2 uc),
+  //    uc = clamp(u, 0, 1), the penalty is mu F(u) and its slope F'(u); the polytope rows are divided by mu when
+  //    they are loaded, the weights are applied once per sample;
+  //  * only the pass that holds the box rows evaluates velocity and acceleration; the other passes need the
+  //    position alone;
+  //  * no jerk and no per-sample d/dt: the sample times t_j = tau_j T move with T, and since
+  //    tau tab[j][d+1][col] = (k-d) tab[j][d][col] the sum over the samples of step tau_j (g_p.v + g_v.a + g_a.j)
+  //    is  (1/T) sum_col c~[col] k gN[col] - Rs,  gN the gradient w.r.t. c~ that is accumulated anyway and Rs the
+  //    scalar sum_j (s1.v + 2 T s2.a) over the samples with a violated box row (s1, s2: their weights in gN);
+  //    with v = a1 / T, a = a2 / T^2 that is (1/T) (sum s1 a1 + 2 sum s2 a2): two accumulators, scaled once.
+  const Penalty pp = pp_in;
+  const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
+  const double step = Ti * inv_res;
+  const double rT = 1.0 / Ti, rT2 = rT * rT;
+  const double wcm = pp.wc * pp.mu, wvm = pp.wv * pp.mu, wam = pp.wa * pp.mu;
+  double ct[3][D];  // c~
+  {
+    double tk = 1.0;
+#pragma unroll
+    for (int col = D - 1; col >= 0; --col) {
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) ct[ax][col] = c[ax][col] * tk;
+      tk *= Ti;
+    }
+  }
+  double gN[3][D];  // gradient w.r.t. c~
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+    for (int col = 0; col < D; ++col) gN[ax][col] = 0.0;
+  double csum = 0.0, Rs1 = 0.0, Rs2 = 0.0;  // sum of the sample costs; Rs = (Rs1 + 2 Rs2) / T, see above
+  const double kv = rT * inv_mu, ka = rT2 * inv_mu, cv = pp.vmax * inv_mu, ca = pp.amax * inv_mu;
+  const double K1 = step * rT * pp.wv, K2 = step * rT2 * pp.wa;
+  // Polytope rows are held in registers, RC at a time, and the sample loop runs inside: re-reading
+  // them from L2 for every sample (res x M x 32 B per lane) was the bottleneck of this kernel.
+  constexpr int RC = 8;
+  const int nchunk = hpolys ? (pp.M + RC - 1) / RC : 0;
+  // chunks of this lane: all of them, or (SPLIT) every second one starting at `half`; at least one pass so
+  // that the box rows are visited
+  const int cstep = SPLIT ? 2 : 1;
+  int npass = SPLIT ? (nchunk - half + 1) / 2 : nchunk;
+  if (npass < 1) npass = 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int ch = half + cstep * pass;
+    double hr[RC][4];
+#pragma unroll
+    for (int r = 0; r < RC; ++r) {
+      const int rr = ch * RC + r;
+      const bool ok = hpolys && rr < pp.M;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        hr[r][q] = ok ? hpolys[(int64_t)((i * pp.M + rr) * 4 + q) * ld + b] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < RC; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hr[r][q] *= inv_mu;
+    const bool first = SPLIT ? (half == 1 && pass == 0) : (ch == 0);  // the pass that also evaluates the box rows
+    // The table rows are scalar loads, a wave waited for each where it was used (~10^2 cycles, five times per sample, the
+    // two waves of a SIMD in phase) and the compiler keeps such a load next to its use: the position row of the NEXT sample
+    // is requested by hand at the top of the sample (tab_row_request: the compiler does not know it is in flight; it is
+    // awaited at the bottom, tab_row_await), the velocity / acceleration rows of THIS sample right behind it -- scalar
+    // loads return out of order, so a wait for any is a wait for all, and the first one stands behind the eight corridor
+    // rows' worth of arithmetic.
+    TabRow<D> nx, r1, r2;
+    if constexpr (!LTAB) {
+      nx.request(tab + (size_t)wv * 4 * D);
+      nx.await();
+    }
+    for (int j = wv; j < pp.res; j += (LTAB ? jstep : SW)) {
+      const double *tb = tab + (size_t)j * (LTAB ? 3 : 4) * D;
+      double t0[D];
+      if constexpr (LTAB) {
+#pragma unroll
+        for (int col = 0; col < D; ++col) t0[col] = tb[col];
+      } else {
+#pragma unroll
+        for (int col = 0; col < D; ++col) t0[col] = nx.v[col];
+        nx.request(tab + (size_t)(j + SW < pp.res ? j + SW : j) * 4 * D);
+        // (by hand as well: behind an asm statement the compiler takes the table for clobbered and loads it per lane; and in
+        // every pass: a request under a condition leaves the registers undefined on the other path, which the register
+        // allocator answers with vector registers)
+        r1.request(tb + D);
+        r2.request(tb + 2 * D);
+      }
+      double pos[3];
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        double acc = 0.0;
+#pragma unroll
+        for (int col = 0; col < D; ++col) acc = __builtin_fma(ct[ax][col], t0[col], acc);
+        pos[ax] = acc;
+      }
+      double Fs = 0.0, G[3] = {0.0, 0.0, 0.0};  // sum of F(u) and of F'(u) a/mu over the rows
+#pragma unroll
+      for (int r = 0; r < RC; ++r) {
+        const double u = __builtin_fma(hr[r][0], pos[0], __builtin_fma(hr[r][1], pos[1], __builtin_fma(hr[r][2], pos[2], -hr[r][3])));
+        if (__any(u > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
+          const double w = fmax(u, 0.0), uc = fmin(w, 1.0), sq = uc * uc;
+          Fs += w - uc;
+          Fs = __builtin_fma(sq * uc, __builtin_fma(-0.5, uc, 1.0), Fs);
+          const double df = sq * __builtin_fma(-2.0, uc, 3.0);
+          G[0] = __builtin_fma(df, hr[r][0], G[0]);
+          G[1] = __builtin_fma(df, hr[r][1], G[1]);
+          G[2] = __builtin_fma(df, hr[r][2], G[2]);
+        }
+      }
+      double cost = wcm * Fs;
+      if (first) {
+        // velocity / acceleration limits in units of mu, straight from the normalised-time sums a1 = sum c~ tab',
+        // a2 = sum c~ tab'':  u = (|a1| / T - vmax) / mu = |a1| kv - cv  (one FMA, |.| is an operand modifier)
+        double a1[3], a2[3], worst = 0.0;
+        double t1[D], t2[D];
+        if constexpr (LTAB) {
+#pragma unroll
+          for (int col = 0; col < D; ++col) {
+            t1[col] = tb[D + col];
+            t2[col] = tb[2 * D + col];
+          }
+        } else {
+          r1.await();
+          r2.await();
+#pragma unroll
+          for (int col = 0; col < D; ++col) {
+            t1[col] = r1.v[col];
+            t2[col] = r2.v[col];
+          }
+        }
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          double x1 = 0.0, x2 = 0.0;
+#pragma unroll
+          for (int col = 0; col < D; ++col) {
+            x1 = __builtin_fma(ct[ax][col], t1[col], x1);
+            x2 = __builtin_fma(ct[ax][col], t2[col], x2);
+          }
+          a1[ax] = x1;
+          a2[ax] = x2;
+          worst = fmax(worst, fmax(__builtin_fma(fabs(x1), kv, -cv), __builtin_fma(fabs(x2), ka, -ca)));
+        }
+        if (__any(worst > 0.0)) {  // only one of +v, -v (+a, -a) can be violated: the slope has the sign of a1 (a2)
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            double f, df;
+            smoothed_l1_unit(__builtin_fma(fabs(a1[ax]), kv, -cv), f, df);
+            cost = __builtin_fma(wvm, f, cost);
+            const double s1 = K1 * copysign(df, a1[ax]);
+            Rs1 = __builtin_fma(s1, a1[ax], Rs1);
+            smoothed_l1_unit(__builtin_fma(fabs(a2[ax]), ka, -ca), f, df);
+            cost = __builtin_fma(wam, f, cost);
+            const double s2 = K2 * copysign(df, a2[ax]);
+            Rs2 = __builtin_fma(s2, a2[ax], Rs2);
+            // (the gradient of the limit rows goes into gN here, while s1 and s2 are at hand)
+#pragma unroll
+            for (int col = 0; col < D; ++col)
+              gN[ax][col] = __builtin_fma(s2, t2[col], __builtin_fma(s1, t1[col], gN[ax][col]));
+          }
+        }
+      }
+      if (__any(cost > 0.0)) {
+        csum += cost;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          const double s0 = step * wcm * G[ax];
+#pragma unroll
+          for (int col = 0; col < D; ++col) gN[ax][col] = __builtin_fma(s0, t0[col], gN[ax][col]);
+        }
+      }
+      if constexpr (!LTAB) nx.await();
+    }
+  }
+  pc = step * csum;
+  {  // d/dT at fixed c: the quadrature weight T/res and the sample times tau_j T
+    double acc = 0.0;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+      for (int col = 0; col < D; ++col)
+        acc = __builtin_fma(ct[ax][col] * (double)(D - 1 - col), gN[ax][col], acc);
+    gT += csum * inv_res + rT * (acc - __builtin_fma(2.0, Rs2, Rs1));
+  }
+  {  // d/dc = T^k d/dc~
+    double tk = 1.0;
+#pragma unroll
+    for (int col = D - 1; col >= 0; --col) {
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) gC[ax][col] = __builtin_fma(gN[ax][col], tk, gC[ax][col]);
+      tk *= Ti;
+    }
+  }
+}
+
+// The energy part of one (trajectory, piece) from its S highest-power coefficients ch: d/dc and d/dT of the piece's share of
+// int (p^(S))^2, added to gC / gT:  d/dc of sum_{j,k>=S} c_j c_k f_j f_k T^(j+k-2S+1)/(j+k-2S+1) ;  d/dT = (p^(S)(T))^2
+template <int S>
+__device__ __forceinline__ void piece_energy_compute(const double (&ch)[3][S], const double Ti, double (&gC)[3][2 * S], double &gT) {
+  constexpr int D = 2 * S;
+  double tp[D];
+  tp[0] = 1.0;
+#pragma unroll
+  for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    double ps = 0.0;
+#pragma unroll
+    for (int j = S; j < D; ++j) {
+      double fj = 1.0;
+#pragma unroll
+      for (int e = 0; e < S; ++e) fj *= (double)(j - e);
+      ps = __builtin_fma(fj * tp[j - S], ch[ax][D - 1 - j], ps);
+      double acc = 0.0;
+#pragma unroll
+      for (int k = S; k < D; ++k) {
+        double fk = 1.0;
+#pragma unroll
+        for (int e = 0; e < S; ++e) fk *= (double)(k - e);
+        acc = __builtin_fma(2.0 * fj * fk / (double)(j + k - 2 * S + 1) * tp[j + k - 2 * S + 1],
+                            ch[ax][D - 1 - k], acc);
+      }
+      gC[ax][D - 1 - j] += acc;
+    }
+    gT = __builtin_fma(ps, ps, gT);
+  }
+}
+
+// The energy part for a lane of k_piece_grad: the coefficients come from global memory.
+template <int S>
+__device__ __forceinline__ void piece_energy_part(const double *coeffs, const int64_t ld, const int64_t b, const int i,
+                                                  const double Ti, const double pc, double (&gC)[3][2 * S], double &gT) {
+  constexpr int D = 2 * S;
+  // (the S highest-power coefficients are read again here: the penalty part above has the registers for itself)
+  // ... and only here: tied to a result of the penalty part, or the scheduler issues these loads before the sample
+  // loops and carries the twelve values across them in scratch
+  int64_t be = b;
+  asm volatile("" : "+v"(be) : "v"(pc));
+  double ch[3][S];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+    for (int col = 0; col < S; ++col) ch[ax][col] = coeffs[(int64_t)((i * 3 + ax) * D + col) * ld + be];
+  piece_energy_compute<S>(ch, Ti, gC, gT);
+}
+
 // SW = 4 (smaller batches still, with SPLIT): the four WAVES of a workgroup take every fourth sample of the SAME 32
 // (trajectory, piece) pairs -- the sample index stays wave-uniform, so the basis table is still read with scalar
 // loads -- and their partial gradients are summed through LDS by wave 0.  A quarter of the dependent chain per lane
@@ -279,227 +539,8 @@ __global__ void __launch_bounds__(256, SW > 1 ? ANET_PG_SW_MINB : ANET_PG_MINB) 
       gC[ax][col] = 0.0;
     }
   double gT = 0.0, pc = 0.0;
-  if (a.with_penalty) {
-    // Normalised time: with c~_k = c_k T^k the state rows at sample j depend on tau_j = j/res only,
-    //   d^d p/dt^d (t_j) = T^-d sum_col c~[col] tab[j][d][col],  tab[j][d][col] = k!/(k-d)! tau_j^(k-d)
-    // (table read with a wave-uniform index: scalar loads).
-    //
-    // Instruction diet (the kernel is bound by FP64 issue, tools/micro/fp64_peak.hip):
-    //  * smoothed L1 in normalised form: with u = x/mu, F(u) = uc^3 (1 - uc/2) + max(u-1, 0), F'(u) = uc^2 (3 - 2 uc),
-    //    uc = clamp(u, 0, 1), the penalty is mu F(u) and its slope F'(u); the polytope rows are divided by mu when
-    //    they are loaded, the weights are applied once per sample;
-    //  * only the pass that holds the box rows evaluates velocity and acceleration; the other passes need the
-    //    position alone;
-    //  * no jerk and no per-sample d/dt: the sample times t_j = tau_j T move with T, and since
-    //    tau tab[j][d+1][col] = (k-d) tab[j][d][col] the sum over the samples of step tau_j (g_p.v + g_v.a + g_a.j)
-    //    is  (1/T) sum_col c~[col] k gN[col] - Rs,  gN the gradient w.r.t. c~ that is accumulated anyway and Rs the
-    //    scalar sum_j (s1.v + 2 T s2.a) over the samples with a violated box row (s1, s2: their weights in gN);
-    //    with v = a1 / T, a = a2 / T^2 that is (1/T) (sum s1 a1 + 2 sum s2 a2): two accumulators, scaled once.
-    const Penalty pp = a.pp;
-    const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
-    const double step = Ti * inv_res;
-    const double rT = 1.0 / Ti, rT2 = rT * rT;
-    const double wcm = pp.wc * pp.mu, wvm = pp.wv * pp.mu, wam = pp.wa * pp.mu;
-    double ct[3][D];  // c~
-    {
-      double tk = 1.0;
-#pragma unroll
-      for (int col = D - 1; col >= 0; --col) {
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) ct[ax][col] = c[ax][col] * tk;
-        tk *= Ti;
-      }
-    }
-    double gN[3][D];  // gradient w.r.t. c~
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax)
-#pragma unroll
-      for (int col = 0; col < D; ++col) gN[ax][col] = 0.0;
-    double csum = 0.0, Rs1 = 0.0, Rs2 = 0.0;  // sum of the sample costs; Rs = (Rs1 + 2 Rs2) / T, see above
-    const double kv = rT * inv_mu, ka = rT2 * inv_mu, cv = pp.vmax * inv_mu, ca = pp.amax * inv_mu;
-    const double K1 = step * rT * pp.wv, K2 = step * rT2 * pp.wa;
-    // Polytope rows are held in registers, RC at a time, and the sample loop runs inside: re-reading
-    // them from L2 for every sample (res x M x 32 B per lane) was the bottleneck of this kernel.
-    constexpr int RC = 8;
-    const int nchunk = a.hpolys ? (pp.M + RC - 1) / RC : 0;
-    // chunks of this lane: all of them, or (SPLIT) every second one starting at `half`; at least one pass so
-    // that the box rows are visited
-    const int cstep = SPLIT ? 2 : 1;
-    int npass = SPLIT ? (nchunk - half + 1) / 2 : nchunk;
-    if (npass < 1) npass = 1;
-    for (int pass = 0; pass < npass; ++pass) {
-      const int ch = half + cstep * pass;
-      double hr[RC][4];
-#pragma unroll
-      for (int r = 0; r < RC; ++r) {
-        const int rr = ch * RC + r;
-        const bool ok = a.hpolys && rr < pp.M;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          hr[r][q] = ok ? a.hpolys[(int64_t)((i * pp.M + rr) * 4 + q) * ld + b] : 0.0;
-      }
-#pragma unroll
-      for (int r = 0; r < RC; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) hr[r][q] *= inv_mu;
-      const bool first = SPLIT ? (half == 1 && pass == 0) : (ch == 0);  // the pass that also evaluates the box rows
-      // The table rows are scalar loads, a wave waited for each where it was used (~10^2 cycles, five times per sample, the
-      // two waves of a SIMD in phase) and the compiler keeps such a load next to its use: the position row of the NEXT sample
-      // is requested by hand at the top of the sample (tab_row_request: the compiler does not know it is in flight; it is
-      // awaited at the bottom, tab_row_await), the velocity / acceleration rows of THIS sample right behind it -- scalar
-      // loads return out of order, so a wait for any is a wait for all, and the first one stands behind the eight corridor
-      // rows' worth of arithmetic.
-      TabRow<D> nx, r1, r2;
-      nx.request(tab + (size_t)wv * 4 * D);
-      nx.await();
-      for (int j = wv; j < pp.res; j += SW) {
-        const double *tb = tab + (size_t)j * 4 * D;
-        double t0[D];
-#pragma unroll
-        for (int col = 0; col < D; ++col) t0[col] = nx.v[col];
-        nx.request(tab + (size_t)(j + SW < pp.res ? j + SW : j) * 4 * D);
-        // (by hand as well: behind an asm statement the compiler takes the table for clobbered and loads it per lane; and in
-        // every pass: a request under a condition leaves the registers undefined on the other path, which the register
-        // allocator answers with vector registers)
-        r1.request(tb + D);
-        r2.request(tb + 2 * D);
-        double pos[3];
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-          double acc = 0.0;
-#pragma unroll
-          for (int col = 0; col < D; ++col) acc = __builtin_fma(ct[ax][col], t0[col], acc);
-          pos[ax] = acc;
-        }
-        double Fs = 0.0, G[3] = {0.0, 0.0, 0.0};  // sum of F(u) and of F'(u) a/mu over the rows
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-          const double u = __builtin_fma(hr[r][0], pos[0], __builtin_fma(hr[r][1], pos[1], __builtin_fma(hr[r][2], pos[2], -hr[r][3])));
-          if (__any(u > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
-            const double w = fmax(u, 0.0), uc = fmin(w, 1.0), sq = uc * uc;
-            Fs += w - uc;
-            Fs = __builtin_fma(sq * uc, __builtin_fma(-0.5, uc, 1.0), Fs);
-            const double df = sq * __builtin_fma(-2.0, uc, 3.0);
-            G[0] = __builtin_fma(df, hr[r][0], G[0]);
-            G[1] = __builtin_fma(df, hr[r][1], G[1]);
-            G[2] = __builtin_fma(df, hr[r][2], G[2]);
-          }
-        }
-        double cost = wcm * Fs;
-        if (first) {
-          // velocity / acceleration limits in units of mu, straight from the normalised-time sums a1 = sum c~ tab',
-          // a2 = sum c~ tab'':  u = (|a1| / T - vmax) / mu = |a1| kv - cv  (one FMA, |.| is an operand modifier)
-          double a1[3], a2[3], worst = 0.0;
-          r1.await();
-          r2.await();
-          double t1[D], t2[D];
-#pragma unroll
-          for (int col = 0; col < D; ++col) {
-            t1[col] = r1.v[col];
-            t2[col] = r2.v[col];
-          }
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            double x1 = 0.0, x2 = 0.0;
-#pragma unroll
-            for (int col = 0; col < D; ++col) {
-              x1 = __builtin_fma(ct[ax][col], t1[col], x1);
-              x2 = __builtin_fma(ct[ax][col], t2[col], x2);
-            }
-            a1[ax] = x1;
-            a2[ax] = x2;
-            worst = fmax(worst, fmax(__builtin_fma(fabs(x1), kv, -cv), __builtin_fma(fabs(x2), ka, -ca)));
-          }
-          if (__any(worst > 0.0)) {  // only one of +v, -v (+a, -a) can be violated: the slope has the sign of a1 (a2)
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-              double f, df;
-              smoothed_l1_unit(__builtin_fma(fabs(a1[ax]), kv, -cv), f, df);
-              cost = __builtin_fma(wvm, f, cost);
-              const double s1 = K1 * copysign(df, a1[ax]);
-              Rs1 = __builtin_fma(s1, a1[ax], Rs1);
-              smoothed_l1_unit(__builtin_fma(fabs(a2[ax]), ka, -ca), f, df);
-              cost = __builtin_fma(wam, f, cost);
-              const double s2 = K2 * copysign(df, a2[ax]);
-              Rs2 = __builtin_fma(s2, a2[ax], Rs2);
-              // (the gradient of the limit rows goes into gN here, while s1 and s2 are at hand)
-#pragma unroll
-              for (int col = 0; col < D; ++col)
-                gN[ax][col] = __builtin_fma(s2, t2[col], __builtin_fma(s1, t1[col], gN[ax][col]));
-            }
-          }
-        }
-        if (__any(cost > 0.0)) {
-          csum += cost;
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            const double s0 = step * wcm * G[ax];
-#pragma unroll
-            for (int col = 0; col < D; ++col) gN[ax][col] = __builtin_fma(s0, t0[col], gN[ax][col]);
-          }
-        }
-        nx.await();
-      }
-    }
-    pc = step * csum;
-    {  // d/dT at fixed c: the quadrature weight T/res and the sample times tau_j T
-      double acc = 0.0;
-#pragma unroll
-      for (int ax = 0; ax < 3; ++ax)
-#pragma unroll
-        for (int col = 0; col < D; ++col)
-          acc = __builtin_fma(ct[ax][col] * (double)(D - 1 - col), gN[ax][col], acc);
-      gT += csum * inv_res + rT * (acc - __builtin_fma(2.0, Rs2, Rs1));
-    }
-    {  // d/dc = T^k d/dc~
-      double tk = 1.0;
-#pragma unroll
-      for (int col = D - 1; col >= 0; --col) {
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) gC[ax][col] = __builtin_fma(gN[ax][col], tk, gC[ax][col]);
-        tk *= Ti;
-      }
-    }
-  }
-  if (a.with_energy && half == 0 && wv == 0) {
-    // d/dc of sum_{j,k>=S} c_j c_k f_j f_k T^(j+k-2S+1)/(j+k-2S+1) ;  d/dT = (p^(S)(T))^2
-    // (the S highest-power coefficients are read again here: the penalty part above has the registers for itself)
-    // ... and only here: tied to a result of the penalty part, or the scheduler issues these loads before the sample
-    // loops and carries the twelve values across them in scratch
-    int64_t be = b;
-    asm volatile("" : "+v"(be) : "v"(pc));
-    double ch[3][S];
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax)
-#pragma unroll
-      for (int col = 0; col < S; ++col) ch[ax][col] = a.coeffs[(int64_t)((i * 3 + ax) * D + col) * ld + be];
-    double tp[D];
-    tp[0] = 1.0;
-#pragma unroll
-    for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-      double ps = 0.0;
-#pragma unroll
-      for (int j = S; j < D; ++j) {
-        double fj = 1.0;
-#pragma unroll
-        for (int e = 0; e < S; ++e) fj *= (double)(j - e);
-        ps = __builtin_fma(fj * tp[j - S], ch[ax][D - 1 - j], ps);
-        double acc = 0.0;
-#pragma unroll
-        for (int k = S; k < D; ++k) {
-          double fk = 1.0;
-#pragma unroll
-          for (int e = 0; e < S; ++e) fk *= (double)(k - e);
-          acc = __builtin_fma(2.0 * fj * fk / (double)(j + k - 2 * S + 1) * tp[j + k - 2 * S + 1],
-                              ch[ax][D - 1 - k], acc);
-        }
-        gC[ax][D - 1 - j] += acc;
-      }
-      gT = __builtin_fma(ps, ps, gT);
-    }
-  }
+  if (a.with_penalty) piece_penalty_part<S, SPLIT, SW>(a.pp, a.hpolys, ld, b, i, half, wv, Ti, c, tab, gC, gT, pc);
+  if (a.with_energy && half == 0 && wv == 0) piece_energy_part<S>(a.coeffs, ld, b, i, Ti, pc, gC, gT);
   if (SPLIT) {
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax)

@@ -3,8 +3,10 @@
 // -mllvm -amdgpu-sched-strategy=max-ilp (allocnet_amd/build.py; why: the comment at launch_piece_grad's declaration).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "minco_kernels.h"
+#include "minco_fused_kernel.h"
 
 namespace anet {
 
@@ -45,6 +47,43 @@ void launch_propagate_axis(int s, const PropArgs &a, dim3 grid, dim3 block, hipS
     case 3: return launch_propagate_axis_t<3>(a, grid, block, st);
     default: return launch_propagate_axis_t<4>(a, grid, block, st);
   }
+}
+
+// ---- the one-launch evaluation of small batches (minco_fused_kernel.h) ----------------------------------------------------------
+template <int S, int NB, bool NEXACT, int NPC>
+static void launch_fused_t(const FusedArgs &a_in, const double *tab, hipStream_t st, int64_t max_groups) {
+  constexpr int GM = FusedShape<NB>::G;
+  FusedArgs a = a_in;
+  // the largest group that still gives (nearly) every CU a workgroup; what the group gives up, the samples split takes
+  int G = GM;
+  while (G > 1 && (a.B + G / 2 - 1) / (G / 2) <= max_groups) G /= 2;
+  a.G = G;
+  const dim3 grid((unsigned)((a.B + G - 1) / G));
+  hipLaunchKernelGGL((k_minco_cost_grad_fused<S, NB, NEXACT, NPC>), grid, dim3(256), 0, st, a, tab);
+}
+
+int cost_grad_fused_group(int s, int n_pieces) {
+  if (s != 3 && s != 4) return 0;
+  if (n_pieces <= 8) return FusedShape<8>::G;
+  if (s == 3 && n_pieces <= 16) return FusedShape<16>::G;
+  return 0;
+}
+
+bool launch_cost_grad_fused(int s, const FusedArgs &a, const double *tab, hipStream_t st, int64_t max_groups) {
+  if (s == 4) {
+    if (a.N == 8 && a.c == 3) launch_fused_t<4, 8, true, 2>(a, tab, st, max_groups);
+    else if (a.N <= 8) launch_fused_t<4, 8, false, -1>(a, tab, st, max_groups);
+    else return false;
+    return true;
+  }
+  if (s == 3) {
+    if (a.N == 16 && a.c == 3) launch_fused_t<3, 16, true, 2>(a, tab, st, max_groups);
+    else if (a.N <= 8) launch_fused_t<3, 8, false, -1>(a, tab, st, max_groups);
+    else if (a.N <= 16) launch_fused_t<3, 16, false, -1>(a, tab, st, max_groups);
+    else return false;
+    return true;
+  }
+  return false;
 }
 
 }  // namespace anet

@@ -162,3 +162,42 @@ def test_large_batch_shapes_agree_with_small_batch_shapes_and_oracle(anet_ctx, s
     if N > 1:
         assert np.abs(gP[idx] - cgP).max() <= 1e-7 * max(1.0, np.abs(cgP).max())
     assert (cost - 3.0 * T.sum(axis=1) > 0).all()
+
+
+@pytest.mark.parametrize("s,c,N,M,res", [(4, 3, 8, 16, 20), (4, 4, 8, 50, 7), (4, 3, 5, 20, 64), (4, 2, 3, 6, 1), (4, 3, 1, 6, 3),
+                                         (3, 3, 16, 16, 20), (3, 3, 13, 9, 10), (3, 3, 5, 16, 20), (3, 2, 8, 0, 5), (3, 1, 2, 7, 2),
+                                         (4, 3, 8, 16, 65)])
+def test_one_launch_evaluation_at_every_group_size(anet_ctx, s, c, N, M, res):
+    """Batches of up to one workgroup per CU are evaluated in ONE launch (csrc/minco_fused_kernel.h: solve, penalty / energy
+    partial gradients and adjoint of a group of G trajectories in one workgroup, G = 16 ... 1 by batch, the lanes a smaller group
+    frees splitting the samples of a piece).  Every group size, ragged last groups, 1 ... 16 pieces, 0 ... 50 corridor rows, 1 ... 64
+    samples per piece (65: the three-launch path), coefficients asked for or not -- the whole batch against the C restatement
+    (classic banded LU + adjoint through the same factors), to the tolerance of the other parity tests."""
+    import allocnet_amd as aa
+    from oracle import cbind
+    from tests.util import corridor_problem
+    rng = np.random.default_rng(9000 + 1000 * s + 50 * N + M + res)
+    kw = dict(res=res, vmax=2.5, amax=3.5, wc=1e3, wv=40.0, wa=15.0, mu=0.03)
+    pen = aa.make_penalty(rho=3.0, w_corridor=kw["wc"], w_vel=kw["wv"], w_acc=kw["wa"], smooth_mu=kw["mu"], max_vel=kw["vmax"],
+                          max_acc=kw["amax"], res=kw["res"], poly_rows=M)
+    gmax = 16 if N <= 8 else 8
+    # (256 workgroups at most: the batch picks G = gmax, gmax / 2, ..., 1; +-1 / odd sizes leave the last group ragged)
+    for B in sorted({1, 2, 3, 255, 256, 257, 300, 512, 513, 1000, 1024 + 7, 2048 - 5, 256 * gmax - 3, 256 * gmax}):
+        if M:
+            head, tail, wps, T, hp = corridor_problem(rng, B, N, c, M)
+        else:
+            head, tail, wps, T = random_problem(rng, B, N, c)
+            hp = None
+        want = bool(B % 2)
+        out = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, want_coeffs=want, ctx=anet_ctx)
+        cost, gP, gT = out[:3]
+        cc, cgP, cgT = cbind.minco_cost_grad_batch(s, head, tail, wps, T, hp, 3.0, nthreads=8, **kw)
+        assert np.abs(cost - cc).max() <= 1e-9 * np.abs(cc).max(), (B, np.abs(cost - cc).max())
+        assert np.abs(gT - cgT).max() <= 1e-7 * max(1.0, np.abs(cgT).max()), B
+        if N > 1:
+            assert np.abs(gP - cgP).max() <= 1e-7 * max(1.0, np.abs(cgP).max()), B
+        if want:
+            co, _ = cbind.minco_solve_batch(s, head, tail, wps, T)
+            assert rel_err(out[3], co) < 1e-9, B
+        if M and res >= 5:
+            assert (cost - 3.0 * T.sum(axis=1) > 0).all()

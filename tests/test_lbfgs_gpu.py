@@ -569,7 +569,9 @@ def test_minco_lbfgs_step_bound_shapes_agree(anet_ctx):
         # min_step as the last bit of tau - tau_min fell -- one class, as in the test against the restatement)
         stuck = np.isin(a["status"], (-1011, -1010)) & np.isin(b["status"], (-1011, -1010)) & (a["iters"] == b["iters"])
         agree = same | stuck
-        assert same.mean() >= 0.8 and agree.mean() >= 0.97, (budget, same.mean(), agree.mean())
+        # (64 problems: at most three may part ways.  The lockstep shape evaluates small batches with the one-launch cost + gradient
+        #  kernel since round 5, minco_fused_kernel.h, whose adjoint rounds differently from the one-launch L-BFGS kernel's.)
+        assert same.mean() >= 0.8 and agree.mean() >= 0.95, (budget, same.mean(), agree.mean())
         assert (a["T"] >= 1.0 - 1e-12).all() and (b["T"] >= 1.0 - 1e-12).all()
         assert np.abs(a["cost"] - b["cost"])[agree].max() <= 1e-7 * np.abs(b["cost"]).max()
         assert np.abs(a["T"] - b["T"])[agree].max() <= 1e-6

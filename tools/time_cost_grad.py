@@ -14,7 +14,7 @@ def run(s, c, N, B, K=200):
     ld = aa.recommended_ld(B)
     rng = np.random.default_rng(1)
     head, tail, wps, T, hp = synth(rng, B, N, c, M)
-    pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20, poly_rows=M)
+    pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=int(os.environ.get('ANET_RES', 20)), poly_rows=M)
     th, tt, tw, tT, thp = (to_bm(torch, x, B, ld, dev) for x in (head, tail, wps, T, hp))
     cost, gP, gT, work = aa.minco_cost_grad_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, ctx=ctx)
     torch.cuda.synchronize()
