@@ -10,7 +10,7 @@ from .minco import MINCO, MINCO_S2NU, MINCO_S3NU, MINCO_S4NU, minco_solve, minco
 from .trajectory import Piece, Trajectory, traj_eval, traj_cost, traj_cost_grad_T, traj_max_rate  # noqa: F401
 from . import lbfgs  # noqa: F401
 from .lbfgs import (lbfgs_parameter_t, lbfgs_strerror, lbfgs_mvie, lbfgs_minco, lbfgs_minco_dev,  # noqa: F401
-                    launch_order_from_counts, lbfgs_optimize_dev)
+                    launch_order_from_counts, lbfgs_optimize_dev, lbfgs_optimize)
 from . import qp  # noqa: F401
 from .qp import (qp_assemble, qp_dims, qp_solve, qp_solve_vjp, qp_solve_dev, qp_solve_vjp_dev, qp_settings,  # noqa: F401
                  QPSolver, QPConfig)

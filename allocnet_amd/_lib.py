@@ -104,6 +104,10 @@ PROTOTYPES = {
     "anet_lbfgs_workspace": (c_int64, [c_int, c_int64, c_void_p]),
     "anet_lbfgs_optimize_dev": (c_int, [c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "anet_piece_normalized_coeffs": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
+    "anet_piece_normalized_coeffs_dev": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "anet_lbfgs_optimize_host": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
     "anet_lbfgs_minco": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),

@@ -932,6 +932,43 @@ int anet_traj_cost(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const doub
   return ANET_OK;
 }
 
+int anet_piece_normalized_coeffs_dev(anet_ctx *ctx, int s, int64_t pieces, const double *coeffs, const double *T, int deriv,
+                                     double *out, void *stream) {
+  ANET_ON_DEVICE(ctx);
+  if (s < 2 || s > 4 || pieces < 0 || deriv < 0 || deriv > 2)
+    return fail(ctx, ANET_ERR_INVALID, "anet_piece_normalized_coeffs: order in [2, 4], pieces >= 0, deriv in [0, 2]");
+  if (pieces == 0) return ANET_OK;
+  if (!coeffs || !T || !out) return fail(ctx, ANET_ERR_INVALID, "anet_piece_normalized_coeffs: NULL pointer");
+  anet::NormArgs a{coeffs, T, out, pieces, deriv};
+  const dim3 grid((unsigned)((pieces + 255) / 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (s == 2) hipLaunchKernelGGL(anet::k_piece_normalize<2>, grid, block, 0, st, a);
+  else if (s == 3) hipLaunchKernelGGL(anet::k_piece_normalize<3>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(anet::k_piece_normalize<4>, grid, block, 0, st, a);
+  ANET_HIP(ctx, hipGetLastError());
+  return ANET_OK;
+}
+
+int anet_piece_normalized_coeffs(anet_ctx *ctx, int s, int64_t pieces, const double *coeffs, const double *T, int deriv,
+                                 double *out) {
+  ANET_ON_DEVICE(ctx);
+  if (s < 2 || s > 4 || pieces < 0 || deriv < 0 || deriv > 2)
+    return fail(ctx, ANET_ERR_INVALID, "anet_piece_normalized_coeffs: order in [2, 4], pieces >= 0, deriv in [0, 2]");
+  if (pieces == 0) return ANET_OK;
+  if (!coeffs || !T || !out) return fail(ctx, ANET_ERR_INVALID, "anet_piece_normalized_coeffs: NULL pointer");
+  const size_t nin = (size_t)pieces * 3 * 2 * s, nout = (size_t)pieces * 3 * (2 * s - deriv);
+  int rc = ensure_scratch(ctx, sizeof(double) * (nin + (size_t)pieces + nout));
+  if (rc) return rc;
+  double *d_co = (double *)ctx->scratch, *d_T = d_co + nin, *d_out = d_T + pieces;
+  hipStream_t st = ctx->stream;
+  ANET_HIP(ctx, hipMemcpyAsync(d_co, coeffs, sizeof(double) * nin, hipMemcpyHostToDevice, st));
+  ANET_HIP(ctx, hipMemcpyAsync(d_T, T, sizeof(double) * pieces, hipMemcpyHostToDevice, st));
+  if ((rc = anet_piece_normalized_coeffs_dev(ctx, s, pieces, d_co, d_T, deriv, d_out, st))) return rc;
+  ANET_HIP(ctx, hipMemcpyAsync(out, d_out, sizeof(double) * nout, hipMemcpyDeviceToHost, st));
+  ANET_HIP(ctx, hipStreamSynchronize(st));
+  return ANET_OK;
+}
+
 // ---- cost / gradient entry points ---------------------------------------------------------------
 static int check_penalty(anet_ctx *ctx, const anet_penalty *pen) {
   if (!pen) return ANET_OK;
@@ -1302,6 +1339,81 @@ int anet_lbfgs_optimize_dev(anet_ctx *ctx, int n, int64_t batch, int64_t ld, dou
   // the run synchronises `stream` as it goes (completion polls); so does its end: status / iters / evals / f are complete
   // when this returns, whatever stream the caller reads them on
   ANET_HIP(ctx, hipStreamSynchronize(st));
+  return ANET_OK;
+}
+
+int anet_lbfgs_optimize_host(anet_ctx *ctx, int n, double *x, double *f, anet_lbfgs_host_evaluate_t proc_evaluate,
+                             anet_lbfgs_host_stepbound_t proc_stepbound, anet_lbfgs_host_progress_t proc_progress,
+                             void *instance, const anet_lbfgs_params *params, int32_t *ret, int32_t *iters, int32_t *evals) {
+  ANET_ON_DEVICE(ctx);
+  if (!x || !f || !proc_evaluate || !ret) return fail(ctx, ANET_ERR_INVALID, "anet_lbfgs_optimize_host: NULL argument");
+  if (iters) *iters = 0;
+  if (evals) *evals = 0;
+  // lbfgs_optimize's own parameter validation, in its order, is its return value (lbfgs.hpp:449-495)
+  const int code = anet_lbfgs_check_params(n, params);
+  if (code) {
+    *ret = code;
+    return ANET_OK;
+  }
+  const int m = params->mem_size, npf = params->past > 1 ? params->past : 1;
+  // device: the optimiser's state (row stride 1: one problem) + f + the cancel word; host: g, xp, d
+  const int64_t wd = LbfgsLayout::doubles(n, m, npf, 1);
+  int rc = ensure_scratch(ctx, sizeof(double) * (size_t)(wd + 4));
+  if (rc) return rc;
+  LbfgsLayout L{n, m, npf, 1};
+  L.carve((double *)ctx->scratch);
+  int *d_cancel = (int *)((double *)ctx->scratch + wd + 2);
+  hipStream_t st = ctx->stream;
+  std::vector<double> hg((size_t)n), hxp((size_t)n), hd((size_t)n);
+  ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_, st));
+  ANET_HIP(ctx, hipMemsetAsync(L.ds, 0, sizeof(double) * anet::DS_COUNT_, st));
+  ANET_HIP(ctx, hipMemsetAsync(d_cancel, 0, sizeof(int), st));
+  ANET_HIP(ctx, hipMemcpyAsync(L.x, x, sizeof(double) * n, hipMemcpyHostToDevice, st));
+  anet::LbfgsArgs a{n, 1, 1, L.x, L.g, L.xp, L.gp, L.d, L.lm_s, L.lm_y, L.lm_ys, L.lm_alpha, L.pf, L.ds, L.feval, L.is,
+                    to_kernel_params(*params), nullptr, 1, 1, nullptr, 0, 0, 0, 0.0, d_cancel};
+  a.host_pg = proc_progress ? 1 : 0;
+  a.host_sb = proc_stepbound ? 1 : 0;
+  int his[anet::IS_COUNT_];
+  double hds[anet::DS_COUNT_];
+  auto tick = [&]() -> int {  // one launch of the state machine, then its state on the host
+    hipLaunchKernelGGL(anet::k_lbfgs_update, dim3(1), dim3(64), 0, st, a);
+    ANET_HIP(ctx, hipGetLastError());
+    ANET_HIP(ctx, hipMemcpyAsync(his, L.is, sizeof(his), hipMemcpyDeviceToHost, st));
+    ANET_HIP(ctx, hipMemcpyAsync(hds, L.ds, sizeof(hds), hipMemcpyDeviceToHost, st));
+    ANET_HIP(ctx, hipStreamSynchronize(st));
+    return ANET_OK;
+  };
+  for (;;) {
+    // the point to evaluate is in L.x (the host's copy in x: the start point, or what the last tick left)
+    const double fv = proc_evaluate(instance, x, hg.data(), n);
+    ANET_HIP(ctx, hipMemcpyAsync(L.g, hg.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
+    ANET_HIP(ctx, hipMemcpyAsync(L.feval, &fv, sizeof(double), hipMemcpyHostToDevice, st));
+    if ((rc = tick())) return rc;
+    while (!his[anet::IS_DONE] && (his[anet::IS_PHASE] == anet::LB_PHASE_AWAIT_PROGRESS || his[anet::IS_PHASE] == anet::LB_PHASE_AWAIT_STEPBOUND)) {
+      if (his[anet::IS_PHASE] == anet::LB_PHASE_AWAIT_PROGRESS) {
+        // lbfgs.hpp:580-587: x is the accepted point (the one just evaluated), g its gradient
+        const int verdict = proc_progress(instance, x, hg.data(), hds[anet::DS_FX], hds[anet::DS_STEP], his[anet::IS_K], his[anet::IS_COUNT], n);
+        const int word = verdict ? 1 : 0;
+        ANET_HIP(ctx, hipMemcpyAsync(d_cancel, &word, sizeof(int), hipMemcpyHostToDevice, st));
+      } else {
+        // lbfgs.hpp:557-565: xp (= the current point) and the search direction
+        ANET_HIP(ctx, hipMemcpyAsync(hxp.data(), L.xp, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        ANET_HIP(ctx, hipMemcpyAsync(hd.data(), L.d, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        ANET_HIP(ctx, hipStreamSynchronize(st));
+        const double bound = proc_stepbound(instance, hxp.data(), hd.data(), n);
+        ANET_HIP(ctx, hipMemcpyAsync(L.ds + anet::DS_SMAX, &bound, sizeof(double), hipMemcpyHostToDevice, st));
+      }
+      if ((rc = tick())) return rc;
+    }
+    // the next point to evaluate -- or, when the run has ended, the result (a failed line search put xp back)
+    ANET_HIP(ctx, hipMemcpyAsync(x, L.x, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    ANET_HIP(ctx, hipStreamSynchronize(st));
+    if (his[anet::IS_DONE]) break;
+  }
+  *ret = his[anet::IS_RET];
+  *f = hds[anet::DS_FX];
+  if (iters) *iters = his[anet::IS_K];
+  if (evals) *evals = his[anet::IS_EVALS];
   return ANET_OK;
 }
 

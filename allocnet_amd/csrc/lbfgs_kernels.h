@@ -47,7 +47,14 @@ struct LbfgsArgs {
   double sb_xmin = 0.0;
   // proc_progress's one effect (lbfgs.hpp:580-587): a device-visible word, non-zero cancels after the running iteration
   const int *cancel = nullptr;
+  // HOST callbacks (anet_lbfgs_optimize_host; lane kernel only): the state machine PARKS where lbfgs_optimize would call
+  // them and the host resumes it -- host_pg: at an accepted step (IS_PHASE = 2: the host calls proc_progress with x, g, fx,
+  // step, k and ls = IS_COUNT, leaves its verdict in the cancel word, launches again); host_sb: at the entry of a line search
+  // (IS_PHASE = 3: xp, gp, d in place; the host calls proc_stepbound(xp, d), leaves its value in DS_SMAX, launches again).
+  // A resuming launch consumes no evaluation.
+  int host_pg = 0, host_sb = 0;
 };
+enum { LB_PHASE_FIRST = 0, LB_PHASE_SEARCH = 1, LB_PHASE_AWAIT_PROGRESS = 2, LB_PHASE_AWAIT_STEPBOUND = 3 };
 __device__ __forceinline__ int read_cancel_word(const int *w) {  // system scope: written while the kernels run
   return w ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
 }
@@ -77,9 +84,11 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
   const int n = a.n, m = a.p.mem_size;
   const LbfgsP &P = a.p;
   double *x = a.x + b, *g = a.g + b, *xp = a.xp + b, *gp = a.gp + b, *d = a.d + b;
-  const double f = a.feval[b];
-  is[IS_EVALS * ld] += 1;
+  const int phase_in = is[IS_PHASE * ld];
+  const bool resume_pg = phase_in == LB_PHASE_AWAIT_PROGRESS, resume_sb = phase_in == LB_PHASE_AWAIT_STEPBOUND;
   double fx = ds[DS_FX * ld];
+  const double f = (resume_pg || resume_sb) ? fx : a.feval[b];  // (a resumed step: the value it parked with)
+  if (!(resume_pg || resume_sb)) is[IS_EVALS * ld] += 1;
   double step = ds[DS_STEP * ld];
   int k = is[IS_K * ld];
   bool start_ls = false;
@@ -94,7 +103,7 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
     return gn / fmax(1.0, xn) < P.g_epsilon;
   };
 
-  if (is[IS_PHASE * ld] == 0) {
+  if (phase_in == LB_PHASE_FIRST) {
     fx = f;
     a.pf[b] = fx;
     double dd = 0.0;
@@ -110,18 +119,22 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
       k = 1;
       is[IS_END * ld] = 0;
       is[IS_BOUND * ld] = 0;
-      is[IS_PHASE * ld] = 1;
+      is[IS_PHASE * ld] = LB_PHASE_SEARCH;
       start_ls = true;
     }
+  } else if (resume_sb) {
+    start_ls = true;  // the direction, xp, gp, step and k are in place; the host's bound is in DS_SMAX
   } else {
     // ---- one trial of line_search_lewisoverton (lbfgs.hpp:307-383)
     const double finit = ds[DS_FINIT * ld], dgtest = ds[DS_DGTEST * ld], dstest = ds[DS_DSTEST * ld];
     double mu = ds[DS_MU * ld], nu = ds[DS_NU * ld];
     const double smax = ds[DS_SMAX * ld];
     int count = is[IS_COUNT * ld] + 1, brackt = is[IS_BRACKT * ld], touched = is[IS_TOUCHED * ld];
-    bool success = false;
+    bool success = resume_pg;  // (parked behind a successful trial: straight to the accepted step)
     int err = 0;
-    if (isinf(f) || isnan(f)) {
+    if (resume_pg) {
+      count -= 1;
+    } else if (isinf(f) || isnan(f)) {
       err = LBERR_INVALID_FUNCVAL;
     } else {
       if (f > finit + step * dgtest) {
@@ -170,9 +183,15 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
       is[IS_COUNT * ld] = count;
       is[IS_BRACKT * ld] = brackt;
       is[IS_TOUCHED * ld] = touched;
+    } else if (a.host_pg && !resume_pg) {
+      // ---- accepted step, host progress callback: park (lbfgs.hpp:580-587 is the host's to run)
+      fx = f;
+      is[IS_COUNT * ld] = count;
+      is[IS_PHASE * ld] = LB_PHASE_AWAIT_PROGRESS;
     } else {
       // ---- accepted step (lbfgs.hpp:579-709); the progress report (:580-587) comes first: non-zero cancels
       fx = f;
+      if (resume_pg) is[IS_PHASE * ld] = LB_PHASE_SEARCH;
       if (read_cancel_word(a.cancel)) {
         finish = LB_CANCELED;
       } else if (conv_test()) {
@@ -247,7 +266,16 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
       dginit = __builtin_fma(gi, d[i * ld], dginit);
     }
     double smax = P.max_step;
-    if (a.sb_on) {  // lbfgs.hpp:557-565: step_max = min(proc_stepbound(xp, d), max_step); step = step < step_max ? step : step_max / 2
+    bool parked = false;
+    if (a.host_sb && !resume_sb) {  // the host's proc_stepbound(xp, d) comes first: park with xp, gp, d in place
+      is[IS_PHASE * ld] = LB_PHASE_AWAIT_STEPBOUND;
+      parked = true;
+    } else if (a.host_sb) {        // lbfgs.hpp:557-565 with the host's value
+      const double bnd = ds[DS_SMAX * ld];
+      smax = bnd < P.max_step ? bnd : P.max_step;
+      step = step < smax ? step : 0.5 * smax;
+      is[IS_PHASE * ld] = LB_PHASE_SEARCH;
+    } else if (a.sb_on) {  // lbfgs.hpp:557-565: step_max = min(proc_stepbound(xp, d), max_step); step = step < step_max ? step : step_max / 2
       double worst = 0.0;
       for (int i = a.sb_lo; i < n; ++i) {
         const double di = d[i * ld], room = x[i * ld] - a.sb_xmin;
@@ -257,8 +285,10 @@ __device__ __forceinline__ void lbfgs_update_lane(const LbfgsArgs &a, const int6
       smax = bnd < P.max_step ? bnd : P.max_step;
       step = step < smax ? step : 0.5 * smax;
     }
-    ds[DS_SMAX * ld] = smax;
-    if (!(step > 0.0)) {
+    if (!parked) ds[DS_SMAX * ld] = smax;
+    if (parked) {
+      // (nothing more until the host has answered)
+    } else if (!(step > 0.0)) {
       finish = LBERR_INVALIDPARAMETERS;
     } else if (0.0 < dginit) {
       finish = LBERR_INCREASEGRADIENT;

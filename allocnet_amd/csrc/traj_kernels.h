@@ -52,6 +52,37 @@ __global__ void __launch_bounds__(256) k_traj_eval(EvalArgs a) {
   }
 }
 
+// Piece<D>::normalizePosCoeffMat / normalizeVelCoeffMat / normalizeAccCoeffMat (trajectory.hpp:135-171): the coefficients of the
+// piece's position / velocity / acceleration polynomial in NORMALISED time, column i of the result = (product of the d falling
+// factors of its power) * coeffMat.col(i) * duration^power -- the running product `t *= duration` of the reference, from the
+// constant column up.  One lane per piece; trajectory-major in and out (pieces of a batch are independent records):
+// coeffs [P][3][D], T [P], out [P][3][D - d].
+struct NormArgs {
+  const double *coeffs, *T;
+  double *out;
+  int64_t P;
+  int deriv;
+};
+template <int S>
+__global__ void __launch_bounds__(256) k_piece_normalize(NormArgs a) {
+  constexpr int D = 2 * S;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.P) return;
+  const int d = a.deriv, W = D - d;
+  const double dur = a.T[p];
+  const double *cm = a.coeffs + p * 3 * D;
+  double *o = a.out + p * 3 * W;
+  double t = 1.0;
+  for (int e = 0; e < d; ++e) t *= dur;          // velocity starts at duration, acceleration at duration^2
+  for (int i = W - 1; i >= 0; --i) {             // column i of the result holds power (W - 1 - i) of the derivative
+    const int k = (D - 1) - i;                   // ... which comes from power k of the position, column i of coeffMat
+    double f = 1.0;
+    for (int e = 0; e < d; ++e) f *= (double)(k - e);   // n (velocity), n * m (acceleration) of the reference's loops
+    for (int ax = 0; ax < 3; ++ax) o[ax * W + i] = f * cm[ax * D + i] * t;
+    t *= dur;
+  }
+}
+
 // Trajectory<D>::getTrajCost (trajectory.hpp:354-427).
 struct CostArgs {
   const double *coeffs, *T;

@@ -223,3 +223,59 @@ def lbfgs_optimize_dev(x, evaluate, batch=None, param=None, max_evals=2000, boun
         raise err[0]
     ctx.check(rc)
     return dict(f=f[:B], status=status[:B], iters=iters[:B], evals=evals[:B])
+
+
+_HOST_EVAL_T = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                ctypes.c_int)
+_HOST_BOUND_T = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                 ctypes.c_int)
+_HOST_PROGRESS_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                    ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int)
+
+
+def lbfgs_optimize(x0, evaluate, stepbound=None, progress=None, param=None, ctx=None):
+    """lbfgs::lbfgs_optimize (lbfgs.hpp:434-717) with HOST callbacks -> anet_lbfgs_optimize_host: one problem, the objective
+    evaluated by `evaluate(x) -> (f, g)` on the host, `stepbound(xp, d) -> float` at the entry of every line search
+    (lbfgs.hpp:557-565), `progress(x, g, fx, step, k, ls) -> int` after every successful one (lbfgs.hpp:580-587; non-zero
+    cancels); the optimiser's vectors and arithmetic stay on the device.  Returns (ret, x, f, iters, evals)."""
+    ctx = ctx or default_context()
+    param = param or lbfgs_parameter_t()
+    x = np.array(x0, dtype=np.float64).ravel()
+    n = x.size
+    err = []
+    arr = lambda p: np.ctypeslib.as_array(p, shape=(n,))
+
+    def _ev(_inst, xp, gp, _n):
+        try:
+            f, g = evaluate(arr(xp).copy())
+            arr(gp)[:] = g
+            return float(f)
+        except Exception as exc:          # (an exception must not unwind through the C frames)
+            err.append(exc)
+            return float("nan")
+
+    def _sb(_inst, xp, dp, _n):
+        try:
+            return float(stepbound(arr(xp).copy(), arr(dp).copy()))
+        except Exception as exc:
+            err.append(exc)
+            return 0.0
+
+    def _pg(_inst, xp, gp, fx, step, k, ls, _n):
+        try:
+            return int(bool(progress(arr(xp).copy(), arr(gp).copy(), fx, step, k, ls)))
+        except Exception as exc:
+            err.append(exc)
+            return 1
+    ev, sb, pg = _HOST_EVAL_T(_ev), _HOST_BOUND_T(_sb), _HOST_PROGRESS_T(_pg)
+    f = ctypes.c_double(0.0)
+    ret, it, nev = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    vp = lambda o: ctypes.cast(o, ctypes.c_void_p)
+    rc = ctx.lib.anet_lbfgs_optimize_host(ctx.handle, n, x.ctypes.data_as(ctypes.c_void_p), vp(ctypes.pointer(f)), vp(ev),
+                                          vp(sb) if stepbound else None, vp(pg) if progress else None, None,
+                                          vp(ctypes.pointer(param)), vp(ctypes.pointer(ret)), vp(ctypes.pointer(it)),
+                                          vp(ctypes.pointer(nev)))
+    if err:
+        raise err[0]
+    ctx.check(rc)
+    return ret.value, x, f.value, it.value, nev.value

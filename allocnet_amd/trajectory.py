@@ -70,6 +70,18 @@ def traj_max_rate(coeffs, T, which, ctx=None):
     return out
 
 
+def piece_normalized_coeffs(coeffs, T, deriv, ctx=None):
+    """Piece::normalizePosCoeffMat / normalizeVelCoeffMat / normalizeAccCoeffMat (trajectory.hpp:135-171) for a batch of pieces:
+    coefficients of position (deriv 0), velocity (1) or acceleration (2) in normalised time.  coeffs (P,3,D), T (P,) -> (P,3,D-deriv)."""
+    ctx = ctx or default_context()
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    P, _, D = coeffs.shape
+    out = np.empty((P, 3, D - int(deriv)))
+    ctx.check(ctx.lib.anet_piece_normalized_coeffs(ctx.handle, D // 2, P, _ptr(coeffs), _ptr(T), int(deriv), _ptr(out)))
+    return out
+
+
 class Piece:
     """Piece<D> (trajectory.hpp:37-316): duration + 3 x (D+1) coefficient matrix, highest power first."""
 
@@ -108,6 +120,16 @@ class Piece:
 
     def getJer(self, t):
         return self._eval(t, 3)
+
+    # trajectory.hpp:135-171
+    def normalizePosCoeffMat(self):
+        return piece_normalized_coeffs(self.coeffMat[None], np.array([self.duration]), 0, ctx=self._ctx)[0]
+
+    def normalizeVelCoeffMat(self):
+        return piece_normalized_coeffs(self.coeffMat[None], np.array([self.duration]), 1, ctx=self._ctx)[0]
+
+    def normalizeAccCoeffMat(self):
+        return piece_normalized_coeffs(self.coeffMat[None], np.array([self.duration]), 2, ctx=self._ctx)[0]
 
     # trajectory.hpp:177-314
     def getMaxVelRate(self):

@@ -195,6 +195,16 @@ int anet_traj_max_rate_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, in
 int anet_traj_max_rate(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const double *coeffs,
                        const double *T, int which, double *rate);
 
+/* Replaces Piece<D>::normalizePosCoeffMat / normalizeVelCoeffMat / normalizeAccCoeffMat (gcopter/trajectory.hpp:135-171) for a
+ * batch of independent pieces: the coefficients of the position (deriv = 0), velocity (1) or acceleration (2) polynomial of each
+ * piece in normalised time tau = t / duration, highest power first: column i = (falling factorial of its power) * coeffMat.col(i) *
+ * duration^power.  coeffs [pieces][3][2s], T [pieces], out [pieces][3][2s - deriv]; HOST pointers (the _dev variant: device
+ * pointers, the same piece-major layout, asynchronous on `stream`). */
+int anet_piece_normalized_coeffs(anet_ctx *ctx, int s, int64_t pieces, const double *coeffs, const double *T, int deriv,
+                                 double *out);
+int anet_piece_normalized_coeffs_dev(anet_ctx *ctx, int s, int64_t pieces, const double *coeffs, const double *T, int deriv,
+                                     double *out, void *stream);
+
 /* ---- cost + analytic gradients ----------------------------------------------------------- */
 /* Penalty functional on the reference's own inequality rows (QPSolver::solve step three,
  * planner/qp_solver.hpp:244-296; MinTrajOpt.fill_ineq, network/utils/min_traj_opt.py:535-613):
@@ -470,6 +480,28 @@ int anet_lbfgs_optimize_dev(anet_ctx *ctx, int n, int64_t batch, int64_t ld, dou
                             anet_lbfgs_evaluate_t proc_evaluate, void *instance, const anet_lbfgs_params *params,
                             int max_evals, int bound_from, double bound_min, double *work, int32_t *status,
                             int32_t *iters, int32_t *evals, void *stream);
+
+/* lbfgs::lbfgs_optimize for an objective evaluated ON THE HOST, with the reference's three callbacks (lbfgs.hpp:186-246, called
+ * as lbfgs.hpp:434-717 calls them): one problem, x [n] host memory (start point in, result out), *f = fx on return, *ret =
+ * lbfgs_optimize's return value (LBFGS_CONVERGENCE / LBFGS_STOP / LBFGS_CANCELED / LBFGSERR_*, parameter errors included),
+ * *iters = k, *evals = objective evaluations (iters / evals may be NULL).
+ *   proc_evaluate (required): returns f(x) and fills g [n]                                    -- lbfgs_evaluate_t
+ *   proc_stepbound (may be NULL): upper bound of the step along d from xp                    -- lbfgs_stepbound_t, lbfgs.hpp:557-565
+ *   proc_progress (may be NULL): called after every successful line search with x, g, fx, step, k, ls;
+ *                 a non-zero return ends the run with LBFGS_CANCELED                        -- lbfgs_progress_t, lbfgs.hpp:580-587
+ * The optimiser's vectors and all its arithmetic (line-search bookkeeping, cautious update, two-loop recursion, stopping
+ * tests) stay on the device -- the lockstep update kernel with a batch of one -- and the state machine parks where the
+ * reference calls back: per evaluation x goes to the host and f, g come back; per line search xp and d go to the host and the
+ * bound comes back.  There is no CPU optimiser in the library.  A PCIe round trip per evaluation: for objectives that can be
+ * evaluated on the device use anet_lbfgs_optimize_dev.  The call returns ANET_OK when the run ended by lbfgs_optimize's own rules,
+ * whatever *ret says. */
+typedef double (*anet_lbfgs_host_evaluate_t)(void *instance, const double *x, double *g, int n);
+typedef double (*anet_lbfgs_host_stepbound_t)(void *instance, const double *xp, const double *d, int n);
+typedef int (*anet_lbfgs_host_progress_t)(void *instance, const double *x, const double *g, double fx, double step, int k,
+                                          int ls, int n);
+int anet_lbfgs_optimize_host(anet_ctx *ctx, int n, double *x, double *f, anet_lbfgs_host_evaluate_t proc_evaluate,
+                             anet_lbfgs_host_stepbound_t proc_stepbound, anet_lbfgs_host_progress_t proc_progress,
+                             void *instance, const anet_lbfgs_params *params, int32_t *ret, int32_t *iters, int32_t *evals);
 
 /* Objective = the MINCO cost  int (p^(s))^2 + rho*sum(T) + J_pen  (anet_minco_cost_grad) over the
  * interior waypoints (opt_flags bit 0) and/or the durations (bit 1), the durations through the

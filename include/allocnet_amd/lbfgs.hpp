@@ -1,12 +1,14 @@
 // L-BFGS facade: the reference's parameter struct, return codes and lbfgs_strerror
 // (src/planner/include/gcopter/lbfgs.hpp:15-129, 135-184, 724-799) with the same names and values.
 // lbfgs_optimize itself takes host callbacks (lbfgs.hpp:200-259, 434) and has a single caller in the
-// reference (firi::maxVolInsEllipsoid, firi.hpp:207-227); its GPU replacement is batched over
-// problems with the objective evaluated on the device: lbfgs_optimize_mvie (that call site) and
-// lbfgs_optimize_minco (the trajectory cost of the north star).
+// reference (firi::maxVolInsEllipsoid, firi.hpp:207-227): that call runs on the device as a whole
+// (lbfgs_optimize_mvie), any other objective through the caller's host callbacks with the optimiser's
+// vectors on the device (anet_lbfgs_optimize_host); batched device objectives: lbfgs_optimize_mvie,
+// anet_lbfgs_minco (the trajectory cost of the north star), lbfgs_optimize_batched.
 #pragma once
 #include <stdexcept>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 #include "core.hpp"
@@ -100,22 +102,79 @@ inline std::vector<int> lbfgs_optimize_mvie(int batch, int M, const std::vector<
   return status;
 }
 
-// lbfgs::lbfgs_optimize (lbfgs.hpp:434-440) for the reference's own call (firi.hpp:221-227): objective
-// &firi::costMVIE, no step bound, no progress monitor, `instance` = firi's optData blob {int M; double smoothEps,
-// penaltyWt; double A[3 M] column-major} (firi.hpp:186-200).  Runs anet_lbfgs_mvie with a batch of one; x and f are
-// updated like the reference's, the return value is its return code.  Any other HOST-evaluated objective is refused: there
-// is no CPU L-BFGS in this library.  Batched device objectives: lbfgs_optimize_mvie above, anet_lbfgs_minco, and -- any
-// objective the caller can evaluate on the device -- lbfgs_optimize_batched below (anet_lbfgs_optimize_dev).  The step-bound
-// mechanism itself (lbfgs.hpp:557-565) is there for the MINCO objective as a built-in bound, a minimum duration:
-// anet_lbfgs_minco_bounded[_dev](..., min_duration, ...); the progress monitor's one effect (lbfgs.hpp:580-587: a non-zero
-// return cancels the run) as a word the caller owns: anet_set_cancel_flag.
+namespace detail {
+// The reference's callbacks take Eigen vectors; the C ABI hands over plain arrays: a V of the right size is built around each
+// call (V needs a size constructor, size() and (i) access -- Eigen::VectorXd has them).
+template <class V>
+struct HostCallbacks {
+  lbfgs_evaluate_t<V> evaluate;
+  lbfgs_stepbound_t<V> stepbound;
+  lbfgs_progress_t<V> progress;
+  void *instance;
+  static V sized(int n, std::true_type) { return V(n); }
+  static V sized(int, std::false_type) {
+    throw std::invalid_argument("lbfgs_optimize: host callbacks need a vector type with a size constructor (Eigen::VectorXd has one)");
+  }
+  static V wrap(const double *p, int n) {
+    V v = sized(n, std::is_constructible<V, int>());
+    for (int i = 0; i < n; ++i) v(i) = p[i];
+    return v;
+  }
+  static double c_evaluate(void *self, const double *x, double *g, int n) {
+    HostCallbacks *h = static_cast<HostCallbacks *>(self);
+    const V xv = wrap(x, n);
+    V gv = wrap(x, n);
+    for (int i = 0; i < n; ++i) gv(i) = 0.0;
+    const double f = h->evaluate(h->instance, xv, gv);
+    for (int i = 0; i < n; ++i) g[i] = gv(i);
+    return f;
+  }
+  static double c_stepbound(void *self, const double *xp, const double *d, int n) {
+    HostCallbacks *h = static_cast<HostCallbacks *>(self);
+    return h->stepbound(h->instance, wrap(xp, n), wrap(d, n));
+  }
+  static int c_progress(void *self, const double *x, const double *g, double fx, double step, int k, int ls, int n) {
+    HostCallbacks *h = static_cast<HostCallbacks *>(self);
+    return h->progress(h->instance, wrap(x, n), wrap(g, n), fx, step, k, ls);
+  }
+};
+}  // namespace detail
+
+// lbfgs::lbfgs_optimize (lbfgs.hpp:434-440), source-compatible: x and f are updated like the reference's, the return value is
+// its return code.
+//  * The reference's own call (firi.hpp:221-227) -- objective &firi::costMVIE, no step bound, no progress monitor, `instance` =
+//    firi's optData blob {int M; double smoothEps, penaltyWt; double A[3 M] column-major} (firi.hpp:186-200) -- runs entirely on
+//    the device (anet_lbfgs_mvie with a batch of one).
+//  * Any other objective is evaluated by the caller's HOST callbacks exactly where lbfgs_optimize calls them -- proc_evaluate per
+//    trial point, proc_stepbound at the entry of every line search (lbfgs.hpp:557-565), proc_progress after every successful one
+//    (lbfgs.hpp:580-587; non-zero cancels) -- while the optimiser's vectors and arithmetic stay on the device
+//    (anet_lbfgs_optimize_host: the library has no CPU optimiser; one PCIe round trip per evaluation).
+//  Batched device objectives: lbfgs_optimize_mvie above, anet_lbfgs_minco, lbfgs_optimize_batched below.
 template <class V>
 inline int lbfgs_optimize(V &x, double &f, lbfgs_evaluate_t<V> proc_evaluate, lbfgs_stepbound_t<V> proc_stepbound,
                           lbfgs_progress_t<V> proc_progress, void *instance, const lbfgs_parameter_t &param) {
-  if (proc_evaluate != static_cast<lbfgs_evaluate_t<V>>(&firi::costMVIE<V>))
-    throw std::invalid_argument("lbfgs_optimize: only firi::costMVIE is available as a host-named objective (device evaluation)");
-  if (proc_stepbound || proc_progress)
-    throw std::invalid_argument("lbfgs_optimize: step-bound / progress callbacks are not supported (the optimisation runs on the device)");
+  if (proc_evaluate != static_cast<lbfgs_evaluate_t<V>>(&firi::costMVIE<V>) || proc_stepbound || proc_progress) {
+    if (proc_evaluate == static_cast<lbfgs_evaluate_t<V>>(&firi::costMVIE<V>))
+      throw std::invalid_argument("lbfgs_optimize: firi::costMVIE is evaluated on the device and takes no host step-bound / progress callbacks");
+    if (!proc_evaluate) throw std::invalid_argument("lbfgs_optimize: proc_evaluate is null");
+    const int n = (int)x.size();
+    detail::HostCallbacks<V> cb{proc_evaluate, proc_stepbound, proc_progress, instance};
+    std::vector<double> xs((size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) xs[i] = x(i);
+    anet_lbfgs_params q = to_c(param);
+    int32_t ret = LBFGSERR_UNKNOWNERROR;
+    double fx = 0.0;
+    anet::Context &ctx = anet::Context::thread_default();
+    ctx.check(anet_lbfgs_optimize_host(ctx.get(), n, xs.data(), &fx, &detail::HostCallbacks<V>::c_evaluate,
+                                       proc_stepbound ? &detail::HostCallbacks<V>::c_stepbound : nullptr,
+                                       proc_progress ? &detail::HostCallbacks<V>::c_progress : nullptr, &cb, &q, &ret, nullptr,
+                                       nullptr));
+    if (ret > LBFGSERR_INVALID_MAXLINESEARCH || ret >= 0) {  // (a parameter error leaves x and f untouched, as the reference does)
+      for (int i = 0; i < n; ++i) x(i) = xs[i];
+      f = fx;
+    }
+    return ret;
+  }
   if ((int)x.size() != 9) return LBFGSERR_INVALID_N;
   int M = 0;
   double eps = 0.0, wt = 0.0;

@@ -47,6 +47,21 @@ class Piece {
   inline anet::Vec3 getAcc(const double &t) const { return eval(t, 2); }
   inline anet::Vec3 getJer(const double &t) const { return eval(t, 3); }
 
+  // Piece::normalizePosCoeffMat / normalizeVelCoeffMat / normalizeAccCoeffMat (trajectory.hpp:135-171): the coefficient matrices
+  // of position, velocity and acceleration in normalised time (3 x (D + 1), 3 x D, 3 x (D - 1); highest power first)
+  typedef anet::Matrix<3, D> VelCoefficientMat;
+  typedef anet::Matrix<3, D - 1> AccCoefficientMat;
+  template <class M>
+  inline M normalized(int deriv) const {
+    M out;
+    anet::Context &ctx = anet::Context::thread_default();
+    ctx.check(anet_piece_normalized_coeffs(ctx.get(), (D + 1) / 2, 1, coeffMat.data(), &duration, deriv, out.data()));
+    return out;
+  }
+  inline CoefficientMat normalizePosCoeffMat() const { return normalized<CoefficientMat>(0); }
+  inline VelCoefficientMat normalizeVelCoeffMat() const { return normalized<VelCoefficientMat>(1); }
+  inline AccCoefficientMat normalizeAccCoeffMat() const { return normalized<AccCoefficientMat>(2); }
+
   inline double maxRate(int which) const {
     double r = 0.0;
     anet::Context &ctx = anet::Context::thread_default();

@@ -170,8 +170,14 @@ def lbfgs_default_param(**over):
     return p
 
 
-def lbfgs_optimize(x0, fun, param=None):
-    """fun(x) -> (f, g).  Returns ret, x, f, iters, evals."""
+BOUND_T = ctypes.CFUNCTYPE(c_double, c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double), c_int)
+PROGRESS_T = ctypes.CFUNCTYPE(c_int, c_void_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double), c_double, c_double, c_int, c_int,
+                              c_int)
+
+
+def lbfgs_optimize(x0, fun, param=None, stepbound=None, progress=None):
+    """fun(x) -> (f, g); stepbound(xp, d) -> float (lbfgs.hpp:557-565); progress(x, g, fx, step, k, ls) -> int, non-zero
+    cancels (lbfgs.hpp:580-587).  Returns ret, x, f, iters, evals."""
     param = param or lbfgs_default_param()
     x = np.array(x0, dtype=np.float64)
     n = x.size
@@ -181,9 +187,19 @@ def lbfgs_optimize(x0, fun, param=None):
         f, g = fun(xv.copy())
         np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
         return float(f)
+
+    def sb(inst, xp, dp, nn):
+        return float(stepbound(np.ctypeslib.as_array(xp, shape=(nn,)).copy(), np.ctypeslib.as_array(dp, shape=(nn,)).copy()))
+
+    def pg(inst, xp, gp, fx, step, k, ls, nn):
+        return int(bool(progress(np.ctypeslib.as_array(xp, shape=(nn,)).copy(), np.ctypeslib.as_array(gp, shape=(nn,)).copy(),
+                                 fx, step, k, ls)))
     f = c_double(0.0); it = c_int(0); ev = c_int(0)
-    ret = lib().oracle_lbfgs_optimize(n, _p(x), ctypes.byref(f), EVAL_T(cb), None, ctypes.byref(param),
-                                      ctypes.byref(it), ctypes.byref(ev))
+    L = lib()
+    L.oracle_lbfgs_optimize_full.restype = c_int
+    ret = L.oracle_lbfgs_optimize_full(n, _p(x), ctypes.byref(f), EVAL_T(cb), BOUND_T(sb) if stepbound else None,
+                                       PROGRESS_T(pg) if progress else None, None, ctypes.byref(param), ctypes.byref(it),
+                                       ctypes.byref(ev))
     return ret, x, f.value, it.value, ev.value
 
 

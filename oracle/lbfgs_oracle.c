@@ -99,8 +99,17 @@ int oracle_lbfgs_optimize(int n, double *x, double *f, oracle_eval_t eval, void 
                           const oracle_lbfgs_param *param, int *iters, int *evals_out) {
   return oracle_lbfgs_optimize_sb(n, x, f, eval, NULL, inst, param, iters, evals_out);
 }
+typedef int (*oracle_progress_t)(void *instance, const double *x, const double *g, double fx, double step, int k, int ls, int n);
+int oracle_lbfgs_optimize_full(int n, double *x, double *f, oracle_eval_t eval, oracle_stepbound_t stepbound,
+                               oracle_progress_t progress, void *inst, const oracle_lbfgs_param *param, int *iters, int *evals_out);
 int oracle_lbfgs_optimize_sb(int n, double *x, double *f, oracle_eval_t eval, oracle_stepbound_t stepbound, void *inst,
                              const oracle_lbfgs_param *param, int *iters, int *evals_out) {
+  return oracle_lbfgs_optimize_full(n, x, f, eval, stepbound, NULL, inst, param, iters, evals_out);
+}
+/* ... and with lbfgs_progress_t (lbfgs.hpp:226-246), called after every successful line search, before the convergence test
+ * (lbfgs.hpp:580-587): a non-zero return ends the run with LBFGS_CANCELED. */
+int oracle_lbfgs_optimize_full(int n, double *x, double *f, oracle_eval_t eval, oracle_stepbound_t stepbound,
+                               oracle_progress_t progress, void *inst, const oracle_lbfgs_param *param, int *iters, int *evals_out) {
   int ret, i, j, k = 0, ls, end, bound, evals = 0;
   double step, fx, ys, yy, gnorm_inf, xnorm_inf, beta, rate, cau;
   const int m = param->mem_size;
@@ -140,6 +149,7 @@ int oracle_lbfgs_optimize_sb(int n, double *x, double *f, oracle_eval_t eval, or
       }
       ls = line_search(n, x, &fx, g, &step, d, xp, gp, param->min_step, step_max, eval, inst, param, &evals);
       if (ls < 0) { memcpy(x, xp, sizeof(double) * n); memcpy(g, gp, sizeof(double) * n); ret = ls; break; }
+      if (progress && progress(inst, x, g, fx, step, k, ls, n)) { ret = LBFGS_CANCELED; break; } /* lbfgs.hpp:580-587 */
       gnorm_inf = maxabs(g, n); xnorm_inf = maxabs(x, n);
       if (gnorm_inf / fmax(1.0, xnorm_inf) < param->g_epsilon) { ret = LBFGS_CONVERGENCE; break; }
       if (0 < param->past) {

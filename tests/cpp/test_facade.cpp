@@ -24,6 +24,7 @@ struct Mat {  // Eigen-like: (r,c) access, default constructible
 struct Vec {
   std::vector<double> a;
   explicit Vec(int n) : a(n, 0.0) {}
+  long size() const { return (long)a.size(); }
   double &operator()(int i) { return a[i]; }
   double operator()(int i) const { return a[i]; }
 };
@@ -125,6 +126,14 @@ int main() {
     printf("\"jer\": [%.17g, %.17g, %.17g],\n", jer(0), jer(1), jer(2));
     printf("\"endp\": [%.17g, %.17g, %.17g],\n", endp(0), endp(1), endp(2));
     printf("\"junc_vel_3\": [%.17g, %.17g, %.17g],\n", copy.getJuncVel(3)(0), copy.getJuncVel(3)(1), copy.getJuncVel(3)(2));
+    {  // Piece::normalize{Pos,Vel,Acc}CoeffMat (trajectory.hpp:135-171) of piece 3
+      const auto np_ = copy[3].normalizePosCoeffMat();
+      const auto nv_ = copy[3].normalizeVelCoeffMat();
+      const auto na_ = copy[3].normalizeAccCoeffMat();
+      print_vec("norm_pos", std::vector<double>(np_.data(), np_.data() + 3 * 8));
+      print_vec("norm_vel", std::vector<double>(nv_.data(), nv_.data() + 3 * 7));
+      print_vec("norm_acc", std::vector<double>(na_.data(), na_.data() + 3 * 6));
+    }
     printf("\"locate\": [%d, %.17g],\n", idx, tloc);
     printf("\"pieces\": %d, \"total\": %.17g,\n", copy.getPieceNum(), copy.getTotalDuration());
     printf("\"max_vel\": %.17g, \"max_acc\": %.17g, \"check_vel\": %d,\n", copy.getMaxVelRate(), copy.getMaxAccRate(),
@@ -299,6 +308,67 @@ int main() {
       printf("\"mvie_ret\": %d, \"mvie_cost\": %.17g,\n", ret, minCost);
       print_vec("mvie_x", std::vector<double>(x.a, x.a + 9));
       delete[] optData;
+    }
+    {
+      // lbfgs::lbfgs_optimize with HOST callbacks (lbfgs.hpp:186-246, 434-440): the extended Rosenbrock function in 10 variables,
+      // once plain, once with a step bound (no variable may move by more than 0.5 per line search) and a progress monitor
+      // that records every call and cancels the run at its 12th
+      struct Rosen {
+        int evals, bounds, reports, cancel_at;
+        std::vector<double> fx_seen;
+        static double eval(void *inst, const Vec &x, Vec &g) {
+          Rosen *r = (Rosen *)inst;
+          r->evals++;
+          const int n = (int)x.a.size();
+          double f = 0.0;
+          for (int i = 0; i < n; ++i) g(i) = 0.0;
+          for (int i = 0; i + 1 < n; i += 2) {
+            const double t1 = 1.0 - x(i), t2 = 10.0 * (x(i + 1) - x(i) * x(i));
+            g(i + 1) = 20.0 * t2;
+            g(i) = -2.0 * (x(i) * g(i + 1) + t1);
+            f += t1 * t1 + t2 * t2;
+          }
+          return f;
+        }
+        static double bound(void *inst, const Vec &xp, const Vec &d) {
+          Rosen *r = (Rosen *)inst;
+          r->bounds++;
+          (void)xp;
+          double m = 0.0;
+          for (size_t i = 0; i < d.a.size(); ++i) m = std::fabs(d(i)) > m ? std::fabs(d(i)) : m;
+          return 0.5 / m;
+        }
+        static int progress(void *inst, const Vec &x, const Vec &g, const double fx, const double step, const int k, const int ls) {
+          Rosen *r = (Rosen *)inst;
+          (void)x; (void)g; (void)step; (void)ls;
+          r->reports++;
+          r->fx_seen.push_back(fx);
+          return (r->cancel_at > 0 && k >= r->cancel_at) ? 1 : 0;
+        }
+      };
+      lbfgs::lbfgs_parameter_t rp;
+      rp.g_epsilon = 1.0e-8;
+      rp.delta = 1.0e-10;
+      for (int mode = 0; mode < 2; ++mode) {
+        Rosen r{0, 0, 0, mode ? 12 : 0, {}};
+        Vec x(10);
+        for (int i = 0; i < 10; ++i) x(i) = (i % 2) ? 1.0 : -1.2;
+        double fmin = -1.0;
+        const int ret = lbfgs::lbfgs_optimize<Vec>(x, fmin, &Rosen::eval, mode ? &Rosen::bound : nullptr, mode ? &Rosen::progress : nullptr,
+                                                   &r, rp);
+        printf("\"rosen%d_ret\": %d, \"rosen%d_f\": %.17g, \"rosen%d_evals\": %d, \"rosen%d_bounds\": %d, \"rosen%d_reports\": %d,\n", mode, ret, mode,
+               fmin, mode, r.evals, mode, r.bounds, mode, r.reports);
+        print_vec(mode ? "rosen1_x" : "rosen0_x", x.a);
+        if (mode) print_vec("rosen1_fx_seen", r.fx_seen);
+      }
+      // a parameter error is lbfgs_optimize's return value and leaves x and f alone (lbfgs.hpp:449-495)
+      lbfgs::lbfgs_parameter_t bad;
+      bad.f_dec_coeff = 1.5;
+      Rosen r{0, 0, 0, 0, {}};
+      Vec x(4);
+      double f0 = 123.0;
+      printf("\"rosen_bad_ret\": %d, \"rosen_bad_evals\": %d, \"rosen_bad_f\": %g,\n",
+             lbfgs::lbfgs_optimize<Vec>(x, f0, &Rosen::eval, nullptr, nullptr, &r, bad), r.evals, f0);
     }
     lbfgs::lbfgs_parameter_t prm;
     printf("\"lbfgs_default_mem\": %d, \"strerror\": \"%s\"\n", prm.mem_size, lbfgs::lbfgs_strerror(lbfgs::LBFGSERR_MAXIMUMLINESEARCH));

@@ -48,6 +48,8 @@ def test_cpp_facade_program():
         assert np.abs(np.array(out[key]) - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max())
     assert np.abs(np.array(out["endp"]) - onp.traj_eval(co, T, 8.25, 0)).max() < 1e-9
     assert np.abs(np.array(out["junc_vel_3"]) - onp.piece_eval(co[3], 0.0, 1)).max() < 1e-12
+    for key, d in (("norm_pos", 0), ("norm_vel", 1), ("norm_acc", 2)):
+        assert np.array_equal(np.array(out[key]).reshape(3, 8 - d), onp.piece_normalized_coeffs(np.array(out["coeffs"]).reshape(N, 3, 8)[3], 1.0, d))
     assert out["locate"][0] == 2 and abs(out["locate"][1] - 0.25) < 1e-15
     assert out["pieces"] == 8 and out["total"] == 8.0
     assert abs(out["max_vel"] - max(onp.piece_max_rate(co[i], 1.0, 1) for i in range(N))) <= 1e-9 * out["max_vel"]
@@ -69,6 +71,30 @@ def test_cpp_facade_program():
     xm = np.array(out["mvie_x"])
     assert np.abs(xm - xo).max() <= 1e-5
     assert np.abs(xm[:3]).max() < 1e-6 and np.abs(xm[3:6] ** 2 - 1.0).max() < 1e-3 and np.abs(xm[6:]).max() < 1e-6
+
+    # lbfgs::lbfgs_optimize with HOST callbacks (include/allocnet_amd/lbfgs.hpp -> anet_lbfgs_optimize_host): the extended
+    # Rosenbrock function, plain and with a step bound + a progress monitor that cancels at k = 12, against the C restatement
+    # of lbfgs_optimize (lbfgs.hpp:434-717) driving the same function through Python callbacks
+    def rosen(x):
+        g = np.zeros_like(x)
+        t1 = 1.0 - x[0::2]; t2 = 10.0 * (x[1::2] - x[0::2] ** 2)
+        g[1::2] = 20.0 * t2
+        g[0::2] = -2.0 * (x[0::2] * g[1::2] + t1)
+        return float((t1 * t1 + t2 * t2).sum()), g
+    x0 = np.where(np.arange(10) % 2 == 1, 1.0, -1.2)
+    prm = cbind.lbfgs_default_param(g_epsilon=1e-8, delta=1e-10)
+    ret0, xo0, fo0, it0, ev0 = cbind.lbfgs_optimize(x0, rosen, prm)
+    assert out["rosen0_ret"] == ret0 and ret0 in (0, 1) and out["rosen0_evals"] == ev0
+    assert abs(out["rosen0_f"] - fo0) <= 1e-12 and np.abs(np.array(out["rosen0_x"]) - xo0).max() <= 1e-6
+    assert np.abs(np.array(out["rosen0_x"]) - 1.0).max() < 1e-4 and out["rosen0_bounds"] == 0 and out["rosen0_reports"] == 0
+    seen = []
+    ret1, xo1, fo1, it1, ev1 = cbind.lbfgs_optimize(x0, rosen, prm, stepbound=lambda xp, d: 0.5 / np.abs(d).max(),
+                                                  progress=lambda x, g, fx, step, k, ls: (seen.append(fx), k >= 12)[1])
+    assert ret1 == 2 and out["rosen1_ret"] == 2 and out["rosen1_evals"] == ev1      # LBFGS_CANCELED at the 12th report
+    assert out["rosen1_reports"] == len(seen) == 12 and out["rosen1_bounds"] == 12
+    assert np.allclose(out["rosen1_fx_seen"], seen, rtol=1e-9, atol=1e-12)
+    assert abs(out["rosen1_f"] - fo1) <= 1e-9 * max(1.0, abs(fo1)) and np.abs(np.array(out["rosen1_x"]) - xo1).max() <= 1e-8
+    assert out["rosen_bad_ret"] == -1016 and out["rosen_bad_evals"] == 0 and out["rosen_bad_f"] == 123.0
 
     # QPSolver facade: solved, ends where asked, inside the velocity box, objective == 1/2 z'Qz of its coefficients
     assert out["qp_ok"] == 1 and out["qp_iters"] > 0

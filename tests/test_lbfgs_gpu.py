@@ -769,3 +769,92 @@ def test_minco_lbfgs_two_launch_form_returns_the_same_bits():
         res[name] = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["two"] == res["one"], res
     assert sum(v["below"] for v in res["two"].values()) > 100 and sum(v["above"] for v in res["two"].values()) > 1000, res
+
+
+def _rosen(x):
+    a, b = x[:-1], x[1:]
+    t = b - a * a
+    g = np.zeros_like(x)
+    g[:-1] += -400.0 * a * t - 2.0 * (1.0 - a)
+    g[1:] += 200.0 * t
+    return (100.0 * t * t + (1.0 - a) ** 2).sum(), g
+
+
+@pytest.mark.parametrize("n", [2, 9, 40, 300])
+def test_host_callback_objective_matches_the_restatement(anet_ctx, n):
+    """anet_lbfgs_optimize_host = lbfgs::lbfgs_optimize with the reference's three HOST callbacks (lbfgs.hpp:186-246): the
+    objective evaluated on the host, the optimiser's vectors and arithmetic on the device, the state machine parked where the
+    reference calls back.  Against the C restatement driving the same Python callbacks: return code and both counters equal at
+    fixed budgets for nearly every start point (a dot product summed in another order may flip a test on its threshold), iterates
+    to 1e-8 where they are -- plain, with a step bound, and with a progress monitor whose every call (k, ls, fx, step) is compared
+    and which cancels the run."""
+    import allocnet_amd as aa
+    rng = np.random.default_rng(700 + n)
+    starts = rng.uniform(-1.5, 1.5, size=(12, n))
+    bound = lambda xp, d: 0.3 / np.abs(d).max()          # no variable moves by more than 0.3 per line search
+    total = same = 0
+    for budget in (2, 7, 25):
+        for x0 in starts:
+            for mode in ("plain", "bound", "progress"):
+                log_g, log_o = [], []
+
+                def mk(log, stop_at):
+                    def progress(x, g, fx, step, k, ls):
+                        log.append((k, ls, fx, step, float(np.abs(g).max())))
+                        return 1 if k >= stop_at else 0
+                    return progress
+                kw_g = dict(stepbound=bound if mode != "plain" else None, progress=mk(log_g, 5) if mode == "progress" else None)
+                kw_o = dict(stepbound=bound if mode != "plain" else None, progress=mk(log_o, 5) if mode == "progress" else None)
+                ret, xg, fg, it, ev = aa.lbfgs_optimize(x0, _rosen, param=aa.lbfgs_parameter_t(max_iterations=budget), ctx=anet_ctx, **kw_g)
+                reto, xo, fo, ito, evo = cbind.lbfgs_optimize(x0, _rosen, cbind.lbfgs_default_param(max_iterations=budget), **kw_o)
+                total += 1
+                if (ret, it, ev) == (reto, ito, evo):
+                    same += 1
+                    assert abs(fg - fo) <= 1e-9 * max(1.0, abs(fo)), (n, budget, mode)
+                    assert np.abs(xg - xo).max() <= 1e-8 * max(1.0, np.abs(xo).max()), (n, budget, mode)
+                    assert len(log_g) == len(log_o)
+                    for a, b in zip(log_g, log_o):
+                        assert a[:2] == b[:2] and np.allclose(a[2:], b[2:], rtol=1e-8, atol=1e-12), (a, b)
+                if mode == "progress" and budget > 5:
+                    assert ret == aa.lbfgs.LBFGS_CANCELED or ret < 0 or it < 5, (ret, it)
+    assert same >= 0.9 * total, (same, total)
+    # left to run from the classic start: the minimum f = 0 at x = 1
+    x0 = np.where(np.arange(n) % 2 == 0, -1.2, 1.0)
+    ret, x, f, it, ev = aa.lbfgs_optimize(x0, _rosen, param=aa.lbfgs_parameter_t(g_epsilon=1e-7, delta=0.0, past=0), ctx=anet_ctx)
+    assert ret == aa.lbfgs.LBFGS_CONVERGENCE or (ret < 0 and np.abs(_rosen(x)[1]).max() < 1e-4), (ret, f)
+    assert f < 4.0 and ev >= it
+
+
+def test_host_callback_objective_validation_and_errors(anet_ctx):
+    """Parameter errors are lbfgs_optimize's return value, in its order (lbfgs.hpp:449-495), before any evaluation; an exception
+    in a callback comes back as the exception; the start point may already be stationary (LBFGS_CONVERGENCE after one evaluation)."""
+    import allocnet_amd as aa
+    calls = []
+
+    def fun(x):
+        calls.append(1)
+        return _rosen(x)
+    ret, x, f, it, ev = aa.lbfgs_optimize(np.zeros(4), fun, param=aa.lbfgs_parameter_t(f_dec_coeff=1.5), ctx=anet_ctx)
+    assert ret == -1016 and not calls and ev == 0
+    ret, *_ = aa.lbfgs_optimize(np.zeros(4), fun, param=aa.lbfgs_parameter_t(mem_size=0), ctx=anet_ctx)
+    assert ret == -1022 and not calls
+    ret, x, f, it, ev = aa.lbfgs_optimize(np.ones(6), fun, ctx=anet_ctx)
+    assert ret == aa.lbfgs.LBFGS_CONVERGENCE and ev == 1 and f == 0.0 and np.array_equal(x, np.ones(6))
+    with pytest.raises(ZeroDivisionError):
+        aa.lbfgs_optimize(np.zeros(4), lambda x: (1.0 / 0.0, x), ctx=anet_ctx)
+    # a non-finite objective value in a line search ends the run as the reference does (LBFGSERR_INVALID_FUNCVAL), x restored
+    state = {"k": 0}
+
+    def poisoned(x):
+        state["k"] += 1
+        f, g = _rosen(x)
+        return (float("inf") if state["k"] == 3 else f), g
+    ret, x, f, it, ev = aa.lbfgs_optimize(np.full(4, -1.0), poisoned, ctx=anet_ctx)
+    st2 = {"k": 0}
+
+    def poisoned2(x):
+        st2["k"] += 1
+        f, g = _rosen(x)
+        return (float("inf") if st2["k"] == 3 else f), g
+    reto, xo, fo, ito, evo = cbind.lbfgs_optimize(np.full(4, -1.0), poisoned2)
+    assert (ret, it, ev) == (reto, ito, evo) and ret == -1012 and np.allclose(x, xo, rtol=0, atol=1e-12)

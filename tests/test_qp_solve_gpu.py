@@ -766,3 +766,44 @@ def test_two_launch_form_returns_the_same_bits():
     assert res["two"] == res["one"], res
     for key, v in res["two"].items():
         assert v["solved"] > 0 and v["longest"] > 4, (key, v)
+
+
+def test_the_c_planners_float_arithmetic_is_bounded_not_reproduced(anet_ctx):
+    """QPSolver::solve in the C++ planner forms the time powers of its dense matrices in FLOAT (`times` is a float vector:
+    get_t_state<float> qp_solver.hpp:90-116, the cost block :183-236, the sample times :252-258).  Two things are checked:
+    (1) the device ASSEMBLY in float mode (anet_qp_assemble, float_time = 1) equals the statement-for-statement float32
+        restatement (oracle/minco_np.qp_assemble_cpp_float) bit for bit on whole matrices;
+    (2) the SOLVE never forms those matrices (Hermite node coordinates, shared basis tables: csrc/qp_ipm.h), so it solves the QP
+        of the float-representable durations in double arithmetic -- its optimum against the optimum of the float-assembled
+        QP (dense interior point on the restated matrices, 1e-10): objective within 5e-6, three orders inside the 1e-3
+        tolerances the reference runs OSQP at (qp_solver.hpp:301-302); the minimiser itself is flat in some directions (8-piece
+        snap: rounding the durations to float alone moves coefficients by 4e-4 of their scale at an objective change of 1e-7),
+        so the trajectories differ by up to 2 cm (measured 1.97 cm) where the cost barely sees it.  The entry-wise float
+        rounding is NOT reproduced; this is the measured size of what that leaves."""
+    import allocnet_amd as aa
+    from allocnet_amd.synth import corridor_problem
+    worst_obj, worst_pos = 0.0, 0.0
+    for (s, N, seed) in ((3, 5, 11), (4, 5, 12), (4, 8, 13)):
+        rng = np.random.default_rng(seed)
+        head, tail, wps, T, hp = corridor_problem(rng, 4, N, 3, 16)
+        Tf = (T * 1.5).astype(np.float32).astype(np.float64)       # what a float `times` vector holds
+        ini, fin = head[:, :, :3], tail[:, :, :3]
+        Qg, Ag, bg, Gg, hg = aa.qp_assemble(s, ini, fin, hp, Tf, res=20, float_time=True, ctx=anet_ctx)
+        out = aa.qp_solve(s, ini, fin, hp, Tf, res=20, settings=aa.qp.qp_settings(eps_abs=1e-9, eps_rel=1e-9), ctx=anet_ctx)
+        for b in range(4):
+            Q, A, bb, G, h = onp.qp_assemble_cpp_float(s, ini[b], fin[b], [hp[b, i] for i in range(N)], Tf[b], 20, 4.0, 6.0)
+            for got, ref in ((Qg[b], Q), (Ag[b], A), (bg[b], bb), (Gg[b], G), (hg[b], h)):
+                assert np.array_equal(got, ref)
+            if out["status"][b] != 1:
+                continue
+            try:
+                z, lam, nu, fo, it = qp_np.qp_ipm(Q, A, bb, G, h, tol=1e-10)
+            except (ValueError, FloatingPointError, np.linalg.LinAlgError):
+                continue
+            worst_obj = max(worst_obj, abs(out["obj"][b] - fo) / max(1.0, abs(fo)))
+            zc = z.reshape(N, 3, 2 * s)
+            for i in range(N):
+                for tq in np.linspace(0.0, Tf[b, i], 7):
+                    worst_pos = max(worst_pos, np.abs(onp.piece_eval(out["coeffs"][b, i], tq, 0) - onp.piece_eval(zc[i], tq, 0)).max())
+    assert 0.0 < worst_obj <= 5e-6, worst_obj
+    assert worst_pos <= 5e-2, worst_pos

@@ -57,6 +57,33 @@ def test_eval_batched_vs_oracle(anet_ctx, s, N):
                 assert abs(got[b] - cbind.traj_cost(s, coeffs[b], T[b], m34)) <= 1e-11 * abs(got[b])
 
 
+@pytest.mark.parametrize("s", [2, 3, 4])
+def test_normalized_coefficient_matrices(anet_ctx, s):
+    """Piece::normalizePosCoeffMat / normalizeVelCoeffMat / normalizeAccCoeffMat (trajectory.hpp:135-171): a batch of pieces against
+    the loop-for-loop restatement, bit for bit (the same products in the same order), and what they mean: evaluated at
+    tau = t / duration the normalised polynomials are the position, duration * velocity and duration^2 * acceleration."""
+    import allocnet_amd as aa
+    from allocnet_amd.trajectory import piece_normalized_coeffs, Piece
+    rng = np.random.default_rng(40 + s)
+    P, D = 300, 2 * s
+    cm = rng.normal(size=(P, 3, D))
+    T = rng.uniform(0.2, 3.0, size=P)
+    for d in range(3):
+        got = piece_normalized_coeffs(cm, T, d, ctx=anet_ctx)
+        assert got.shape == (P, 3, D - d)
+        for p in range(P):
+            assert np.array_equal(got[p], onp.piece_normalized_coeffs(cm[p], T[p], d)), (d, p)
+    pc = Piece(T[7], cm[7], ctx=anet_ctx)
+    tau = 0.37
+    for d, mat in ((0, pc.normalizePosCoeffMat()), (1, pc.normalizeVelCoeffMat()), (2, pc.normalizeAccCoeffMat())):
+        val = np.array([np.polyval(mat[ax], tau) for ax in range(3)])
+        ref = onp.piece_eval(cm[7], tau * T[7], d) * T[7] ** d
+        assert np.abs(val - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    assert piece_normalized_coeffs(np.zeros((0, 3, D)), np.zeros(0), 1, ctx=anet_ctx).shape == (0, 3, D - 1)
+    with pytest.raises(Exception):
+        piece_normalized_coeffs(cm, T, 3, ctx=anet_ctx)
+
+
 def test_solve_then_cost_consistency(anet_ctx):
     """energy from the solve == 2 x getTrajCost(1440) of its coefficients; junction accessors."""
     import allocnet_amd as aa
