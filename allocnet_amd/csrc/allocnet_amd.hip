@@ -2211,10 +2211,24 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
       return e ? (int64_t)atoll(e) : (int64_t)513;
     }();
     const bool two_per_cu = batch >= ipm_two_per_cu_min_batch && 2 * ldsb <= 160 * 1024;
+    // ... and THREE for jerk problems whose LDS allows it, from a batch on that fills them several times over (registers bounded
+    // to 168: 464 B of scratch).  Measured (round 5, same box, 5 jerk pieces): 4096 problems 3.96-4.00 -> 3.77-3.85 ms; 3000:
+    // 3.02-3.07 -> 3.21-3.25; 2048: 2.09-2.12 -> 2.42-2.43 (1024: 1.60 -> 1.91 in round 4) -- selected by batch like every other
+    // shape here (ANET_IPM_THREE_PER_CU_MIN_BATCH overrides; 0 disables)
+    static const int64_t ipm_three_per_cu_min_batch = [] {
+      const char *e = getenv("ANET_IPM_THREE_PER_CU_MIN_BATCH");
+      return e ? (int64_t)atoll(e) : (int64_t)4096;
+    }();
+    const bool three_per_cu = s == 3 && two_per_cu && ipm_three_per_cu_min_batch > 0 && batch >= ipm_three_per_cu_min_batch &&
+                              3 * ldsb <= 160 * 1024;
     auto launch_ipm = [&](auto kern) -> int {
       ANET_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
       hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(256), ldsb, sti, ia);
       return ANET_OK;
+    };
+    auto launch_throughput = [&]() -> int {  // the shape of large batches: four row passes, registers bounded for 2 or 3 per CU
+      if (s == 4) return launch_ipm(anet::k_qp_ipm<4, 2, false>);
+      return three_per_cu ? launch_ipm(anet::k_qp_ipm<3, 3, false>) : launch_ipm(anet::k_qp_ipm<3, 1, false>);
     };
     int rc_l;
     // Large batches in TWO launches (qp_ipm.h, IpmArgs::it_stop): the first takes every problem through the same number of Newton
@@ -2231,7 +2245,7 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
       int32_t *bins = order2 + batch + (batch & 1);
       ia.cont = cont;
       ia.it_stop = ipm_split_steps;
-      rc_l = s == 4 ? launch_ipm(anet::k_qp_ipm<4, 2, false>) : launch_ipm(anet::k_qp_ipm<3, 1, false>);
+      rc_l = launch_throughput();
       if (rc_l != ANET_OK) return rc_l;
       hipLaunchKernelGGL(k_qp_resume_score, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, sti, status, cont, batch, ny, tol, score);
       rc_l = launch_order_impl(ctx, batch, score, order2, bins, sti, 0);
@@ -2239,7 +2253,7 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
       ia.it_stop = 0;
       ia.resume = 1;
       ia.order = order2;
-      rc_l = s == 4 ? launch_ipm(anet::k_qp_ipm<4, 2, false>) : launch_ipm(anet::k_qp_ipm<3, 1, false>);
+      rc_l = launch_throughput();
       if (rc_l != ANET_OK) return rc_l;
       ANET_HIP(ctx, hipGetLastError());
       return ANET_OK;
@@ -2251,8 +2265,7 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     if (!two_per_cu) {  // (qp_ipm_fuse_unit.hip: the FUSE instantiations, scheduled for ILP)
       ANET_HIP(ctx, (hipError_t)anet::launch_qp_ipm_fuse(s, batch, ldsb, sti, ia));
       rc_l = ANET_OK;
-    } else if (s == 4) rc_l = launch_ipm(anet::k_qp_ipm<4, 2, false>);
-    else rc_l = launch_ipm(anet::k_qp_ipm<3, 1, false>);
+    } else rc_l = launch_throughput();
     if (rc_l != ANET_OK) return rc_l;
     ANET_HIP(ctx, hipGetLastError());
     return ANET_OK;
