@@ -807,3 +807,55 @@ def test_the_c_planners_float_arithmetic_is_bounded_not_reproduced(anet_ctx):
                     worst_pos = max(worst_pos, np.abs(onp.piece_eval(out["coeffs"][b, i], tq, 0) - onp.piece_eval(zc[i], tq, 0)).max())
     assert 0.0 < worst_obj <= 5e-6, worst_obj
     assert worst_pos <= 5e-2, worst_pos
+
+
+def test_every_infeasible_verdict_is_confirmed_by_a_linear_programme(anet_ctx):
+    """ANET_QP_PRIMAL_INFEASIBLE is reported when the window heuristic of k_qp_ipm suspects a problem AND its multipliers pass
+    the Farkas test (csrc/qp_ipm.h certified_infeasible) -- or when the iteration diverges outright.  Soundness of what comes out:
+    random problems at durations x 0.25 ... 1.6 (infeasible, barely feasible, comfortable), both orders; for every problem called
+    infeasible the dense constraints A z = b, G z <= h (reference-pinned assembly, oracle/minco_np.qp_assemble) are handed to an
+    exact LP solver (scipy / HiGHS, zero objective): it must find no feasible point either (phase-1 optimum t* > 0 of min t : G z <= h + t); a Solved
+    problem has t* <= 0; and every problem the LP calls feasible with a margin (t* <= -1e-3) comes back Solved."""
+    import allocnet_amd as aa
+    from scipy.optimize import linprog
+    from allocnet_amd.synth import corridor_problem
+    checked_inf = checked_feas = 0
+    for (s, N, res, seed) in ((3, 3, 8, 1), (4, 3, 8, 2), (3, 5, 6, 3), (4, 4, 5, 4)):
+        rng = np.random.default_rng(100 + seed)
+        B, M, D = 96, 8, 2 * s
+        head, tail, wps, T, hp = corridor_problem(rng, B, N, 3, M)
+        T = T * rng.uniform(0.25, 1.6, size=(B, 1))
+        out = aa.qp_solve(s, head[:, :, :3], tail[:, :, :3], hp, T, res=res, max_vel=4.0, max_acc=6.0, ctx=anet_ctx)
+        n = 3 * D * N
+        for b in range(B):
+            if out["status"][b] not in (1, -3):
+                continue
+            st9 = np.zeros((9, 2))
+            for ax in range(3):
+                st9[3 * ax:3 * ax + 3, 0] = head[b, ax, :3]; st9[3 * ax:3 * ax + 3, 1] = tail[b, ax, :3]
+            Q, A, bb, G1, h1, G2, h2 = onp.qp_assemble(s, st9, np.transpose(hp[b], (1, 2, 0)), np.full(N, M), T[b], res, 4.0, 6.0)
+            G = np.zeros((G1.shape[0] + G2.shape[0], n)); r = 0
+            for i in range(N):
+                for _ in range(res):
+                    G[r:r + M, i * 3 * D:(i + 1) * 3 * D] = G1[r:r + M]; r += M
+            r2 = 0
+            for i in range(N):
+                for _ in range(res):
+                    for j in range(3):
+                        G[r + r2:r + r2 + 4, i * 3 * D + j * D:i * 3 * D + (j + 1) * D] = G2[r2:r2 + 4]; r2 += 4
+            hh = np.r_[h1, h2]
+            # phase 1: min t  s.t.  A z = b, G z - t <= h   (t* > 0: infeasible; t* < 0: strictly feasible by |t*|)
+            c = np.r_[np.zeros(n), 1.0]
+            lp = linprog(c, A_ub=np.c_[G, -np.ones(G.shape[0])], b_ub=hh, A_eq=np.c_[A, np.zeros(A.shape[0])], b_eq=bb,
+                         bounds=[(None, None)] * n + [(-1.0, None)], method="highs")
+            if lp.status != 0:
+                continue
+            if out["status"][b] == -3:
+                assert lp.x[-1] > 1e-7, (s, N, b, lp.x[-1])          # no point satisfies the rows: the verdict stands
+                checked_inf += 1
+            else:
+                assert lp.x[-1] <= 1e-6, (s, N, b, lp.x[-1])         # Solved: the LP finds the rows satisfiable too
+                checked_feas += 1
+            if lp.x[-1] <= -1e-3:                                    # feasible with a margin: never anything but Solved
+                assert out["status"][b] == 1, (s, N, b, lp.x[-1], out["status"][b], out["iters"][b])
+    assert checked_inf >= 40 and checked_feas >= 40, (checked_inf, checked_feas)
