@@ -1798,6 +1798,10 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
     // batch of BASELINE configs[3] (4096 problems, 300..7400 evaluations) otherwise ends with whichever long problem happened to
     // start in the second round: 0.160 s against 0.117 s with the problems longest first by their true counts.
     const int split_evals = lbfgs_split_evals();
+    // (a SECOND park / re-sort, measured in round 5 and left off: profiles/r05_lbfgs_second_park.txt -- every stage boundary is a
+    //  barrier for the whole batch, and what the better order of the third stage gains is less than what the second stage's own
+    //  tail loses: configs[3] 136 -> 147 / 157 / 165 ms with the second boundary at 2000 / 2500 / 3000 evaluations)
+    static const int split_evals2 = [] { const char *e = getenv("ANET_LBFGS_SPLIT_EVALS2"); return e ? atoi(e) : 0; }();
     const int64_t split_min_batch = lbfgs_split_min_batch();
     // ... where it was measured to pay (tools/time_lbfgs_batch.py, 4096 problems unless noted, one launch -> two): 16 jerk pieces
     // 165 -> 140 ms (bench: 0.169 -> 0.133 s), 16 snap pieces 424 -> 389, 12 jerk pieces 107 -> 98, 10 jerk pieces 79 -> 77, 16 jerk
@@ -1816,21 +1820,28 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
         hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
         return;
       }
+      // stages: [0, split) for everybody, then the problems still running, each stage's workgroups handed their problems
+      // longest-expected first by what the stage before parked ([split, split2), [split2, ...) with ANET_LBFGS_SPLIT_EVALS2 set)
+      const int stops[3] = {split_evals, (split_evals2 > split_evals && max_evals > split_evals2) ? split_evals2 : 0, max_evals};
       pa.cont = cont;
-      pa.park = 1;
-      pa.half_mark = split_evals / 2;
-      pa.max_evals = split_evals;
-      hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
-      hipLaunchKernelGGL(k_lbfgs_resume_score, g256, b256, 0, st, L.is, cont, batch, ld, score);
-      if (launch_order_impl(ctx, batch, score, order2, bins, st, 0) != ANET_OK) {  // (cannot fail with these arguments; if it ever does:
-        order_failed = true;                                                       //  the error is the caller's return code)
-        return;
+      int prev = 0;
+      for (int stage = 0; stage < 3; ++stage) {
+        if (stops[stage] <= 0) continue;
+        const bool last = stage == 2;
+        pa.park = last ? 0 : 1;
+        pa.resume = prev > 0 ? 1 : 0;
+        pa.half_mark = (prev + stops[stage]) / 2;
+        pa.max_evals = stops[stage];
+        hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
+        if (last) break;
+        hipLaunchKernelGGL(k_lbfgs_resume_score, g256, b256, 0, st, L.is, cont, batch, ld, score);
+        if (launch_order_impl(ctx, batch, score, order2, bins, st, 0) != ANET_OK) {  // (cannot fail with these arguments; if it ever does:
+          order_failed = true;                                                       //  the error is the caller's return code)
+          return;
+        }
+        pa.order = order2;
+        prev = stops[stage];
       }
-      pa.park = 0;
-      pa.resume = 1;
-      pa.max_evals = max_evals;
-      pa.order = order2;
-      hipLaunchKernelGGL(kernel, dim3((unsigned)batch), dim3(64), fixed_bytes + row_bytes, st, pa);
     };
     const size_t lds_cap = 64 * 1024;
     bool launched = true;
