@@ -308,9 +308,11 @@ int anet_qp_assemble(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res,
  * solution is (same convex problem) -- parity is checked through the KKT conditions.  Two methods:
  *   INTERIOR_POINT (default): the optimum to 1e-6 in 10-20 Newton steps.  On random corridor problems it returns
  *       `Solved` for every problem either method can solve (profiles/r02_qp_unsolved.json);
- *   ADMM: OSQP's own iteration with OSQP's default settings (below) and stopping rule.  Without OSQP's Ruiz
- *       equilibration it leaves 4-6 % of feasible 8-piece snap problems at max_iter, which QPSolver::solve's
- *       caller treats as a failed plan (qp_solver.hpp:334-352) -- hence not the default.
+ *   ADMM: OSQP's own iteration (Stellato et al. 2020, Algorithm 1) with OSQP's default settings (below), its modified Ruiz
+ *       equilibration (`scaling` = 10 passes on the reference's own matrices, cost scaling included), its stopping rule on the
+ *       UNSCALED residuals and its rho estimate from the scaled ones.  At max_iter = 4000 it leaves 1-6 % of feasible 5- and
+ *       8-piece snap problems unsolved (profiles/r05_qp_unsolved_admm.json), which QPSolver::solve's caller treats as a failed
+ *       plan (qp_solver.hpp:334-352) -- hence not the default.  OSQP itself is not in the image: its iterates remain unpinned.
  * The solve never forms Q, A, G: see allocnet_amd/csrc/qp_ipm.h, qp_admm.h.                          */
 typedef struct anet_qp_settings {
   double rho;        /* 0.1   OSQP default; equality rows use 1e3*rho like OSQP                 */
