@@ -370,6 +370,53 @@ int main() {
       printf("\"rosen_bad_ret\": %d, \"rosen_bad_evals\": %d, \"rosen_bad_f\": %g,\n",
              lbfgs::lbfgs_optimize<Vec>(x, f0, &Rosen::eval, nullptr, nullptr, &r, bad), r.evals, f0);
     }
+    {
+      // lbfgs::lbfgs_optimize_batched (anet_lbfgs_optimize_dev): a batch of 5 Rosenbrock problems in 6 variables, batch-minor on the
+      // device; this program links no HIP runtime, so its "device" evaluation goes through the library's own copies
+      struct Dev {
+        anet_ctx *ctx;
+        static int eval(void *inst, const double *x, double *f, double *g, int64_t batch, int64_t ld, int n, void *) {
+          Dev *d = (Dev *)inst;
+          std::vector<double> hx((size_t)n * ld), hg((size_t)n * ld, 0.0), hf((size_t)ld, 0.0);
+          if (anet_dev_download(d->ctx, hx.data(), x, hx.size())) return 1;
+          for (int64_t b = 0; b < batch; ++b)
+            for (int i = 0; i + 1 < n; i += 2) {
+              const double xa = hx[(size_t)i * ld + b], xb = hx[(size_t)(i + 1) * ld + b];
+              const double t1 = 1.0 - xa, t2 = 10.0 * (xb - xa * xa);
+              hg[(size_t)(i + 1) * ld + b] = 20.0 * t2;
+              hg[(size_t)i * ld + b] = -2.0 * (xa * 20.0 * t2 + t1);
+              hf[b] += t1 * t1 + t2 * t2;
+            }
+          return anet_dev_upload(d->ctx, g, hg.data(), hg.size()) || anet_dev_upload(d->ctx, f, hf.data(), hf.size());
+        }
+      };
+      anet::Context &ctx = anet::Context::thread_default();
+      const int n = 6;
+      const int64_t B = 5, ld = 64;
+      std::vector<double> hx((size_t)n * ld, 0.0);
+      for (int64_t b = 0; b < B; ++b)
+        for (int i = 0; i < n; ++i) hx[(size_t)i * ld + b] = ((i % 2) ? 1.0 : -1.2) + 0.1 * (double)b;
+      double *dx = nullptr, *df = nullptr, *dg = nullptr;
+      ctx.check(anet_dev_alloc(ctx.get(), hx.size(), &dx));
+      ctx.check(anet_dev_alloc(ctx.get(), (size_t)ld, &df));
+      ctx.check(anet_dev_alloc(ctx.get(), hx.size(), &dg));
+      ctx.check(anet_dev_upload(ctx.get(), dx, hx.data(), hx.size()));
+      Dev dev{ctx.get()};
+      lbfgs::lbfgs_parameter_t bp;
+      bp.g_epsilon = 1.0e-8;
+      bp.delta = 1.0e-10;
+      const std::vector<int> st = lbfgs::lbfgs_optimize_batched(n, B, ld, dx, df, dg, &Dev::eval, &dev, bp, 4000);
+      std::vector<double> hf((size_t)ld);
+      ctx.check(anet_dev_download(ctx.get(), hx.data(), dx, hx.size()));
+      ctx.check(anet_dev_download(ctx.get(), hf.data(), df, hf.size()));
+      printf("\"batched_status\": [%d, %d, %d, %d, %d],\n", st[0], st[1], st[2], st[3], st[4]);
+      print_vec("batched_f", std::vector<double>(hf.begin(), hf.begin() + B));
+      std::vector<double> xs;
+      for (int64_t b = 0; b < B; ++b)
+        for (int i = 0; i < n; ++i) xs.push_back(hx[(size_t)i * ld + b]);
+      print_vec("batched_x", xs);
+      anet_dev_free(dx); anet_dev_free(df); anet_dev_free(dg);
+    }
     lbfgs::lbfgs_parameter_t prm;
     printf("\"lbfgs_default_mem\": %d, \"strerror\": \"%s\"\n", prm.mem_size, lbfgs::lbfgs_strerror(lbfgs::LBFGSERR_MAXIMUMLINESEARCH));
     printf("}\n");

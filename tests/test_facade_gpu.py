@@ -96,6 +96,15 @@ def test_cpp_facade_program():
     assert abs(out["rosen1_f"] - fo1) <= 1e-9 * max(1.0, abs(fo1)) and np.abs(np.array(out["rosen1_x"]) - xo1).max() <= 1e-8
     assert out["rosen_bad_ret"] == -1016 and out["rosen_bad_evals"] == 0 and out["rosen_bad_f"] == 123.0
 
+    # lbfgs::lbfgs_optimize_batched (anet_lbfgs_optimize_dev through the facade; the status row is complete on return): five
+    # Rosenbrock problems, each against the restatement from its own start point
+    assert len(out["batched_status"]) == 5
+    for bq in range(5):
+        xq = np.where(np.arange(6) % 2 == 1, 1.0, -1.2) + 0.1 * bq
+        retq, xoq, foq, _, _ = cbind.lbfgs_optimize(xq, rosen, prm)
+        assert out["batched_status"][bq] in (0, 1) and retq in (0, 1)
+        assert abs(out["batched_f"][bq] - foq) <= 1e-10 and np.abs(np.array(out["batched_x"]).reshape(5, 6)[bq] - 1.0).max() < 1e-3
+
     # QPSolver facade: solved, ends where asked, inside the velocity box, objective == 1/2 z'Qz of its coefficients
     assert out["qp_ok"] == 1 and out["qp_iters"] > 0
     assert np.abs(np.array(out["qp_end"]) - np.array([6.0, 3.0, 1.0])).max() < 5e-2

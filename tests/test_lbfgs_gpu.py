@@ -721,7 +721,47 @@ def test_generic_device_objective_matches_the_restatement(anet_ctx, n, B):
             same += 1
             assert abs(fg[b] - fo) <= 1e-9 * max(1.0, abs(fo)), b
             assert np.abs(xg[b] - xo).max() <= 1e-8 * max(1.0, np.abs(xo).max()), b
+        else:
+            # a problem whose counters differ is not excused: a flipped line-search test costs a trial or an iteration, not the
+            # run -- the same kind of outcome, within a few evaluations, and a cost the same order of magnitude
+            assert (st[b] < 0) == (ret < 0) and abs(int(ev[b]) - evo) <= 6 and abs(int(it[b]) - ito) <= 2, (b, st[b], it[b], ev[b], ret, ito, evo)
+            assert fg[b] <= 10.0 * fo + 1.0 and fo <= 10.0 * fg[b] + 1.0, (b, fg[b], fo)
     assert same >= 0.9 * B, (same, B)
+    # the built-in step bound (bound_from / bound_min: the last variables may not fall below a floor within a line search,
+    # lbfgs.hpp:557-565) against the restatement running the same bound as its proc_stepbound callback
+    nb = max(1, n // 3)
+    floor_ = -1.75
+    x = start()
+    out = aa.lbfgs_optimize_dev(x, evaluate, batch=B, param=aa.lbfgs_parameter_t(max_iterations=budget), max_evals=400,
+                                bound_from=n - nb, bound_min=floor_, ctx=anet_ctx)
+    st, it, ev = (out[k].cpu().numpy() for k in ("status", "iters", "evals"))
+    xg = x[:, :B].cpu().numpy().T
+
+    def sb(xp, d):
+        worst = 0.0
+        for i in range(n - nb, n):
+            if d[i] < 0.0:
+                worst = max(worst, -d[i] / max(xp[i] - floor_, 1e-300))
+        return 1.0 / worst if worst > 0.0 else np.inf
+    same_b = 0
+    for b in range(B):
+        ret, xo, fo, ito, evo = cbind.lbfgs_optimize(x0[b], fun, cbind.lbfgs_default_param(max_iterations=budget), stepbound=sb)
+        if (st[b], it[b], ev[b]) == (ret, ito, evo):
+            same_b += 1
+            assert np.abs(xg[b] - xo).max() <= 1e-8 * max(1.0, np.abs(xo).max()), b
+    assert same_b >= 0.85 * B, (same_b, B)
+    assert (xg[:, n - nb:] >= floor_ - 1e-12).all()
+    # the cancel word (proc_progress's one effect): set from the start, every problem stops after its first iteration
+    flag = torch.ones(1, dtype=torch.int32, device=dev)
+    anet_ctx.set_cancel_flag(flag)
+    try:
+        x = start()
+        out = aa.lbfgs_optimize_dev(x, evaluate, batch=B, max_evals=400, ctx=anet_ctx)
+        stc, itc = out["status"].cpu().numpy(), out["iters"].cpu().numpy()
+        assert ((stc == aa.lbfgs.LBFGS_CANCELED) | (stc < 0) | (stc == aa.lbfgs.LBFGS_CONVERGENCE)).all() and (itc <= 1).all()
+        assert (stc == aa.lbfgs.LBFGS_CANCELED).mean() >= 0.9
+    finally:
+        anet_ctx.set_cancel_flag(None)
     # left to run: every problem reaches the minimum f = 0 at x = 1 (a local minimum near x_0 = -1 exists for n >= 4: accept it)
     x = start()
     out = aa.lbfgs_optimize_dev(x, evaluate, batch=B, param=aa.lbfgs_parameter_t(g_epsilon=1e-6, delta=0.0, past=0), max_evals=20000,
