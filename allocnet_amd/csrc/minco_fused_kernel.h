@@ -6,10 +6,11 @@
 // kernel start with cold loads from beyond the L2 (what the previous kernel wrote is written back at its end), the adjoint
 // re-factorises the system the solve factorised and re-reads the node states it had in registers.  Here a workgroup owns G
 // trajectories from their waypoints to their gradients:
-//   phase 1  wave 0, lane = (trajectory, axis): k_minco_solve_axis' chain; the coefficients go to LDS (and to coeffs_out if
-//            asked for), the factor, the node states and the energy STAY IN REGISTERS for phase 3;
-//   phase 2  all 256 lanes, at least two per (trajectory, piece): k_piece_grad's penalty / energy code on the coefficients
-//            from LDS; the pair's partial gradient w.r.t. the piece's coefficients is turned into its adjoint
+//   phase 1  wave 0, lane = (trajectory, axis): k_minco_solve_axis' chain WITHOUT its per-piece output step -- factor and the two
+//            sweeps --; factor and node states are parked in LDS for phases 2 and 3;
+//   phase 2  all 256 lanes, at least two per (trajectory, piece): the piece's coefficients (and energy share) from its two node
+//            states (emit_piece, the same function the solve kernels call: same bits; to coeffs_out if asked for), then
+//            k_piece_grad's penalty / energy code on them; the pair's partial gradient w.r.t. the piece's coefficients is turned into its adjoint
 //            w.r.t. the piece's two node states right there (what the adjoint kernel's first loop does piece after piece on
 //            one lane) and handed over through LDS;
 //   phase 3  wave 0 again: the two sweeps of the adjoint with the factor and the node states of phase 1.
@@ -54,15 +55,15 @@ struct FusedShape {
 template <int S, int NB, bool NEXACT = false, int NPC = -1>
 __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, const double *__restrict__ tab) {
   constexpr int m = S - 1, D = 2 * S, GM = FusedShape<NB>::G, PST = FusedShape<NB>::PST;
-  constexpr int ROW_T = 3 * D, ROW_GX = ROW_T + 1, ROW_GTD = ROW_GX + 3 * D, ROW_GDT = ROW_GTD + 3, ROW_PC = ROW_GDT + 1;
+  constexpr int ROW_T = 0, ROW_GX = ROW_T + 1, ROW_GTD = ROW_GX + 3 * D, ROW_GDT = ROW_GTD + 3, ROW_PC = ROW_GDT + 1, ROW_EN = ROW_PC + 1;
   constexpr int NRED = 3 * D + 2;  // values a lane pair hands to the pair that adds up a piece: gC, gT, pc
-  __shared__ double lds[(ROW_PC + 1) * PST];
+  __shared__ double lds[(ROW_EN + 1) * PST];
   __shared__ double lred[NRED * 128];
   __shared__ double ltab[kFusedMaxRes * 3 * D];
   // What phase 3 needs of phase 1 (factor, node states, durations, energy: ~100 doubles per chain lane) waits in LDS, not in
   // registers across phase 2: with them the sample loop (whose table rows are per-lane values) goes into scratch
   constexpr int nl = Factor<S, NB>::nl > 0 ? Factor<S, NB>::nl : 1;
-  constexpr int NST = (NB + 1) * (nl + 2 * m + 1) + 2 * NB + 1, SST = 3 * GM;
+  constexpr int NST = (NB + 1) * (nl + 2 * m + 1) + 2 * NB, SST = 3 * GM;
   __shared__ double lst[NST * SST];
   const int G = a.G;                              // trajectories of this workgroup
   const int LPQ = 2 * G * NB;                     // lanes of one sample subset (a power of two <= 256)
@@ -92,7 +93,6 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   // ---- phase 1 (wave 0): the coefficient solve, one lane per (trajectory, axis) ---------------------------------------------
   Factor<S, NB> F;
   double P[NB + 1], X[NB + 1][m], tt[NB];
-  double e_axis = 0.0;
   const int t1 = tid / 3, ax1 = tid % 3;
   const bool chain_lane = wave == 0 && tid < 3 * G;
   const bool live1 = chain_lane && b0 + t1 < a.B;
@@ -122,11 +122,17 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     ANET_FP(1);
     F.factorize(N, np);
     ANET_FP(2);
-    double *cp = (a.coeffs_out && live1) ? a.coeffs_out + (int64_t)(ax1 * D) * ld + bb1 : nullptr;
-    e_axis = solve_axis<S, NB>(F, N, np, P, hv, tv, X, [&](int piece, int col, double v) {
-      if (chain_lane) lds[(ax1 * D + col) * PST + piece * G + t1] = v;
-      if (cp) cp[(int64_t)(piece * 3 * D + col) * ld] = v;
-    });
+    // the two sweeps ONLY: the coefficients of a piece (emit_piece: a quarter of the chain's instructions when it runs here)
+    // are formed from the node states by the lanes of phase 2, in parallel
+    {
+      double rr[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(F.r[i]) : 0.0;
+      sweep_forward<S, NB>(F, N, np, rr, X, [&](int k, double (&y)[m]) { rhs_primal_node<S, NB>(k, N, np, rr, P, hv, tv, y); });
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
+      sweep_backward<S, NB>(F, N, np, rr, X, [&](int, const Pw<S> &) {});
+    }
     ANET_FP(3);
     if (chain_lane && ax1 == 0) {
 #pragma unroll
@@ -152,7 +158,6 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
           put(F.r[i]);
           put(tt[i]);
         }
-        put(e_axis);
       }
     }
   }
@@ -166,13 +171,33 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     double gT = 0.0, pc = 0.0, Ti = 1.0;
     if (pair_ok) {
       Ti = lds[ROW_T * PST + pair];
+      // the piece's coefficients from its two node states (phase 1 parked them: lst[value][3 t + axis]), as solve_axis emits them
+      {
+        constexpr int PER = nl + 2 * m + 1;  // values parked per node: L, dinv, X, P
+        const Pw<S> pw(fast_rcp(Ti));
+        double e_piece = 0.0;
+        double *cp = (a.coeffs_out && q2 == 0 && half == 0 && b0 + t2 < a.B) ? a.coeffs_out + (int64_t)(piece * 3 * D) * ld + bb2 : nullptr;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          const double *ns = lst + 3 * t2 + ax;
+          double x0[m], x1[m];
+#pragma unroll
+          for (int j = 0; j < m; ++j) {
+            x0[j] = ns[(size_t)(piece * PER + nl + m + j) * SST];
+            x1[j] = ns[(size_t)((piece + 1) * PER + nl + m + j) * SST];
+          }
+          const double P0 = ns[(size_t)(piece * PER + nl + 2 * m) * SST], P1 = ns[(size_t)((piece + 1) * PER + nl + 2 * m) * SST];
+          e_piece += emit_piece<S>(piece, pw, P0, P1, x0, x1, [&](int, int col, double v) {
+            cf[ax][col] = v;
+            if (cp) cp[(int64_t)(ax * D + col) * ld] = v;
+          });
+        }
+        if (q2 == 0 && half == 0) lds[ROW_EN * PST + pair] = e_piece;
+      }
 #pragma unroll
       for (int ax = 0; ax < 3; ++ax)
 #pragma unroll
-        for (int col = 0; col < D; ++col) {
-          cf[ax][col] = lds[(ax * D + col) * PST + pair];
-          gC[ax][col] = 0.0;
-        }
+        for (int col = 0; col < D; ++col) gC[ax][col] = 0.0;
       ANET_FP(5);
       // The 2 Q lanes of a (trajectory, piece) split its SAMPLES (lane h of pair q takes j = 2q + h, 2q + h + 2Q, ...) and each
       // visits every corridor row: the position is evaluated once per sample and pass, the limit rows once per sample.  (With
@@ -305,7 +330,6 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
       F.r[i] = get();
       tt[i] = get();
     }
-    e_axis = get();
   }
   {
     double GP[NB + 1], XA[NB + 1][m], gTl[NB], rr[NB];
@@ -381,8 +405,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
         if (k < N) gp[(int64_t)((k - 1) * 3) * ld] = GP[k];
     }
     // per trajectory: the three axes' shares (adjacent lanes), the partial dJ/dT of phase 2, rho, the chain rule of tau
-    const double e_tot = e_axis + __shfl_down(e_axis, 1) + __shfl_down(e_axis, 2);
-    double csum = 0.0, tsum = 0.0;
+    double e_tot = 0.0, csum = 0.0, tsum = 0.0;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       if (i < N) {
@@ -391,6 +414,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
           const double gt = lds[ROW_GDT * PST + i * G + t1] + tot + a.pp.rho;
           a.gradT[(int64_t)i * ld + bb1] = a.tau ? gt * dforward_T(a.tau[(int64_t)i * ld + bb1]) : gt;
           csum += lds[ROW_PC * PST + i * G + t1];
+          e_tot += lds[ROW_EN * PST + i * G + t1];
           tsum += tt[i];
         }
       }
