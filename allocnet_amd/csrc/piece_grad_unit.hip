@@ -54,9 +54,10 @@ template <int S, int NB, bool NEXACT, int NPC>
 static void launch_fused_t(const FusedArgs &a_in, const double *tab, hipStream_t st, int64_t max_groups) {
   constexpr int GM = FusedShape<NB>::G;
   FusedArgs a = a_in;
-  // the largest group that still gives (nearly) every CU a workgroup; what the group gives up, the samples split takes
+  // the largest group that still gives (nearly) every CU a workgroup (256 CUs); what the group gives up, the samples split takes
+  (void)max_groups;
   int G = GM;
-  while (G > 1 && (a.B + G / 2 - 1) / (G / 2) <= max_groups) G /= 2;
+  while (G > 1 && (a.B + G / 2 - 1) / (G / 2) <= 256) G /= 2;
   a.G = G;
   const dim3 grid((unsigned)((a.B + G - 1) / G));
   hipLaunchKernelGGL((k_minco_cost_grad_fused<S, NB, NEXACT, NPC>), grid, dim3(256), 0, st, a, tab);
