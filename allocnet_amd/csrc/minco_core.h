@@ -70,10 +70,14 @@ struct Factor {
   __device__ __forceinline__ static int li(int i, int j) { return i * (i - 1) / 2 + j; }  // i>j
 
   // masked constant of Ko: pinned rows (node i = 0) / columns (node i+1 = N) are zero
+  // (TF, "tail free": the chain is the HALF of a trajectory that is eliminated from both ends -- its last node is the interior
+  //  node where the halves meet, nothing is pinned there; minco_fused_kernel.h)
+  template <bool TF = false>
   __device__ __forceinline__ static double ko_const(int i, int N, int np, int j, int l) {
-    return ((i == 0 && j < np) || (i == N - 1 && l < np)) ? 0.0 : Tab<S>::M[1 + j][S + 1 + l];
+    return ((i == 0 && j < np) || (!TF && i == N - 1 && l < np)) ? 0.0 : Tab<S>::M[1 + j][S + 1 + l];
   }
   // out[l] -= sum_j Ko_i(j,l) v[j]      (Ko' v)
+  template <bool TF = false>
   __device__ __forceinline__ static void sub_KoT(int i, int N, int np, const Pw<S> &p, const double (&v)[m],
                                                  double (&out)[m]) {
     double sv[m];
@@ -83,11 +87,12 @@ struct Factor {
     for (int l = 0; l < m; ++l) {
       double acc = 0.0;
 #pragma unroll
-      for (int j = 0; j < m; ++j) acc = __builtin_fma(ko_const(i, N, np, j, l), sv[j], acc);
+      for (int j = 0; j < m; ++j) acc = __builtin_fma(ko_const<TF>(i, N, np, j, l), sv[j], acc);
       out[l] = __builtin_fma(-acc, p[S - 1 - l], out[l]);
     }
   }
   // out[j] = sum_l Ko_i(j,l) v[l]       (Ko v)
+  template <bool TF = false>
   __device__ __forceinline__ static void mul_Ko(int i, int N, int np, const Pw<S> &p, const double (&v)[m],
                                                 double (&out)[m]) {
     double sv[m];
@@ -97,7 +102,7 @@ struct Factor {
     for (int j = 0; j < m; ++j) {
       double acc = 0.0;
 #pragma unroll
-      for (int l = 0; l < m; ++l) acc = __builtin_fma(ko_const(i, N, np, j, l), sv[l], acc);
+      for (int l = 0; l < m; ++l) acc = __builtin_fma(ko_const<TF>(i, N, np, j, l), sv[l], acc);
       out[j] = acc * p[S - 2 - j];
     }
   }
@@ -117,6 +122,11 @@ struct Factor {
   }
 
   __device__ __forceinline__ void factorize(int N, int np) {
+    factorize_chain<false>(N, np, [](double (&)[m][m]) {});
+  }
+  // TF: node N is free and its block is completed by `meet(Dk)` (lower triangle) before it is factored
+  template <bool TF, class Meet>
+  __device__ __forceinline__ void factorize_chain(int N, int np, Meet &&meet) {
     // lower triangle of the current diagonal block (symmetric): Dk[j][l], l <= j
     double Dk[m][m];
 #pragma unroll
@@ -144,13 +154,14 @@ struct Factor {
               Dk[j][l] =
                   __builtin_fma(Tab<S>::M[S + 1 + j][S + 1 + l], p[2 * S - 3 - j - l], Dk[j][l]);
         }
-        if (k == 0 || k == N) {
+        if (k == 0 || (!TF && k == N)) {
 #pragma unroll
           for (int j = 0; j < m; ++j)
 #pragma unroll
             for (int l = 0; l <= j; ++l)
               if (j < np || l < np) Dk[j][l] = (j == l) ? 1.0 : 0.0;
         }
+        if (TF && k == N) meet(Dk);
         // --- LDL^T of the m x m block
         double d[m];
 #pragma unroll
@@ -180,7 +191,7 @@ struct Factor {
           for (int l = 0; l < m; ++l) {
             double col[m];
 #pragma unroll
-            for (int j = 0; j < m; ++j) col[j] = ko_const(k, N, np, j, l) * p[2 * S - 3 - j - l];
+            for (int j = 0; j < m; ++j) col[j] = ko_const<TF>(k, N, np, j, l) * p[2 * S - 3 - j - l];
             solve_L(k, col);
 #pragma unroll
             for (int j = 0; j < m; ++j) {
@@ -209,10 +220,11 @@ struct Factor {
 //           the powers of r it needs are shared with the elimination step).
 // backward: X <- x,   x_k = L_k^-T dinv (w_k - L_k^-1 Ko_k x_{k+1});  after(k, p) runs for every piece
 //           k (k < N) as soon as X[k] and X[k+1] are final, with p = powers of r_k.
-template <int S, int NB, class Rhs>
-__device__ __forceinline__ void sweep_forward(const Factor<S, NB> &F, int N, int np,
-                                              const double (&rr)[NB], double (&X)[NB + 1][S - 1],
-                                              Rhs &&rhs) {
+// TF: node N is free; `meet(y)` completes its right-hand side (after this chain's own Schur term) before L_N^-1 is applied
+template <bool TF, int S, int NB, class Rhs, class Meet>
+__device__ __forceinline__ void sweep_forward_chain(const Factor<S, NB> &F, int N, int np,
+                                                    const double (&rr)[NB], double (&X)[NB + 1][S - 1],
+                                                    Rhs &&rhs, Meet &&meet) {
   constexpr int m = S - 1;
 #pragma unroll
   for (int k = 0; k <= NB; ++k) {
@@ -225,8 +237,9 @@ __device__ __forceinline__ void sweep_forward(const Factor<S, NB> &F, int N, int
 #pragma unroll
         for (int j = 0; j < m; ++j) v[j] = X[k - 1][j] * F.dinv[k - 1][j];
         F.solve_LT(k - 1, v);
-        Factor<S, NB>::sub_KoT(k - 1, N, np, p, v, y);
+        Factor<S, NB>::template sub_KoT<TF>(k - 1, N, np, p, v, y);
       }
+      if (TF && k == N) meet(y);
       F.solve_L(k, y);
 #pragma unroll
       for (int l = 0; l < m; ++l) X[k][l] = y[l];
@@ -234,10 +247,10 @@ __device__ __forceinline__ void sweep_forward(const Factor<S, NB> &F, int N, int
   }
 }
 
-template <int S, int NB, class After>
-__device__ __forceinline__ void sweep_backward(const Factor<S, NB> &F, int N, int np,
-                                               const double (&rr)[NB], double (&X)[NB + 1][S - 1],
-                                               After &&after) {
+template <bool TF, int S, int NB, class After>
+__device__ __forceinline__ void sweep_backward_chain(const Factor<S, NB> &F, int N, int np,
+                                                     const double (&rr)[NB], double (&X)[NB + 1][S - 1],
+                                                     After &&after) {
   constexpr int m = S - 1;
 #pragma unroll
   for (int k = NB; k >= 0; --k) {
@@ -248,7 +261,7 @@ __device__ __forceinline__ void sweep_backward(const Factor<S, NB> &F, int N, in
       if (k < N) {
         Pw<S> p(rr[k]);
         double t[m];
-        Factor<S, NB>::mul_Ko(k, N, np, p, X[k + 1], t);
+        Factor<S, NB>::template mul_Ko<TF>(k, N, np, p, X[k + 1], t);
         F.solve_L(k, t);
 #pragma unroll
         for (int l = 0; l < m; ++l) x[l] -= t[l];
@@ -266,10 +279,24 @@ __device__ __forceinline__ void sweep_backward(const Factor<S, NB> &F, int N, in
   }
 }
 
+template <int S, int NB, class Rhs>
+__device__ __forceinline__ void sweep_forward(const Factor<S, NB> &F, int N, int np,
+                                              const double (&rr)[NB], double (&X)[NB + 1][S - 1],
+                                              Rhs &&rhs) {
+  sweep_forward_chain<false, S, NB>(F, N, np, rr, X, rhs, [](double (&)[S - 1]) {});
+}
+
+template <int S, int NB, class After>
+__device__ __forceinline__ void sweep_backward(const Factor<S, NB> &F, int N, int np,
+                                               const double (&rr)[NB], double (&X)[NB + 1][S - 1],
+                                               After &&after) {
+  sweep_backward_chain<false, S, NB>(F, N, np, rr, X, after);
+}
+
 // Right-hand side of the primal problem for one axis: stationarity rows moved to the right,
 //   rhs_free = -sum W[free, known] x_known   (known = node positions and pinned end derivatives).
 //   P[k]: node positions, hv/tv: pinned head/tail derivatives (orders 1..np).
-template <int S, int NB>
+template <int S, int NB, bool TF = false>
 __device__ __forceinline__ void rhs_primal_node(int k, int N, int np, const double (&rr)[NB],
                                                 const double (&P)[NB + 1], const double (&hv)[S - 1],
                                                 const double (&tv)[S - 1], double (&y)[S - 1]) {
@@ -283,7 +310,7 @@ __device__ __forceinline__ void rhs_primal_node(int k, int N, int np, const doub
         const double dl = P[k + 1] - P[k];
 #pragma unroll
         for (int l = 0; l < m; ++l) y[l] = Tab<S>::M[1 + l][0] * p[2 * S - 2 - l] * dl;
-        if (k == N - 1) {  // pinned tail derivatives couple into node N-1 through piece N-1
+        if (!TF && k == N - 1) {  // pinned tail derivatives couple into node N-1 through piece N-1
 #pragma unroll
           for (int l = 0; l < m; ++l)
 #pragma unroll
@@ -307,7 +334,7 @@ __device__ __forceinline__ void rhs_primal_node(int k, int N, int np, const doub
                 y[l] = __builtin_fma(-Tab<S>::M[1 + j][S + 1 + l] * p[2 * S - 3 - l - j], hv[j], y[l]);
         }
       }
-      if (k == 0 || k == N) {
+      if (k == 0 || (!TF && k == N)) {
         // unknowns of an end node also see that node's own pinned derivatives
         if (k == 0) {
           Pw<S> p(rr[0]);

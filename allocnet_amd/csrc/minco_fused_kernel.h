@@ -15,6 +15,9 @@
 //            one lane) and handed over through LDS;
 //   phase 3  wave 0 again: the two sweeps of the adjoint with the factor and the node states of phase 1.
 // No global round trip between the phases, one launch, no second factorisation.
+// The exact shapes (8-piece snap, 16-piece jerk, c = 3) eliminate the chain FROM BOTH ENDS in phases 1 and 3: two lanes per
+// (trajectory, axis), the second one working on the trajectory reversed in time with the same code, the halves meeting at the
+// middle node through a DPP swap (TW below; 4096 x 8 snap 29.8 -> 28.6 us, 2048 x 16 jerk 31.4 -> 25.6, 512 x 8 snap 20.3 -> 17.1).
 // The group size G is a run-time value (a power of two, at most FusedShape<NB>::G): a batch too small to give every CU a
 // workgroup of G trajectories takes a smaller G, and the lanes that frees split the SAMPLES of a piece further: Q = 128 / (G NB)
 // lane pairs per (trajectory, piece), 2 Q lanes taking every 2 Q-th sample each (the basis table from a copy in LDS, since the
@@ -63,8 +66,15 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   // What phase 3 needs of phase 1 (factor, node states, durations, energy: ~100 doubles per chain lane) waits in LDS, not in
   // registers across phase 2: with them the sample loop (whose table rows are per-lane values) goes into scratch
   constexpr int nl = Factor<S, NB>::nl > 0 ? Factor<S, NB>::nl : 1;
-  constexpr int NST = (NB + 1) * (nl + 2 * m + 1) + 2 * NB, SST = 3 * GM;
+  // TW: the chain of an exact shape with an even number of pieces is eliminated from BOTH ends (see phase 1): two lanes per
+  // (trajectory, axis), each with a chain of NC = NB / 2 pieces
+  constexpr bool TW = NEXACT && NB % 2 == 0;
+  constexpr int NC = TW ? NB / 2 : NB, CL = TW ? 6 : 3;  // pieces of a chain, chain lanes per trajectory
+  constexpr int NST = (NC + 1) * (nl + 2 * m + 1) + 2 * NC, SST = CL * GM;
   __shared__ double lst[NST * SST];
+  // (TW) the node states in the trajectory's own direction, for phase 2: value (node, j) of (trajectory, axis) at [(node (m + 1) + j) XST + 3 t + axis]
+  constexpr int XST = 3 * GM;
+  __shared__ double lxs[TW ? (NB + 1) * (m + 1) * XST : 1];
   const int G = a.G;                              // trajectories of this workgroup
   const int LPQ = 2 * G * NB;                     // lanes of one sample subset (a power of two <= 256)
   const int Q = 256 / LPQ;                        // lane pairs per (trajectory, piece)
@@ -78,8 +88,9 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   {
     // the rows of position, velocity and acceleration of every sample (read by other threads behind the barrier); by the waves
     // that have no chain to start: a load-to-store round trip in front of wave 0's chain would be in front of everything
-    if (wave != 0)
-      for (int e = tid - 64; e < a.pp.res * 3 * D; e += 192) ltab[e] = tab[(size_t)(e / (3 * D)) * 4 * D + e % (3 * D)];
+    constexpr int CW = TW ? 2 : 1;  // waves with chain lanes
+    if (wave >= CW)
+      for (int e = tid - 64 * CW; e < a.pp.res * 3 * D; e += 256 - 64 * CW) ltab[e] = tab[(size_t)(e / (3 * D)) * 4 * D + e % (3 * D)];
   }
 
   // phase 2's lane mapping
@@ -91,13 +102,116 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   const int64_t bb2 = (pair_ok && b0 + t2 < a.B) ? b0 + t2 : (a.B - 1);
 
   // ---- phase 1 (wave 0): the coefficient solve, one lane per (trajectory, axis) ---------------------------------------------
-  Factor<S, NB> F;
-  double P[NB + 1], X[NB + 1][m], tt[NB];
-  const int t1 = tid / 3, ax1 = tid % 3;
-  const bool chain_lane = wave == 0 && tid < 3 * G;
+  Factor<S, NC> F;
+  double P[NC + 1], X[NC + 1][m], tt[NC];
+  // (TW: lane = 2 (3 t + axis) + role; role 0 walks the first half of the chain, role 1 the second half BACKWARDS IN TIME)
+  // (ten trajectories per wave, four lanes of a wave idle: the lanes of a trajectory add up across the axes by wave shuffles)
+  const int lw6 = (tid & 63) % 6;
+  const int role = TW ? (lw6 & 1) : 0;
+  const int t1 = TW ? 10 * wave + (tid & 63) / 6 : tid / 3, ax1 = TW ? (lw6 >> 1) : tid % 3;
+  const bool chain_lane = TW ? (tid < 128 && (tid & 63) < 60 && t1 < G) : tid < 3 * G;
+  const int ci = TW ? 6 * t1 + lw6 : tid;  // the lane's column of the parking area
   const bool live1 = chain_lane && b0 + t1 < a.B;
   const int64_t bb1 = live1 ? b0 + t1 : (a.B - 1);
   double hv[m], tv[m];
+  // Seen backwards in time a trajectory is a trajectory: node k' = N - k, piece i' = N - 1 - i, every derivative of odd order
+  // changes its sign -- and the minimum-effort problem is the same problem.  So the second half of the chain is eliminated by
+  // the SAME code on the reversed data (factorize_chain / sweep_*_chain<TF = true>: the last node of a half is the interior node
+  // where the halves meet, nothing pinned there); where the halves meet, the two lanes exchange what their half contributes to
+  // the middle node's block and right-hand side (a DPP swap, the partner's values with the signs of the reversal) and both
+  // finish the middle node for themselves.  Half the sequential depth of the factorisation and of all four sweeps.
+  auto pair_swap = [](double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  auto meet_block = [&](double (&Dk)[m][m]) {
+#pragma unroll
+    for (int j = 0; j < m; ++j)
+#pragma unroll
+      for (int l = 0; l <= j; ++l) {
+        const double o = pair_swap(Dk[j][l]);
+        Dk[j][l] += ((j + l) & 1) ? -o : o;
+      }
+  };
+  auto meet_vector = [&](double (&y)[m]) {  // (component l is the derivative of order l + 1)
+#pragma unroll
+    for (int l = 0; l < m; ++l) {
+      const double o = pair_swap(y[l]);
+      y[l] += ((l + 1) & 1) ? -o : o;
+    }
+  };
+  if constexpr (TW) {
+    if (tid < 128) {  // waves 0 and 1
+      const double *hp = a.head + (int64_t)(ax1 * c) * ld + bb1;
+      const double *tp = a.tail + (int64_t)(ax1 * c) * ld + bb1;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) tt[i] = a.T[(int64_t)(role ? N - 1 - i : i) * ld + bb1];
+#pragma unroll
+      for (int k = 0; k <= NC; ++k) {
+        const int kr = role ? N - k : k;
+        const double *src = (kr == 0) ? hp : (kr < N) ? a.wps + (int64_t)((kr - 1) * 3 + ax1) * ld + bb1 : tp;
+        P[k] = *src;
+      }
+#pragma unroll
+      for (int j = 0; j < m; ++j) {
+        const int64_t row = (j < np) ? 1 + j : 0;
+        const double h = (role ? tp : hp)[row * ld];
+        hv[j] = (j < np) ? ((role && ((j + 1) & 1)) ? -h : h) : 0.0;
+        tv[j] = 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < NC; ++i) F.r[i] = fast_rcp(tt[i]);
+      ANET_FP(1);
+      F.template factorize_chain<true>(NC, np, meet_block);
+      ANET_FP(2);
+      {
+        double rr[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) rr[i] = launder(F.r[i]);
+        sweep_forward_chain<true, S, NC>(F, NC, np, rr, X,
+                                         [&](int k, double (&y)[m]) { rhs_primal_node<S, NC, true>(k, NC, np, rr, P, hv, tv, y); }, meet_vector);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) rr[i] = launder(rr[i]);
+        sweep_backward_chain<true, S, NC>(F, NC, np, rr, X, [&](int, const Pw<S> &) {});
+      }
+      ANET_FP(3);
+      if (chain_lane) {
+        if (ax1 == 0) {
+#pragma unroll
+          for (int i = 0; i < NC; ++i) lds[ROW_T * PST + (role ? N - 1 - i : i) * G + t1] = tt[i];
+        }
+        // the node states as phase 2 reads them: role 0 has nodes 0 .. N/2, role 1 nodes N .. N/2 + 1 with the signs of the reversal
+#pragma unroll
+        for (int k = 0; k <= NC; ++k) {
+          if (role && k == NC) continue;
+          const int kr = role ? N - k : k;
+          double *dst = lxs + (size_t)(kr * (m + 1)) * XST + 3 * t1 + ax1;
+#pragma unroll
+          for (int j = 0; j < m; ++j) dst[(size_t)j * XST] = (role && ((j + 1) & 1)) ? -X[k][j] : X[k][j];
+          dst[(size_t)m * XST] = P[k];
+        }
+        int v = 0;
+        auto put = [&](double x) { lst[(v++) * SST + ci] = x; };
+#pragma unroll
+        for (int k = 0; k <= NC; ++k) {
+#pragma unroll
+          for (int j = 0; j < nl; ++j) put(F.L[k][j]);
+#pragma unroll
+          for (int j = 0; j < m; ++j) put(F.dinv[k][j]);
+#pragma unroll
+          for (int j = 0; j < m; ++j) put(X[k][j]);
+          put(P[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+          put(F.r[i]);
+          put(tt[i]);
+        }
+      }
+    }
+  } else
   if (wave == 0) {
     const double *hp = a.head + (int64_t)(ax1 * c) * ld + bb1;
     const double *tp = a.tail + (int64_t)(ax1 * c) * ld + bb1;
@@ -142,7 +256,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     {
       if (chain_lane) {
         int v = 0;
-        auto put = [&](double x) { lst[(v++) * SST + tid] = x; };
+        auto put = [&](double x) { lst[(v++) * SST + ci] = x; };
 #pragma unroll
         for (int k = 0; k <= NB; ++k) {
 #pragma unroll
@@ -179,14 +293,26 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
         double *cp = (a.coeffs_out && q2 == 0 && half == 0 && b0 + t2 < a.B) ? a.coeffs_out + (int64_t)(piece * 3 * D) * ld + bb2 : nullptr;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-          const double *ns = lst + 3 * t2 + ax;
-          double x0[m], x1[m];
+          double x0[m], x1[m], P0, P1;
+          if constexpr (TW) {
+            const double *ns = lxs + 3 * t2 + ax;
 #pragma unroll
-          for (int j = 0; j < m; ++j) {
-            x0[j] = ns[(size_t)(piece * PER + nl + m + j) * SST];
-            x1[j] = ns[(size_t)((piece + 1) * PER + nl + m + j) * SST];
+            for (int j = 0; j < m; ++j) {
+              x0[j] = ns[(size_t)(piece * (m + 1) + j) * XST];
+              x1[j] = ns[(size_t)((piece + 1) * (m + 1) + j) * XST];
+            }
+            P0 = ns[(size_t)(piece * (m + 1) + m) * XST];
+            P1 = ns[(size_t)((piece + 1) * (m + 1) + m) * XST];
+          } else {
+            const double *ns = lst + 3 * t2 + ax;
+#pragma unroll
+            for (int j = 0; j < m; ++j) {
+              x0[j] = ns[(size_t)(piece * PER + nl + m + j) * SST];
+              x1[j] = ns[(size_t)((piece + 1) * PER + nl + m + j) * SST];
+            }
+            P0 = ns[(size_t)(piece * PER + nl + 2 * m) * SST];
+            P1 = ns[(size_t)((piece + 1) * PER + nl + 2 * m) * SST];
           }
-          const double P0 = ns[(size_t)(piece * PER + nl + 2 * m) * SST], P1 = ns[(size_t)((piece + 1) * PER + nl + 2 * m) * SST];
           e_piece += emit_piece<S>(piece, pw, P0, P1, x0, x1, [&](int, int col, double v) {
             cf[ax][col] = v;
             if (cp) cp[(int64_t)(ax * D + col) * ld] = v;
@@ -310,13 +436,13 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   ANET_FP(9);
 
   // ---- phase 3 (wave 0): the adjoint sweeps with the factor and the node states of phase 1 -----------------------------------------
-  if (wave != 0) return;
+  if (wave >= (TW ? 2 : 1)) return;
   {
-    const int lane = chain_lane ? tid : 0;
+    const int lane = chain_lane ? ci : 0;
     int v = 0;
     auto get = [&]() { return lst[(v++) * SST + lane]; };
 #pragma unroll
-    for (int k = 0; k <= NB; ++k) {
+    for (int k = 0; k <= NC; ++k) {
 #pragma unroll
       for (int j = 0; j < nl; ++j) F.L[k][j] = get();
 #pragma unroll
@@ -326,11 +452,125 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
       P[k] = get();
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
+    for (int i = 0; i < NC; ++i) {
       F.r[i] = get();
       tt[i] = get();
     }
   }
+  // (W_k lam^)[position row of node k] (the row of node k+1 is its negative) and - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab
+  // r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b, of piece k of a chain; x^ from phase 1's registers
+  auto piece_terms = [&](int k, const Pw<S> &p, const double (&la)[m], const double (&lb)[m], double &wl, double &acc) {
+    wl = 0.0;
+#pragma unroll
+    for (int l = 0; l < m; ++l) {
+      wl = __builtin_fma(Tab<S>::M[0][1 + l] * p[2 * S - 2 - l], la[l], wl);
+      wl = __builtin_fma(Tab<S>::M[0][S + 1 + l] * p[2 * S - 2 - l], lb[l], wl);
+    }
+    double xs[2 * S];
+#pragma unroll
+    for (int bb = 0; bb < 2 * S; ++bb) {
+      const int dg = bb % S;
+      const double xv = dg == 0 ? P[bb < S ? k : k + 1] : X[bb < S ? k : k + 1][dg - 1];
+      xs[bb] = xv * p[S - dg];
+    }
+    acc = 0.0;
+#pragma unroll
+    for (int aa = 0; aa < 2 * S; ++aa) {
+      const int da = aa % S;
+      if (da == 0) continue;
+      double row = 0.0;
+#pragma unroll
+      for (int bb = 0; bb < 2 * S; ++bb)
+        row = __builtin_fma(Tab<S>::M[aa][bb] * (double)(2 * S - 1 - da - bb % S), xs[bb], row);
+      const double ls = ((aa < S) ? la[da - 1] : lb[da - 1]) * p[S - da];
+      acc = __builtin_fma(ls, row, acc);
+    }
+  };
+  if constexpr (TW) {
+    double GP[NC + 1], XA[NC + 1][m], gTl[NC], rr[NC];
+    // the partial gradients of this half's pieces, in the half's own direction: its piece i is the trajectory's piece ir, and for
+    // role 1 start and end of a piece change places and the odd derivatives their sign
+#pragma unroll
+    for (int k = 0; k <= NC; ++k) {
+      GP[k] = 0.0;
+#pragma unroll
+      for (int l = 0; l < m; ++l) XA[k][l] = 0.0;
+      if (chain_lane) {
+        if (k < NC) {  // the half's piece k starts at its node k
+          const int ir = role ? N - 1 - k : k, off = role ? S : 0;
+          const double *src = lds + (size_t)(ROW_GX + ax1 * D + off) * PST + ir * G + t1;
+          GP[k] = src[0];
+#pragma unroll
+          for (int l = 0; l < m; ++l) {
+            const double v = src[(size_t)(1 + l) * PST];
+            XA[k][l] = (role && ((l + 1) & 1)) ? -v : v;
+          }
+        }
+        if (k > 0) {  // the half's piece k - 1 ends there
+          const int ir = role ? N - k : k - 1, off = role ? 0 : S;
+          const double *src = lds + (size_t)(ROW_GX + ax1 * D + off) * PST + ir * G + t1;
+          GP[k] += src[0];
+#pragma unroll
+          for (int l = 0; l < m; ++l) {
+            const double v = src[(size_t)(1 + l) * PST];
+            XA[k][l] += (role && ((l + 1) & 1)) ? -v : v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      gTl[i] = chain_lane ? lds[(ROW_GTD + ax1) * PST + (role ? N - 1 - i : i) * G + t1] : 0.0;
+      rr[i] = launder(F.r[i]);
+    }
+    ANET_FP(10);
+    sweep_forward_chain<true, S, NC>(F, NC, np, rr, XA,
+                                     [&](int k, double (&y)[m]) {
+#pragma unroll
+                                       for (int l = 0; l < m; ++l) y[l] = (k == 0 && l < np) ? 0.0 : XA[k][l];
+                                     },
+                                     meet_vector);
+    ANET_FP(11);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) rr[i] = launder(rr[i]);
+    sweep_backward_chain<true, S, NC>(F, NC, np, rr, XA, [&](int k, const Pw<S> &p) {
+      double wl, acc;
+      piece_terms(k, p, XA[k], XA[k + 1], wl, acc);
+      GP[k] -= wl;
+      GP[k + 1] += wl;
+      gTl[k] += acc;
+    });
+    ANET_FP(12);
+    {
+      const double gmid = pair_sum(GP[NC]);  // the middle node: both halves' shares
+      if (live1 && a.gradP) {
+        double *gp = a.gradP + (int64_t)ax1 * ld + bb1;
+#pragma unroll
+        for (int k = 1; k < NC; ++k) gp[(int64_t)(((role ? N - k : k) - 1) * 3) * ld] = GP[k];
+        if (!role) gp[(int64_t)((NC - 1) * 3) * ld] = gmid;
+      }
+    }
+    double e_tot = 0.0, csum = 0.0, tsum = 0.0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const double tot = gTl[i] + __shfl_down(gTl[i], 2) + __shfl_down(gTl[i], 4);  // the three axes: lanes two apart
+      if (live1 && ax1 == 0) {
+        const int ir = role ? N - 1 - i : i;
+        const double gt = lds[ROW_GDT * PST + ir * G + t1] + tot + a.pp.rho;
+        a.gradT[(int64_t)ir * ld + bb1] = a.tau ? gt * dforward_T(a.tau[(int64_t)ir * ld + bb1]) : gt;
+      }
+    }
+    if (a.cost && live1 && ax1 == 0 && !role) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        csum += lds[ROW_PC * PST + i * G + t1];
+        e_tot += lds[ROW_EN * PST + i * G + t1];
+        tsum += lds[ROW_T * PST + i * G + t1];
+      }
+      a.cost[bb1] = e_tot + a.pp.rho * tsum + csum;
+    }
+    ANET_FP(13);
+  } else
   {
     double GP[NB + 1], XA[NB + 1][m], gTl[NB], rr[NB];
 #pragma unroll
@@ -366,35 +606,10 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
 #pragma unroll
     for (int i = 0; i < NB; ++i) rr[i] = (i < N) ? launder(rr[i]) : 0.0;
     sweep_backward<S, NB>(F, N, np, rr, XA, [&](int k, const Pw<S> &p) {
-      // (W_k lam^)[position row of node k]; the row of node k+1 is its negative
-      double wl = 0.0;
-#pragma unroll
-      for (int l = 0; l < m; ++l) {
-        wl = __builtin_fma(Tab<S>::M[0][1 + l] * p[2 * S - 2 - l], XA[k][l], wl);
-        wl = __builtin_fma(Tab<S>::M[0][S + 1 + l] * p[2 * S - 2 - l], XA[k + 1][l], wl);
-      }
+      double wl, acc;
+      piece_terms(k, p, XA[k], XA[k + 1], wl, acc);
       GP[k] -= wl;
       GP[k + 1] += wl;
-      // - lam^' (dW/dT) x^ = sum_ab lam_a M_ab e_ab r^(e_ab+1) x_b,  e_ab = 2S-1-deg a-deg b; x^ from phase 1's registers
-      double xs[2 * S];
-#pragma unroll
-      for (int bb = 0; bb < 2 * S; ++bb) {
-        const int dg = bb % S;
-        const double xv = dg == 0 ? P[bb < S ? k : k + 1] : X[bb < S ? k : k + 1][dg - 1];
-        xs[bb] = xv * p[S - dg];
-      }
-      double acc = 0.0;
-#pragma unroll
-      for (int aa = 0; aa < 2 * S; ++aa) {
-        const int da = aa % S;
-        if (da == 0) continue;
-        double row = 0.0;
-#pragma unroll
-        for (int bb = 0; bb < 2 * S; ++bb)
-          row = __builtin_fma(Tab<S>::M[aa][bb] * (double)(2 * S - 1 - da - bb % S), xs[bb], row);
-        const double ls = ((aa < S) ? XA[k][da - 1] : XA[k + 1][da - 1]) * p[S - da];
-        acc = __builtin_fma(ls, row, acc);
-      }
       gTl[k] += acc;
     });
     ANET_FP(12);
