@@ -168,7 +168,7 @@ def test_large_batch_shapes_agree_with_small_batch_shapes_and_oracle(anet_ctx, s
                                          (3, 3, 16, 16, 20), (3, 3, 13, 9, 10), (3, 3, 5, 16, 20), (3, 2, 8, 0, 5), (3, 1, 2, 7, 2),
                                          (4, 3, 8, 16, 65)])
 def test_one_launch_evaluation_at_every_group_size(anet_ctx, s, c, N, M, res):
-    """Batches of up to one workgroup per CU are evaluated in ONE launch (csrc/minco_fused_kernel.h: solve, penalty / energy
+    """Batches of up to one workgroup per CU (two rounds of them for <= 8 pieces) are evaluated in ONE launch (csrc/minco_fused_kernel.h: solve, penalty / energy
     partial gradients and adjoint of a group of G trajectories in one workgroup, G = 16 ... 1 by batch, the lanes a smaller group
     frees splitting the samples of a piece).  Every group size, ragged last groups, 1 ... 16 pieces, 0 ... 50 corridor rows, 1 ... 64
     samples per piece (65: the three-launch path), coefficients asked for or not -- the whole batch against the C restatement
@@ -201,3 +201,26 @@ def test_one_launch_evaluation_at_every_group_size(anet_ctx, s, c, N, M, res):
             assert rel_err(out[3], co) < 1e-9, B
         if M and res >= 5:
             assert (cost - 3.0 * T.sum(axis=1) > 0).all()
+
+
+@pytest.mark.parametrize("s,N", [(4, 8), (3, 16), (3, 5), (4, 3)])
+def test_time_reversal_is_a_symmetry_of_the_evaluation(anet_ctx, s, N):
+    """A size-independent property of the path: the trajectory run backwards in time -- waypoints and durations reversed, head and
+    tail swapped with the sign of every odd derivative changed -- has the same control effort, and the gradients come out reversed.
+    The one-launch evaluation of the exact shapes RELIES on it (the second half of its chain is eliminated on the reversed data,
+    csrc/minco_fused_kernel.h); here it is checked from outside on both families of kernels (4096 trajectories: one launch; 20000: the
+    streaming kernels), with the penalty weights at zero -- the penalty's samples tau_j = j / res, j < res, are not symmetric."""
+    import allocnet_amd as aa
+    c = 3
+    pen = aa.make_penalty(rho=2.5, w_corridor=0.0, w_vel=0.0, w_acc=0.0, smooth_mu=0.05, max_vel=2.0, max_acc=3.0, res=8, poly_rows=0)
+    sign = np.array([1.0, -1.0, 1.0, -1.0])[:c]
+    for B in (4096, 20000):
+        rng = np.random.default_rng(31 * s + N + B)
+        head, tail, wps, T = random_problem(rng, B, N, c)
+        cost, gP, gT = aa.minco_cost_grad(head, tail, wps, T, s, penalty=pen, ctx=anet_ctx)
+        rc, rgP, rgT = aa.minco_cost_grad(tail * sign, head * sign, wps[:, ::-1].copy(), T[:, ::-1].copy(), s, penalty=pen, ctx=anet_ctx)
+        assert np.abs(rc - cost).max() <= 1e-11 * np.abs(cost).max(), (B, np.abs(rc - cost).max())
+        st = np.maximum(1.0, np.abs(gT).max(axis=1, keepdims=True))
+        assert (np.abs(rgT[:, ::-1] - gT) <= 1e-9 * st).all(), (B, (np.abs(rgT[:, ::-1] - gT) / st).max())
+        sp = np.maximum(1.0, np.abs(gP).reshape(B, -1).max(axis=1))[:, None, None]
+        assert (np.abs(rgP[:, ::-1] - gP) <= 1e-9 * sp).all(), (B, (np.abs(rgP[:, ::-1] - gP) / sp).max())
