@@ -1081,12 +1081,13 @@ static int cost_grad_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t
   if (batch == 0) return ANET_OK;
   if (!work || !cost || !gradT || (n_pieces > 1 && !gradP))
     return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad_dev: NULL output or workspace");
-  // Small batches in ONE launch (minco_fused_kernel.h): up to one workgroup per CU, two rounds for problems of up to eight pieces
-  // (measured: 8192 x 8-seg snap 64.9 -> 59.2 us, 6000: 63.2 -> 57.3; 4096 x 16-seg jerk in two rounds 60.5 -> 61.1: not taken;
-  // four rounds lose everywhere) -- beyond that the three streaming kernels have the chip full anyway and are the better shape
+  // Small batches in ONE launch (minco_fused_kernel.h): up to THREE rounds of one workgroup per CU for problems of up to eight pieces,
+  // two rounds for longer ones (measured with the chains eliminated from both ends, one launch against three: 8192 x 8-seg snap 54.0
+  // against 64.9 us, 12000: 79.5 / 83.8, 16384 = four rounds: 105.5 / 102.4 -- not taken; 4096 x 16-seg jerk 51.8 / 61.0, 2500: 48.7 /
+  // 59.3) -- beyond that the three streaming kernels have the chip full anyway and are the better shape
   // (ANET_FUSED_MAX_GROUPS overrides; 0 disables).
   static const int64_t fused_groups_env = [] { const char *e = getenv("ANET_FUSED_MAX_GROUPS"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
-  const int64_t fused_max_groups = fused_groups_env >= 0 ? fused_groups_env : (n_pieces <= 8 ? 512 : 256);
+  const int64_t fused_max_groups = fused_groups_env >= 0 ? fused_groups_env : (n_pieces <= 8 ? 768 : 512);
   const int fg = pen ? anet::cost_grad_fused_group(s, n_pieces) : 0;
   if (fg > 0 && (batch + fg - 1) / fg <= fused_max_groups && pen->res <= anet::kFusedMaxRes) {
     if (!head || !tail || !T || (n_pieces > 1 && !wps) || ld < batch)

@@ -181,8 +181,9 @@ def test_one_launch_evaluation_at_every_group_size(anet_ctx, s, c, N, M, res):
     pen = aa.make_penalty(rho=3.0, w_corridor=kw["wc"], w_vel=kw["wv"], w_acc=kw["wa"], smooth_mu=kw["mu"], max_vel=kw["vmax"],
                           max_acc=kw["amax"], res=kw["res"], poly_rows=M)
     gmax = 16 if N <= 8 else 8
-    # (256 workgroups at most: the batch picks G = gmax, gmax / 2, ..., 1; +-1 / odd sizes leave the last group ragged)
-    for B in sorted({1, 2, 3, 255, 256, 257, 300, 512, 513, 1000, 1024 + 7, 2048 - 5, 256 * gmax - 3, 256 * gmax}):
+    # (up to 256 workgroups the batch picks G = gmax, gmax / 2, ..., 1; +-1 / odd sizes leave the last group ragged; beyond, two rounds of
+    #  groups of gmax)
+    for B in sorted({1, 2, 3, 255, 256, 257, 300, 512, 513, 1000, 1024 + 7, 2048 - 5, 256 * gmax - 3, 256 * gmax, 512 * gmax - 3}):
         if M:
             head, tail, wps, T, hp = corridor_problem(rng, B, N, c, M)
         else:
