@@ -179,6 +179,15 @@ int launch_solve(anet_ctx *ctx, const anet::SolveArgs &a, hipStream_t st) {
   if (a.B <= axis_variant_max_batch()) {
     const dim3 g3((unsigned)((a.B + 20) / 21));
     bool done = true;
+    // (exact shapes with an even number of pieces, batches that leave SIMDs empty: the chain from both ends, two lanes per axis)
+    static const int64_t two_max = [] { const char *e = getenv("ANET_AXIS_TWO_MAX_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+    const dim3 g6((unsigned)((a.B + 9) / 10));
+    if (a.B <= two_max && a.c == 3 && ((S == 4 && a.N == 8) || (S == 3 && a.N == 16))) {
+      if constexpr (S == 4) hipLaunchKernelGGL((anet::k_minco_solve_axis_two<4, 8, 2>), g6, block, 0, st, a);
+      else if constexpr (S == 3) hipLaunchKernelGGL((anet::k_minco_solve_axis_two<3, 16, 2>), g6, block, 0, st, a);
+      ANET_HIP(ctx, hipGetLastError());
+      return ANET_OK;
+    }
     if constexpr (S == 4) {
       if (a.N == 8 && a.c == 3) hipLaunchKernelGGL((anet::k_minco_solve_axis<4, 8, true, 2>), g3, block, 0, st, a);
       else if (a.N == 8 && a.c == 4) hipLaunchKernelGGL((anet::k_minco_solve_axis<4, 8, true, 3>), g3, block, 0, st, a);

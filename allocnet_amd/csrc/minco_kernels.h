@@ -150,6 +150,96 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_solve_axis(SolveArgs a) {
   if (a.energy && live && ax == 0) a.energy[bb] = e + e1 + e2;
 }
 
+// The same solve with the chain eliminated FROM BOTH ENDS (exact shapes with an even number of pieces): two lanes per (trajectory,
+// axis).  Seen backwards in time a trajectory is a trajectory -- node k' = N - k, piece i' = N - 1 - i, every derivative of odd order
+// changes its sign -- and its minimum-effort problem is the same problem: the second lane runs the same code on the reversed data for
+// the second half of the chain (minco_core.h, the *_chain<TF> functions: the last node of a half is the interior node where the
+// halves meet, nothing pinned there).  At the middle node the two lanes exchange what their half contributes to its diagonal
+// block and right-hand side (a DPP swap of adjacent lanes, the partner's values with the signs of the reversal) and both finish
+// the middle node for themselves.  Half the sequential depth, twice the waves: the shape of batches that leave most SIMDs empty
+// (1024 trajectories: 9.4 -> see DESIGN 4.1).  Lane order: 6 lanes per trajectory (axis, role), ten trajectories per wave.
+__device__ __forceinline__ double lane_pair_swap(double v) {  // the value of the other lane of the pair (lanes 2k, 2k+1)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int S, int NB, int NPC>
+__global__ void __launch_bounds__(kSolveBlock) k_minco_solve_axis_two(SolveArgs a) {
+  static_assert(NB % 2 == 0 && NB >= 2, "an even number of pieces");
+  constexpr int m = S - 1, D = 2 * S, NC = NB / 2, N = NB, np = NPC, c = NPC + 1;
+  const int l6 = (int)threadIdx.x % 6;
+  const int role = l6 & 1, ax = l6 >> 1;
+  const int64_t b = (int64_t)blockIdx.x * 10 + threadIdx.x / 6;
+  const bool live = threadIdx.x < 60 && b < a.B;
+  const int64_t ld = a.ld;
+  const int64_t bb = live ? b : 0;  // idle lanes compute on trajectory 0 and store nothing
+  Factor<S, NC> F;
+  double P[NC + 1], hv[m], tv[m], X[NC + 1][m], tt[NC];
+  const double *hp = a.head + (int64_t)(ax * c) * ld + bb;
+  const double *tp = a.tail + (int64_t)(ax * c) * ld + bb;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) tt[i] = a.T[(int64_t)(role ? N - 1 - i : i) * ld + bb];
+#pragma unroll
+  for (int k = 0; k <= NC; ++k) {
+    const int kr = role ? N - k : k;
+    const double *src = (kr == 0) ? hp : (kr < N) ? a.wps + (int64_t)((kr - 1) * 3 + ax) * ld + bb : tp;
+    P[k] = *src;
+  }
+#pragma unroll
+  for (int j = 0; j < m; ++j) {
+    const int64_t row = (j < np) ? 1 + j : 0;
+    const double h = (role ? tp : hp)[row * ld];
+    hv[j] = (j < np) ? ((role && ((j + 1) & 1)) ? -h : h) : 0.0;
+    tv[j] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) F.r[i] = fast_rcp(tt[i]);
+  F.template factorize_chain<true>(NC, np, [&](double (&Dk)[m][m]) {
+#pragma unroll
+    for (int j = 0; j < m; ++j)
+#pragma unroll
+      for (int l = 0; l <= j; ++l) {
+        const double o = lane_pair_swap(Dk[j][l]);
+        Dk[j][l] += ((j + l) & 1) ? -o : o;
+      }
+  });
+  double rr[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) rr[i] = launder(F.r[i]);
+  sweep_forward_chain<true, S, NC>(F, NC, np, rr, X, [&](int k, double (&y)[m]) { rhs_primal_node<S, NC, true>(k, NC, np, rr, P, hv, tv, y); },
+                                   [&](double (&y)[m]) {
+#pragma unroll
+                                     for (int l = 0; l < m; ++l) {
+                                       const double o = lane_pair_swap(y[l]);
+                                       y[l] += ((l + 1) & 1) ? -o : o;
+                                     }
+                                   });
+#pragma unroll
+  for (int i = 0; i < NC; ++i) rr[i] = launder(rr[i]);
+  double *cp = (a.coeffs && live) ? a.coeffs + (int64_t)(ax * D) * ld + bb : nullptr;
+  double e = 0.0;
+  // the pieces are emitted in the trajectory's own direction: for the reversed half start and end of a piece change places and the
+  // odd derivatives their sign
+  sweep_backward_chain<true, S, NC>(F, NC, np, rr, X, [&](int k, const Pw<S> &p) {
+    double x0[m], x1[m];
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      const double u = X[k][j], w = X[k + 1][j];
+      x0[j] = role ? (((j + 1) & 1) ? -w : w) : u;
+      x1[j] = role ? (((j + 1) & 1) ? -u : u) : w;
+    }
+    const int piece = role ? N - 1 - k : k;
+    e += emit_piece<S>(piece, p, role ? P[k + 1] : P[k], role ? P[k] : P[k + 1], x0, x1, [&](int, int col, double v) {
+      if (cp) cp[(int64_t)(piece * 3 * D + col) * ld] = v;
+    });
+  });
+  // energy of the trajectory = sum over its six adjacent lanes (in a fixed order)
+  const double e01 = e + lane_pair_swap(e);
+  const double tot = (e01 + __shfl_down(e01, 2)) + __shfl_down(e01, 4);
+  if (a.energy && live && l6 == 0) a.energy[bb] = tot;
+}
+
 // ------------------------------------------------------------------------------------------
 // cost / gradient path: partial gradients per piece, then adjoint propagation per trajectory
 // ------------------------------------------------------------------------------------------
