@@ -17,8 +17,17 @@ def build(force=False):
                                              "minco_cpu_reduced.cpp")]
     srcs += [os.path.join(os.path.dirname(_HERE), "allocnet_amd", "csrc", f) for f in ("minco_core.h", "minco_tables.h")]
     outs = (_PATH, _CPU_PATH)
-    if force or not all(os.path.exists(o) for o in outs) or any(os.path.getmtime(o) < os.path.getmtime(s) for o in outs for s in srcs):
-        subprocess.run(["make", "-C", _HERE, "-B", "all"], check=True, capture_output=True)
+    stale = lambda: not all(os.path.exists(o) for o in outs) or any(os.path.getmtime(o) < os.path.getmtime(s) for o in outs for s in srcs)
+    if force or stale():
+        # one builder at a time: the ranks of a multi-process test all get here together when a source is newer than the libraries
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if force or stale():
+                    subprocess.run(["make", "-C", _HERE, "-B", "all"], check=True, capture_output=True)
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return _PATH
 
 

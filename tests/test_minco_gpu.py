@@ -253,3 +253,46 @@ def test_time_allocation_sampling_matches_the_replicated_solve(anet_ctx, s, c, N
         refp = ep + rho * T[p].sum(axis=1)
         assert np.abs(cost[p] - refp).max() <= 1e-13 * np.abs(refp).max(), p
     assert np.array_equal(cost[0], cost0)
+
+
+@pytest.mark.gpu
+def test_bound_solve_call_is_the_same_launch(anet_ctx):
+    """bind_minco_solve: the arguments of minco_solve_dev checked and converted once; calling the bound object gives the same bits
+    as the wrapper, sees new CONTENTS of the bound tensors, runs on another stream through with_stream, and a tensor of the wrong
+    kind is refused when it is bound (not at the launch)."""
+    import torch
+    import allocnet_amd as aa
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda", 0)
+    for s, c, N, B in ((4, 3, 8, 1024), (3, 3, 16, 100), (4, 4, 5, 37)):
+        head, tail, wps, T = random_problem(rng, B, N, c)
+        ld = aa.recommended_ld(B)
+
+        def bm(x):
+            f = np.ascontiguousarray(x.reshape(B, -1).T)
+            t = torch.zeros(f.shape[0], ld, device=dev, dtype=torch.float64)
+            t[:, :B] = torch.from_numpy(f).to(dev)
+            return t
+        th, tt, tw, tT = bm(head), bm(tail), bm(wps), bm(T)
+        co = torch.empty(N * 3 * 2 * s, ld, device=dev, dtype=torch.float64); en = torch.empty(ld, device=dev, dtype=torch.float64)
+        aa.minco_solve_dev(th, tt, tw, tT, s, c, N, B, coeffs=co, energy=en, ctx=anet_ctx)
+        torch.cuda.synchronize()
+        ref_c, ref_e = co[:, :B].clone(), en[:B].clone()
+        co2 = torch.zeros_like(co); en2 = torch.zeros_like(en)
+        call = aa.bind_minco_solve(th, tt, tw, tT, s, c, N, B, coeffs=co2, energy=en2, ctx=anet_ctx)
+        call()
+        torch.cuda.synchronize()
+        assert torch.equal(co2[:, :B], ref_c) and torch.equal(en2[:B], ref_e)
+        tT[:, :B] *= 1.25                                         # new contents, same storage
+        aa.minco_solve_dev(th, tt, tw, tT, s, c, N, B, coeffs=co, energy=en, ctx=anet_ctx)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        call.with_stream(side.cuda_stream)()
+        side.synchronize(); torch.cuda.synchronize()
+        assert torch.equal(co2[:, :B], co[:, :B]) and torch.equal(en2[:B], en[:B]) and not torch.equal(en2[:B], ref_e)
+        cc, ec = cbind.minco_solve_batch(s, head, tail, wps, T * 1.25)
+        assert rel_err(en2[:B].cpu().numpy(), ec) < 1e-10
+    with pytest.raises(ValueError):
+        aa.bind_minco_solve(th.float(), tt, tw, tT, s, c, N, B, coeffs=co2, energy=en2, ctx=anet_ctx)
+    with pytest.raises(ValueError):
+        aa.bind_minco_solve(th, tt, tw, tT, s, c, N, B, coeffs=co2, energy=en2[: B - 1], ctx=anet_ctx)

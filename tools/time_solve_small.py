@@ -24,6 +24,18 @@ for arg in sys.argv[1:] or ["4,3,8,1024"]:
         for _ in range(500): run()
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / 500 * 1e6)
+    # the C entry point with its arguments converted once (what a C++ caller pays per launch, plus the ctypes trampoline)
+    import ctypes
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    args = (ctx.handle, s, c, N, B, ld, vp(th), vp(tt), vp(tw), vp(tT), vp(coeffs), vp(energy), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    fn = ctx.lib.anet_minco_solve_dev
+    tb = []
+    for rep in range(5):
+        t0 = time.perf_counter()
+        for _ in range(500): fn(*args)
+        torch.cuda.synchronize()
+        tb.append((time.perf_counter() - t0) / 500 * 1e6)
+    print("   bound arguments: stream us/launch %.2f" % sorted(tb)[2], flush=True)
     cap = torch.cuda.Stream(device=dev); graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=cap):
         for _ in range(64): run(torch.cuda.current_stream(dev).cuda_stream)
