@@ -153,3 +153,44 @@ def test_config3_leg_snapshots_before_the_kernel_split():
     body = src[src.index("def run_config3"):src.index("def qp_newton_step_flops")]
     assert body.index("snap = (cost[:B].cpu()") < body.index("cost_grad_kernel_split(torch")
     assert "gP2, gT2)" in body and "gpu_vs_cpu_max_rel_gradP_err" in body
+
+
+def test_time_steps_retimes_a_pass_the_runtime_stall_fell_into():
+    """bench.time_steps: a pass whose wall time is far beyond what its per-step events say (the HIP runtime's one-off host stall
+    between two steps) is discarded and the same steps are timed again, once; a clean pass is kept; a slow STEP (events and wall
+    agree) is not a stall."""
+    import time
+    import types
+    import bench
+
+    class Ev:
+        def __init__(self, enable_timing=True):
+            self.t = None
+
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+    fake = types.SimpleNamespace(cuda=types.SimpleNamespace(Event=Ev))
+    calls = {"n": 0, "stall_at": 7}
+
+    def step(i, ev):
+        calls["n"] += 1
+        if calls["n"] == calls["stall_at"]:
+            time.sleep(0.05)                    # the host blocks BETWEEN two event pairs
+        ev[0].record()
+        time.sleep(0.0005)
+        ev[1].record()
+    elapsed, ev, retimed = bench.time_steps(fake, None, False, None, 10, step, lambda: None)
+    assert retimed and calls["n"] == 20 and elapsed < 0.03 and len(ev) == 10
+    calls.update(n=0, stall_at=-1)
+    elapsed, ev, retimed = bench.time_steps(fake, None, False, None, 10, step, lambda: None)
+    assert not retimed and calls["n"] == 10
+
+    def slow_steps(i, ev):                      # 3 ms per step inside the events: nothing to re-time
+        ev[0].record()
+        time.sleep(0.003)
+        ev[1].record()
+    elapsed, ev, retimed = bench.time_steps(fake, None, False, None, 10, slow_steps, lambda: None)
+    assert not retimed and elapsed >= 0.03
