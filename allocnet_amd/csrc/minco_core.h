@@ -247,10 +247,11 @@ __device__ __forceinline__ void sweep_forward_chain(const Factor<S, NB> &F, int 
   }
 }
 
-template <bool TF, int S, int NB, class After>
+// (TF: `mid(x)` sees -- and may replace -- the solution of node N, the node where the halves of a trajectory meet)
+template <bool TF, int S, int NB, class After, class Mid>
 __device__ __forceinline__ void sweep_backward_chain(const Factor<S, NB> &F, int N, int np,
                                                      const double (&rr)[NB], double (&X)[NB + 1][S - 1],
-                                                     After &&after) {
+                                                     After &&after, Mid &&mid) {
   constexpr int m = S - 1;
 #pragma unroll
   for (int k = NB; k >= 0; --k) {
@@ -269,6 +270,7 @@ __device__ __forceinline__ void sweep_backward_chain(const Factor<S, NB> &F, int
 #pragma unroll
       for (int l = 0; l < m; ++l) x[l] *= F.dinv[k][l];
       F.solve_LT(k, x);
+      if (TF && k == N) mid(x);
 #pragma unroll
       for (int l = 0; l < m; ++l) X[k][l] = x[l];
       if (k < N) {
@@ -290,7 +292,7 @@ template <int S, int NB, class After>
 __device__ __forceinline__ void sweep_backward(const Factor<S, NB> &F, int N, int np,
                                                const double (&rr)[NB], double (&X)[NB + 1][S - 1],
                                                After &&after) {
-  sweep_backward_chain<false, S, NB>(F, N, np, rr, X, after);
+  sweep_backward_chain<false, S, NB>(F, N, np, rr, X, after, [](double (&)[S - 1]) {});
 }
 
 // Right-hand side of the primal problem for one axis: stationarity rows moved to the right,

@@ -15,9 +15,10 @@
 //            one lane) and handed over through LDS;
 //   phase 3  wave 0 again: the two sweeps of the adjoint with the factor and the node states of phase 1.
 // No global round trip between the phases, one launch, no second factorisation.
-// The exact shapes (8-piece snap, 16-piece jerk, c = 3) eliminate the chain FROM BOTH ENDS in phases 1 and 3: two lanes per
-// (trajectory, axis), the second one working on the trajectory reversed in time with the same code, the halves meeting at the
-// middle node through a DPP swap (TW below; 4096 x 8 snap 29.8 -> 28.6 us, 2048 x 16 jerk 31.4 -> 25.6, 512 x 8 snap 20.3 -> 17.1).
+// Every shape of two pieces and more eliminates the chain FROM BOTH ENDS in phases 1 and 3: two lanes per (trajectory, axis), the
+// second one working on the trajectory reversed in time with the same code, the halves meeting at the middle node -- through a
+// DPP swap in the exact shapes (8-piece snap, 16-piece jerk, c = 3: equal halves), through LDS otherwise (TW below; 4096 x 8 snap
+// 29.8 -> 28.6 us, 2048 x 16 jerk 31.4 -> 25.6, 512 x 8 snap 20.3 -> 17.1, 700 x 6 snap c = 4 27.5 -> 19.8).
 // The group size G is a run-time value (a power of two, at most FusedShape<NB>::G): a batch too small to give every CU a
 // workgroup of G trajectories takes a smaller G, and the lanes that frees split the SAMPLES of a piece further: Q = 128 / (G NB)
 // lane pairs per (trajectory, piece), 2 Q lanes taking every 2 Q-th sample each (the basis table from a copy in LDS, since the
@@ -68,8 +69,13 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   constexpr int nl = Factor<S, NB>::nl > 0 ? Factor<S, NB>::nl : 1;
   // TW: the chain of an exact shape with an even number of pieces is eliminated from BOTH ends (see phase 1): two lanes per
   // (trajectory, axis), each with a chain of NC = NB / 2 pieces
-  constexpr bool TW = NEXACT && NB % 2 == 0;
+  // (shapes with a run-time piece count, 2 <= N <= NB: halves of (N + 1) / 2 and N / 2 pieces -- the lanes of a pair reach the middle
+  //  node at different steps of the unrolled loops when N is odd, so their exchange goes through LDS, in program order, instead of
+  //  a DPP swap: the second half hands over its share of the middle node, the first half finishes the node and hands back its solution)
+  constexpr bool TW = NB % 2 == 0;
   constexpr int NC = TW ? NB / 2 : NB, CL = TW ? 6 : 3;  // pieces of a chain, chain lanes per trajectory
+  constexpr int MROWS = m * (m + 1) / 2 + m;             // what the halves exchange through LDS: a block's lower triangle, or a vector
+  __shared__ double lmeet[(TW && !NEXACT) ? MROWS * 3 * GM : 1];
   constexpr int NST = (NC + 1) * (nl + 2 * m + 1) + 2 * NC, SST = CL * GM;
   __shared__ double lst[NST * SST];
   // (TW) the node states in the trajectory's own direction, for phase 2: value (node, j) of (trajectory, axis) at [(node (m + 1) + j) XST + 3 t + axis]
@@ -111,6 +117,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   const int t1 = TW ? 10 * wave + (tid & 63) / 6 : tid / 3, ax1 = TW ? (lw6 >> 1) : tid % 3;
   const bool chain_lane = TW ? (tid < 128 && (tid & 63) < 60 && t1 < G) : tid < 3 * G;
   const int ci = TW ? 6 * t1 + lw6 : tid;  // the lane's column of the parking area
+  const int Nh = (!TW || NEXACT) ? NC : (role ? N / 2 : (N + 1) / 2);  // pieces of this lane's chain
   const bool live1 = chain_lane && b0 + t1 < a.B;
   const int64_t bb1 = live1 ? b0 + t1 : (a.B - 1);
   double hv[m], tv[m];
@@ -126,20 +133,81 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
   };
+  double *const mt = lmeet + ((TW && !NEXACT && chain_lane) ? 3 * t1 + ax1 : 0);  // the pair's column of the exchange area
   auto meet_block = [&](double (&Dk)[m][m]) {
+    if constexpr (NEXACT) {
 #pragma unroll
-    for (int j = 0; j < m; ++j)
+      for (int j = 0; j < m; ++j)
 #pragma unroll
-      for (int l = 0; l <= j; ++l) {
-        const double o = pair_swap(Dk[j][l]);
-        Dk[j][l] += ((j + l) & 1) ? -o : o;
+        for (int l = 0; l <= j; ++l) {
+          const double o = pair_swap(Dk[j][l]);
+          Dk[j][l] += ((j + l) & 1) ? -o : o;
+        }
+    } else {
+      if (role && chain_lane) {
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+          for (int l = 0; l <= j; ++l) mt[(size_t)(j * (j + 1) / 2 + l) * 3 * GM] = Dk[j][l];
       }
+      // (the two branches must stay two branches IN THIS ORDER: mutually exclusive per lane, the compiler may otherwise fold them
+      //  into one if / else and run the reading side first -- seen with an even piece count, where both lanes of a pair are here in
+      //  the same step; LDS instructions of a wave execute in order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (!role && chain_lane) {
+#pragma unroll
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+          for (int l = 0; l <= j; ++l) {
+            const double o = mt[(size_t)(j * (j + 1) / 2 + l) * 3 * GM];
+            Dk[j][l] += ((j + l) & 1) ? -o : o;
+          }
+      }
+    }
   };
   auto meet_vector = [&](double (&y)[m]) {  // (component l is the derivative of order l + 1)
+    if constexpr (NEXACT) {
 #pragma unroll
-    for (int l = 0; l < m; ++l) {
-      const double o = pair_swap(y[l]);
-      y[l] += ((l + 1) & 1) ? -o : o;
+      for (int l = 0; l < m; ++l) {
+        const double o = pair_swap(y[l]);
+        y[l] += ((l + 1) & 1) ? -o : o;
+      }
+    } else {
+      if (role && chain_lane) {
+#pragma unroll
+        for (int l = 0; l < m; ++l) mt[(size_t)l * 3 * GM] = y[l];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (!role && chain_lane) {
+#pragma unroll
+        for (int l = 0; l < m; ++l) {
+          const double o = mt[(size_t)l * 3 * GM];
+          y[l] += ((l + 1) & 1) ? -o : o;
+        }
+      }
+    }
+  };
+  // (the solution of the middle node: both halves have it themselves when they met by the swap; through LDS the first half has)
+  auto meet_solution = [&](double (&x)[m]) {
+    if constexpr (!NEXACT) {
+      if (!role && chain_lane) {
+#pragma unroll
+        for (int l = 0; l < m; ++l) mt[(size_t)(m + l) * 3 * GM] = x[l];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (role && chain_lane) {
+#pragma unroll
+        for (int l = 0; l < m; ++l) {
+          const double o = mt[(size_t)(m + l) * 3 * GM];
+          x[l] = ((l + 1) & 1) ? -o : o;
+        }
+      }
     }
   };
   if constexpr (TW) {
@@ -147,10 +215,10 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
       const double *hp = a.head + (int64_t)(ax1 * c) * ld + bb1;
       const double *tp = a.tail + (int64_t)(ax1 * c) * ld + bb1;
 #pragma unroll
-      for (int i = 0; i < NC; ++i) tt[i] = a.T[(int64_t)(role ? N - 1 - i : i) * ld + bb1];
+      for (int i = 0; i < NC; ++i) tt[i] = a.T[(int64_t)(i < Nh ? (role ? N - 1 - i : i) : 0) * ld + bb1];
 #pragma unroll
       for (int k = 0; k <= NC; ++k) {
-        const int kr = role ? N - k : k;
+        const int kr = k <= Nh ? (role ? N - k : k) : 0;
         const double *src = (kr == 0) ? hp : (kr < N) ? a.wps + (int64_t)((kr - 1) * 3 + ax1) * ld + bb1 : tp;
         P[k] = *src;
       }
@@ -164,28 +232,29 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
 #pragma unroll
       for (int i = 0; i < NC; ++i) F.r[i] = fast_rcp(tt[i]);
       ANET_FP(1);
-      F.template factorize_chain<true>(NC, np, meet_block);
+      F.template factorize_chain<true>(Nh, np, meet_block);
       ANET_FP(2);
       {
         double rr[NC];
 #pragma unroll
         for (int i = 0; i < NC; ++i) rr[i] = launder(F.r[i]);
-        sweep_forward_chain<true, S, NC>(F, NC, np, rr, X,
-                                         [&](int k, double (&y)[m]) { rhs_primal_node<S, NC, true>(k, NC, np, rr, P, hv, tv, y); }, meet_vector);
+        sweep_forward_chain<true, S, NC>(F, Nh, np, rr, X,
+                                         [&](int k, double (&y)[m]) { rhs_primal_node<S, NC, true>(k, Nh, np, rr, P, hv, tv, y); }, meet_vector);
 #pragma unroll
         for (int i = 0; i < NC; ++i) rr[i] = launder(rr[i]);
-        sweep_backward_chain<true, S, NC>(F, NC, np, rr, X, [&](int, const Pw<S> &) {});
+        sweep_backward_chain<true, S, NC>(F, Nh, np, rr, X, [&](int, const Pw<S> &) {}, meet_solution);
       }
       ANET_FP(3);
       if (chain_lane) {
         if (ax1 == 0) {
 #pragma unroll
-          for (int i = 0; i < NC; ++i) lds[ROW_T * PST + (role ? N - 1 - i : i) * G + t1] = tt[i];
+          for (int i = 0; i < NC; ++i)
+            if (i < Nh) lds[ROW_T * PST + (role ? N - 1 - i : i) * G + t1] = tt[i];
         }
-        // the node states as phase 2 reads them: role 0 has nodes 0 .. N/2, role 1 nodes N .. N/2 + 1 with the signs of the reversal
+        // the node states as phase 2 reads them: role 0 has nodes 0 .. its last, role 1 the others, backwards, with the signs of the reversal
 #pragma unroll
         for (int k = 0; k <= NC; ++k) {
-          if (role && k == NC) continue;
+          if (k > Nh || (role && k == Nh)) continue;
           const int kr = role ? N - k : k;
           double *dst = lxs + (size_t)(kr * (m + 1)) * XST + 3 * t1 + ax1;
 #pragma unroll
@@ -495,8 +564,8 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
       GP[k] = 0.0;
 #pragma unroll
       for (int l = 0; l < m; ++l) XA[k][l] = 0.0;
-      if (chain_lane) {
-        if (k < NC) {  // the half's piece k starts at its node k
+      if (chain_lane && k <= Nh) {
+        if (k < Nh) {  // the half's piece k starts at its node k
           const int ir = role ? N - 1 - k : k, off = role ? S : 0;
           const double *src = lds + (size_t)(ROW_GX + ax1 * D + off) * PST + ir * G + t1;
           GP[k] = src[0];
@@ -520,11 +589,11 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     }
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-      gTl[i] = chain_lane ? lds[(ROW_GTD + ax1) * PST + (role ? N - 1 - i : i) * G + t1] : 0.0;
+      gTl[i] = (chain_lane && i < Nh) ? lds[(ROW_GTD + ax1) * PST + (role ? N - 1 - i : i) * G + t1] : 0.0;
       rr[i] = launder(F.r[i]);
     }
     ANET_FP(10);
-    sweep_forward_chain<true, S, NC>(F, NC, np, rr, XA,
+    sweep_forward_chain<true, S, NC>(F, Nh, np, rr, XA,
                                      [&](int k, double (&y)[m]) {
 #pragma unroll
                                        for (int l = 0; l < m; ++l) y[l] = (k == 0 && l < np) ? 0.0 : XA[k][l];
@@ -533,28 +602,34 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     ANET_FP(11);
 #pragma unroll
     for (int i = 0; i < NC; ++i) rr[i] = launder(rr[i]);
-    sweep_backward_chain<true, S, NC>(F, NC, np, rr, XA, [&](int k, const Pw<S> &p) {
+    sweep_backward_chain<true, S, NC>(F, Nh, np, rr, XA, [&](int k, const Pw<S> &p) {
       double wl, acc;
       piece_terms(k, p, XA[k], XA[k + 1], wl, acc);
       GP[k] -= wl;
       GP[k + 1] += wl;
       gTl[k] += acc;
-    });
+    }, meet_solution);
     ANET_FP(12);
     {
-      const double gmid = pair_sum(GP[NC]);  // the middle node: both halves' shares
+      double gown = GP[NC];  // this half's share of the middle node (the last node of its chain)
+      if constexpr (!NEXACT) {
+#pragma unroll
+        for (int k = 1; k < NC; ++k) gown = (k == Nh) ? GP[k] : gown;
+      }
+      const double gmid = pair_sum(gown);  // both halves' shares
       if (live1 && a.gradP) {
         double *gp = a.gradP + (int64_t)ax1 * ld + bb1;
 #pragma unroll
-        for (int k = 1; k < NC; ++k) gp[(int64_t)(((role ? N - k : k) - 1) * 3) * ld] = GP[k];
-        if (!role) gp[(int64_t)((NC - 1) * 3) * ld] = gmid;
+        for (int k = 1; k < NC; ++k)
+          if (k < Nh) gp[(int64_t)(((role ? N - k : k) - 1) * 3) * ld] = GP[k];
+        if (!role) gp[(int64_t)((Nh - 1) * 3) * ld] = gmid;
       }
     }
     double e_tot = 0.0, csum = 0.0, tsum = 0.0;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const double tot = gTl[i] + __shfl_down(gTl[i], 2) + __shfl_down(gTl[i], 4);  // the three axes: lanes two apart
-      if (live1 && ax1 == 0) {
+      if (live1 && ax1 == 0 && i < Nh) {
         const int ir = role ? N - 1 - i : i;
         const double gt = lds[ROW_GDT * PST + ir * G + t1] + tot + a.pp.rho;
         a.gradT[(int64_t)ir * ld + bb1] = a.tau ? gt * dforward_T(a.tau[(int64_t)ir * ld + bb1]) : gt;
@@ -562,11 +637,12 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     }
     if (a.cost && live1 && ax1 == 0 && !role) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        csum += lds[ROW_PC * PST + i * G + t1];
-        e_tot += lds[ROW_EN * PST + i * G + t1];
-        tsum += lds[ROW_T * PST + i * G + t1];
-      }
+      for (int i = 0; i < NB; ++i)
+        if (i < N) {
+          csum += lds[ROW_PC * PST + i * G + t1];
+          e_tot += lds[ROW_EN * PST + i * G + t1];
+          tsum += lds[ROW_T * PST + i * G + t1];
+        }
       a.cost[bb1] = e_tot + a.pp.rho * tsum + csum;
     }
     ANET_FP(13);

@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(kSolveBlock) k_minco_solve_axis_two(SolveArgs 
     e += emit_piece<S>(piece, p, role ? P[k + 1] : P[k], role ? P[k] : P[k + 1], x0, x1, [&](int, int col, double v) {
       if (cp) cp[(int64_t)(piece * 3 * D + col) * ld] = v;
     });
-  });
+  }, [](double (&)[m]) {});
   // energy of the trajectory = sum over its six adjacent lanes (in a fixed order)
   const double e01 = e + lane_pair_swap(e);
   const double tot = (e01 + __shfl_down(e01, 2)) + __shfl_down(e01, 4);
