@@ -124,3 +124,50 @@ def test_overlapped_cost_gather_disabled_is_a_plain_double_buffer():
     assert [og.acquire(i) for i in range(4)] == [0, 1, 0, 1]
     assert og.submit(0) is None and og.issued == 0 and og.recv is None
     og.drain()
+
+
+def _retime_worker(rank, world, port, ret):
+    """bench.time_steps with two ranks: the runtime stall falls into rank 1's pass only -- BOTH ranks must time the steps again
+    (the decision is an all-reduce), and the time reported is the maximum over the ranks of the second pass."""
+    import time
+    import types
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class Ev:
+            def __init__(self, enable_timing=True):
+                self.t = None
+
+            def record(self):
+                self.t = time.perf_counter()
+
+            def elapsed_time(self, other):
+                return (other.t - self.t) * 1e3
+        fake = types.SimpleNamespace(cuda=types.SimpleNamespace(Event=Ev), tensor=torch.tensor, float64=torch.float64)
+        calls = {"n": 0}
+
+        def step(i, ev):
+            calls["n"] += 1
+            if rank == 1 and calls["n"] == 4:
+                time.sleep(0.08)
+            ev[0].record()
+            time.sleep(0.0005 * (1 + rank))
+            ev[1].record()
+        elapsed, ev, retimed = bench.time_steps(fake, dist, True, "cpu", 10, step, dist.barrier)
+        ret[rank] = (elapsed, retimed, calls["n"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_time_steps_retimes_on_every_rank_gloo_world2():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_retime_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    (e0, r0, n0), (e1, r1, n1) = ret[0], ret[1]
+    assert r0 and r1 and n0 == 20 and n1 == 20          # both ranks ran the steps twice
+    assert e0 == e1 and 0.009 <= e0 < 0.06              # the maximum over the ranks of the second, clean pass
