@@ -447,9 +447,23 @@ __device__ __forceinline__ void piece_penalty_part(const Penalty &pp_in, const d
         pos[ax] = acc;
       }
       double Fs = 0.0, G[3] = {0.0, 0.0, 0.0};  // sum of F(u) and of F'(u) a/mu over the rows
+      double ur[RC];
+#pragma unroll
+      for (int r = 0; r < RC; ++r)
+        ur[r] = __builtin_fma(hr[r][0], pos[0], __builtin_fma(hr[r][1], pos[1], __builtin_fma(hr[r][2], pos[2], -hr[r][3])));
+      bool any_row = true;
+      if constexpr (LTAB) {
+        // (the one-launch kernel runs one wave per SIMD: every wave-uniform branch is a compare-to-branch bubble nothing fills;
+        //  one test for the eight rows first -- inside the corridor of all of them the per-row tests are skipped as well)
+        double um = ur[0];
+#pragma unroll
+        for (int r = 1; r < RC; ++r) um = fmax(um, ur[r]);
+        any_row = __any(um > 0.0);
+      }
+      if (any_row)
 #pragma unroll
       for (int r = 0; r < RC; ++r) {
-        const double u = __builtin_fma(hr[r][0], pos[0], __builtin_fma(hr[r][1], pos[1], __builtin_fma(hr[r][2], pos[2], -hr[r][3])));
+        const double u = ur[r];
         if (__any(u > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
           const double w = fmax(u, 0.0), uc = fmin(w, 1.0), sq = uc * uc;
           Fs += w - uc;
