@@ -394,7 +394,54 @@ __device__ __forceinline__ void piece_penalty_part(const Penalty &pp_in, const d
   // that the box rows are visited
   const int cstep = SPLIT ? 2 : 1;
   int npass = SPLIT ? (nchunk - half + 1) / 2 : nchunk;
-  if (npass < 1) npass = 1;
+  if (npass < 1 && !LTAB) npass = 1;
+  if constexpr (LTAB) {
+    // The one-launch kernel visits the velocity / acceleration limits in a pass of ITS OWN, ahead of the corridor passes: with the
+    // basis rows in VGPRs (the sample index differs from lane to lane) the first pass's live set -- eight corridor rows, c~, the
+    // gradient, three basis rows -- was ~20 values over the 256 registers and every sample paid 66 v_accvgpr moves of 516
+    // instructions; the limits need neither the rows nor the position.  Same formulas as below; the sample costs of the limits are
+    // added to csum here and those of the corridor rows there (a different order of the same sum).
+    for (int j = wv; j < pp.res; j += jstep) {
+      const double *tb = tab + (size_t)j * 3 * D;
+      double t1[D], t2[D], a1[3], a2[3], worst = 0.0;
+#pragma unroll
+      for (int col = 0; col < D; ++col) {
+        t1[col] = tb[D + col];
+        t2[col] = tb[2 * D + col];
+      }
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        double x1 = 0.0, x2 = 0.0;
+#pragma unroll
+        for (int col = 0; col < D; ++col) {
+          x1 = __builtin_fma(ct[ax][col], t1[col], x1);
+          x2 = __builtin_fma(ct[ax][col], t2[col], x2);
+        }
+        a1[ax] = x1;
+        a2[ax] = x2;
+        worst = fmax(worst, fmax(__builtin_fma(fabs(x1), kv, -cv), __builtin_fma(fabs(x2), ka, -ca)));
+      }
+      if (__any(worst > 0.0)) {
+        double cost = 0.0;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          double f, df;
+          smoothed_l1_unit(__builtin_fma(fabs(a1[ax]), kv, -cv), f, df);
+          cost = __builtin_fma(wvm, f, cost);
+          const double s1 = K1 * copysign(df, a1[ax]);
+          Rs1 = __builtin_fma(s1, a1[ax], Rs1);
+          smoothed_l1_unit(__builtin_fma(fabs(a2[ax]), ka, -ca), f, df);
+          cost = __builtin_fma(wam, f, cost);
+          const double s2 = K2 * copysign(df, a2[ax]);
+          Rs2 = __builtin_fma(s2, a2[ax], Rs2);
+#pragma unroll
+          for (int col = 0; col < D; ++col)
+            gN[ax][col] = __builtin_fma(s2, t2[col], __builtin_fma(s1, t1[col], gN[ax][col]));
+        }
+        csum += cost;
+      }
+    }
+  }
   for (int pass = 0; pass < npass; ++pass) {
     const int ch = half + cstep * pass;
     double hr[RC][4];
@@ -410,7 +457,7 @@ __device__ __forceinline__ void piece_penalty_part(const Penalty &pp_in, const d
     for (int r = 0; r < RC; ++r)
 #pragma unroll
       for (int q = 0; q < 4; ++q) hr[r][q] *= inv_mu;
-    const bool first = SPLIT ? (half == 1 && pass == 0) : (ch == 0);  // the pass that also evaluates the box rows
+    const bool first = LTAB ? false : (SPLIT ? (half == 1 && pass == 0) : (ch == 0));  // the pass that also evaluates the box rows
     // The table rows are scalar loads, a wave waited for each where it was used (~10^2 cycles, five times per sample, the
     // two waves of a SIMD in phase) and the compiler keeps such a load next to its use: the position row of the NEXT sample
     // is requested by hand at the top of the sample (tab_row_request: the compiler does not know it is in flight; it is
