@@ -23,6 +23,7 @@ PROTOTYPES = {
     "anet_create": (c_int, [c_int, POINTER(c_void_p)]),
     "anet_destroy": (None, [c_void_p]),
     "anet_last_error": (c_char_p, [c_void_p]),
+    "anet_compute_units": (c_int, [c_void_p]),
     "anet_stream": (c_void_p, [c_void_p]),
     "anet_synchronize": (c_int, [c_void_p]),
     "anet_recommended_ld": (c_int64, [c_int64]),
@@ -61,6 +62,7 @@ PROTOTYPES = {
     "anet_minco_propagate_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "anet_minco_cost_grad_workspace": (c_int64, [c_int, c_int, c_int64]),
+    "anet_minco_cost_grad_launches": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p]),
     "anet_minco_cost_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64] + [c_void_p] * 12),
     "anet_minco_cost_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_int64] + [c_void_p] * 10),
     "anet_qp_dims_of": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p]),

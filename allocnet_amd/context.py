@@ -20,6 +20,11 @@ class Context:
     def check(self, rc):
         _lib.check(self.handle, rc)
 
+    @property
+    def compute_units(self):
+        """anet_compute_units: the device's compute units, which every launch-shape threshold of the library scales with."""
+        return int(self.lib.anet_compute_units(self.handle))
+
     def synchronize(self):
         self.check(self.lib.anet_synchronize(self.handle))
 

@@ -34,6 +34,10 @@
 // ------------------------------------------------------------------------------------------
 struct anet_ctx {
   int device = -1;
+  // compute units of the device (hipDeviceAttributeMultiprocessorCount, read once in anet_create): every launch-shape threshold
+  // below was measured on the 256 CUs of an MI355X in SPX mode and is scaled by cus / 256 (per_cu()), so that a partitioned
+  // compute mode (CPX: 32 CUs per logical device) or another part picks its shapes by rounds of workgroups per CU, not by literals
+  int cus = 256;
   hipStream_t stream = nullptr;
   std::string err;
   // grow-only device scratch for the host (trajectory-major) entry points
@@ -130,6 +134,9 @@ int ensure_scratch(anet_ctx *ctx, size_t bytes) {
 
 inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// a batch / group-count threshold measured on 256 compute units, for this context's device
+inline int64_t per_cu(const anet_ctx *ctx, int64_t at_256_cus) { return at_256_cus * (int64_t)ctx->cus / 256; }
+
 // Per-context tables (basis rows of k_piece_grad per (order, res); tables of k_qp_ipm per (order, res, m34)) live until
 // anet_destroy; their number is bounded, and a table whose build fails half-way is released, not leaked.
 constexpr size_t kMaxTablesPerContext = 256;
@@ -163,12 +170,12 @@ constexpr double kWideSpread = 50.0;
 // once); measured crossover on MI355X in DESIGN.md section 4.
 constexpr int64_t kPieceSampleSplitMaxPairs = 16384;  // (trajectory, piece) pairs up to which k_piece_grad splits the samples over waves
 constexpr int64_t kAxisVariantMaxBatchDefault = 16384;
-inline int64_t axis_variant_max_batch() {  // ANET_AXIS_MAX_BATCH overrides (tuning / A-B runs)
+inline int64_t axis_variant_max_batch(const anet_ctx *ctx) {  // ANET_AXIS_MAX_BATCH overrides (tuning / A-B runs)
   static const int64_t v = [] {
     const char *e = getenv("ANET_AXIS_MAX_BATCH");
-    return e ? (int64_t)atoll(e) : kAxisVariantMaxBatchDefault;
+    return e ? (int64_t)atoll(e) : (int64_t)-1;
   }();
-  return v;
+  return v >= 0 ? v : per_cu(ctx, kAxisVariantMaxBatchDefault);
 }
 
 template <int S>
@@ -176,11 +183,12 @@ int launch_solve(anet_ctx *ctx, const anet::SolveArgs &a, hipStream_t st) {
   const dim3 grid((unsigned)((a.B + anet::kSolveBlock - 1) / anet::kSolveBlock));
   const dim3 block(anet::kSolveBlock);
   // small batches: lane per (trajectory, axis) -- three times the waves, ~2.4x shorter dependent chains
-  if (a.B <= axis_variant_max_batch()) {
+  if (a.B <= axis_variant_max_batch(ctx)) {
     const dim3 g3((unsigned)((a.B + 20) / 21));
     bool done = true;
     // (exact shapes with an even number of pieces, batches that leave SIMDs empty: the chain from both ends, two lanes per axis)
-    static const int64_t two_max = [] { const char *e = getenv("ANET_AXIS_TWO_MAX_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+    static const int64_t two_env = [] { const char *e = getenv("ANET_AXIS_TWO_MAX_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
+    const int64_t two_max = two_env >= 0 ? two_env : per_cu(ctx, 4096);
     const dim3 g6((unsigned)((a.B + 9) / 10));
     if (a.B <= two_max && a.c == 3 && ((S == 4 && a.N == 8) || (S == 3 && a.N == 16))) {
       if constexpr (S == 4) hipLaunchKernelGGL((anet::k_minco_solve_axis_two<4, 8, 2>), g6, block, 0, st, a);
@@ -276,7 +284,7 @@ template <int S>
 int launch_prop(anet_ctx *ctx, const anet::PropArgs &a, hipStream_t st) {
   const dim3 grid((unsigned)((a.B + anet::kSolveBlock - 1) / anet::kSolveBlock));
   const dim3 block(anet::kSolveBlock);
-  if (a.B <= axis_variant_max_batch()) {  // same small-batch split as launch_solve
+  if (a.B <= axis_variant_max_batch(ctx)) {  // same small-batch split as launch_solve
     const dim3 g3((unsigned)((a.B + 20) / 21));
     anet::launch_propagate_axis(S, a, g3, block, st);  // (piece_grad_unit.hip: scheduled for ILP)
     ANET_HIP(ctx, hipGetLastError());
@@ -507,6 +515,8 @@ int anet_device_count(void) {
   return n;
 }
 
+int anet_compute_units(const anet_ctx *ctx) { return ctx ? ctx->cus : 0; }
+
 int anet_create(int device, anet_ctx **out) {
   if (!out) return fail(nullptr, ANET_ERR_INVALID, "anet_create: out is NULL");
   *out = nullptr;
@@ -521,6 +531,11 @@ int anet_create(int device, anet_ctx **out) {
   ctx->device = device;
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    int cus = 0;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (e == hipSuccess && cus > 0) ctx->cus = cus;
+  }
   if (e != hipSuccess) {
     int rc = hip_fail(nullptr, e, "anet_create");
     delete ctx;
@@ -1043,12 +1058,13 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
   const double *tab = nullptr;
   if (pen && (rc = basis_table(ctx, s, pen->res, st, &tab))) return rc;
   // ANET_PIECE_SW_MAX_PAIRS overrides (tuning / A-B runs)
-  static const int64_t sw_max_pairs = [] { const char *e = getenv("ANET_PIECE_SW_MAX_PAIRS"); return e ? (int64_t)atoll(e) : kPieceSampleSplitMaxPairs; }();
-  if (pen && batch <= axis_variant_max_batch() && batch * n_pieces <= sw_max_pairs) {
+  static const int64_t sw_env = [] { const char *e = getenv("ANET_PIECE_SW_MAX_PAIRS"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
+  const int64_t sw_max_pairs = sw_env >= 0 ? sw_env : per_cu(ctx, kPieceSampleSplitMaxPairs);
+  if (pen && batch <= axis_variant_max_batch(ctx) && batch * n_pieces <= sw_max_pairs) {
     // fewest waves: two lanes per (trajectory, piece) AND the samples spread over the four waves of a workgroup
     const dim3 g4((unsigned)((2 * batch + 63) / 64), (unsigned)n_pieces);
     anet::launch_piece_grad(s, 2, g4, block, st, a, tab);
-  } else if (pen && batch <= axis_variant_max_batch()) {  // small batches: two lanes per (trajectory, piece)
+  } else if (pen && batch <= axis_variant_max_batch(ctx)) {  // small batches: two lanes per (trajectory, piece)
     const dim3 g2((unsigned)((2 * batch + 255) / 256), (unsigned)n_pieces);
     anet::launch_piece_grad(s, 1, g2, block, st, a, tab);
   } else {
@@ -1077,6 +1093,19 @@ int64_t anet_minco_cost_grad_workspace(int s, int n_pieces, int64_t ld) {
   return ((int64_t)n_pieces * 3 * 2 * s * 2 + 2 * (int64_t)n_pieces + 1) * ld;
 }
 
+// Does this evaluation run as ONE launch (k_minco_cost_grad_fused) or as solve -> piece gradients -> adjoint?
+static bool cost_grad_in_one_launch(const anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen) {
+  // Small batches in ONE launch (minco_fused_kernel.h): up to THREE rounds of one workgroup per CU for problems of up to eight pieces,
+  // two rounds for longer ones (measured with the chains eliminated from both ends, one launch against three: 8192 x 8-seg snap 54.0
+  // against 64.9 us, 12000: 79.5 / 83.8, 16384 = four rounds: 105.5 / 102.4 -- not taken; 4096 x 16-seg jerk 51.8 / 61.0, 2500: 48.7 /
+  // 59.3) -- beyond that the three streaming kernels have the chip full anyway and are the better shape
+  // (ANET_FUSED_MAX_GROUPS overrides; 0 disables).
+  static const int64_t fused_groups_env = [] { const char *e = getenv("ANET_FUSED_MAX_GROUPS"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
+  const int64_t fused_max_groups = fused_groups_env >= 0 ? fused_groups_env : (n_pieces <= 8 ? 3 : 2) * (int64_t)ctx->cus;
+  const int fg = pen ? anet::cost_grad_fused_group(s, n_pieces) : 0;
+  return fg > 0 && (batch + fg - 1) / fg <= fused_max_groups && pen->res <= anet::kFusedMaxRes;
+}
+
 // tau != nullptr: the durations are T = forward_T(tau) and gradT is returned as dJ/dtau (L-BFGS driver)
 static int cost_grad_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                               const double *head, const double *tail, const double *wps,
@@ -1090,15 +1119,7 @@ static int cost_grad_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t
   if (batch == 0) return ANET_OK;
   if (!work || !cost || !gradT || (n_pieces > 1 && !gradP))
     return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad_dev: NULL output or workspace");
-  // Small batches in ONE launch (minco_fused_kernel.h): up to THREE rounds of one workgroup per CU for problems of up to eight pieces,
-  // two rounds for longer ones (measured with the chains eliminated from both ends, one launch against three: 8192 x 8-seg snap 54.0
-  // against 64.9 us, 12000: 79.5 / 83.8, 16384 = four rounds: 105.5 / 102.4 -- not taken; 4096 x 16-seg jerk 51.8 / 61.0, 2500: 48.7 /
-  // 59.3) -- beyond that the three streaming kernels have the chip full anyway and are the better shape
-  // (ANET_FUSED_MAX_GROUPS overrides; 0 disables).
-  static const int64_t fused_groups_env = [] { const char *e = getenv("ANET_FUSED_MAX_GROUPS"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
-  const int64_t fused_max_groups = fused_groups_env >= 0 ? fused_groups_env : (n_pieces <= 8 ? 768 : 512);
-  const int fg = pen ? anet::cost_grad_fused_group(s, n_pieces) : 0;
-  if (fg > 0 && (batch + fg - 1) / fg <= fused_max_groups && pen->res <= anet::kFusedMaxRes) {
+  if (cost_grad_in_one_launch(ctx, s, n_pieces, batch, pen)) {
     if (!head || !tail || !T || (n_pieces > 1 && !wps) || ld < batch)
       return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad_dev: NULL input or ld < batch");
     const double *tab = nullptr;
@@ -1111,7 +1132,7 @@ static int cost_grad_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t
     if (!d_fprof) ANET_HIP(ctx, hipMalloc((void **)&d_fprof, 16 * sizeof(long long)));
     fa.prof = d_fprof;
 #endif
-    if (anet::launch_cost_grad_fused(s, fa, tab, (hipStream_t)stream, fused_max_groups)) {
+    if (anet::launch_cost_grad_fused(s, fa, tab, (hipStream_t)stream, ctx->cus)) {
       ANET_HIP(ctx, hipGetLastError());
 #ifdef ANET_FUSED_PROF
       if (getenv("ANET_FUSED_PROF_PRINT")) {
@@ -1142,6 +1163,13 @@ static int cost_grad_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t
   anet::PropArgs a{T, w_co, w_gdC, w_gdT, gradP, gradT, w_en, pen ? w_pc : nullptr, cost,
                    pen ? pen->rho : 0.0, batch, ld, n_pieces, c, tau};
   return do_propagate(ctx, s, a, (hipStream_t)stream);
+}
+
+int anet_minco_cost_grad_launches(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen) {
+  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  if (s < 2 || s > 4 || n_pieces < 1 || n_pieces > ANET_MAX_PIECES || batch < 0)
+    return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad_launches: bad shape");
+  return cost_grad_in_one_launch(ctx, s, n_pieces, batch, pen) ? 1 : 3;
 }
 
 int anet_minco_cost_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
@@ -1369,13 +1397,26 @@ int anet_lbfgs_optimize_host(anet_ctx *ctx, int n, double *x, double *f, anet_lb
     return ANET_OK;
   }
   const int m = params->mem_size, npf = params->past > 1 ? params->past : 1;
-  // device: the optimiser's state (row stride 1: one problem) + f + the cancel word; host: g, xp, d
+  // device: the optimiser's state (row stride 1: one problem) + f + the cancel word; host: g, xp, d.  An allocation of THIS
+  // call, not the context's scratch: the callbacks run while the state is live and may call any host-staged entry point on
+  // the same context (anet_minco_cost_grad, anet_traj_*, another anet_lbfgs_optimize_host ...), which re-carve -- or free and
+  // re-allocate -- that scratch (lbfgs::lbfgs_optimize<V>, Piece and Trajectory all use Context::thread_default()).
   const int64_t wd = LbfgsLayout::doubles(n, m, npf, 1);
-  int rc = ensure_scratch(ctx, sizeof(double) * (size_t)(wd + 4));
-  if (rc) return rc;
+  struct OwnBuffer {
+    void *p = nullptr;
+    ~OwnBuffer() { if (p) (void)hipFree(p); }
+  } own;
+  {
+    hipError_t e = hipMalloc(&own.p, sizeof(double) * (size_t)(wd + 4));
+    if (e != hipSuccess) {
+      own.p = nullptr;
+      return fail(ctx, ANET_ERR_NOMEM, std::string("anet_lbfgs_optimize_host: hipMalloc: ") + hipGetErrorString(e));
+    }
+  }
+  int rc = ANET_OK;
   LbfgsLayout L{n, m, npf, 1};
-  L.carve((double *)ctx->scratch);
-  int *d_cancel = (int *)((double *)ctx->scratch + wd + 2);
+  L.carve((double *)own.p);
+  int *d_cancel = (int *)((double *)own.p + wd + 2);
   hipStream_t st = ctx->stream;
   std::vector<double> hg((size_t)n), hxp((size_t)n), hd((size_t)n);
   ANET_HIP(ctx, hipMemsetAsync(L.is, 0, sizeof(int) * anet::IS_COUNT_, st));
@@ -1388,6 +1429,9 @@ int anet_lbfgs_optimize_host(anet_ctx *ctx, int n, double *x, double *f, anet_lb
   a.host_sb = proc_stepbound ? 1 : 0;
   int his[anet::IS_COUNT_];
   double hds[anet::DS_COUNT_];
+  // sources of the small host-to-device copies below: they live until the stream is synchronised in tick()
+  double fv = 0.0, bound = 0.0;
+  int word = 0;
   auto tick = [&]() -> int {  // one launch of the state machine, then its state on the host
     hipLaunchKernelGGL(anet::k_lbfgs_update, dim3(1), dim3(64), 0, st, a);
     ANET_HIP(ctx, hipGetLastError());
@@ -1398,7 +1442,7 @@ int anet_lbfgs_optimize_host(anet_ctx *ctx, int n, double *x, double *f, anet_lb
   };
   for (;;) {
     // the point to evaluate is in L.x (the host's copy in x: the start point, or what the last tick left)
-    const double fv = proc_evaluate(instance, x, hg.data(), n);
+    fv = proc_evaluate(instance, x, hg.data(), n);
     ANET_HIP(ctx, hipMemcpyAsync(L.g, hg.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
     ANET_HIP(ctx, hipMemcpyAsync(L.feval, &fv, sizeof(double), hipMemcpyHostToDevice, st));
     if ((rc = tick())) return rc;
@@ -1406,14 +1450,14 @@ int anet_lbfgs_optimize_host(anet_ctx *ctx, int n, double *x, double *f, anet_lb
       if (his[anet::IS_PHASE] == anet::LB_PHASE_AWAIT_PROGRESS) {
         // lbfgs.hpp:580-587: x is the accepted point (the one just evaluated), g its gradient
         const int verdict = proc_progress(instance, x, hg.data(), hds[anet::DS_FX], hds[anet::DS_STEP], his[anet::IS_K], his[anet::IS_COUNT], n);
-        const int word = verdict ? 1 : 0;
+        word = verdict ? 1 : 0;
         ANET_HIP(ctx, hipMemcpyAsync(d_cancel, &word, sizeof(int), hipMemcpyHostToDevice, st));
       } else {
         // lbfgs.hpp:557-565: xp (= the current point) and the search direction
         ANET_HIP(ctx, hipMemcpyAsync(hxp.data(), L.xp, sizeof(double) * n, hipMemcpyDeviceToHost, st));
         ANET_HIP(ctx, hipMemcpyAsync(hd.data(), L.d, sizeof(double) * n, hipMemcpyDeviceToHost, st));
         ANET_HIP(ctx, hipStreamSynchronize(st));
-        const double bound = proc_stepbound(instance, hxp.data(), hd.data(), n);
+        bound = proc_stepbound(instance, hxp.data(), hd.data(), n);
         ANET_HIP(ctx, hipMemcpyAsync(L.ds + anet::DS_SMAX, &bound, sizeof(double), hipMemcpyHostToDevice, st));
       }
       if ((rc = tick())) return rc;
@@ -1635,7 +1679,10 @@ int anet_polytope_depth(anet_ctx *ctx, int64_t batch, int max_rows, const double
 
 // Thresholds of the two-launch form of the one-launch L-BFGS (lbfgs_minco_dev_impl; the environment overrides are for A/B runs)
 static int lbfgs_split_evals() { static const int v = [] { const char *e = getenv("ANET_LBFGS_SPLIT_EVALS"); return e ? atoi(e) : 1000; }(); return v; }
-static int64_t lbfgs_split_min_batch() { static const int64_t v = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)4096; }(); return v; }
+static int64_t lbfgs_split_min_batch(const anet_ctx *ctx) {  // (4096 problems on 256 CUs = twice the resident waves)
+  static const int64_t v = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
+  return v >= 0 ? v : per_cu(ctx, 4096);
+}
 static int lbfgs_split_min_vars() { static const int v = [] { const char *e = getenv("ANET_LBFGS_SPLIT_MIN_VARS"); return e ? atoi(e) : 36; }(); return v; }
 
 int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_lbfgs_params *params) {
@@ -1644,10 +1691,11 @@ int64_t anet_lbfgs_minco_workspace(int s, int n_pieces, int64_t ld, const anet_l
   const int npf = params->past > 1 ? params->past : 1;
   // L-BFGS state + cost/grad workspace + gradP + gradT ...
   int64_t w = LbfgsLayout::doubles(n, params->mem_size, npf, ld) + anet_minco_cost_grad_workspace(s, n_pieces, ld) + (int64_t)n * ld;
-  // ... then, only where the two-launch form of the one-launch shape can run (ld >= batch >= its minimum batch, enough
-  // variables: 12 KB per problem otherwise reserved for nothing), the parked optimisers, their scores and the order of the
-  // second launch (int32 each) and the bins of the counting sort
-  if (lbfgs_split_evals() > 1 && ld >= lbfgs_split_min_batch() && n >= lbfgs_split_min_vars())
+  // ... then, where the two-launch form of the one-launch shape can run (enough variables; whether a BATCH takes it is the
+  // context's decision -- lbfgs_minco_dev_impl, by the device's compute units -- and does not enter the size: a workspace of
+  // this size is enough for either form at any batch <= ld), the parked optimisers, their scores and the order of the second
+  // launch (int32 each) and the bins of the counting sort
+  if (lbfgs_split_evals() > 1 && n >= lbfgs_split_min_vars())
     w += (int64_t)anet::kPersistContDoubles * ld + ld + 2 + kOrderBuckets / 2;
   return w;
 }
@@ -1815,7 +1863,7 @@ static int lbfgs_minco_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64
     //  barrier for the whole batch, and what the better order of the third stage gains is less than what the second stage's own
     //  tail loses: configs[3] 136 -> 147 / 157 / 165 ms with the second boundary at 2000 / 2500 / 3000 evaluations)
     static const int split_evals2 = [] { const char *e = getenv("ANET_LBFGS_SPLIT_EVALS2"); return e ? atoi(e) : 0; }();
-    const int64_t split_min_batch = lbfgs_split_min_batch();
+    const int64_t split_min_batch = lbfgs_split_min_batch(ctx);
     // ... where it was measured to pay (tools/time_lbfgs_batch.py, 4096 problems unless noted, one launch -> two): 16 jerk pieces
     // 165 -> 140 ms (bench: 0.169 -> 0.133 s), 16 snap pieces 424 -> 389, 12 jerk pieces 107 -> 98, 10 jerk pieces 79 -> 77, 16 jerk
     // pieces x 8192 235 -> 216, x 16384 415 -> 403, x 3072 no change; 8 snap pieces 102 -> 100..109, 5 jerk pieces 23.5 -> 25, 5
@@ -2227,22 +2275,24 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     } prof_dump{ctx, d_iprof, sti};
 #endif
     // two workgroups per CU (registers bounded to 256) from this batch on, when two fit the LDS
-    static const int64_t ipm_two_per_cu_min_batch = [] {
+    static const int64_t two_per_cu_env = [] {
       const char *e = getenv("ANET_IPM_TWO_PER_CU_MIN_BATCH");
-      // more than two rounds of one workgroup per CU (256 CUs): below that a batch lasts as long as its slowest problem and
-      // a problem alone on its CU is faster (measured: 512 problems are a draw -- 2.86 / 1.88 / 2.95 ms against 2.64 / 1.63 /
-      // 3.42 ms for 8 snap / 5 jerk / 5 snap pieces --, 768 problems gain 15-20 % from two per CU, 320 lose 15 %)
-      return e ? (int64_t)atoll(e) : (int64_t)513;
+      return e ? (int64_t)atoll(e) : (int64_t)-1;
     }();
+    // more than two rounds of one workgroup per CU (measured on 256 CUs): below that a batch lasts as long as its slowest problem
+    // and a problem alone on its CU is faster (512 problems are a draw -- 2.86 / 1.88 / 2.95 ms against 2.64 / 1.63 /
+    // 3.42 ms for 8 snap / 5 jerk / 5 snap pieces --, 768 problems gain 15-20 % from two per CU, 320 lose 15 %)
+    const int64_t ipm_two_per_cu_min_batch = two_per_cu_env >= 0 ? two_per_cu_env : 2 * (int64_t)ctx->cus + 1;
     const bool two_per_cu = batch >= ipm_two_per_cu_min_batch && 2 * ldsb <= 160 * 1024;
     // ... and THREE for jerk problems whose LDS allows it, from a batch on that fills them several times over (registers bounded
     // to 168: 464 B of scratch).  Measured (round 5, same box, 5 jerk pieces): 4096 problems 3.96-4.00 -> 3.77-3.85 ms; 3000:
     // 3.02-3.07 -> 3.21-3.25; 2048: 2.09-2.12 -> 2.42-2.43 (1024: 1.60 -> 1.91 in round 4) -- selected by batch like every other
     // shape here (ANET_IPM_THREE_PER_CU_MIN_BATCH overrides; 0 disables)
-    static const int64_t ipm_three_per_cu_min_batch = [] {
+    static const int64_t three_per_cu_env = [] {
       const char *e = getenv("ANET_IPM_THREE_PER_CU_MIN_BATCH");
-      return e ? (int64_t)atoll(e) : (int64_t)4096;
+      return e ? (int64_t)atoll(e) : (int64_t)-1;
     }();
+    const int64_t ipm_three_per_cu_min_batch = three_per_cu_env >= 0 ? three_per_cu_env : per_cu(ctx, 4096);
     const bool three_per_cu = s == 3 && two_per_cu && ipm_three_per_cu_min_batch > 0 && batch >= ipm_three_per_cu_min_batch &&
                               3 * ldsb <= 160 * 1024;
     auto launch_ipm = [&](auto kern) -> int {
@@ -2259,7 +2309,8 @@ static int qp_solve_dev_impl(anet_ctx *ctx, int s, int n_pieces, int64_t batch, 
     // steps -- no tail: all workgroups are equally long --, the second resumes the unfinished ones longest-expected first.  A batch
     // of 4096 in one launch ends 27 % above its balanced figure because its 30..50-step problems start whenever their turn comes.
     static const int ipm_split_steps = [] { const char *e = getenv("ANET_IPM_SPLIT_STEPS"); return e ? atoi(e) : 4; }();
-    static const int64_t ipm_split_min_batch = [] { const char *e = getenv("ANET_IPM_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)576; }();  // (measured: 520..560 problems lose 7-10 %, 600..1280 gain 10-19 %)
+    static const int64_t ipm_split_env = [] { const char *e = getenv("ANET_IPM_SPLIT_MIN_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
+    const int64_t ipm_split_min_batch = ipm_split_env >= 0 ? ipm_split_env : per_cu(ctx, 576);  // (256 CUs: 520..560 problems lose 7-10 %, 600..1280 gain 10-19 %)
     if (two_per_cu && ipm_split_steps > 0 && batch >= ipm_split_min_batch && !launch_order && ia.max_iter > ipm_split_steps) {
       const int ny = 3 * s * (n_pieces + 1);
       const int64_t m_adm = 3 * (6 + (int64_t)s * (n_pieces - 1)) + mi;

@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
 }
 
 // false: no instantiation for this shape (the caller takes the three-launch path)
-bool launch_cost_grad_fused(int s, const FusedArgs &a, const double *tab, hipStream_t st, int64_t max_groups);
+bool launch_cost_grad_fused(int s, const FusedArgs &a, const double *tab, hipStream_t st, int cus);
 int cost_grad_fused_group(int s, int n_pieces);  // trajectories per workgroup of the instantiation that would run (0: none)
 
 }  // namespace anet

@@ -51,14 +51,14 @@ void launch_propagate_axis(int s, const PropArgs &a, dim3 grid, dim3 block, hipS
 
 // ---- the one-launch evaluation of small batches (minco_fused_kernel.h) ----------------------------------------------------------
 template <int S, int NB, bool NEXACT, int NPC>
-static void launch_fused_t(const FusedArgs &a_in, const double *tab, hipStream_t st, int64_t max_groups) {
+static void launch_fused_t(const FusedArgs &a_in, const double *tab, hipStream_t st, int cus) {
   constexpr int GM = FusedShape<NB>::G;
   FusedArgs a = a_in;
-  // the largest group that still gives (nearly) every CU a workgroup (256 CUs); what the group gives up, the samples split takes
-  (void)max_groups;
+  // the largest group that still gives (nearly) every CU a workgroup (`cus` = the device's compute units: 256 on an MI355X in
+  // SPX mode); what the group gives up, the samples split takes
   int G = GM;
   // (and at most 16 lane pairs per piece: their partial sums are added by ONE lane, in order)
-  while (G > 1 && (a.B + G / 2 - 1) / (G / 2) <= 256 && (G / 2) * NB >= 8) G /= 2;
+  while (G > 1 && (a.B + G / 2 - 1) / (G / 2) <= cus && (G / 2) * NB >= 8) G /= 2;
   a.G = G;
   const dim3 grid((unsigned)((a.B + G - 1) / G));
   hipLaunchKernelGGL((k_minco_cost_grad_fused<S, NB, NEXACT, NPC>), grid, dim3(256), 0, st, a, tab);
@@ -71,19 +71,19 @@ int cost_grad_fused_group(int s, int n_pieces) {
   return 0;
 }
 
-bool launch_cost_grad_fused(int s, const FusedArgs &a, const double *tab, hipStream_t st, int64_t max_groups) {
+bool launch_cost_grad_fused(int s, const FusedArgs &a, const double *tab, hipStream_t st, int cus) {
   if (s == 4) {
-    if (a.N == 8 && a.c == 3) launch_fused_t<4, 8, true, 2>(a, tab, st, max_groups);
-    else if (a.N == 1) launch_fused_t<4, 1, false, -1>(a, tab, st, max_groups);  // (one piece: no halves to walk from both ends)
-    else if (a.N <= 8) launch_fused_t<4, 8, false, -1>(a, tab, st, max_groups);
+    if (a.N == 8 && a.c == 3) launch_fused_t<4, 8, true, 2>(a, tab, st, cus);
+    else if (a.N == 1) launch_fused_t<4, 1, false, -1>(a, tab, st, cus);  // (one piece: no halves to walk from both ends)
+    else if (a.N <= 8) launch_fused_t<4, 8, false, -1>(a, tab, st, cus);
     else return false;
     return true;
   }
   if (s == 3) {
-    if (a.N == 16 && a.c == 3) launch_fused_t<3, 16, true, 2>(a, tab, st, max_groups);
-    else if (a.N == 1) launch_fused_t<3, 1, false, -1>(a, tab, st, max_groups);
-    else if (a.N <= 8) launch_fused_t<3, 8, false, -1>(a, tab, st, max_groups);
-    else if (a.N <= 16) launch_fused_t<3, 16, false, -1>(a, tab, st, max_groups);
+    if (a.N == 16 && a.c == 3) launch_fused_t<3, 16, true, 2>(a, tab, st, cus);
+    else if (a.N == 1) launch_fused_t<3, 1, false, -1>(a, tab, st, cus);
+    else if (a.N <= 8) launch_fused_t<3, 8, false, -1>(a, tab, st, cus);
+    else if (a.N <= 16) launch_fused_t<3, 16, false, -1>(a, tab, st, cus);
     else return false;
     return true;
   }

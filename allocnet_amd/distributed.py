@@ -48,6 +48,43 @@ def allgather_costs(local_costs, total, group=None, out=None):
     return res
 
 
+def pack_cost_status(costs, status, m):
+    """One send buffer of a rank for allgather_costs_status: m float64 costs followed by m int32 status words in the bytes of
+    (m + 1) // 2 more float64 slots (SURVEY 8(e): "fuse status + cost into one buffer" -- the collective is latency-bound, so one
+    all-gather of 12 B per trajectory costs what one of 8 B does and saves the second one whole)."""
+    import torch
+    n = costs.numel()
+    buf = torch.zeros(m + (m + 1) // 2, dtype=torch.float64, device=costs.device)
+    buf[:n] = costs
+    buf[m:].view(torch.int32)[:n] = status.to(torch.int32)
+    return buf
+
+
+def allgather_costs_status(local_costs, local_status, total, group=None):
+    """allgather_costs for a solver that also returns a status per trajectory (the L-BFGS: lbfgs_optimize's return code;
+    the QP: OSQP's status): ONE all_gather_into_tensor of the packed buffers, unpacked into global trajectory order.
+    -> (costs float64 [total], status int32 [total])."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(total, world, rank)
+    if local_costs.numel() != hi - lo or local_status.numel() != hi - lo:
+        raise ValueError(f"rank {rank} holds {local_costs.numel()} costs / {local_status.numel()} status words, expected {hi - lo}")
+    m = max_shard(total, world)
+    w = m + (m + 1) // 2
+    send = pack_cost_status(local_costs, local_status, m)
+    gathered = torch.empty(world * w, dtype=torch.float64, device=local_costs.device)
+    dist.all_gather_into_tensor(gathered, send, group=group)
+    costs = torch.empty(total, dtype=torch.float64, device=local_costs.device)
+    status = torch.empty(total, dtype=torch.int32, device=local_costs.device)
+    for r in range(world):
+        a, b = shard_bounds(total, world, r)
+        costs[a:b] = gathered[r * w:r * w + (b - a)]
+        status[a:b] = gathered[r * w + m:(r + 1) * w].view(torch.int32)[:b - a]
+    return costs, status
+
+
 class NativeComm:
     """RCCL communicator owned by an allocnet_amd Context (anet_comm_*): the all-gather of costs for
     hosts that do not run torch.distributed.  The 128-byte unique id made by rank 0 must reach the other

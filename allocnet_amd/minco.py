@@ -265,6 +265,17 @@ def _tptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def minco_cost_grad_launches(s, N, B, penalty=None, ctx=None):
+    """anet_minco_cost_grad_launches: 1 if a cost + gradient evaluation of this shape runs as ONE launch
+    (k_minco_cost_grad_fused) on this context's device, 3 for solve -> piece gradients -> adjoint."""
+    ctx = ctx or default_context(0)
+    n = ctx.lib.anet_minco_cost_grad_launches(ctx.handle, s, N, B, ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p)
+                                              if penalty is not None else None)
+    if n < 0:
+        ctx.check(n)
+    return n
+
+
 def minco_cost_grad_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, work=None, cost=None,
                         gradP=None, gradT=None, coeffs=None, stream=None, ctx=None):
     """Device entry point -> anet_minco_cost_grad_dev (torch CUDA float64, batch-minor, common ld)."""

@@ -67,6 +67,35 @@ def pmc_traffic_bytes(B, N, s):
     return best
 
 
+def pmc_leg_traffic(leg, picks, tag=None):
+    """HBM bytes per step of one leg from the committed rocprofv3 PMC passes of THAT leg (tools/profile_leg.sh runs
+    `bench.py --workload <leg> --main-only` under `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs and
+    tools/summarize_leg.py writes profiles/<round>_<leg>_pmc.json: per (kernel, grid) the mean KiB per launch): the sum over
+    `picks` = [(kernel-name substring, grid or None, launches per step)] of launches x (WRITE_SIZE + 2 x FETCH_SIZE) x 1024 (gfx950's
+    FETCH_SIZE counts half of a coalesced read stream, MI355X_MICROARCH.md, HBM section).  The newest file wins; None when a
+    pick has no entry (no profile of this leg committed, or the launch shape changed since)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{leg}_pmc.json")))
+    if tag:
+        files = [f for f in files if os.path.basename(f).startswith(tag + "_")]
+    for f in reversed(files):
+        try:
+            kernels = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        total = 0.0
+        for sub, grid, per_step in picks:
+            hits = [k for k in kernels if sub in k["name"] and (grid is None or k["grid"] == grid)
+                    and k.get("fetch_kib") is not None and k.get("write_kib") is not None]
+            if len(hits) != 1:
+                total = None
+                break
+            total += per_step * (2.0 * hits[0]["fetch_kib"] + hits[0]["write_kib"]) * 1024.0
+        if total is not None:
+            return total
+    return None
+
+
 def config5_bytes(s, c, N, M):
     """compulsory bytes of one cost + gradient evaluation per trajectory: the energy-only figure plus
     the corridor rows 8*4*sum(M_i) and the gradient outputs 8*(N + 3(N-1)) (6248 B at N = 8, s = 4, M = 16)."""
@@ -128,13 +157,25 @@ def lbfgs_update_flops(n, m):
     return 4 * m * n * 2 + 10 * n * 2
 
 
-def fp64_roofline(flops_per_launch, seconds, hbm_bytes_per_launch, kernel):
+def fp64_roofline(flops_per_launch, seconds, hbm_bytes_per_launch, kernel, traffic=None):
     ach = flops_per_launch / seconds / 1e12
     hb = hbm_bytes_per_launch / seconds / 1e9
-    # (FLOPs: analytic, data-independent -- cost_grad_flops; "hbm": SURVEY 8(d)'s compulsory bytes over the same time)
+    # (FLOPs: analytic, data-independent -- cost_grad_flops; "hbm": SURVEY 8(d)'s compulsory bytes over the same time;
+    #  "traffic": HBM bytes per step from the committed PMC passes of this leg, pmc_leg_traffic -- a constant of the tree)
     return {"bound": "fp64", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-            "traffic": None, "kernel": kernel,
-            "hbm": {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS}}
+            "traffic": traffic, "kernel": kernel,
+            "hbm": {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS,
+                    "traffic_over_algorithmic": (traffic / hbm_bytes_per_launch) if traffic else None}}
+
+
+COST_GRAD_KERNELS = {1: "k_minco_cost_grad_fused", 3: "k_piece_grad (+ k_minco_solve, k_minco_propagate)"}
+
+
+def cost_grad_picks(launches):
+    """the kernels of one cost + gradient evaluation as pmc_leg_traffic picks"""
+    if launches == 1:
+        return [("k_minco_cost_grad_fused", None, 1)]
+    return [("k_minco_solve<", None, 1), ("k_piece_grad<", None, 1), ("k_minco_propagate<", None, 1)]
 
 
 PEN = dict(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20)
@@ -217,10 +258,12 @@ def cost_grad_kernel_split(torch, aa, ctx, s, c, N, B, ld, th, tt, tw, tT, thp, 
     return {n: 1e3 * sum(ev[i].elapsed_time(ev[i + 1]) for ev in evs) / K for i, n in enumerate(names)}
 
 
-def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
+def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds, split=True):
     """BASELINE configs[2] (SURVEY 8(d) "config 3"): B = 4096 x 8-segment min-snap, corridor (M = 16) + limit penalties,
-    gradients w.r.t. waypoints and durations, seed 1.  One step = one cost + gradient evaluation of the whole batch
-    (k_minco_solve -> k_piece_grad -> k_minco_propagate), timed with events on the launch stream."""
+    gradients w.r.t. waypoints and durations, seed 1.  One step = one cost + gradient evaluation of the whole batch -- ONE
+    launch (k_minco_cost_grad_fused) at the literal batch, k_minco_solve -> k_piece_grad -> k_minco_propagate at the saturating
+    one; the line names the kernel that ran (anet_minco_cost_grad_launches) -- timed with events on the launch stream.
+    `split`: also time the three streaming launches one by one on the same buffers (never under a profiler: `--main-only`)."""
     import numpy as np
     from allocnet_amd.synth import corridor_problem
     s, c, N, M = 4, 3, 8, 16
@@ -250,15 +293,20 @@ def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
         if key == "b4096":
             torch.cuda.synchronize()
             snap = (cost[:B].cpu().numpy(), gT[:, :B].cpu().numpy().T.copy(), gP[:, :B].cpu().numpy().T.copy())
-        gP2, gT2 = torch.empty_like(gP), torch.empty_like(gT)
         # (timing: 5 repetitions of K back-to-back evaluations after >= 10 ms of warm-up and, for the small batch, a burst of 450
         #  evaluations that takes the runtime's one-off launch-backlog stall; median repetition: DESIGN.md section 7)
+        launches = aa.minco_cost_grad_launches(s, N, B, penalty=pen, ctx=ctx)
         out[key] = {"batch": B, "ms_per_step": dt * 1e3, "stream_ms_per_step": kms, "value": B / dt,
-                    "stream_ms_min_median_max": [st_ms[0], kms, st_ms[-1]],
-                    "kernel_split_us": cost_grad_kernel_split(torch, aa, ctx, s, c, N, B, ld, th, tt, tw, tT, thp, pen, work, gP2, gT2),
-                    "roofline": fp64_roofline(B * flops, kms * 1e-3, B * ab,
-                                              "k_piece_grad (+ k_minco_solve, k_minco_propagate)")}
-        del gP2, gT2
+                    "stream_ms_min_median_max": [st_ms[0], kms, st_ms[-1]], "launches_per_step": launches,
+                    "roofline": fp64_roofline(B * flops, kms * 1e-3, B * ab, COST_GRAD_KERNELS[launches],
+                                              traffic=pmc_leg_traffic("config3", cost_grad_picks(launches)))}
+        if split:
+            # the three streaming launches one by one (at a one-launch batch this is NOT what the step above ran: it is the
+            # path the one launch replaces, reported under a name that says so)
+            gP2, gT2 = torch.empty_like(gP), torch.empty_like(gT)
+            out[key]["kernel_split_us" if launches == 3 else "three_launch_split_us"] = cost_grad_kernel_split(
+                torch, aa, ctx, s, c, N, B, ld, th, tt, tw, tT, thp, pen, work, gP2, gT2)
+            del gP2, gT2
     out["flops_per_evaluation"] = flops
     out["algorithmic_bytes_per_trajectory"] = ab
     gpu_cost, gpu_gT, gpu_gP = snap
@@ -298,7 +346,7 @@ def qp_newton_step_flops(s, N, M, res):
     return passes + states + assembly + chol
 
 
-def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
+def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds, extras=True):
     """The reference's ONLINE solve (SURVEY 8(a) a6 / 8(f)2): the inequality QP QPSolver::solve hands to OSQP
     (planner/qp_solver.hpp:119-358) -- corridor rows and velocity / acceleration boxes at `res` samples per piece -- for
     4096 problems in one launch of k_qp_ipm (interior point; one workgroup per problem), inputs resident, events on the
@@ -340,8 +388,13 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
                     # (FLOPs: analytic per Newton step, qp_newton_step_flops, x the steps taken; the kernel is latency-bound --
                     #  block-Cholesky chains and row passes of one 256-thread workgroup per problem: DESIGN.md 8b)
                     "ms_reps": reps_ms, "infeasible_frac": float((r["status"] == -3).double().mean()),
+                    # (traffic: slacks and multipliers live in global memory -- L2-resident while a problem runs --, everything else in
+                    #  LDS and registers; two launches per batch: Newton steps 1-4 of every problem, then the unfinished ones)
                     "roofline": {"bound": "fp64", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": ach / FP64_PEAK_TFLOPS, "traffic": None, "kernel": "k_qp_ipm"}}
+                                 "frac": ach / FP64_PEAK_TFLOPS, "kernel": "k_qp_ipm",
+                                 "traffic": pmc_leg_traffic("qp", [(f"k_qp_ipm<{s},", None, 2)])}}
+        if not extras:
+            continue
         # the same batch with a launch order (anet_qp_solve_ordered_dev: a re-solve of the same / a similar batch): longest first by
         # this batch's own step counts, and by the counts of a PERTURBED copy (durations x U(0.97, 1.03)) -- what a receding-horizon
         # re-solve has.  Beside the as-given number, never instead of it.
@@ -362,8 +415,8 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
         if key == "snap8":
             out[key]["gpu_obj"] = r["obj"].cpu().numpy()
             out[key]["gpu_status"] = r["status"].cpu().numpy()
-    gpu_obj, gpu_status = out["snap8"].pop("gpu_obj"), out["snap8"].pop("gpu_status")
-    if cpu_baseline:
+    gpu_obj, gpu_status = out["snap8"].pop("gpu_obj", None), out["snap8"].pop("gpu_status", None)
+    if cpu_baseline and extras:
         # dense Mehrotra interior point in numpy / LAPACK (oracle/qp_np.py) on the reference's assembled Q, A, b, G, h
         from oracle import qp_np, minco_np as onp
         s, N, M, state, T, hp = host
@@ -458,7 +511,8 @@ def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
     ld = aa.recommended_ld(B)
     cap = 40000                                     # a cap, not the stop: every problem must end with its own status
     th, tt, tw, tT, thp = (_to_bm(torch, x, B, ld, device) for x in (head, tail, wps, T, hp))
-    aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, param=prm, max_evals=50, ctx=ctx)   # warm-up
+    # warm-up: one whole run (the same launches as the timed ones, so a profile of this leg holds only one launch shape)
+    aa.lbfgs_minco_dev(th, tt, tw, tT, s, c, N, B, hpolys=thp, penalty=pen, param=prm, max_evals=cap, ctx=ctx)
     secs = []
     for rep in range(2):
         th, tt, tw, tT = (_to_bm(torch, x, B, ld, device) for x in (head, tail, wps, T))
@@ -484,7 +538,9 @@ def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
            "evals_max": int(ev.max()), "evaluations_per_s": float(ev.sum()) / dt,
            "status_hist": {str(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))},
            "cost_final_mean": float(cf.mean()), "flops_per_evaluation": cost_grad_flops(s, N, M, PEN["res"]),
-           "roofline": fp64_roofline(flops, kdt, ab, "k_lbfgs_minco_persistent")}
+           # (traffic: two launches per run -- 1000 evaluations of every problem, then the unfinished ones: DESIGN.md 5)
+           "roofline": fp64_roofline(flops, kdt, ab, "k_lbfgs_minco_persistent",
+                                     traffic=pmc_leg_traffic("config4", [("k_lbfgs_minco_persistent<", None, 2)]))}
     # (run time = the LAST problem to stop, so the fraction mixes kernel quality with the spread of the evaluation counts)
     if cpu_baseline:
         from oracle import cbind
@@ -591,11 +647,18 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
     if os.environ.get("ANET_BENCH_DEBUG"):
         print("config5 per-step event ms:", ["%.3f" % a.elapsed_time(b) for a, b in ev], file=sys.stderr)
     ab = config5_bytes(s, c, N, M)
-    roof = fp64_roofline(B * cost_grad_flops(s, N, M, 20), kernel_ms * 1e-3, B * ab,
-                         "k_piece_grad (+ k_minco_solve, k_minco_propagate)")
+    launches = aa.minco_cost_grad_launches(s, N, B, penalty=pen, ctx=ctx)
+    # (traffic: the committed PMC passes are of the one-rank shard, 32768 trajectories; another shard size has no entry)
+    roof = fp64_roofline(B * cost_grad_flops(s, N, M, 20), kernel_ms * 1e-3, B * ab, COST_GRAD_KERNELS[launches],
+                         traffic=pmc_leg_traffic("config5", cost_grad_picks(launches)) if B == total == 32768 else None)
     roof.update(kernel_ms=kernel_ms, algorithmic_bytes_per_trajectory=ab, flops_per_evaluation=cost_grad_flops(s, N, M, 20))
+    ms_step = elapsed / steps * 1e3
     return {"value": total * steps / elapsed, "unit": "trajectory cost+gradient evaluations/s", "total_batch": total,
-            "batch_this_rank": B, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kernel_ms, "steps": steps,
+            "batch_this_rank": B, "ms_per_step": ms_step, "kernel_ms": kernel_ms, "steps": steps,
+            # shard_ms: this rank's evaluation alone (events around it, mean over the timed steps); exposed_allgather_ms: what a
+            # step costs beyond it -- the copy into the send slot, the collective's issue and whatever of it the next
+            # evaluation does not hide (the max over ranks of the step time against THIS rank's compute)
+            "shard_ms": kernel_ms, "exposed_allgather_ms": max(0.0, ms_step - kernel_ms), "launches_per_step": launches,
             "scaling": "strong", "pieces": N, "order": s, "poly_rows": M, "res": 20, "retimed_after_runtime_stall": retimed,
             "penalty_active_frac": float((cost[:B] > 0).double().mean().item()),
             "allgather": allgather_probe(torch, dist, og, device, use_dist), "roofline": roof}
@@ -603,10 +666,11 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
 
 def time_steps(torch, dist, use_dist, device, steps, run_step, sync):
     """Time EXACTLY `steps` calls of run_step(i, (event0, event1)) followed by sync() with the host clock -> (seconds, events of
-    the timed pass, retimed).  The HIP runtime blocks the host ONCE per process for 20-60 ms at some launch (absorb_runtime_stall
+    the timed pass, the discarded pass's figures or None).  The HIP runtime blocks the host ONCE per process for 20-60 ms at some launch (absorb_runtime_stall
     below makes it happen early, and mostly succeeds); when it still lands in this loop -- the wall time is then more than twice
     what the per-step HIP events say plus 10 ms -- the pass is discarded and the same `steps` steps are timed again, once (the
-    stall never comes twice), and the line says so (`retimed_after_runtime_stall`).  All ranks decide together."""
+    stall never comes twice), and the line says so AND carries the discarded pass's own figures (`retimed_after_runtime_stall`:
+    null, or {ms_per_step, event_ms_max_step, event_ms_median_step} of the pass that was thrown away).  All ranks decide together."""
     def one_pass():
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
@@ -621,13 +685,17 @@ def time_steps(torch, dist, use_dist, device, steps, run_step, sync):
         f = torch.tensor([1.0 if stalled else 0.0], device=device, dtype=torch.float64)
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
         stalled = bool(f.item() > 0.0)
+    discarded = None
     if stalled:
+        # what is thrown away is reported, so that a systematic slowness (a collective that blocks the host, say) cannot hide
+        # behind the re-timing: its wall time per step, the largest single step by the events, the median step by the events
+        discarded = {"ms_per_step": elapsed / steps * 1e3, "event_ms_max_step": per[-1], "event_ms_median_step": per[len(per) // 2]}
         elapsed, ev = one_pass()
     if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, ev, stalled
+    return elapsed, ev, discarded
 
 
 def absorb_runtime_stall(torch, aa, ctx, device, launches=1400):
@@ -776,8 +844,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--allgather-every", type=int, default=1,
                     help="issue the all-gather of the costs every k-th step only (N > 1; default 1 = every step, the north star)")
-    ap.add_argument("--workload", choices=("solve", "config5"), default="solve",
-                    help="solve: the headline (configs[1] problem at a saturating batch); config5: BASELINE configs[4]")
+    ap.add_argument("--workload", choices=("solve", "config5", "config3", "config4", "qp"), default="solve",
+                    help="solve: the headline (configs[1] problem at a saturating batch); config5: BASELINE configs[4]; config3 / "
+                         "config4 / qp: that leg of the default line ALONE, as the line's main workload (one GPU; with --main-only: "
+                         "no CPU baseline, no per-kernel split -- the form tools/profile_leg.sh runs under rocprofv3)")
     args = ap.parse_args()
 
     import torch
@@ -812,6 +882,38 @@ def main():
     ld = aa.recommended_ld(B)      # non-power-of-two row stride (HBM channel/bank spread)
     ctx = aa.Context(local_rank)
     absorb_runtime_stall(torch, aa, ctx, device)
+    if args.workload in ("config3", "config4", "qp"):
+        # one leg of the default line alone (same generator, same timing code: run_config3 / run_config4 / run_qp), so that a
+        # rocprofv3 run holds the kernels of that leg only and profiles/<round>_<leg>_* can be checked against the default line
+        if world != 1:
+            raise SystemExit(f"--workload {args.workload} is a single-GPU leg")
+        cpu = not args.no_cpu_baseline and not args.main_only
+        if args.workload == "config3":
+            leg = run_config3(torch, aa, ctx, device, cpu, 0.25 * args.cpu_seconds, split=not args.main_only)
+            sub = leg["b4096"]
+            head_ = {"value": sub["value"], "unit": leg["unit"], "ms_per_step": sub["ms_per_step"], "roofline": sub["roofline"],
+                     "workload": "configs[2]: 4096 x 8-segment min-snap, corridor penalties + time-allocation gradients, one cost + "
+                                 "gradient evaluation per step (the saturating batch beside it)", "steps": 200}
+        elif args.workload == "config4":
+            leg = run_config4(torch, aa, ctx, device, cpu, 0.5 * args.cpu_seconds)
+            head_ = {"value": leg["value"], "unit": leg["unit"], "ms_per_step": leg["seconds"] * 1e3, "roofline": leg["roofline"],
+                     "workload": "configs[3]: 4096 x 16-segment min-jerk, L-BFGS to each problem's own stop, one optimisation of the "
+                                 "batch per step", "steps": 1}
+        else:
+            leg = run_qp(torch, aa, ctx, device, cpu, 0.5 * args.cpu_seconds, extras=not args.main_only)
+            sub = leg["snap8"]
+            head_ = {"value": sub["value"], "unit": leg["unit"], "ms_per_step": sub["ms_per_batch"], "roofline": sub["roofline"],
+                     "workload": "the reference's online solve: 4096 x 8-segment min-snap inequality QPs (interior point), one batch "
+                                 "per step (the planner's 5 jerk pieces beside it)", "steps": 5}
+        out = {"metric": "MINCO trajectories solved/sec (8-seg min-snap)", "value": head_["value"], "unit": head_["unit"],
+               "n_gpus": 1, "steps": head_["steps"], "warmup": args.warmup, "ms_per_step": head_["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": head_["workload"], "leg": args.workload, "main_only": bool(args.main_only)},
+               "roofline": head_["roofline"], {"config3": "config3", "config4": "config4", "qp": "qp_solve"}[args.workload]: leg}
+        if "cpu_baseline" in leg:
+            out["cpu_baseline"] = leg["cpu_baseline"]
+        print(finalize_line(out), flush=True)
+        return
     if args.workload == "config5":
         c5 = run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, args.steps, args.warmup, every=args.allgather_every)
         if use_dist:
@@ -826,7 +928,7 @@ def main():
                                       "cost + gradient evaluation per trajectory per step, sharded, costs all-gathered",
                           "global_batch": c5["total_batch"], "batch_this_rank": c5["batch_this_rank"],
                           "parallelism": f"dp{world}" + ("+allgather(costs)" if use_dist else "")},
-               "roofline": dict(c5["roofline"], traffic=None), "config5": c5}
+               "roofline": c5["roofline"], "config5": c5}
         out["config"].update(ranks_seen=c5["allgather"]["ranks_seen"], allgather_ms=c5["allgather"]["allgather_ms"],
                              allgather_bytes_per_rank=c5["allgather"]["allgather_bytes_per_rank"],
                              allgather_every=c5["allgather"]["every"])

@@ -67,6 +67,11 @@ int anet_device_count(void);
 int anet_create(int device, anet_ctx **out);
 void anet_destroy(anet_ctx *ctx);
 const char *anet_last_error(const anet_ctx *ctx);
+/* Compute units of the context's device (hipDeviceAttributeMultiprocessorCount, read once by anet_create: 256 on an
+ * MI355X in SPX mode, 32 per logical device in CPX).  Every launch-shape threshold of the library -- lane per trajectory or
+ * per (trajectory, axis), one launch or three per cost + gradient evaluation, workgroups per CU of the QP, one or two
+ * launches of the batched optimisers -- is a number of rounds of workgroups per compute unit and scales with it.           */
+int anet_compute_units(const anet_ctx *ctx);
 /* hipStream_t the plain (host) entry points run on. */
 void *anet_stream(anet_ctx *ctx);
 int anet_synchronize(anet_ctx *ctx);
@@ -251,6 +256,10 @@ int anet_minco_propagate_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int
  * work: device scratch of anet_minco_cost_grad_workspace(s, N, ld) doubles.
  * coeffs_out may be NULL.  cost: [batch].                                                     */
 int64_t anet_minco_cost_grad_workspace(int s, int n_pieces, int64_t ld);
+/* Kernel launches anet_minco_cost_grad_dev makes for this shape on this context's device: 1 (k_minco_cost_grad_fused: batches
+ * of up to three rounds of one workgroup per compute unit, orders 3 and 4, res <= 64) or 3 (k_minco_solve -> k_piece_grad ->
+ * k_minco_propagate); negative = error.  For callers that label a measurement with the kernel that ran (bench.py).          */
+int anet_minco_cost_grad_launches(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen);
 int anet_minco_cost_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                              const double *head, const double *tail, const double *wps,
                              const double *T, const double *hpolys, const anet_penalty *pen,
@@ -361,8 +370,10 @@ int anet_qp_solve_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res
  * (device, int32 [batch], a permutation of 0..batch-1) is the problem each successive workgroup takes; longest first from the
  * iters[] of a previous solve of the same or a similar batch (anet_launch_order_from_steps_dev) -- the re-solve of a receding-
  * horizon planner or a sampler.  Results are bit-identical for any order; NULL = as given; the ADMM method ignores it.
- * Entries are not checked on the host (device memory): an entry outside [0, batch) is skipped, a repeated one solves its problem
- * twice, and a problem no entry names reports status ANET_QP_UNSOLVED, iters 0 and obj NaN (its coeffs are left untouched).
+ * Entries are not checked on the host (device memory): an entry outside [0, batch) is skipped and a problem no entry names
+ * reports status ANET_QP_UNSOLVED, iters 0 and obj NaN (its coeffs are left untouched).  A REPEATED entry is undefined
+ * behaviour for the problem it names: two workgroups then run on the same per-problem slack / multiplier state and write
+ * the same coeffs / status concurrently (a race, not a redundant solve) -- the order must be a permutation.
  * No reference counterpart (QPSolver::solve takes one problem: qp_solver.hpp:119).                                        */
 int anet_qp_solve_ordered_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int res, int M, double max_vel,
                               double max_acc, double m34, const double *state, const double *T, const double *hpolys,
@@ -546,8 +557,9 @@ int anet_lbfgs_minco_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batc
  * started late and runs long, so handing over the problems longest-first shortens the run (4096 x 16-segment jerk:
  * 0.19 s as given, 0.12 s by the true evaluation counts, 0.14 s by the counts of a previous solve of a perturbed copy
  * of the batch -- the re-solve case of a sampler or a receding-horizon planner: feed evals[] of the last call,
- * sorted descending).  Entries are not checked beyond their range (an out-of-range entry is skipped, a repeated one
- * solves its problem twice and leaves another unsolved with its status untouched).  Ignored by the lockstep shape. */
+ * sorted descending).  Entries are not checked beyond their range: an out-of-range entry is skipped and a problem no
+ * entry names is left unsolved (ANET_LBFGS_RUNNING, zero counters); a REPEATED entry is undefined behaviour for the
+ * problem it names (two waves race on its state) -- the order must be a permutation.  Ignored by the lockstep shape.  */
 int anet_lbfgs_minco_ordered_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                                  const double *head, const double *tail, double *wps, double *T,
                                  const double *hpolys, const anet_penalty *pen,

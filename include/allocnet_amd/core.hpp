@@ -28,7 +28,10 @@ class Context {
     int rc = anet_create(device, &h_);
     if (rc != ANET_OK) throw Error(rc, anet_last_error(nullptr));
   }
-  ~Context() { anet_destroy(h_); }
+  ~Context() {
+    if (ws_) anet_dev_free(ws_);
+    anet_destroy(h_);
+  }
   Context(const Context &) = delete;
   Context &operator=(const Context &) = delete;
   anet_ctx *get() const { return h_; }
@@ -39,9 +42,24 @@ class Context {
     static thread_local Context ctx(0);
     return ctx;
   }
+  // Grow-only device workspace of this context for the facade calls that need one (lbfgs_optimize_batched): allocated on first
+  // use, kept across calls (a receding-horizon caller pays no hipMalloc / hipFree per plan), released with the context.  The
+  // caller must not hold it across another facade call that asks for one.
+  double *workspace(size_t n_doubles) {
+    if (n_doubles > ws_n_) {
+      if (ws_) anet_dev_free(ws_);
+      ws_ = nullptr;
+      ws_n_ = 0;
+      check(anet_dev_alloc(h_, n_doubles, &ws_));
+      ws_n_ = n_doubles;
+    }
+    return ws_;
+  }
 
  private:
   anet_ctx *h_ = nullptr;
+  double *ws_ = nullptr;
+  size_t ws_n_ = 0;
 };
 
 struct Vec3 {
@@ -91,6 +109,27 @@ struct Matrix {
     M m;
     for (int r = 0; r < R; ++r)
       for (int c = 0; c < C; ++c) m(r, c) = (*this)(r, c);
+    return m;
+  }
+};
+
+// Row-major rows x cols block of doubles with run-time shape (what the reference returns as Eigen::MatrixXd).
+struct MatrixX {
+  int r_ = 0, c_ = 0;
+  std::vector<double> a;
+  MatrixX() = default;
+  MatrixX(int r, int c) : r_(r), c_(c), a((size_t)r * c, 0.0) {}
+  double &operator()(int r, int c) { return a[(size_t)r * c_ + c]; }
+  double operator()(int r, int c) const { return a[(size_t)r * c_ + c]; }
+  int rows() const { return r_; }
+  int cols() const { return c_; }
+  const double *data() const { return a.data(); }
+  // fill any matrix type M constructible from (rows, cols) with (r,c) access (Eigen::MatrixXd among them)
+  template <class M>
+  M as() const {
+    M m(r_, c_);
+    for (int r = 0; r < r_; ++r)
+      for (int c = 0; c < c_; ++c) m(r, c) = (*this)(r, c);
     return m;
   }
 };

@@ -201,15 +201,13 @@ inline std::vector<int> lbfgs_optimize_batched(int n, int64_t batch, int64_t ld,
   anet_lbfgs_params q = to_c(param);
   anet::Context &ctx = anet::Context::thread_default();
   const int64_t nwork = anet_lbfgs_workspace(n, ld, &q);
-  double *work = nullptr, *st3 = nullptr;  // st3: the int32 status row in a buffer of doubles
-  ctx.check(anet_dev_alloc(ctx.get(), (size_t)nwork, &work));
-  ctx.check(anet_dev_alloc(ctx.get(), (size_t)(ld + 1) / 2, &st3));
+  // one persistent workspace of the context (grown, never freed between calls): the optimiser's state, then the int32 status row
+  double *work = ctx.workspace((size_t)nwork + (size_t)(ld + 1) / 2);
+  double *st3 = work + nwork;
   std::vector<int32_t> status32((size_t)(ld + 2));
   const int rc = anet_lbfgs_optimize_dev(ctx.get(), n, batch, ld, x_dev, f_dev, g_dev, proc_evaluate, instance, &q, max_evals, n,
                                          0.0, work, (int32_t *)st3, nullptr, nullptr, stream ? stream : anet_stream(ctx.get()));
   if (rc == ANET_OK) anet_dev_download(ctx.get(), (double *)status32.data(), st3, (size_t)(ld + 1) / 2);
-  anet_dev_free(work);
-  anet_dev_free(st3);
   std::vector<int> status(status32.begin(), status32.begin() + batch);
   ctx.check(rc);
   return status;

@@ -51,11 +51,22 @@ class Piece {
   // of position, velocity and acceleration in normalised time (3 x (D + 1), 3 x D, 3 x (D - 1); highest power first)
   typedef anet::Matrix<3, D> VelCoefficientMat;
   typedef anet::Matrix<3, D - 1> AccCoefficientMat;
+  // One piece = 3 x (D + 1 - d) multiplications: done here on the host with the statements of k_piece_normalize
+  // (csrc/traj_kernels.h: running product t *= duration from the constant column up, factor * coefficient * t) -- a GPU round
+  // trip would cost ~20 us for 24 products.  Batches of pieces: anet_piece_normalized_coeffs[_dev].
   template <class M>
   inline M normalized(int deriv) const {
     M out;
-    anet::Context &ctx = anet::Context::thread_default();
-    ctx.check(anet_piece_normalized_coeffs(ctx.get(), (D + 1) / 2, 1, coeffMat.data(), &duration, deriv, out.data()));
+    const int W = D + 1 - deriv;
+    double t = 1.0;
+    for (int e = 0; e < deriv; ++e) t *= duration;
+    for (int i = W - 1; i >= 0; --i) {
+      const int k = D - i;
+      double f = 1.0;
+      for (int e = 0; e < deriv; ++e) f *= (double)(k - e);
+      for (int ax = 0; ax < 3; ++ax) out(ax, i) = f * coeffMat(ax, i) * t;
+      t *= duration;
+    }
     return out;
   }
   inline CoefficientMat normalizePosCoeffMat() const { return normalized<CoefficientMat>(0); }

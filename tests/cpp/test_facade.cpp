@@ -177,7 +177,25 @@ int main() {
       printf("\"qp_end\": [%.17g, %.17g, %.17g],\n", qe(0), qe(1), qe(2));
       printf("\"qp_vel\": [%.17g, %.17g, %.17g],\n", qv(0), qv(1), qv(2));
       print_vec("qp_coeffs", flatten_coffmats.a);
+      // getTimeGrad (extension): not computed by the solve above (nobody had asked); the first request re-solves the remembered
+      // problem with the epilogue, later solves carry it
       print_vec("qp_time_grad", qp.getTimeGrad());
+      {
+        VecX again;
+        qp.solve(ini, fin, hPolys, times, again);
+        print_vec("qp_time_grad_inline", qp.getTimeGrad());
+      }
+      // get_t_state<T> (qp_solver.hpp:88-116) in the planner's float and in double, orders 3 and 4
+      {
+        const anet::MatrixX f3 = qp.get_t_state<float>(0.37f), d3 = qp.get_t_state<double>(0.37);
+        print_vec("qp_tstate_f3", f3.a);
+        print_vec("qp_tstate_d3", d3.a);
+        QPSolver qp4(QPConfig(3.0, 4.0, 10));
+        qp4.setOrder(4);
+        const anet::MatrixX f4 = qp4.get_t_state<float>(1.7f);
+        printf("\"qp_tstate_f4_shape\": [%d, %d],\n", f4.rows(), f4.cols());
+        print_vec("qp_tstate_f4", f4.a);
+      }
       qp.setMethod(ANET_QP_METHOD_INTERIOR_POINT);
       VecX sol_ipm;
       const bool ok_ipm = qp.solve(ini, fin, hPolys, times, sol_ipm);
@@ -316,9 +334,20 @@ int main() {
       struct Rosen {
         int evals, bounds, reports, cancel_at;
         std::vector<double> fx_seen;
+        int reenter = 0;
         static double eval(void *inst, const Vec &x, Vec &g) {
           Rosen *r = (Rosen *)inst;
           r->evals++;
+          if (r->reenter) {
+            // a callback that uses the library on the SAME context while the optimiser's state is live: a host-staged coefficient
+            // solve whose batch grows with every call, so the context's scratch is freed and re-allocated under the run
+            const int64_t B = 256 * (int64_t)r->evals;
+            std::vector<double> head((size_t)B * 9, 0.0), tail((size_t)B * 9, 0.0), wps((size_t)B * 3, 0.5), T((size_t)B * 2, 1.0),
+                co((size_t)B * 2 * 3 * 6), en((size_t)B);
+            for (int64_t b = 0; b < B; ++b) tail[(size_t)b * 9] = tail[(size_t)b * 9 + 3] = tail[(size_t)b * 9 + 6] = 1.0;
+            anet::Context &c = anet::Context::thread_default();
+            c.check(anet_minco_solve(c.get(), 3, 3, 2, B, head.data(), tail.data(), wps.data(), T.data(), co.data(), en.data()));
+          }
           const int n = (int)x.a.size();
           double f = 0.0;
           for (int i = 0; i < n; ++i) g(i) = 0.0;
@@ -349,22 +378,23 @@ int main() {
       lbfgs::lbfgs_parameter_t rp;
       rp.g_epsilon = 1.0e-8;
       rp.delta = 1.0e-10;
-      for (int mode = 0; mode < 2; ++mode) {
-        Rosen r{0, 0, 0, mode ? 12 : 0, {}};
+      for (int mode = 0; mode < 3; ++mode) {
+        Rosen r{0, 0, 0, mode == 1 ? 12 : 0, {}, 0};
+        r.reenter = mode == 2;
         Vec x(10);
         for (int i = 0; i < 10; ++i) x(i) = (i % 2) ? 1.0 : -1.2;
         double fmin = -1.0;
-        const int ret = lbfgs::lbfgs_optimize<Vec>(x, fmin, &Rosen::eval, mode ? &Rosen::bound : nullptr, mode ? &Rosen::progress : nullptr,
+        const int ret = lbfgs::lbfgs_optimize<Vec>(x, fmin, &Rosen::eval, mode == 1 ? &Rosen::bound : nullptr, mode == 1 ? &Rosen::progress : nullptr,
                                                    &r, rp);
         printf("\"rosen%d_ret\": %d, \"rosen%d_f\": %.17g, \"rosen%d_evals\": %d, \"rosen%d_bounds\": %d, \"rosen%d_reports\": %d,\n", mode, ret, mode,
                fmin, mode, r.evals, mode, r.bounds, mode, r.reports);
-        print_vec(mode ? "rosen1_x" : "rosen0_x", x.a);
-        if (mode) print_vec("rosen1_fx_seen", r.fx_seen);
+        print_vec(mode == 0 ? "rosen0_x" : (mode == 1 ? "rosen1_x" : "rosen2_x"), x.a);
+        if (mode == 1) print_vec("rosen1_fx_seen", r.fx_seen);
       }
       // a parameter error is lbfgs_optimize's return value and leaves x and f alone (lbfgs.hpp:449-495)
       lbfgs::lbfgs_parameter_t bad;
       bad.f_dec_coeff = 1.5;
-      Rosen r{0, 0, 0, 0, {}};
+      Rosen r{0, 0, 0, 0, {}, 0};
       Vec x(4);
       double f0 = 123.0;
       printf("\"rosen_bad_ret\": %d, \"rosen_bad_evals\": %d, \"rosen_bad_f\": %g,\n",

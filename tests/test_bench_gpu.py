@@ -94,3 +94,37 @@ def test_default_line_carries_the_north_star_loop():
     assert out["config"]["ranks_seen"] == 1 and out["qp_solve"]["snap8"]["batch"] == 4096
     b1 = out["config1_b1024"]
     assert b1["stream_ms_min_median_max"][0] <= b1["stream_ms_per_step"] <= b1["stream_ms_min_median_max"][2]
+
+
+@pytest.mark.parametrize("leg,key", [("config3", "config3"), ("qp", "qp_solve")])
+def test_one_leg_alone_is_a_contract_line(leg, key):
+    """`--workload config3|qp --main-only`: the form tools/profile_leg.sh runs under rocprofv3 -- the leg's own generator and
+    timing, nothing else launched beside it; the line names the kernel that ran and carries the committed PMC traffic."""
+    out = _bench(["--workload", leg, "--main-only", "--no-cpu-baseline"])
+    for k in KEYS:
+        assert k in out, k
+    assert out["config"]["leg"] == leg and out["config"]["main_only"] is True and key in out and out["value"] > 0
+    if leg == "config3":
+        b, sat = out["config3"]["b4096"], out["config3"]["saturating"]
+        assert b["launches_per_step"] == 1 and b["roofline"]["kernel"] == "k_minco_cost_grad_fused"
+        assert sat["launches_per_step"] == 3 and sat["roofline"]["kernel"].startswith("k_piece_grad")
+        assert "kernel_split_us" not in b and "three_launch_split_us" not in b        # no split under --main-only
+        assert out["roofline"] == b["roofline"] and abs(out["ms_per_step"] - b["ms_per_step"]) < 1e-9
+        for r in (b["roofline"], sat["roofline"]):
+            if r["traffic"] is not None:      # (a committed profile of this leg: traffic >= the compulsory bytes, within reason)
+                assert 0.9 < r["hbm"]["traffic_over_algorithmic"] < 4.0
+
+
+def test_launch_shapes_follow_the_devices_compute_units():
+    """anet_compute_units = the device's multiprocessor count; the one-launch / three-launch decision of the cost + gradient
+    evaluation is a number of rounds of workgroups per compute unit (three rounds of groups of 16 for <= 8 pieces)."""
+    import torch
+    import allocnet_amd as aa
+    ctx = aa.Context(0)
+    cus = ctx.compute_units
+    assert cus == torch.cuda.get_device_properties(0).multi_processor_count and cus > 0
+    pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20, poly_rows=16)
+    assert aa.minco_cost_grad_launches(4, 8, 16 * 3 * cus, penalty=pen, ctx=ctx) == 1
+    assert aa.minco_cost_grad_launches(4, 8, 16 * 3 * cus + 1, penalty=pen, ctx=ctx) == 3
+    assert aa.minco_cost_grad_launches(4, 8, 64, penalty=None, ctx=ctx) == 3          # no penalty: the streaming kernels
+    assert aa.minco_cost_grad_launches(2, 8, 64, penalty=pen, ctx=ctx) == 3           # order 2 has no one-launch instantiation

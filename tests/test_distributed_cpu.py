@@ -69,6 +69,35 @@ def test_allgather_costs_gloo_world2(total):
     assert ret["err"] == 0.0
 
 
+def _status_worker(rank, world, port, total, ret):
+    import torch
+    import torch.distributed as dist
+    from allocnet_amd.distributed import shard_bounds, allgather_costs_status
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(5)
+        cost_all = torch.rand(total, dtype=torch.float64, generator=g) * 1e3
+        status_all = torch.randint(-1030, 3, (total,), dtype=torch.int32, generator=g)      # lbfgs.hpp's return codes are negative too
+        lo, hi = shard_bounds(total, world, rank)
+        c, st = allgather_costs_status(cost_all[lo:hi].clone(), status_all[lo:hi].clone(), total)
+        ret[rank] = bool(torch.equal(c, cost_all) and torch.equal(st, status_all) and st.dtype == torch.int32)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [64, 37, 5])       # even, ragged (odd shard length: the int32 half-slot), tiny
+def test_allgather_costs_and_status_in_one_buffer_gloo_world2(total):
+    """status + cost fused into ONE gather buffer per rank -- one collective, both arrays back bit for bit in
+    global trajectory order on every rank."""
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_status_worker, args=(2, _free_port(), total, ret), nprocs=2, join=True)
+    assert ret[0] is True and ret[1] is True
+
+
 def _overlap_worker(rank, world, port, steps, every, ret):
     """bench.py's step(): slot j = i & 1 is overwritten by the (fake) solve of step i only after the gather issued from it at
     step i - 2 has completed; every gather must deliver the costs of ITS step from every rank."""

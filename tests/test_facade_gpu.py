@@ -94,6 +94,10 @@ def test_cpp_facade_program():
     assert out["rosen1_reports"] == len(seen) == 12 and out["rosen1_bounds"] == 12
     assert np.allclose(out["rosen1_fx_seen"], seen, rtol=1e-9, atol=1e-12)
     assert abs(out["rosen1_f"] - fo1) <= 1e-9 * max(1.0, abs(fo1)) and np.abs(np.array(out["rosen1_x"]) - xo1).max() <= 1e-8
+    # the same run with an evaluate callback that calls a host-staged entry point on the SAME context (a coefficient solve whose
+    # batch grows per call, so the context's scratch is re-allocated under the live optimiser): bit for bit the plain run
+    assert out["rosen2_ret"] == out["rosen0_ret"] and out["rosen2_evals"] == out["rosen0_evals"]
+    assert out["rosen2_f"] == out["rosen0_f"] and out["rosen2_x"] == out["rosen0_x"]
     assert out["rosen_bad_ret"] == -1016 and out["rosen_bad_evals"] == 0 and out["rosen_bad_f"] == 123.0
 
     # lbfgs::lbfgs_optimize_batched (anet_lbfgs_optimize_dev through the facade; the status row is complete on return): five
@@ -114,6 +118,30 @@ def test_cpp_facade_program():
     # getTimeGrad (extension): one entry per segment; giving a rest-to-rest trajectory more time lowers its cost
     gT = np.array(out["qp_time_grad"])
     assert gT.shape == (3,) and np.isfinite(gT).all() and gT.sum() < 0
+    # ... asked for after a solve that did not compute it (re-solve of the remembered problem) = carried by the next solve
+    assert np.array_equal(gT, np.array(out["qp_time_grad_inline"]))
+
+    # get_t_state<T> (qp_solver.hpp:88-116): row k = k-th derivative of (t^(d-1) ... t 1), evaluated in T with the reference's
+    # multiplication tree for the powers; the float instantiation bit for bit against a float32 restatement
+    def t_state(t, order, ft):
+        t = ft(t)
+        p = [ft(1), t, t * t]
+        p.append(t * p[2]); p.append(p[2] * p[2]); p.append(p[2] * p[3]); p.append(p[3] * p[3]); p.append(p[4] * p[3])
+        d = 2 * order
+        A = np.zeros((order, d))
+        for k in range(order):
+            for j in range(d):
+                e = d - 1 - j
+                if e >= k:
+                    ff = int(np.prod([e - q for q in range(k)])) if k else 1
+                    A[k, j] = ff if e == k else float(ft(ff) * p[e - k])
+        return A
+    assert np.array_equal(np.array(out["qp_tstate_f3"]).reshape(3, 6), t_state(0.37, 3, np.float32))
+    assert np.array_equal(np.array(out["qp_tstate_d3"]).reshape(3, 6), t_state(0.37, 3, np.float64))
+    assert out["qp_tstate_f4_shape"] == [4, 8]
+    assert np.array_equal(np.array(out["qp_tstate_f4"]).reshape(4, 8), t_state(1.7, 4, np.float32))
+    # (and it is what the oracle's float assembly has as its rows: the d = 0 row is the position row of get_t_state)
+    assert abs(t_state(0.37, 3, np.float64)[1, 0] - 5 * 0.37 ** 4) < 1e-15
     # setMethod(interior point): same optimum (OSQP's 1e-3 tolerances leave the ADMM objective within a few 1e-3 of it)
     assert out["qp_ipm_ok"] == 1 and out["qp_ipm_iters"] <= 40
     assert abs(out["qp_ipm_obj"] - out["qp_obj"]) <= 2e-2 * max(1.0, out["qp_obj"])
