@@ -164,7 +164,8 @@ def fp64_roofline(flops_per_launch, seconds, hbm_bytes_per_launch, kernel, traff
     #  "traffic": HBM bytes per step from the committed PMC passes of this leg, pmc_leg_traffic -- a constant of the tree)
     return {"bound": "fp64", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
             "traffic": traffic, "kernel": kernel,
-            "hbm": {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS,
+            # (hbm: GB/s of the compulsory bytes and their fraction of the 8 TB/s peak)
+            "hbm": {"achieved": hb, "frac": hb / HBM_PEAK_GBS,
                     "traffic_over_algorithmic": (traffic / hbm_bytes_per_launch) if traffic else None}}
 
 
@@ -175,7 +176,7 @@ def cost_grad_picks(launches):
     """the kernels of one cost + gradient evaluation as pmc_leg_traffic picks"""
     if launches == 1:
         return [("k_minco_cost_grad_fused", None, 1)]
-    return [("k_minco_solve<", None, 1), ("k_piece_grad<", None, 1), ("k_minco_propagate<", None, 1)]
+    return [("k_minco_solve<4, 8, true, 2>", None, 1), ("k_piece_grad<", None, 1), ("k_minco_propagate<", None, 1)]
 
 
 PEN = dict(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20)
@@ -297,7 +298,7 @@ def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds, split=True):
         #  evaluations that takes the runtime's one-off launch-backlog stall; median repetition: DESIGN.md section 7)
         launches = aa.minco_cost_grad_launches(s, N, B, penalty=pen, ctx=ctx)
         out[key] = {"batch": B, "ms_per_step": dt * 1e3, "stream_ms_per_step": kms, "value": B / dt,
-                    "stream_ms_min_median_max": [st_ms[0], kms, st_ms[-1]], "launches_per_step": launches,
+                    "stream_ms_min_max": [st_ms[0], st_ms[-1]], "launches_per_step": launches,
                     "roofline": fp64_roofline(B * flops, kms * 1e-3, B * ab, COST_GRAD_KERNELS[launches],
                                               traffic=pmc_leg_traffic("config3", cost_grad_picks(launches)))}
         if split:
@@ -387,7 +388,7 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds, extras=True):
                     "newton_steps_mean": float(iters.mean()), "newton_steps_max": int(iters.max()),
                     # (FLOPs: analytic per Newton step, qp_newton_step_flops, x the steps taken; the kernel is latency-bound --
                     #  block-Cholesky chains and row passes of one 256-thread workgroup per problem: DESIGN.md 8b)
-                    "ms_reps": reps_ms, "infeasible_frac": float((r["status"] == -3).double().mean()),
+                    "infeasible_frac": float((r["status"] == -3).double().mean()),
                     # (traffic: slacks and multipliers live in global memory -- L2-resident while a problem runs --, everything else in
                     #  LDS and registers; two launches per batch: Newton steps 1-4 of every problem, then the unfinished ones)
                     "roofline": {"bound": "fp64", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -532,7 +533,7 @@ def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
     ab = B * (config5_bytes(s, c, N, M) + 8)        # compulsory: problem data in, optimised waypoints / durations / cost out
     out = {"batch": B, "pieces": N, "order": s, "poly_rows": M, "res": PEN["res"], "seed": 2,
            "seconds": dt, "stream_seconds": kdt, "value": B / dt, "unit": "trajectories optimised to convergence/s",
-           "lbfgs_params": "lbfgs_parameter_t defaults (lbfgs.hpp:25-128): mem 8, g_eps 1e-5, past 3, delta 1e-6",
+           # (lbfgs_parameter_t defaults, lbfgs.hpp:25-128: mem 8, g_eps 1e-5, past 3, delta 1e-6)
            "max_evals_cap": cap, "iters_mean": float(it.mean()), "iters_max": int(it.max()),
            "evals_mean": float(ev.mean()), "evals_p50_p90_p99": [float(v) for v in np.percentile(ev, [50, 90, 99])],
            "evals_max": int(ev.max()), "evaluations_per_s": float(ev.sum()) / dt,
@@ -562,6 +563,40 @@ def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
                                "gpu_vs_cpu_final_cost_rel_median": float(np.median(rel)),
                                "gpu_vs_cpu_final_cost_rel_max": float(rel.max()),
                                "gpu_vs_cpu_same_eval_count_frac": float((o["evals"] == ev[idx]).mean())}
+        # "rounding amplified over ~2500 iterations" as a measurement: 256 strided problems at growing iteration budgets
+        i256 = np.linspace(0, B - 1, 256).astype(int)
+        out["cpu_baseline"]["divergence"] = lbfgs_divergence_profile(aa, cbind, s, head[i256], tail[i256], wps[i256], T[i256],
+                                                                     hp[i256], pen, nthreads, ctx=ctx)
+    return out
+
+
+DIVERGENCE_BUDGETS = (25, 50, 100, 200, 400)
+
+
+def lbfgs_divergence_profile(aa, cbind, s, head, tail, wps, T, hp, pen, nthreads, budgets=DIVERGENCE_BUDGETS, ctx=None):
+    """Where do the device run and the C restatement of lbfgs_optimize part ways?  The SAME problems on both sides under
+    lbfgs_parameter_t defaults with max_iterations = each of `budgets` (lbfgs.hpp:690-695: the run stops with
+    LBFGSERR_MAXIMUMITERATION unless it stopped on its own earlier): per budget the fraction of problems with identical
+    (status, iterations, evaluations) and, among those, the largest relative difference of the costs; and per problem the
+    first budget at which the counters differ.  Identical counters = the two runs took the same branches at every Armijo /
+    Wolfe test so far, so their costs may differ by accumulated rounding only: the caller asserts <= 1e-6 on them."""
+    import numpy as np
+    B = head.shape[0]
+    first = np.full(B, 0, dtype=np.int64)                      # 0 = never within the budgets tried
+    out = {"problems": int(B), "same_counters_frac": {}, "max_rel_cost_diff_same_counters": {}}
+    for mi in budgets:
+        g = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=aa.lbfgs_parameter_t(max_iterations=mi),
+                           max_evals=40 * mi, want_coeffs=False, ctx=ctx)
+        r = cbind.lbfgs_minco_batch(s, head, tail, wps, T, hp, param=cbind.lbfgs_default_param(max_iterations=mi),
+                                    nthreads=nthreads, **PEN_ORACLE)
+        same = (g["status"] == r["status"]) & (g["iters"] == r["iters"]) & (g["evals"] == r["evals"])
+        rel = np.abs(g["cost"] - r["cost"]) / np.abs(r["cost"])
+        out["same_counters_frac"][str(mi)] = float(same.mean())
+        out["max_rel_cost_diff_same_counters"][str(mi)] = float(rel[same].max()) if same.any() else None
+        first[(first == 0) & ~same] = mi
+    div = first[first > 0]
+    out["diverged_within_budgets_frac"] = float(div.size) / B
+    out["median_first_diverging_budget"] = float(np.median(div)) if div.size else None
     return out
 
 
@@ -705,7 +740,9 @@ def absorb_runtime_stall(torch, aa, ctx, device, launches=1400):
     (one step of 40.4 ms among 49 of 0.155: "0.85 ms per step").  So it is made to happen HERE, before anything is timed: 1400
     launches of a 32768-trajectory solve (~20 us of GPU each against ~5 us of host: the host gets ~10^3 launches ahead, which is
     the other condition the profile names), not synchronised until the end."""
-    s, c, N, B = 4, 3, 8, 32768
+    # (c = 4, MINCO's boundary count: k_minco_solve<4, 8, true, 3>, an instantiation no timed leg launches, so that a profile of
+    #  a leg holds the leg's kernels only)
+    s, c, N, B = 4, 4, 8, 32768
     ld = aa.recommended_ld(B)
     head, tail, wps, T = synth_batch_minor(torch, B, ld, N, c, 7, device)
     energy = torch.empty(ld, device=device, dtype=torch.float64)
@@ -1107,7 +1144,6 @@ def main():
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / 20
                 smp[label] = {"samples": Ks, "ms_per_launch": ms, "value": Ks / (ms * 1e-3),
-                              "hbm_frac": Ks * 8 * (N + 1) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "fp64_frac_at_4.1_kflop_per_sample": Ks * 4100.0 / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
             # (time-allocation samples/s in one launch; 8 (N + 1) bytes per sample: bound by its FP64 work, ~4.1 kFLOP per sample)
             out["config1_b1024"]["sampler"] = smp

@@ -307,8 +307,106 @@ def main_vjp():
               f"size={os.path.getsize(path)/1024:.0f}KB")
 
 
+def main_layers():
+    """The reference's OWN post-solve code executed: network/utils/learning/layers.py OsqpLayer.forward (:51-151) and
+    forward4lstm (:153-247) are imported and run -- their loss terms (mean time, padding MSE, reference-time MSE, stop-token
+    BCE + 5.0 penalties at 0.42, objc = 1/2 z'Qz / path_length), their KKT hook (:129-141) and torch.autograd's d/dTimes
+    through the reference's Q(T) -- on qp_traj objects the reference's MinTrajOpt.update built.
+
+    What is NOT the reference's: OSQP.  `osqp` is not in this image; the module's `osqp.OSQP` is replaced by an injector with
+    OSQP's setup / solve interface that returns the optimum (x, y = [nu; lam]) of the matrices it is handed from the float64
+    interior-point oracle (oracle/qp_np.py), or status 'maximum iterations reached' when told to fail (the unsolved branches).
+    So these fixtures pin everything layers.py does AROUND the solve, at the exact optimum; they do not pin OSQP's iterates."""
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle.qp_np import qp_ipm
+    MinTrajOpt, _ = _import_reference()
+    import importlib
+    layers = importlib.import_module("utils.learning.layers")
+
+    class Injector:
+        fail = False
+
+        def setup(self, P, q, A, l, u, **kw):
+            self.P = np.asarray(P.todense(), dtype=np.float64)
+            A = np.asarray(A.todense(), dtype=np.float64)
+            eq = np.isfinite(l)
+            self.A, self.b, self.G, self.h = A[eq], u[eq], A[~eq], u[~eq]
+            self.n_eq = int(eq.sum())
+            assert eq[:self.n_eq].all()                    # layers.py stacks the equality rows first
+
+        def solve(self):
+            info = types.SimpleNamespace(status="maximum iterations reached" if Injector.fail else "solved")
+            if Injector.fail:
+                return types.SimpleNamespace(x=None, y=None, info=info)
+            z, lam, nu, obj, it = qp_ipm(self.P, self.A, self.b, self.G, self.h, tol=1e-12, max_iter=300)
+            assert it < 300
+            return types.SimpleNamespace(x=z, y=np.r_[nu, lam], info=info)
+    layers.osqp.OSQP = Injector
+    cases = [("layers_snap_n3", 4, 3, 6, 45, 2, [0.1, 0.2, 0.9, 0.95, 0.99]),
+             ("layers_jerk_n4", 3, 4, 5, 41, 1, [0.5, 0.2, 0.9, 0.3, 0.99]),
+             ("layers_snap_n5", 4, 5, 4, 52, 2, [0.43, 0.9, 0.41, 0.1, 0.2])]
+    for name, order, N, res, seed, phase, pred in cases:
+        rng = np.random.default_rng(seed)
+        state, hpolys, T, pts = synth_problem(rng, N, M_max=9, rest=False)
+        seglen = np.linalg.norm(np.diff(pts, axis=0), axis=1)
+        T5 = np.zeros(5); T5[:N] = seglen / rng.uniform(2.0, 3.0, size=N)
+        T5[N:] = rng.uniform(0.1, 0.6, size=5 - N)           # what the network emits for unused segments: the padding loss's input
+        ref5 = np.zeros(5); ref5[:N] = T5[:N] * rng.uniform(0.8, 1.3, size=N)
+        hp5 = np.zeros((50, 4, 5)); hp5[:, :, :N] = hpolys
+        out = dict(order=order, N=N, res=res, phase=phase, state=state, hpolys=hp5[:16], Times=T5, ref_times=ref5,
+                   pred_stop_tokens=np.array(pred))
+        assert not hp5[16:].any()
+        for mode in ("forward", "forward4lstm"):
+            for fail in (False, True):
+                Injector.fail = fail
+                Tt = torch.tensor(T5, dtype=torch.float64, requires_grad=True)
+                opt = MinTrajOpt(make_params(order, res))
+                layer = layers.OsqpLayer()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    opt.update(torch.tensor(state), torch.tensor(hp5), Tt, phase=phase, traj_times=torch.tensor(ref5), seq_len=5)
+                    if mode == "forward":
+                        r = layer.forward(opt)
+                    else:
+                        r = layer.forward4lstm(opt, torch.tensor(pred, dtype=torch.float32), seq_len=5)
+                z, obj1, objt, objc, last = r
+                key = f"{mode}_{'unsolved' if fail else 'solved'}"
+                assert opt.seg == N
+                out[key + "_obj1"] = float(obj1)
+                out[key + "_last"] = float(last)              # padding loss (forward) / stop-token loss (forward4lstm)
+                (g1,) = torch.autograd.grad(obj1, Tt, retain_graph=True)
+                out[key + "_dobj1_dT"] = g1.numpy().astype(np.float64)
+                if fail:
+                    assert z is None and objc is None
+                    out[key + "_objt"] = float(objt)
+                    (gt,) = torch.autograd.grad(objt, Tt)
+                    out[key + "_dobjt_dT"] = gt.numpy().astype(np.float64)
+                else:
+                    assert objt is None
+                    out[key + "_objc"] = float(objc)
+                    out[key + "_z"] = z.detach().numpy().astype(np.float64)
+                    # the leaf z behind hstack((z, lam, nu))[0:n]: its .grad after backward is what the reference's hook leaves
+                    leaf = z.grad_fn.next_functions[0][0].next_functions[0][0].variable
+                    objc.backward()
+                    out[key + "_dobjc_dT"] = Tt.grad.numpy().astype(np.float64)
+                    out[key + "_hook_grad_z"] = leaf.grad.numpy().astype(np.float64)
+                    out["path_length"] = float(opt.path_length)
+        if "forward_solved_last" in out and N < 5:
+            (gp,) = torch.autograd.grad(torch.nn.MSELoss()(Tt[N:], torch.zeros(5 - N, dtype=torch.float64)), Tt)
+            out["dpadding_dT"] = gp.numpy().astype(np.float64)
+        path = os.path.join(OUT, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: objc={out['forward_solved_objc']:.6g} obj1={out['forward_solved_obj1']:.6g} pad={out['forward_solved_last']:.6g} "
+              f"stop={out['forward4lstm_solved_last']:.6g} objt(unsolved)={out['forward_unsolved_objt']:.6g} / "
+              f"{out['forward4lstm_unsolved_objt']:.6g} dobjc_dT={out['forward_solved_dobjc_dT']} size={os.path.getsize(path)/1024:.0f}KB")
+
+
 if __name__ == "__main__":
+    if "--only-layers" in sys.argv:
+        main_layers()
+        sys.exit(0)
     if "--only-vjp" not in sys.argv:
         main()
         main_time_factor()
     main_vjp()
+    main_layers()

@@ -207,3 +207,28 @@ def test_config3_converged_costs_against_the_cpu_restatement(anet_ctx):
     assert worse <= 0.62
     # both ends are stationary to the same degree: the evaluation counts have the same scale
     assert 0.8 < out["evals"].mean() / ref["evals"].mean() < 1.25
+
+
+def test_config3_divergence_of_the_two_runs_is_rounding_not_a_late_defect(anet_ctx):
+    """Between the budgets where the counters are exact (2 / 6) or nearly so (3 / 12) and the ~2500 iterations of a run to
+    convergence there was no evidence: 256 strided problems of configs[3] at iteration budgets 25 / 50 / 100 / 200 / 400 on
+    both sides (bench.lbfgs_divergence_profile, the figures the bench line carries).  A problem whose (status, iterations,
+    evaluations) still agree has taken the same branch at every line-search test so far, so its two costs differ by
+    accumulated rounding only: <= 1e-6 at EVERY budget -- a defect of the device optimiser that only shows late would break
+    exactly this.  The fraction that still agrees falls with the budget (each Armijo / Wolfe comparison that sits within
+    rounding of its threshold is a coin toss); the numbers are printed, and bounded from below where they were measured."""
+    import allocnet_amd as aa
+    import bench
+    B, s, c, N, M = 4096, 3, 3, 16, 16
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(2), B, N, c, M)
+    idx = np.linspace(0, B - 1, 256).astype(int)
+    prof = bench.lbfgs_divergence_profile(aa, cbind, s, head[idx], tail[idx], wps[idx], T[idx], hp[idx], _penalty(aa, M), 8,
+                                          ctx=anet_ctx)
+    print("configs[3] divergence profile:", prof)
+    fr = prof["same_counters_frac"]
+    for mi in bench.DIVERGENCE_BUDGETS:
+        worst = prof["max_rel_cost_diff_same_counters"][str(mi)]
+        assert worst is None or worst <= 1e-6, (mi, worst)
+    assert fr["25"] >= 0.9                                        # (3 / 12 iterations: >= 0.99, test above)
+    vals = [fr[str(mi)] for mi in bench.DIVERGENCE_BUDGETS]
+    assert all(a >= b - 0.02 for a, b in zip(vals, vals[1:]))      # agreement only ever decays with the budget

@@ -111,8 +111,8 @@ def test_one_leg_alone_is_a_contract_line(leg, key):
         assert "kernel_split_us" not in b and "three_launch_split_us" not in b        # no split under --main-only
         assert out["roofline"] == b["roofline"] and abs(out["ms_per_step"] - b["ms_per_step"]) < 1e-9
         for r in (b["roofline"], sat["roofline"]):
-            if r["traffic"] is not None:      # (a committed profile of this leg: traffic >= the compulsory bytes, within reason)
-                assert 0.9 < r["hbm"]["traffic_over_algorithmic"] < 4.0
+            if r["traffic"] is not None:      # (a committed profile of this leg; the 25 MB of the literal batch partly stay in the L2s from launch to launch: < 1)
+                assert 0.5 < r["hbm"]["traffic_over_algorithmic"] < 4.0
 
 
 def test_launch_shapes_follow_the_devices_compute_units():

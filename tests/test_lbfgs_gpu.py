@@ -726,6 +726,7 @@ def test_generic_device_objective_matches_the_restatement(anet_ctx, n, B):
             # run -- the same kind of outcome, within a few evaluations, and a cost the same order of magnitude
             assert (st[b] < 0) == (ret < 0) and abs(int(ev[b]) - evo) <= 6 and abs(int(it[b]) - ito) <= 2, (b, st[b], it[b], ev[b], ret, ito, evo)
             assert fg[b] <= 10.0 * fo + 1.0 and fo <= 10.0 * fg[b] + 1.0, (b, fg[b], fo)
+    print("device-objective L-BFGS, n = %d: identical (status, k, evals) in %d of %d problems" % (n, same, B))
     assert same >= 0.9 * B, (same, B)
     # the built-in step bound (bound_from / bound_min: the last variables may not fall below a floor within a line search,
     # lbfgs.hpp:557-565) against the restatement running the same bound as its proc_stepbound callback
@@ -855,8 +856,12 @@ def test_host_callback_objective_matches_the_restatement(anet_ctx, n):
                     assert len(log_g) == len(log_o)
                     for a, b in zip(log_g, log_o):
                         assert a[:2] == b[:2] and np.allclose(a[2:], b[2:], rtol=1e-8, atol=1e-12), (a, b)
+                else:
+                    # not excused: a line-search test that flipped on its threshold costs a trial or an iteration, not the run
+                    assert (ret < 0) == (reto < 0) and abs(ev - evo) <= 6 and abs(it - ito) <= 2, (n, budget, mode, ret, it, ev, reto, ito, evo)
                 if mode == "progress" and budget > 5:
                     assert ret == aa.lbfgs.LBFGS_CANCELED or ret < 0 or it < 5, (ret, it)
+    print("host-callback L-BFGS, n = %d: identical (ret, k, evals) in %d of %d runs" % (n, same, total))
     assert same >= 0.9 * total, (same, total)
     # left to run from the classic start: the minimum f = 0 at x = 1
     x0 = np.where(np.arange(n) % 2 == 0, -1.2, 1.0)

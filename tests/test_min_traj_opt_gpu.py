@@ -170,3 +170,59 @@ def test_osqp_layer_forward_batch(anet_ctx):
         else:
             one = layer.backward(o, gzs[i])
             assert np.abs(one - gb[i]).max() <= 1e-7 * max(1.0, np.abs(one).max())
+
+
+@pytest.mark.parametrize("name", ["layers_snap_n3", "layers_jerk_n4", "layers_snap_n5"])
+def test_osqp_layer_against_the_references_own_layers_py(anet_ctx, name):
+    """Fixtures made by RUNNING network/utils/learning/layers.py (OsqpLayer.forward :51-151, forward4lstm :153-247, its KKT hook
+    and torch.autograd through the reference's Q(T)) on qp_traj objects built by the reference's MinTrajOpt.update, with
+    `osqp.OSQP` replaced by an injector that returns the float64 optimum (tests/golden/make_golden.py main_layers: this pins the
+    code around the solve, not OSQP's iterates).  Compared: every loss term of both entry points in the solved and the unsolved
+    branch, the solution, and d objc / d Times as the reference's backward pass delivers it."""
+    import os
+    import allocnet_amd as aa
+    from tests.util import GOLDEN
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    s, N, res, phase = int(d["order"]), int(d["N"]), int(d["res"]), int(d["phase"])
+    hp50 = np.zeros((50, 4, 5)); hp50[:16] = d["hpolys"]
+    opt = aa.MinTrajOpt(make_params(s, res), ctx=anet_ctx)
+    opt.update(d["state"], hp50, d["Times"], phase=phase, traj_times=d["ref_times"], seq_len=5)
+    assert opt.seg == N and abs(opt.path_length - float(d["path_length"])) <= 1e-12
+    layer = aa.OsqpLayer(ctx=anet_ctx)                      # interior point: the optimum, as the injector returns it
+    z, obj1, objt, objc, pad = layer.forward(opt)
+    assert z is not None and objt is None
+    assert abs(obj1 - float(d["forward_solved_obj1"])) <= 1e-15 * max(1.0, abs(obj1))
+    assert abs(pad - float(d["forward_solved_last"])) <= 1e-15
+    zr = d["forward_solved_z"]
+    assert np.abs(z - zr).max() <= 2e-5 * np.abs(zr).max()                     # two interior-point solves of the same QP
+    assert abs(objc - float(d["forward_solved_objc"])) <= 1e-6 * float(d["forward_solved_objc"])
+    # the reference's backward pass: d objc / d Times = 1/2 z'(dQ/dT)z / path_length, z detached (zeros beyond the segments used)
+    gr = d["forward_solved_dobjc_dT"]
+    assert layer.time_grad.shape == gr.shape and (layer.time_grad[N:] == 0).all() and (gr[N:] == 0).all()
+    assert np.abs(layer.time_grad - gr).max() <= 2e-5 * np.abs(gr).max()
+    # forward4lstm: same solve, the stop-token loss instead of the padding loss
+    pred = d["pred_stop_tokens"]
+    z4, o1, ot, oc, stl = layer.forward4lstm(opt, pred.astype(np.float32), seq_len=5)
+    assert z4 is not None and ot is None and abs(o1 - float(d["forward4lstm_solved_obj1"])) <= 1e-15 * max(1.0, abs(o1))
+    assert abs(oc - float(d["forward4lstm_solved_objc"])) <= 1e-6 * float(d["forward4lstm_solved_objc"])
+    # (the reference's BCELoss runs in float32 on float32 tokens: agreement to float32 rounding)
+    assert abs(stl - float(d["forward4lstm_solved_last"])) <= 2e-6 * max(1.0, abs(stl)), (stl, float(d["forward4lstm_solved_last"]))
+    assert np.abs(layer.time_grad - d["forward4lstm_solved_dobjc_dT"]).max() <= 2e-5 * np.abs(gr).max()
+    # the unsolved branches (layers.py:98-116, 206-215): an infeasible twin of the problem -- limits no trajectory of these
+    # durations can meet -- gives None / None and the reference-time loss; the loss terms do not depend on WHY the solve failed
+    bad = aa.MinTrajOpt(make_params(s, res, vmax=1e-3, amax=1e-3, vmax1=1e-3, amax1=1e-3), ctx=anet_ctx)
+    bad.update(d["state"], hp50, d["Times"], phase=phase, traj_times=d["ref_times"], seq_len=5)
+    zb, b1, bt, bc, bpad = layer.forward(bad)
+    assert zb is None and bc is None and layer.time_grad is None
+    assert abs(b1 - float(d["forward_unsolved_obj1"])) <= 1e-15 * max(1.0, abs(b1))
+    assert abs(bt - float(d["forward_unsolved_objt"])) <= 1e-14 * max(1.0, abs(bt)) and abs(bpad - float(d["forward_unsolved_last"])) <= 1e-15
+    zb, b1, bt, bc, bstl = layer.forward4lstm(bad, pred.astype(np.float32), seq_len=5)
+    assert zb is None and bc is None
+    assert abs(bt - float(d["forward4lstm_unsolved_objt"])) <= 1e-14 * max(1.0, abs(bt))
+    assert abs(bstl - float(d["forward4lstm_unsolved_last"])) <= 2e-6 * max(1.0, abs(bstl))
+    # analytic gradients of the plain loss terms, as torch.autograd gave them through the reference's code
+    g1 = np.zeros(5); g1[:N] = 1.0 / N
+    assert np.array_equal(d["forward_solved_dobj1_dT"], g1)
+    if N < 5:
+        gp = np.zeros(5); gp[N:] = 2.0 * d["Times"][N:] / (5 - N)
+        assert np.abs(d["dpadding_dT"] - gp).max() <= 1e-15

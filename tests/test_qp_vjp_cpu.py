@@ -55,3 +55,30 @@ def test_backward_pass_is_the_derivative_of_the_loss(path):
         Tm = T.copy(); Tm[i] -= h
         fd[i] = (loss(Tp) - loss(Tm)) / (2 * h)
     assert np.abs(fd - d["dloss_dT"]).max() <= 1e-4 * np.abs(fd).max(), (fd, d["dloss_dT"])
+
+
+@pytest.mark.parametrize("name", ["layers_snap_n3", "layers_jerk_n4", "layers_snap_n5"])
+def test_numpy_hook_matches_what_the_references_own_hook_left(name):
+    """tests/golden/layers_*.npz (make_golden.py main_layers) hold z.grad after `objc.backward()` through the reference's OWN
+    layers.py code -- its J (layers.py:129-134) and hook (:136-141) executed, not restated.  The numpy backward pass with
+    dloss/dz = Q z / path_length (objc's gradient) must leave the same vector on z, and the same optimum and objc."""
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    s, N, res, phase = int(d["order"]), int(d["N"]), int(d["res"]), int(d["phase"])
+    vmax, amax = LIMITS[phase]
+    hp = d["hpolys"][:, :, :N]
+    m_rows = np.array([int(np.sum(np.linalg.norm(hp[:, :, i], axis=1) > 0)) for i in range(N)])
+    T = d["Times"][:N]
+    pl = float(d["path_length"])
+    Q = qp_vjp_np.assemble_dense(s, d["state"], hp, m_rows, T, res, vmax, amax)[0]
+    out = qp_vjp_np.qp_vjp(s, d["state"], hp, m_rows, T, res, vmax, amax, lambda z: (Q @ z) / pl)
+    zr = d["forward_solved_z"]
+    assert np.abs(out["z"] - zr).max() <= 1e-8 * np.abs(zr).max()
+    assert abs(out["obj"] / pl - float(d["forward_solved_objc"])) <= 1e-9 * float(d["forward_solved_objc"])
+    # For THIS loss the hook's exact output on z is zero: J w = -[Qz; 0; 0] is solved by w = (0, 1 on the active rows, nu)
+    # because Qz = -G'lam - A'nu at the optimum (the envelope theorem: through z the optimal objective has no first-order
+    # sensitivity) -- what the reference's executed hook left is rounding at 1e-12 of the incoming gradient, and so is the
+    # restatement's.  (A loss other than objc is never back-propagated by the reference; vjp_*.npz cover that case.)
+    hk = d["forward_solved_hook_grad_z"]
+    scale = np.abs(Q @ zr).max() / pl
+    assert np.abs(hk).max() <= 1e-9 * scale and np.abs(out["hook"][:zr.size]).max() <= 1e-9 * scale
+    assert np.array_equal(hk, d["forward4lstm_solved_hook_grad_z"])
