@@ -162,11 +162,17 @@ def fp64_roofline(flops_per_launch, seconds, hbm_bytes_per_launch, kernel, traff
     hb = hbm_bytes_per_launch / seconds / 1e9
     # (FLOPs: analytic, data-independent -- cost_grad_flops; "hbm": SURVEY 8(d)'s compulsory bytes over the same time;
     #  "traffic": HBM bytes per step from the committed PMC passes of this leg, pmc_leg_traffic -- a constant of the tree)
-    return {"bound": "fp64", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-            "traffic": traffic, "kernel": kernel,
+    # (sub-leg rooflines: TFLOP/s against FP64_PEAK_TFLOPS, stated once per line as "fp64_peak_tflops"; a leg that is the
+    #  line's main workload gets "peak" and "unit" back: with_peak)
+    return {"bound": "fp64", "achieved": ach, "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic, "kernel": kernel,
             # (hbm: GB/s of the compulsory bytes and their fraction of the 8 TB/s peak)
             "hbm": {"achieved": hb, "frac": hb / HBM_PEAK_GBS,
                     "traffic_over_algorithmic": (traffic / hbm_bytes_per_launch) if traffic else None}}
+
+
+def with_peak(roof):
+    """the contract's keys for a roofline object that is a line's MAIN one"""
+    return dict(roof, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
 
 
 COST_GRAD_KERNELS = {1: "k_minco_cost_grad_fused", 3: "k_piece_grad (+ k_minco_solve, k_minco_propagate)"}
@@ -326,7 +332,7 @@ def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds, split=True):
         rate = 4096 * reps / (time.perf_counter() - t0)
         # (classic banded-LU MINCO + adjoint through the same factors + penalty partials in scalar C: oracle/minco_costgrad.c)
         out["cpu_baseline"] = {"value": rate, "unit": out["unit"], "cores": nthreads, "kind": "port",
-                               "sample": f"the same 4096 trajectories x {reps} passes, oracle/minco_costgrad.c",
+                               "sample": f"the 4096 trajectories x {reps} passes, oracle/minco_costgrad.c",
                                "gpu_vs_cpu_max_rel_cost_err": float(np.abs(gpu_cost - cc).max() / np.abs(cc).max()),
                                "gpu_vs_cpu_max_rel_gradT_err": float(np.abs(gpu_gT - cgT).max() / np.abs(cgT).max()),
                                "gpu_vs_cpu_max_rel_gradP_err": float(np.abs(gpu_gP - cgP.reshape(gpu_gP.shape)).max()
@@ -391,8 +397,7 @@ def run_qp(torch, aa, ctx, device, cpu_baseline, cpu_seconds, extras=True):
                     "infeasible_frac": float((r["status"] == -3).double().mean()),
                     # (traffic: slacks and multipliers live in global memory -- L2-resident while a problem runs --, everything else in
                     #  LDS and registers; two launches per batch: Newton steps 1-4 of every problem, then the unfinished ones)
-                    "roofline": {"bound": "fp64", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": ach / FP64_PEAK_TFLOPS, "kernel": "k_qp_ipm",
+                    "roofline": {"bound": "fp64", "achieved": ach, "frac": ach / FP64_PEAK_TFLOPS, "kernel": "k_qp_ipm",
                                  "traffic": pmc_leg_traffic("qp", [(f"k_qp_ipm<{s},", None, 2)])}}
         if not extras:
             continue
@@ -571,32 +576,58 @@ def run_config4(torch, aa, ctx, device, cpu_baseline, cpu_seconds):
 
 
 DIVERGENCE_BUDGETS = (25, 50, 100, 200, 400)
+DIVERGENCE_CONTROL_EPS = 1e-13      # the relative difference of the two OBJECTIVES (cost 1e-13, gradients 1.5e-13: config3 leg)
 
 
-def lbfgs_divergence_profile(aa, cbind, s, head, tail, wps, T, hp, pen, nthreads, budgets=DIVERGENCE_BUDGETS, ctx=None):
-    """Where do the device run and the C restatement of lbfgs_optimize part ways?  The SAME problems on both sides under
-    lbfgs_parameter_t defaults with max_iterations = each of `budgets` (lbfgs.hpp:690-695: the run stops with
-    LBFGSERR_MAXIMUMITERATION unless it stopped on its own earlier): per budget the fraction of problems with identical
-    (status, iterations, evaluations) and, among those, the largest relative difference of the costs; and per problem the
-    first budget at which the counters differ.  Identical counters = the two runs took the same branches at every Armijo /
-    Wolfe test so far, so their costs may differ by accumulated rounding only: the caller asserts <= 1e-6 on them."""
+def _pair_stats(np, g, r):
+    same = (g["status"] == r["status"]) & (g["iters"] == r["iters"]) & (g["evals"] == r["evals"])
+    rel = np.abs(g["cost"] - r["cost"]) / np.abs(r["cost"])
+    return same, float(same.mean()), (float(rel[same].max()) if same.any() else None), float(np.median(rel))
+
+
+def lbfgs_divergence_profile(aa, cbind, s, head, tail, wps, T, hp, pen, nthreads, budgets=DIVERGENCE_BUDGETS, ctx=None,
+                             eps=DIVERGENCE_CONTROL_EPS):
+    """Where do the device run and the C restatement of lbfgs_optimize part ways -- and is that more than rounding?  The SAME
+    problems on both sides under lbfgs_parameter_t defaults with max_iterations = each of `budgets` (lbfgs.hpp:690-695: the run
+    stops with LBFGSERR_MAXIMUMITERATION unless it stopped on its own earlier).  Per budget: the fraction of problems with
+    identical (status, iterations, evaluations), the largest relative cost difference among those, the median over all.
+    CONTROL: the C restatement against ITSELF from a start point perturbed by `eps` relative (waypoints and durations times
+    1 + eps N(0, 1)) -- how fast this objective amplifies a difference of the size the two objectives have anyway.  A defect
+    of the device optimiser that only shows late would make the first profile fall off faster than the second.
+    `aa` None: the control alone (no GPU: the CPU suite)."""
     import numpy as np
     B = head.shape[0]
-    first = np.full(B, 0, dtype=np.int64)                      # 0 = never within the budgets tried
-    out = {"problems": int(B), "same_counters_frac": {}, "max_rel_cost_diff_same_counters": {}}
+    rng = np.random.default_rng(99)
+    wps2 = wps * (1.0 + eps * rng.standard_normal(wps.shape))
+    T2 = T * (1.0 + eps * rng.standard_normal(T.shape))
+    first = np.zeros(B, dtype=np.int64)                        # 0 = never within the budgets tried
+    out = {"problems": int(B), "budgets": list(budgets), "control_eps": eps}
+    pairs = {"gpu_vs_cpu": ([], [], []), "cpu_vs_cpu_perturbed": ([], [], [])}
     for mi in budgets:
-        g = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=aa.lbfgs_parameter_t(max_iterations=mi),
-                           max_evals=40 * mi, want_coeffs=False, ctx=ctx)
         r = cbind.lbfgs_minco_batch(s, head, tail, wps, T, hp, param=cbind.lbfgs_default_param(max_iterations=mi),
                                     nthreads=nthreads, **PEN_ORACLE)
-        same = (g["status"] == r["status"]) & (g["iters"] == r["iters"]) & (g["evals"] == r["evals"])
-        rel = np.abs(g["cost"] - r["cost"]) / np.abs(r["cost"])
-        out["same_counters_frac"][str(mi)] = float(same.mean())
-        out["max_rel_cost_diff_same_counters"][str(mi)] = float(rel[same].max()) if same.any() else None
-        first[(first == 0) & ~same] = mi
-    div = first[first > 0]
-    out["diverged_within_budgets_frac"] = float(div.size) / B
-    out["median_first_diverging_budget"] = float(np.median(div)) if div.size else None
+        r2 = cbind.lbfgs_minco_batch(s, head, tail, wps2, T2, hp, param=cbind.lbfgs_default_param(max_iterations=mi),
+                                     nthreads=nthreads, **PEN_ORACLE)
+        todo = [("cpu_vs_cpu_perturbed", r2)]
+        if aa is not None:
+            g = aa.lbfgs_minco(head, tail, wps, T, s, hpolys=hp, penalty=pen, param=aa.lbfgs_parameter_t(max_iterations=mi),
+                               max_evals=40 * mi, want_coeffs=False, ctx=ctx)
+            todo.append(("gpu_vs_cpu", g))
+        for key, other in todo:
+            same, frac, worst, med = _pair_stats(np, other, r)
+            for lst, v in zip(pairs[key], (frac, worst, med)):
+                lst.append(v)
+            if key == "gpu_vs_cpu":
+                first[(first == 0) & ~same] = mi
+    r3 = lambda v: None if v is None else float(f"{v:.3g}")
+    # ("same": fraction with identical (status, iterations, evaluations); "max_rel_same": largest relative cost difference among
+    #  those; "median_rel": median relative cost difference over all problems; one entry per budget)
+    for key, (frac, worst, med) in pairs.items():
+        if frac:
+            out[key] = {"same": [r3(v) for v in frac], "max_rel_same": [r3(v) for v in worst], "median_rel": [r3(v) for v in med]}
+    if aa is not None:
+        div = first[first > 0]
+        out["median_first_diverging_budget"] = float(np.median(div)) if div.size else None
     return out
 
 
@@ -688,6 +719,7 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
                          traffic=pmc_leg_traffic("config5", cost_grad_picks(launches)) if B == total == 32768 else None)
     roof.update(kernel_ms=kernel_ms, algorithmic_bytes_per_trajectory=ab, flops_per_evaluation=cost_grad_flops(s, N, M, 20))
     ms_step = elapsed / steps * 1e3
+    ag = allgather_probe(torch, dist, og, device, use_dist)
     return {"value": total * steps / elapsed, "unit": "trajectory cost+gradient evaluations/s", "total_batch": total,
             "batch_this_rank": B, "ms_per_step": ms_step, "kernel_ms": kernel_ms, "steps": steps,
             # shard_ms: this rank's evaluation alone (events around it, mean over the timed steps); exposed_allgather_ms: what a
@@ -696,7 +728,7 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
             "shard_ms": kernel_ms, "exposed_allgather_ms": max(0.0, ms_step - kernel_ms), "launches_per_step": launches,
             "scaling": "strong", "pieces": N, "order": s, "poly_rows": M, "res": 20, "retimed_after_runtime_stall": retimed,
             "penalty_active_frac": float((cost[:B] > 0).double().mean().item()),
-            "allgather": allgather_probe(torch, dist, og, device, use_dist), "roofline": roof}
+            "allgather": ag, "roofline": roof}
 
 
 def time_steps(torch, dist, use_dist, device, steps, run_step, sync):
@@ -946,7 +978,7 @@ def main():
                "n_gpus": 1, "steps": head_["steps"], "warmup": args.warmup, "ms_per_step": head_["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": head_["workload"], "leg": args.workload, "main_only": bool(args.main_only)},
-               "roofline": head_["roofline"], {"config3": "config3", "config4": "config4", "qp": "qp_solve"}[args.workload]: leg}
+               "roofline": with_peak(head_["roofline"]), {"config3": "config3", "config4": "config4", "qp": "qp_solve"}[args.workload]: leg}
         if "cpu_baseline" in leg:
             out["cpu_baseline"] = leg["cpu_baseline"]
         print(finalize_line(out), flush=True)
@@ -965,7 +997,7 @@ def main():
                                       "cost + gradient evaluation per trajectory per step, sharded, costs all-gathered",
                           "global_batch": c5["total_batch"], "batch_this_rank": c5["batch_this_rank"],
                           "parallelism": f"dp{world}" + ("+allgather(costs)" if use_dist else "")},
-               "roofline": c5["roofline"], "config5": c5}
+               "roofline": with_peak(c5["roofline"]), "config5": c5}
         out["config"].update(ranks_seen=c5["allgather"]["ranks_seen"], allgather_ms=c5["allgather"]["allgather_ms"],
                              allgather_bytes_per_rank=c5["allgather"]["allgather_bytes_per_rank"],
                              allgather_every=c5["allgather"]["every"])
@@ -1044,12 +1076,14 @@ def main():
                      "frac_of_measured_copy_6290": achieved / 6290.0},
     }
 
+    out["fp64_peak_tflops"] = FP64_PEAK_TFLOPS        # what the sub-legs' "frac" are fractions of
     out["roofline"]["traffic"] = pmc_traffic_bytes(B, N, s)
     # (the committed rocprofv3 PMC pass of this launch shape, WRITE_SIZE + 2 x FETCH_SIZE: a constant of the tree, not counted
     #  during this run)
-    out["roofline"]["traffic_source"] = "profiles/*_pmc.json (committed PMC pass, not this run)"
+    out["roofline"]["traffic_source"] = "profiles/*_pmc.json"
     if c5 is not None:
-        out["config5"] = c5
+        # (one rank, no process group: the collective's description says nothing -- ranks_seen etc. are in "config")
+        out["config5"] = c5 if use_dist else dict(c5, allgather=None)
     if world == 1 and not args.main_only:
         # BASELINE configs[2] and configs[3] are single-GPU configurations: the north-star loop (cost + gradient, L-BFGS)
         del coeffs
@@ -1143,9 +1177,9 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / 20
-                smp[label] = {"samples": Ks, "ms_per_launch": ms, "value": Ks / (ms * 1e-3),
+                smp[label] = {"ms_per_launch": ms, "value": Ks / (ms * 1e-3),
                               "fp64_frac_at_4.1_kflop_per_sample": Ks * 4100.0 / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
-            # (time-allocation samples/s in one launch; 8 (N + 1) bytes per sample: bound by its FP64 work, ~4.1 kFLOP per sample)
+            # (time-allocation samples/s in one launch of 2^20 samples; 8 (N + 1) bytes per sample: bound by its FP64 work, ~4.1 kFLOP per sample)
             out["config1_b1024"]["sampler"] = smp
         except Exception as exc:
             out["config1_b1024"]["sampler"] = {"error": str(exc)[:200]}

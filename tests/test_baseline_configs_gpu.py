@@ -211,12 +211,16 @@ def test_config3_converged_costs_against_the_cpu_restatement(anet_ctx):
 
 def test_config3_divergence_of_the_two_runs_is_rounding_not_a_late_defect(anet_ctx):
     """Between the budgets where the counters are exact (2 / 6) or nearly so (3 / 12) and the ~2500 iterations of a run to
-    convergence there was no evidence: 256 strided problems of configs[3] at iteration budgets 25 / 50 / 100 / 200 / 400 on
-    both sides (bench.lbfgs_divergence_profile, the figures the bench line carries).  A problem whose (status, iterations,
-    evaluations) still agree has taken the same branch at every line-search test so far, so its two costs differ by
-    accumulated rounding only: <= 1e-6 at EVERY budget -- a defect of the device optimiser that only shows late would break
-    exactly this.  The fraction that still agrees falls with the budget (each Armijo / Wolfe comparison that sits within
-    rounding of its threshold is a coin toss); the numbers are printed, and bounded from below where they were measured."""
+    convergence there was no evidence that the end points differ by amplified rounding and not by a defect that only shows late.
+    256 strided problems of configs[3] at iteration budgets 25 / 50 / 100 / 200 / 400 on both sides (bench.lbfgs_divergence_profile,
+    the figures the bench line carries) WITH A CONTROL: the C restatement against itself from a start point perturbed by 1e-13
+    relative -- the size of the difference the two objectives have anyway.  Measured (round 6): identical counters for
+    1.00 / 1.00 / 0.90 / 0.07 / 0.08 of the problems device-vs-restatement and 1.00 / 1.00 / 0.75 / 0.14 / 0.08 restatement-vs-
+    perturbed-restatement; costs of identical-counter problems apart by at most 1e-10 / 9e-6 / 5e-3 / 1e-2 against 2e-9 / 2e-4 /
+    1e-2 / 2e-2: this objective amplifies a rounding-level difference about 10^5-fold per 25 iterations, whoever computes it.
+    Asserted: the device-vs-restatement profile is NO WORSE than the control's at any budget (a late defect would fall off
+    faster), and up to 25 iterations -- before the amplification reaches the seventh digit -- identical counters come with
+    costs equal to 1e-8."""
     import allocnet_amd as aa
     import bench
     B, s, c, N, M = 4096, 3, 3, 16, 16
@@ -225,10 +229,13 @@ def test_config3_divergence_of_the_two_runs_is_rounding_not_a_late_defect(anet_c
     prof = bench.lbfgs_divergence_profile(aa, cbind, s, head[idx], tail[idx], wps[idx], T[idx], hp[idx], _penalty(aa, M), 8,
                                           ctx=anet_ctx)
     print("configs[3] divergence profile:", prof)
-    fr = prof["same_counters_frac"]
-    for mi in bench.DIVERGENCE_BUDGETS:
-        worst = prof["max_rel_cost_diff_same_counters"][str(mi)]
-        assert worst is None or worst <= 1e-6, (mi, worst)
-    assert fr["25"] >= 0.9                                        # (3 / 12 iterations: >= 0.99, test above)
-    vals = [fr[str(mi)] for mi in bench.DIVERGENCE_BUDGETS]
-    assert all(a >= b - 0.02 for a, b in zip(vals, vals[1:]))      # agreement only ever decays with the budget
+    dev, ctl = prof["gpu_vs_cpu"], prof["cpu_vs_cpu_perturbed"]
+    assert prof["budgets"] == [25, 50, 100, 200, 400]
+    assert dev["same"][0] == 1.0 and dev["max_rel_same"][0] <= 1e-8
+    for k, mi in enumerate(prof["budgets"]):
+        # agreement at least the control's (binomial noise of 256 problems: three sigma ~ 0.1) ...
+        assert dev["same"][k] >= ctl["same"][k] - 0.1, (mi, dev, ctl)
+        # ... and the costs no further apart than the control's, over all problems (median) and among identical counters (max)
+        assert dev["median_rel"][k] <= 10.0 * ctl["median_rel"][k] + 1e-12, (mi, dev, ctl)
+        if dev["max_rel_same"][k] is not None and ctl["max_rel_same"][k] is not None:
+            assert dev["max_rel_same"][k] <= 30.0 * ctl["max_rel_same"][k] + 1e-9, (mi, dev, ctl)

@@ -91,3 +91,25 @@ def test_c_lbfgs_driver_equals_the_callback_driven_loop():
         assert np.abs(out["wps"][b].reshape(-1) - xo[:nw]).max() <= 1e-7 * np.abs(xo[:nw]).max()
         assert np.abs(out["T"][b] - _fwd(xo[nw:])).max() <= 1e-7 * out["T"][b].max()
     assert (out["cost"] < cbind.minco_cost_grad_batch(s, head, tail, wps, T, hp, RHO, **KW)[0]).all()
+
+
+def test_configs3_objective_amplifies_rounding_in_the_restatement_alone():
+    """No GPU involved: the C restatement of lbfgs_optimize (lbfgs.hpp:434-717) on the C cost + gradient, 64 strided problems of
+    BASELINE configs[3], against ITSELF from a start point perturbed by 1e-15 relative (one unit in the last place).  Up to 50
+    iterations every problem keeps identical (status, iterations, evaluations); by 200 iterations most do not, and the costs of
+    those that do are apart by more than 1e-4: the L-BFGS on this objective (smoothed-L1 penalties of weight 1e4 at mu = 1e-2)
+    amplifies a last-bit difference roughly 10^5-fold per 25 iterations.  This is why the converged end points of the device
+    run and the restatement can only be compared statistically (tests/test_baseline_configs_gpu.py has the device side of the
+    same profile, asserted to be no worse than this control)."""
+    import bench
+    from allocnet_amd.synth import corridor_problem
+    B, s, c, N, M = 4096, 3, 3, 16, 16
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(2), B, N, c, M)
+    idx = np.linspace(0, B - 1, 64).astype(int)
+    prof = bench.lbfgs_divergence_profile(None, cbind, s, head[idx], tail[idx], wps[idx], T[idx], hp[idx], None, 4,
+                                          budgets=(25, 50, 200), eps=1e-15)
+    ctl = prof["cpu_vs_cpu_perturbed"]
+    assert "gpu_vs_cpu" not in prof
+    assert ctl["same"][0] == 1.0 and ctl["max_rel_same"][0] <= 1e-8
+    assert ctl["same"][1] >= 0.95
+    assert ctl["same"][2] <= 0.5 and ctl["median_rel"][2] >= 1e-5

@@ -727,7 +727,9 @@ def test_generic_device_objective_matches_the_restatement(anet_ctx, n, B):
             assert (st[b] < 0) == (ret < 0) and abs(int(ev[b]) - evo) <= 6 and abs(int(it[b]) - ito) <= 2, (b, st[b], it[b], ev[b], ret, ito, evo)
             assert fg[b] <= 10.0 * fo + 1.0 and fo <= 10.0 * fg[b] + 1.0, (b, fg[b], fo)
     print("device-objective L-BFGS, n = %d: identical (status, k, evals) in %d of %d problems" % (n, same, B))
-    assert same >= 0.9 * B, (same, B)
+    # measured (round 6): every problem of every shape (200 / 5 / 33 / 9) -- deterministic on both sides; the bounded branch above
+    # stays for the day a reordered sum flips a test on its threshold, but at most one problem in fifty may take it
+    assert same >= B - B // 50, (same, B)
     # the built-in step bound (bound_from / bound_min: the last variables may not fall below a floor within a line search,
     # lbfgs.hpp:557-565) against the restatement running the same bound as its proc_stepbound callback
     nb = max(1, n // 3)
@@ -862,7 +864,8 @@ def test_host_callback_objective_matches_the_restatement(anet_ctx, n):
                 if mode == "progress" and budget > 5:
                     assert ret == aa.lbfgs.LBFGS_CANCELED or ret < 0 or it < 5, (ret, it)
     print("host-callback L-BFGS, n = %d: identical (ret, k, evals) in %d of %d runs" % (n, same, total))
-    assert same >= 0.9 * total, (same, total)
+    # measured (round 6): 108 of 108 runs for every n -- the arithmetic is deterministic on both sides, so anything less is a change
+    assert same == total, (same, total)
     # left to run from the classic start: the minimum f = 0 at x = 1
     x0 = np.where(np.arange(n) % 2 == 0, -1.2, 1.0)
     ret, x, f, it, ev = aa.lbfgs_optimize(x0, _rosen, param=aa.lbfgs_parameter_t(g_epsilon=1e-7, delta=0.0, past=0), ctx=anet_ctx)
