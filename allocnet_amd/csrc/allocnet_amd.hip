@@ -1036,6 +1036,14 @@ static int basis_table(anet_ctx *ctx, int s, int res, hipStream_t st, const doub
   return rc;
 }
 
+// The large-batch penalty kernel with the basis-table contractions on the FP64 matrix instructions (csrc/piece_grad_mx.h): built for
+// res = 20; ANET_PG_MX=0/1 overrides the default (A-B runs).
+static int anet_piece_grad_mx_res() { return 20; }
+static bool piece_grad_mx_enabled() {
+  static const int v = [] { const char *e = getenv("ANET_PG_MX"); return e ? atoi(e) : 0; }();
+  return v != 0;
+}
+
 int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
                                  const double *coeffs, const double *T, const double *hpolys,
                                  const anet_penalty *pen, int with_energy, double *gdC, double *gdT,
@@ -1067,6 +1075,8 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
   } else if (pen && batch <= axis_variant_max_batch(ctx)) {  // small batches: two lanes per (trajectory, piece)
     const dim3 g2((unsigned)((2 * batch + 255) / 256), (unsigned)n_pieces);
     anet::launch_piece_grad(s, 1, g2, block, st, a, tab);
+  } else if (pen && pen->res == anet_piece_grad_mx_res() && (s == 3 || s == 4) && piece_grad_mx_enabled()) {
+    anet::launch_piece_grad(s, 3, grid, block, st, a, tab);
   } else {
     anet::launch_piece_grad(s, 0, grid, block, st, a, tab);
   }

@@ -7,11 +7,15 @@
 
 #include "minco_kernels.h"
 #include "minco_fused_kernel.h"
+#include "piece_grad_mx.h"
 
 namespace anet {
 
 void launch_piece_grad(int s, int shape, dim3 grid, dim3 block, hipStream_t st, const PieceGradArgs &a, const double *tab) {
-  if (shape == 2) {
+  if (shape == 3) {  // large batches, res = 20, orders 3 / 4: the table contractions on the matrix instructions (piece_grad_mx.h)
+    if (s == 3) hipLaunchKernelGGL((k_piece_grad_mx<3>), grid, block, 0, st, a, tab);
+    else hipLaunchKernelGGL((k_piece_grad_mx<4>), grid, block, 0, st, a, tab);
+  } else if (shape == 2) {
     if (s == 2) hipLaunchKernelGGL((k_piece_grad<2, true, 4>), grid, block, 0, st, a, tab);
     else if (s == 3) hipLaunchKernelGGL((k_piece_grad<3, true, 4>), grid, block, 0, st, a, tab);
     else hipLaunchKernelGGL((k_piece_grad<4, true, 4>), grid, block, 0, st, a, tab);
