@@ -113,18 +113,27 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
   // Row blocks travel global -> registers (a block ahead, issued before the arithmetic of the block at work) -> LDS -> registers:
   // lane (r, col) fetches the rows r, r + 4, r + 8, r + 12 of its pair's block -- every row is fetched by ONE lane, not by the
   // four that use it -- and all four read them back.  (LDS instructions of a wave execute in order: no barrier.)
+  // Addresses: a wave-uniform base (scalar registers) plus ONE 64-bit lane offset per column set -- r selects among four
+  // multiples of ld, never a per-lane 64-bit multiplication.
+  const int64_t rld = r == 0 ? 0 : (r == 1 ? ld : (r == 2 ? 2 * ld : 3 * ld));
+  auto lane_b = [&](const int cs) {
+    const int64_t bq = b0 + 16 * cs + col;
+    return bq < a.B ? bq : a.B - 1;
+  };
   double hn[4][4];
   auto fetch_rows = [&](const int cs, const int rb) {
-    const int64_t bq = b0 + 16 * cs + col;
-    const int64_t b = bq < a.B ? bq : a.B - 1;
+    const int64_t lofs = 4 * rld + lane_b(cs);              // rows r + 4 m: (4 r) ld + b
+    const double *const pb = a.hpolys + (int64_t)(i * pp.M) * 4 * ld;  // the pair's row 0 (uniform part)
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const int rr = rb * RB + r + 4 * m;
-      const bool ok = rr < M;
-      const int rc = ok ? rr : 0;
+      const int ru = rb * RB + 4 * m;                       // uniform part of the row index
+      const bool ok = ru + r < M;
+      const double *const pm = pb + (int64_t)ru * 4 * ld;
+      // (a lane whose row does not exist reads the block's first row, which does, and keeps zeros)
+      const int64_t lo = ok ? lofs : lane_b(cs) - (int64_t)(4 * m) * 4 * ld;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const double v = M > 0 ? a.hpolys[(int64_t)((i * pp.M + rc) * 4 + e) * ld + b] : 0.0;
+        const double v = (pm + (int64_t)e * ld)[lo];
         hn[m][e] = ok ? v : 0.0;
       }
     }
@@ -141,13 +150,13 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
   };
   double cn[3][2], Tn;  // the next column set's coefficients and duration
   auto fetch_coeffs = [&](const int cs) {
-    const int64_t bq = b0 + 16 * cs + col;
-    const int64_t b = bq < a.B ? bq : a.B - 1;
-    Tn = a.T[(int64_t)i * ld + b];
+    const int64_t b = lane_b(cs), lofs = rld + b;
+    Tn = (a.T + (int64_t)i * ld)[b];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-      cn[ax][0] = a.coeffs[(int64_t)((i * 3 + ax) * D + r) * ld + b];
-      cn[ax][1] = a.coeffs[(int64_t)((i * 3 + ax) * D + (has1 ? 4 + r : r)) * ld + b];
+      const double *const pc0 = a.coeffs + (int64_t)((i * 3 + ax) * D) * ld;
+      cn[ax][0] = pc0[lofs];
+      cn[ax][1] = (has1 ? pc0 + 4 * ld : pc0)[lofs];
     }
   };
   fetch_coeffs(0);
@@ -196,13 +205,11 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
     mx_d4 V[3][4];
     auto forward_tile = [&](const int t) {
       const double af0 = laf[(t * 64 + lane_o) * 2], af1 = laf[(t * 64 + lane_o) * 2 + 1];
+      const mx_d4 z = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ax = 0; ax < 3; ++ax) {
-        mx_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af0, cb[ax][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af1, cb[ax][1], acc, 0, 0, 0);
-        V[ax][t] = acc;
-      }
+      for (int ax = 0; ax < 3; ++ax) V[ax][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0, cb[ax][0], z, 0, 0, 0);
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) V[ax][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1, cb[ax][1], V[ax][t], 0, 0, 0);
     };
     forward_tile(1);
     forward_tile(2);
@@ -271,20 +278,27 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
       park_rows();  // the block fetched a block ago
       const double *src = lr + col * TST;
       const int nq = M - rb * RB < RB ? M - rb * RB : RB;
-#pragma unroll 4
-      for (int q = 0; q < nq; ++q) {
-        const double h0 = src[q * 4], h1 = src[q * 4 + 1], h2 = src[q * 4 + 2], h3 = src[q * 4 + 3];
+#pragma unroll 1
+      for (int q0 = 0; q0 < nq; q0 += 4) {  // (rows beyond M are zero rows: inside every corridor)
+        double h[4][4];
 #pragma unroll
-        for (int ii = 0; ii < NSL; ++ii) {
-          const double u = __builtin_fma(h0, ps[0][ii], __builtin_fma(h1, ps[1][ii], __builtin_fma(h2, ps[2][ii], -h3)));
-          if (__any(u > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
-            const double w = fmax(u, 0.0), uc = fmin(w, 1.0), sq = uc * uc;
-            Fs[ii] += w - uc;
-            Fs[ii] = __builtin_fma(sq * uc, __builtin_fma(-0.5, uc, 1.0), Fs[ii]);
-            const double df = sq * __builtin_fma(-2.0, uc, 3.0);
-            G[0][ii] = __builtin_fma(df, h0, G[0][ii]);
-            G[1][ii] = __builtin_fma(df, h1, G[1][ii]);
-            G[2][ii] = __builtin_fma(df, h2, G[2][ii]);
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[q][e] = src[(q0 + q) * 4 + e];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int ii = 0; ii < NSL; ++ii) {
+            const double u = __builtin_fma(h[q][0], ps[0][ii], __builtin_fma(h[q][1], ps[1][ii], __builtin_fma(h[q][2], ps[2][ii], -h[q][3])));
+            if (__any(u > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
+              const double w = fmax(u, 0.0), uc = fmin(w, 1.0), sq = uc * uc;
+              Fs[ii] += w - uc;
+              Fs[ii] = __builtin_fma(sq * uc, __builtin_fma(-0.5, uc, 1.0), Fs[ii]);
+              const double df = sq * __builtin_fma(-2.0, uc, 3.0);
+              G[0][ii] = __builtin_fma(df, h[q][0], G[0][ii]);
+              G[1][ii] = __builtin_fma(df, h[q][1], G[1][ii]);
+              G[2][ii] = __builtin_fma(df, h[q][2], G[2][ii]);
+            }
           }
         }
       }
@@ -297,8 +311,10 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
 #pragma unroll
     for (int ii = 0; ii < NSL; ++ii) {
       csum = __builtin_fma(wcm, Fs[ii], csum);
-      const double w0[3] = {K0 * G[0][ii], K0 * G[1][ii], K0 * G[2][ii]};
-      grad_step(ii, w0);
+      if (__any(Fs[ii] > 0.0)) {  // (no violated row at this sample in the whole wave: its weights are zeros)
+        const double w0[3] = {K0 * G[0][ii], K0 * G[1][ii], K0 * G[2][ii]};
+        grad_step(ii, w0);
+      }
     }
     // ---- d/dT at fixed c (quadrature weight and sample times, as in piece_penalty_part); the sums over the pair's four lanes as
     //      products with a matrix of ones (every lane receives the sum) ----
@@ -327,10 +343,12 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
       }
     }
     if (live) {
+      const int64_t lofs = rld + b;
 #pragma unroll
       for (int ax = 0; ax < 3; ++ax) {
-        a.gdC[(int64_t)((i * 3 + ax) * D + r) * ld + b] = g0[ax];
-        if (has1) a.gdC[(int64_t)((i * 3 + ax) * D + 4 + r) * ld + b] = g1[ax];
+        double *const pg0 = a.gdC + (int64_t)((i * 3 + ax) * D) * ld;
+        pg0[lofs] = g0[ax];
+        if (has1) (pg0 + 4 * ld)[lofs] = g1[ax];
       }
       if (r == 0) {
         a.gdT[(int64_t)i * ld + b] = gT;
