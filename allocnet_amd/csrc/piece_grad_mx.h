@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
     const int64_t bq = b0 + 16 * cs + col;
     return bq < a.B ? bq : a.B - 1;
   };
-  double hn[4][4];
+  double hn[4][4], hok[4];
   auto fetch_rows = [&](const int cs, const int rb) {
     const int64_t lofs = 4 * rld + lane_b(cs);              // rows r + 4 m: (4 r) ld + b
     const double *const pb = a.hpolys + (int64_t)(i * pp.M) * 4 * ld;  // the pair's row 0 (uniform part)
@@ -132,20 +132,19 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
       // (a lane whose row does not exist reads the block's first row, which does, and keeps zeros)
       const int64_t lo = ok ? lofs : lane_b(cs) - (int64_t)(4 * m) * 4 * ld;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const double v = (pm + (int64_t)e * ld)[lo];
-        hn[m][e] = ok ? v : 0.0;
-      }
+      for (int e = 0; e < 4; ++e) hn[m][e] = (pm + (int64_t)e * ld)[lo];
+      // (raw: the zeros go in where the block is parked -- a select here is a wait for the load right behind its issue)
+      hok[m] = ok ? 1.0 : 0.0;
     }
   };
   auto park_rows = [&]() {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       double *dst = lr + col * TST + (r + 4 * m) * 4;
-      dst[0] = hn[m][0];
-      dst[1] = hn[m][1];
-      dst[2] = hn[m][2];
-      dst[3] = hn[m][3] * inv_mu;
+      dst[0] = hn[m][0] * hok[m];
+      dst[1] = hn[m][1] * hok[m];
+      dst[2] = hn[m][2] * hok[m];
+      dst[3] = hn[m][3] * (hok[m] * inv_mu);
     }
   };
   double cn[3][2], Tn;  // the next column set's coefficients and duration
@@ -159,8 +158,15 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
       cn[ax][1] = (has1 ? pc0 + 4 * ld : pc0)[lofs];
     }
   };
+  // Prefetched values must not be carried across the loop's back edge as loads in flight: the compiler then sinks the loads to
+  // the end of the body and waits for everything (vmcnt counts in order) at the top.  `landed` ties a value to an empty asm
+  // statement -- the wait stands where it is written, the value crosses the back edge as a plain register.
+  auto landed = [](double &v) { asm volatile("" : "+v"(v)); };
   fetch_coeffs(0);
-  if (nrb > 0) fetch_rows(0, 0);
+  if (nrb > 0) {
+    fetch_rows(0, 0);
+    park_rows();
+  }
 
 #pragma unroll 1
   for (int cs = 0; cs < NCS; ++cs) {
@@ -275,7 +281,10 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
     }
 #pragma unroll 1
     for (int rb = 0; rb < nrb; ++rb) {
-      park_rows();  // the block fetched a block ago
+      // the next block on its way -- this pair's next, or the next column set's first -- while this one is walked; it is parked
+      // (the same LDS rows: this block is done with them then) behind the walk
+      const int rbn = rb + 1 < nrb ? rb + 1 : 0, csn = rb + 1 < nrb ? cs : cs + 1;
+      if (csn < NCS) fetch_rows(csn, rbn);
       const double *src = lr + col * TST;
       const int nq = M - rb * RB < RB ? M - rb * RB : RB;
 #pragma unroll 1
@@ -302,10 +311,12 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
           }
         }
       }
-      {  // the next block on its way (this pair's next, or the next column set's first): its latency passes behind the gradient
-         // steps, the stores and the next column set's limits; its registers are not live while the rows are walked
-        const int rbn = rb + 1 < nrb ? rb + 1 : 0, csn = rb + 1 < nrb ? cs : cs + 1;
-        if (csn < NCS) fetch_rows(csn, rbn);
+      if (csn < NCS) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) landed(hn[m][e]);
+        park_rows();
       }
     }
 #pragma unroll
@@ -353,6 +364,14 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
       if (r == 0) {
         a.gdT[(int64_t)i * ld + b] = gT;
         if (a.pcost) a.pcost[(int64_t)i * ld + b] = pc;
+      }
+    }
+    if (cs + 1 < NCS) {
+      landed(Tn);
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        landed(cn[ax][0]);
+        landed(cn[ax][1]);
       }
     }
   }
