@@ -5,7 +5,7 @@ runs in hand-written HIP kernels behind the C ABI in include/allocnet_amd.h.
 """
 from ._lib import AnetError, load, LIB_PATH  # noqa: F401
 from .context import Context, default_context  # noqa: F401
-from .minco import MINCO, MINCO_S2NU, MINCO_S3NU, MINCO_S4NU, minco_solve, minco_solve_dev, bind_minco_solve, BoundMincoSolve, recommended_ld, minco_cost_grad, minco_cost_grad_dev, minco_cost_grad_launches, make_penalty, minco_sample_costs, minco_sample_costs_dev  # noqa: F401
+from .minco import MINCO, MINCO_S2NU, MINCO_S3NU, MINCO_S4NU, minco_solve, minco_solve_dev, bind_minco_solve, BoundMincoSolve, recommended_ld, minco_cost_grad, minco_cost_grad_dev, minco_cost_grad_launches, minco_piece_grad_shape, make_penalty, minco_sample_costs, minco_sample_costs_dev  # noqa: F401
 
 from .trajectory import Piece, Trajectory, traj_eval, traj_cost, traj_cost_grad_T, traj_max_rate  # noqa: F401
 from . import lbfgs  # noqa: F401

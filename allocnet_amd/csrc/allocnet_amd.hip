@@ -1037,11 +1037,32 @@ static int basis_table(anet_ctx *ctx, int s, int res, hipStream_t st, const doub
 }
 
 // The large-batch penalty kernel with the basis-table contractions on the FP64 matrix instructions (csrc/piece_grad_mx.h): built for
-// res = 20; ANET_PG_MX=0/1 overrides the default (A-B runs).
+// res = 20.  Order 4 takes it by default (131 072 x 8 pieces: 310 us against 344, profiles/r06_piece_grad_mx.txt); order 3 does not
+// (six coefficients fill three quarters of the instructions' k and column tiles: 312 us against 293 for 65 536 x 16 pieces).
+// ANET_PG_MX = 0: never, 1: order 4 (default), 2: orders 3 and 4 (A-B runs).
 static int anet_piece_grad_mx_res() { return 20; }
-static bool piece_grad_mx_enabled() {
-  static const int v = [] { const char *e = getenv("ANET_PG_MX"); return e ? atoi(e) : 0; }();
-  return v != 0;
+static int piece_grad_mx_level() {
+  static const int v = [] { const char *e = getenv("ANET_PG_MX"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
+// The launch shape of the penalty / energy-gradient kernel (launch_piece_grad): 0 a lane per (trajectory, piece); 1 two lanes per
+// pair (small batches); 2 two lanes and the samples over a workgroup's four waves (fewest pairs); 3 k_piece_grad_mx
+static int piece_grad_shape(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen) {
+  // ANET_PIECE_SW_MAX_PAIRS overrides (tuning / A-B runs)
+  static const int64_t sw_env = [] { const char *e = getenv("ANET_PIECE_SW_MAX_PAIRS"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
+  const int64_t sw_max_pairs = sw_env >= 0 ? sw_env : per_cu(ctx, kPieceSampleSplitMaxPairs);
+  if (pen && batch <= axis_variant_max_batch(ctx)) return batch * n_pieces <= sw_max_pairs ? 2 : 1;
+  if (pen && pen->res == anet_piece_grad_mx_res() && (s == 4 ? piece_grad_mx_level() >= 1 : (s == 3 && piece_grad_mx_level() >= 2)))
+    return 3;
+  return 0;
+}
+
+int anet_minco_piece_grad_shape(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen) {
+  if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
+  if (s < 2 || s > 4 || n_pieces < 1 || n_pieces > ANET_MAX_PIECES || batch < 0)
+    return fail(ctx, ANET_ERR_INVALID, "anet_minco_piece_grad_shape: bad shape");
+  return piece_grad_shape(ctx, s, n_pieces, batch, pen);
 }
 
 int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t batch, int64_t ld,
@@ -1065,20 +1086,16 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
   hipStream_t st = (hipStream_t)stream;
   const double *tab = nullptr;
   if (pen && (rc = basis_table(ctx, s, pen->res, st, &tab))) return rc;
-  // ANET_PIECE_SW_MAX_PAIRS overrides (tuning / A-B runs)
-  static const int64_t sw_env = [] { const char *e = getenv("ANET_PIECE_SW_MAX_PAIRS"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
-  const int64_t sw_max_pairs = sw_env >= 0 ? sw_env : per_cu(ctx, kPieceSampleSplitMaxPairs);
-  if (pen && batch <= axis_variant_max_batch(ctx) && batch * n_pieces <= sw_max_pairs) {
+  const int shape = piece_grad_shape(ctx, s, n_pieces, batch, pen);
+  if (shape == 2) {
     // fewest waves: two lanes per (trajectory, piece) AND the samples spread over the four waves of a workgroup
     const dim3 g4((unsigned)((2 * batch + 63) / 64), (unsigned)n_pieces);
     anet::launch_piece_grad(s, 2, g4, block, st, a, tab);
-  } else if (pen && batch <= axis_variant_max_batch(ctx)) {  // small batches: two lanes per (trajectory, piece)
+  } else if (shape == 1) {  // small batches: two lanes per (trajectory, piece)
     const dim3 g2((unsigned)((2 * batch + 255) / 256), (unsigned)n_pieces);
     anet::launch_piece_grad(s, 1, g2, block, st, a, tab);
-  } else if (pen && pen->res == anet_piece_grad_mx_res() && (s == 3 || s == 4) && piece_grad_mx_enabled()) {
-    anet::launch_piece_grad(s, 3, grid, block, st, a, tab);
-  } else {
-    anet::launch_piece_grad(s, 0, grid, block, st, a, tab);
+  } else {  // 0: a lane per (trajectory, piece); 3: four lanes per pair and the matrix instructions -- 64 pairs per wave either way
+    anet::launch_piece_grad(s, shape, grid, block, st, a, tab);
   }
   ANET_HIP(ctx, hipGetLastError());
   return ANET_OK;

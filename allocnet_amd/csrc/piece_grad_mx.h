@@ -128,9 +128,15 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
     for (int m = 0; m < 4; ++m) {
       const int ru = rb * RB + 4 * m;                       // uniform part of the row index
       const bool ok = ru + r < M;
+      if (ru >= M) {                                        // (wave-uniform: none of the four rows exists)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hn[m][e] = 0.0;
+        hok[m] = 0.0;
+        continue;
+      }
       const double *const pm = pb + (int64_t)ru * 4 * ld;
-      // (a lane whose row does not exist reads the block's first row, which does, and keeps zeros)
-      const int64_t lo = ok ? lofs : lane_b(cs) - (int64_t)(4 * m) * 4 * ld;
+      // (a lane whose row does not exist reads row `ru`, which does, and keeps zeros)
+      const int64_t lo = ok ? lofs : lofs - 4 * rld;
 #pragma unroll
       for (int e = 0; e < 4; ++e) hn[m][e] = (pm + (int64_t)e * ld)[lo];
       // (raw: the zeros go in where the block is parked -- a select here is a wait for the load right behind its issue)
@@ -204,6 +210,7 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
     if (cs + 1 < NCS) fetch_coeffs(cs + 1);
     const double rT = fast_rcp(Ti), rT2 = rT * rT, step = Ti * inv_res;
     const double kv = rT * inv_mu, ka = rT2 * inv_mu;
+    const double thr1 = pp.vmax * Ti, thr2 = pp.amax * (Ti * Ti);
     const double K0 = step * pp.wc, K1 = step * rT * pp.wv, K2 = step * rT2 * pp.wa;
     // ---- forward, tiles 1 .. 3: velocity and acceleration of this lane's samples (and the position of its fifth) ----
     // Stage order (registers): limits -> their gradient steps u = 5 .. 14 -> position tile 0 -> corridor rows -> steps u = 0 .. 4;
@@ -237,14 +244,15 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
     // ---- velocity / acceleration limits (the formulas of piece_penalty_part) ----
 #pragma unroll
     for (int ii = 0; ii < NSL; ++ii) {
-      double a1[3], a2[3], worst = 0.0;
+      double a1[3], a2[3];
 #pragma unroll
       for (int ax = 0; ax < 3; ++ax) {
         a1[ax] = val(ax, NSL + ii);
         a2[ax] = val(ax, 2 * NSL + ii);
-        worst = fmax(worst, fmax(__builtin_fma(fabs(a1[ax]), kv, -cv), __builtin_fma(fabs(a2[ax]), ka, -ca)));
       }
-      if (__any(worst > 0.0)) {  // only one of +v, -v (+a, -a) can be violated: the slope has the sign of a1 (a2)
+      // (|a1| kv - cv > 0 <=> |a1| > vmax T: two maxima and two compares instead of six FMAs and five maxima)
+      const double m1 = fmax(fmax(fabs(a1[0]), fabs(a1[1])), fabs(a1[2])), m2 = fmax(fmax(fabs(a2[0]), fabs(a2[1])), fabs(a2[2]));
+      if (__any(m1 > thr1 || m2 > thr2)) {  // only one of +v, -v (+a, -a) can be violated: the slope has the sign of a1 (a2)
         double cost = 0.0, s1[3], s2[3];
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {

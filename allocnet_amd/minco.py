@@ -276,6 +276,18 @@ def minco_cost_grad_launches(s, N, B, penalty=None, ctx=None):
     return n
 
 
+def minco_piece_grad_shape(s, N, B, penalty=None, ctx=None):
+    """anet_minco_piece_grad_shape: the launch shape of the penalty / energy-gradient kernel for this batch -- 0 a lane per
+    (trajectory, piece), 1 / 2 the small-batch shapes, 3 k_piece_grad_mx (the basis-table contractions on the FP64 matrix
+    instructions: large batches, order 4, 20 samples per piece)."""
+    ctx = ctx or default_context(0)
+    n = ctx.lib.anet_minco_piece_grad_shape(ctx.handle, s, N, B, ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p)
+                                            if penalty is not None else None)
+    if n < 0:
+        ctx.check(n)
+    return n
+
+
 def minco_cost_grad_dev(head, tail, wps, T, s, c, N, B, hpolys=None, penalty=None, work=None, cost=None,
                         gradP=None, gradT=None, coeffs=None, stream=None, ctx=None):
     """Device entry point -> anet_minco_cost_grad_dev (torch CUDA float64, batch-minor, common ld)."""

@@ -176,13 +176,22 @@ def with_peak(roof):
 
 
 COST_GRAD_KERNELS = {1: "k_minco_cost_grad_fused", 3: "k_piece_grad (+ k_minco_solve, k_minco_propagate)"}
+PIECE_GRAD_KERNELS = {0: "k_piece_grad", 1: "k_piece_grad", 2: "k_piece_grad", 3: "k_piece_grad_mx"}
+
+
+def cost_grad_kernel_label(aa, ctx, s, N, B, pen):
+    """the kernels of one cost + gradient evaluation of this shape, dominant first: what the library's own predicates say runs
+    (anet_minco_cost_grad_launches, anet_minco_piece_grad_shape)"""
+    if aa.minco_cost_grad_launches(s, N, B, penalty=pen, ctx=ctx) == 1:
+        return COST_GRAD_KERNELS[1]
+    return PIECE_GRAD_KERNELS[aa.minco_piece_grad_shape(s, N, B, penalty=pen, ctx=ctx)] + " (+ k_minco_solve, k_minco_propagate)"
 
 
 def cost_grad_picks(launches):
     """the kernels of one cost + gradient evaluation as pmc_leg_traffic picks"""
     if launches == 1:
         return [("k_minco_cost_grad_fused", None, 1)]
-    return [("k_minco_solve<4, 8, true, 2>", None, 1), ("k_piece_grad<", None, 1), ("k_minco_propagate<", None, 1)]
+    return [("k_minco_solve<4, 8, true, 2>", None, 1), ("k_piece_grad", None, 1), ("k_minco_propagate<", None, 1)]
 
 
 PEN = dict(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20)
@@ -261,7 +270,7 @@ def cost_grad_kernel_split(torch, aa, ctx, s, c, N, B, ld, th, tt, tw, tT, thp, 
     for ev in evs:
         three(ev)
     torch.cuda.synchronize()
-    names = ("k_minco_solve", "k_piece_grad", "k_minco_propagate")
+    names = ("k_minco_solve", PIECE_GRAD_KERNELS[aa.minco_piece_grad_shape(s, N, B, penalty=pen, ctx=ctx)], "k_minco_propagate")
     return {n: 1e3 * sum(ev[i].elapsed_time(ev[i + 1]) for ev in evs) / K for i, n in enumerate(names)}
 
 
@@ -305,7 +314,7 @@ def run_config3(torch, aa, ctx, device, cpu_baseline, cpu_seconds, split=True):
         launches = aa.minco_cost_grad_launches(s, N, B, penalty=pen, ctx=ctx)
         out[key] = {"batch": B, "ms_per_step": dt * 1e3, "stream_ms_per_step": kms, "value": B / dt,
                     "stream_ms_min_max": [st_ms[0], st_ms[-1]], "launches_per_step": launches,
-                    "roofline": fp64_roofline(B * flops, kms * 1e-3, B * ab, COST_GRAD_KERNELS[launches],
+                    "roofline": fp64_roofline(B * flops, kms * 1e-3, B * ab, cost_grad_kernel_label(aa, ctx, s, N, B, pen),
                                               traffic=pmc_leg_traffic("config3", cost_grad_picks(launches)))}
         if split:
             # the three streaming launches one by one (at a one-launch batch this is NOT what the step above ran: it is the
@@ -715,7 +724,7 @@ def run_config5(torch, dist, aa, ctx, device, world, rank, use_dist, steps, warm
     ab = config5_bytes(s, c, N, M)
     launches = aa.minco_cost_grad_launches(s, N, B, penalty=pen, ctx=ctx)
     # (traffic: the committed PMC passes are of the one-rank shard, 32768 trajectories; another shard size has no entry)
-    roof = fp64_roofline(B * cost_grad_flops(s, N, M, 20), kernel_ms * 1e-3, B * ab, COST_GRAD_KERNELS[launches],
+    roof = fp64_roofline(B * cost_grad_flops(s, N, M, 20), kernel_ms * 1e-3, B * ab, cost_grad_kernel_label(aa, ctx, s, N, B, pen),
                          traffic=pmc_leg_traffic("config5", cost_grad_picks(launches)) if B == total == 32768 else None)
     roof.update(kernel_ms=kernel_ms, algorithmic_bytes_per_trajectory=ab, flops_per_evaluation=cost_grad_flops(s, N, M, 20))
     ms_step = elapsed / steps * 1e3

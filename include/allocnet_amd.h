@@ -260,6 +260,12 @@ int64_t anet_minco_cost_grad_workspace(int s, int n_pieces, int64_t ld);
  * of up to three rounds of one workgroup per compute unit, orders 3 and 4, res <= 64) or 3 (k_minco_solve -> k_piece_grad ->
  * k_minco_propagate); negative = error.  For callers that label a measurement with the kernel that ran (bench.py).          */
 int anet_minco_cost_grad_launches(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen);
+/* The launch shape anet_minco_partial_grads_dev picks for this shape on this context's device: 0 one lane per (trajectory,
+ * piece) (k_piece_grad, large batches); 1 two lanes per pair; 2 two lanes and the samples over a workgroup's four waves (the small
+ * batches); 3 k_piece_grad_mx -- four lanes per pair, the contractions with the basis table on the FP64 matrix instructions
+ * (large batches, order 4, res = 20: the penalty functional of qp_solver.hpp:244-296's rows at planner.yaml:21's sampling);
+ * negative = error.  For callers that label a measurement with the kernel that ran (bench.py).                                */
+int anet_minco_piece_grad_shape(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen);
 int anet_minco_cost_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,
                              const double *head, const double *tail, const double *wps,
                              const double *T, const double *hpolys, const anet_penalty *pen,

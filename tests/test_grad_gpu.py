@@ -118,10 +118,15 @@ def test_random_shapes_against_both_oracles(anet_ctx):
     assert len(seen) >= 20
 
 
-@pytest.mark.parametrize("s,c,N,M", [(4, 3, 8, 16), (4, 4, 8, 9), (4, 3, 5, 16), (3, 3, 8, 12), (3, 3, 5, 7), (4, 3, 1, 6),
-                                     (4, 3, 2, 6), (3, 2, 3, 0)])
-def test_large_batch_shapes_agree_with_small_batch_shapes_and_oracle(anet_ctx, s, c, N, M):
-    """Batches above 16384 run the lane-per-trajectory solve / adjoint and the lane-per-piece penalty kernel, batches up to
+@pytest.mark.parametrize("s,c,N,M,res", [(4, 3, 8, 16, 9), (4, 4, 8, 9, 9), (4, 3, 5, 16, 9), (3, 3, 8, 12, 9), (3, 3, 5, 7, 9),
+                                         (4, 3, 1, 6, 9), (4, 3, 2, 6, 9), (3, 2, 3, 0, 9),
+                                         # res = 20, order 4: k_piece_grad_mx (the table contractions on the matrix instructions) --
+                                         # one full row block, two blocks with a ragged second, a partial group of four, no rows
+                                         (4, 3, 8, 16, 20), (4, 4, 5, 21, 20), (4, 2, 3, 7, 20), (4, 3, 2, 0, 20), (4, 3, 1, 37, 20),
+                                         (3, 3, 8, 12, 20)])
+def test_large_batch_shapes_agree_with_small_batch_shapes_and_oracle(anet_ctx, s, c, N, M, res):
+    """Batches above 16384 run the lane-per-trajectory solve / adjoint and the lane-per-piece penalty kernel (order 4 at 20 samples
+    per piece: four lanes per piece and the FP64 matrix instructions, csrc/piece_grad_mx.h), batches up to
     16384 the lane-per-(trajectory, axis) and two-lanes-per-piece shapes: the same 16384 + 257 trajectories (a ragged last
     workgroup) through both agree to rounding -- whole batch against chunks of 8192 -- and a strided sample agrees with the C
     restatement (classic banded LU + adjoint) to the tolerance of the other parity tests."""
@@ -135,7 +140,7 @@ def test_large_batch_shapes_agree_with_small_batch_shapes_and_oracle(anet_ctx, s
     else:
         head, tail, wps, T = random_problem(rng, B, N, c)
         hp = None
-    kw = dict(res=9, vmax=2.5, amax=3.5, wc=1e3, wv=40.0, wa=15.0, mu=0.03)
+    kw = dict(res=res, vmax=2.5, amax=3.5, wc=1e3, wv=40.0, wa=15.0, mu=0.03)
     pen = aa.make_penalty(rho=3.0, w_corridor=kw["wc"], w_vel=kw["wv"], w_acc=kw["wa"], smooth_mu=kw["mu"], max_vel=kw["vmax"],
                           max_acc=kw["amax"], res=kw["res"], poly_rows=M)
     cost, gP, gT = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, ctx=anet_ctx)          # large-batch shapes

@@ -6,7 +6,7 @@ variant chosen by the environment variable the library reads once, so each side 
 
 Prints per side the median kernel time of anet_minco_partial_grads_dev (events on the stream, 5 x 20 launches) and of the whole
 cost + gradient evaluation, then the largest relative differences of the partial gradients, dJ/dT partials and piece costs between
-the two sides and of the evaluation's results against the C restatement (oracle/minco_costgrad.c) on the first 2048 trajectories."""
+the two sides (each side's parity with the C restatement is tests/test_grad_gpu.py's business)."""
 import argparse
 import json
 import os
@@ -72,15 +72,6 @@ def child(args):
     torch.cuda.synchronize()
     np.savez(args.dump, gdC=gdC[:, :B].cpu().numpy(), gdT=gdT[:, :B].cpu().numpy(), pcs=pcs[:, :B].cpu().numpy(),
              cost=cost[:B].cpu().numpy(), gT=gT[:, :B].cpu().numpy(), gP=gP[:, :B].cpu().numpy())
-    if args.oracle:
-        from oracle import cbind
-        from bench import PEN_ORACLE
-        n = min(B, 2048)
-        cc, cgP, cgT = cbind.minco_cost_grad_batch(s, head[:n], tail[:n], wps[:n], T[:n], hp[:n], nthreads=8, **PEN_ORACLE)
-        gc, ggT, ggP = cost[:n].cpu().numpy(), gT[:, :n].cpu().numpy().T, gP[:, :n].cpu().numpy().T
-        res["vs_oracle"] = {"cost": float(np.abs(gc - cc).max() / np.abs(cc).max()),
-                            "gradT": float(np.abs(ggT - cgT).max() / np.abs(cgT).max()),
-                            "gradP": float(np.abs(ggP - cgP.reshape(ggP.shape)).max() / np.abs(cgP).max())}
     print(json.dumps(res))
 
 
@@ -90,7 +81,6 @@ def main():
     ap.add_argument("--order", type=int, default=4)
     ap.add_argument("--pieces", type=int, default=8)
     ap.add_argument("--dump", default=None)
-    ap.add_argument("--oracle", type=int, default=1)
     args = ap.parse_args()
     if args.dump:
         return child(args)
@@ -101,7 +91,7 @@ def main():
             dump = os.path.join(td, f"mx{mx}.npz")
             env = dict(os.environ, ANET_PG_MX=str(mx))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", str(args.batch), "--order", str(args.order),
-                                "--pieces", str(args.pieces), "--dump", dump, "--oracle", str(args.oracle)],
+                                "--pieces", str(args.pieces), "--dump", dump],
                                capture_output=True, text=True, env=env, cwd=ROOT)
             if r.returncode != 0:
                 print(r.stderr[-3000:])
