@@ -13,8 +13,18 @@ namespace anet {
 
 void launch_piece_grad(int s, int shape, dim3 grid, dim3 block, hipStream_t st, const PieceGradArgs &a, const double *tab) {
   if (shape == 3) {  // large batches, res = 20, orders 3 / 4: the table contractions on the matrix instructions (piece_grad_mx.h)
-    if (s == 3) hipLaunchKernelGGL((k_piece_grad_mx<3>), grid, block, 0, st, a, tab);
-    else hipLaunchKernelGGL((k_piece_grad_mx<4>), grid, block, 0, st, a, tab);
+    // (ANET_PGMX_DYNLDS: bytes of unused dynamic LDS per workgroup -- an occupancy probe for tools/, never set otherwise)
+    static const int dyn = [] {
+      const char *e = getenv("ANET_PGMX_DYNLDS");
+      const int v = e ? atoi(e) : 0;
+      if (v > 0) {
+        (void)hipFuncSetAttribute((const void *)k_piece_grad_mx<4>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+        (void)hipFuncSetAttribute((const void *)k_piece_grad_mx<3>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+      }
+      return v;
+    }();
+    if (s == 3) hipLaunchKernelGGL((k_piece_grad_mx<3>), grid, block, dyn, st, a, tab);
+    else hipLaunchKernelGGL((k_piece_grad_mx<4>), grid, block, dyn, st, a, tab);
   } else if (shape == 2) {
     if (s == 2) hipLaunchKernelGGL((k_piece_grad<2, true, 4>), grid, block, 0, st, a, tab);
     else if (s == 3) hipLaunchKernelGGL((k_piece_grad<3, true, 4>), grid, block, 0, st, a, tab);
