@@ -48,6 +48,142 @@ __device__ __forceinline__ double mx_xor_sum(double v) {  // sum over the four l
   return v;
 }
 
+// One column set of 16 pairs on a wave: the states of every lane's five samples from the B operands cb (c~ of the lane's pair, columns r
+// and 4 + r), the limit and corridor penalties, the gradient w.r.t. c~ (gN: columns r and 4 + r) -- the part k_piece_grad_mx and the
+// one-launch evaluation (minco_fused_kernel.h, MX) share.  rows: the pair's parked row block in LDS ([row][4], b / mu); before(rb) /
+// after(rb): called around the walk of row block rb (the callers' prefetch of the next block and its parking).  lag / laf: the
+// constant A operands in LDS, read through lane_o (an index the compiler cannot hoist the reads through).
+template <int S, class Before, class After>
+__device__ __forceinline__ void mx_column_set(const Penalty &pp, const double inv_mu, const double inv_res, const int lane_o,
+                                              const double *lag, const double *laf, const double *rows, const int M, const int nrb,
+                                              const double Ti, const double (&cb)[3][2], Before &&before, After &&after,
+                                              double (&gN)[3][2], double &csum, double &Rs1, double &Rs2, double &rT, double &step) {
+  constexpr int NSL = kMxNSL, RB = 16;
+  const double wcm = pp.wc * pp.mu, wvm = pp.wv * pp.mu, wam = pp.wa * pp.mu;
+  const double cv = pp.vmax * inv_mu, ca = pp.amax * inv_mu;
+  rT = fast_rcp(Ti);
+  step = Ti * inv_res;
+  const double rT2 = rT * rT;
+  const double kv = rT * inv_mu, ka = rT2 * inv_mu;
+  const double thr1 = pp.vmax * Ti, thr2 = pp.amax * (Ti * Ti);
+  const double K0 = step * pp.wc, K1 = step * rT * pp.wv, K2 = step * rT2 * pp.wa;
+  // ---- forward, tiles 1 .. 3: velocity and acceleration of this lane's samples (and the position of its fifth) ----
+  // Stage order (registers): limits -> their gradient steps u = 5 .. 14 -> position tile 0 -> corridor rows -> steps u = 0 .. 4;
+  // a weight lives from its sample's penalty to its matrix instruction and no longer.
+  mx_d4 V[3][4];
+  auto forward_tile = [&](const int t) {
+    const double af0 = laf[(t * 64 + lane_o) * 2], af1 = laf[(t * 64 + lane_o) * 2 + 1];
+    const mx_d4 z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) V[ax][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0, cb[ax][0], z, 0, 0, 0);
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) V[ax][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1, cb[ax][1], V[ax][t], 0, 0, 0);
+  };
+  forward_tile(1);
+  forward_tile(2);
+  forward_tile(3);
+  auto val = [&](int ax, int u) { return V[ax][u >> 2][u & 3]; };  // (u compile-time after unrolling)
+  const double p4[3] = {val(0, 4), val(1, 4), val(2, 4)};          // (the position of the fifth sample sits in tile 1)
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) gN[ax][0] = gN[ax][1] = 0.0;
+  auto grad_step = [&](const int u, const double (&w)[3]) {  // gN += tab[slot u]' w: two 4x4x4 instructions per axis
+    const double ag0 = lag[(u * 64 + lane_o) * 2], ag1 = lag[(u * 64 + lane_o) * 2 + 1];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      gN[ax][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ag0, w[ax], gN[ax][0], 0, 0, 0);
+      gN[ax][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ag1, w[ax], gN[ax][1], 0, 0, 0);
+    }
+  };
+  csum = Rs1 = Rs2 = 0.0;
+  // ---- velocity / acceleration limits (the formulas of piece_penalty_part) ----
+#pragma unroll
+  for (int ii = 0; ii < NSL; ++ii) {
+    double a1[3], a2[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      a1[ax] = val(ax, NSL + ii);
+      a2[ax] = val(ax, 2 * NSL + ii);
+    }
+    // (|a1| kv - cv > 0 <=> |a1| > vmax T: two maxima and two compares instead of six FMAs and five maxima)
+    const double m1 = fmax(fmax(fabs(a1[0]), fabs(a1[1])), fabs(a1[2])), m2 = fmax(fmax(fabs(a2[0]), fabs(a2[1])), fabs(a2[2]));
+    if (__any(m1 > thr1 || m2 > thr2)) {  // only one of +v, -v (+a, -a) can be violated: the slope has the sign of a1 (a2)
+      double cost = 0.0, s1[3], s2[3];
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        double f, df;
+        smoothed_l1_unit(__builtin_fma(fabs(a1[ax]), kv, -cv), f, df);
+        cost = __builtin_fma(wvm, f, cost);
+        s1[ax] = K1 * copysign(df, a1[ax]);
+        Rs1 = __builtin_fma(s1[ax], a1[ax], Rs1);
+        smoothed_l1_unit(__builtin_fma(fabs(a2[ax]), ka, -ca), f, df);
+        cost = __builtin_fma(wam, f, cost);
+        s2[ax] = K2 * copysign(df, a2[ax]);
+        Rs2 = __builtin_fma(s2[ax], a2[ax], Rs2);
+      }
+      csum += cost;
+      grad_step(NSL + ii, s1);
+      grad_step(2 * NSL + ii, s2);
+    }
+  }
+  // ---- corridor rows: positions and offsets in units of mu, normals as given ----
+  forward_tile(0);
+  double ps[3][NSL];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) ps[ax][ii] = V[ax][0][ii];
+    ps[ax][4] = p4[ax];
+  }
+  double Fs[NSL], G[3][NSL];
+#pragma unroll
+  for (int ii = 0; ii < NSL; ++ii) {
+    Fs[ii] = 0.0;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) G[ax][ii] = 0.0;
+  }
+#pragma unroll 1
+  for (int rb = 0; rb < nrb; ++rb) {
+    // before(rb): the next block on its way while this one is walked; after(rb): it is parked (the same LDS rows: this block is
+    // done with them then)
+    before(rb);
+    const double *src = rows;
+    const int nq = M - rb * RB < RB ? M - rb * RB : RB;
+#pragma unroll 1
+    for (int q0 = 0; q0 < nq; q0 += 4) {  // (rows beyond M are zero rows: inside every corridor)
+      double h[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[q][e] = src[(q0 + q) * 4 + e];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int ii = 0; ii < NSL; ++ii) {
+          const double u = __builtin_fma(h[q][0], ps[0][ii], __builtin_fma(h[q][1], ps[1][ii], __builtin_fma(h[q][2], ps[2][ii], -h[q][3])));
+          if (__any(u > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
+            const double w = fmax(u, 0.0), uc = fmin(w, 1.0), sq = uc * uc;
+            Fs[ii] += w - uc;
+            Fs[ii] = __builtin_fma(sq * uc, __builtin_fma(-0.5, uc, 1.0), Fs[ii]);
+            const double df = sq * __builtin_fma(-2.0, uc, 3.0);
+            G[0][ii] = __builtin_fma(df, h[q][0], G[0][ii]);
+            G[1][ii] = __builtin_fma(df, h[q][1], G[1][ii]);
+            G[2][ii] = __builtin_fma(df, h[q][2], G[2][ii]);
+          }
+        }
+      }
+    }
+    after(rb);
+  }
+#pragma unroll
+  for (int ii = 0; ii < NSL; ++ii) {
+    csum = __builtin_fma(wcm, Fs[ii], csum);
+    if (__any(Fs[ii] > 0.0)) {  // (no violated row at this sample in the whole wave: its weights are zeros)
+      const double w0[3] = {K0 * G[0][ii], K0 * G[1][ii], K0 * G[2][ii]};
+      grad_step(ii, w0);
+    }
+  }
+}
+
 template <int S>
 __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGradArgs a, const double *__restrict__ tab) {
   static_assert(S == 3 || S == 4, "orders 3 and 4");
@@ -103,8 +239,6 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
   __syncthreads();
   const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
   if (b0 >= a.B) return;
-  const double wcm = pp.wc * pp.mu, wvm = pp.wv * pp.mu, wam = pp.wa * pp.mu;
-  const double cv = pp.vmax * inv_mu, ca = pp.amax * inv_mu;
   const int M = a.hpolys ? pp.M : 0;
   const int nrb = (M + RB - 1) / RB;                       // row blocks of 16 per pair
   double *const lr = lrow[wave];
@@ -120,7 +254,8 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
     const int64_t bq = b0 + 16 * cs + col;
     return bq < a.B ? bq : a.B - 1;
   };
-  double hn[4][4], hok[4];
+  double hn[4][4];
+  int hok = 0;  // bit m: row r + 4 m of the fetched block exists
   auto fetch_rows = [&](const int cs, const int rb) {
     const int64_t lofs = 4 * rld + lane_b(cs);              // rows r + 4 m: (4 r) ld + b
     const double *const pb = a.hpolys + (int64_t)(i * pp.M) * 4 * ld;  // the pair's row 0 (uniform part)
@@ -128,10 +263,10 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
     for (int m = 0; m < 4; ++m) {
       const int ru = rb * RB + 4 * m;                       // uniform part of the row index
       const bool ok = ru + r < M;
+      if (m == 0) hok = 0;
       if (ru >= M) {                                        // (wave-uniform: none of the four rows exists)
 #pragma unroll
         for (int e = 0; e < 4; ++e) hn[m][e] = 0.0;
-        hok[m] = 0.0;
         continue;
       }
       const double *const pm = pb + (int64_t)ru * 4 * ld;
@@ -140,17 +275,18 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
 #pragma unroll
       for (int e = 0; e < 4; ++e) hn[m][e] = (pm + (int64_t)e * ld)[lo];
       // (raw: the zeros go in where the block is parked -- a select here is a wait for the load right behind its issue)
-      hok[m] = ok ? 1.0 : 0.0;
+      hok |= ok ? (1 << m) : 0;
     }
   };
   auto park_rows = [&]() {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       double *dst = lr + col * TST + (r + 4 * m) * 4;
-      dst[0] = hn[m][0] * hok[m];
-      dst[1] = hn[m][1] * hok[m];
-      dst[2] = hn[m][2] * hok[m];
-      dst[3] = hn[m][3] * (hok[m] * inv_mu);
+      const bool ok = (hok >> m) & 1;
+      dst[0] = ok ? hn[m][0] : 0.0;
+      dst[1] = ok ? hn[m][1] : 0.0;
+      dst[2] = ok ? hn[m][2] : 0.0;
+      dst[3] = ok ? hn[m][3] * inv_mu : 0.0;
     }
   };
   double cn[3][2], Tn;  // the next column set's coefficients and duration
@@ -189,152 +325,33 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
     tp[0] = 1.0;
 #pragma unroll
     for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
-    double tsel[2], tB, TA;
+    double tsel[2];
     tsel[0] = mx_sel4(r, tp[D - 1], tp[D - 2], tp[D - 3], tp[D - 4]);
-    if constexpr (D == 8) {
-      tsel[1] = mx_sel4(r, tp[3], tp[2], tp[1], tp[0]);
-      tB = tsel[1];                                   // T^(S - 1 - r)
-      TA = mx_sel4(r, tp[4], tp[3], tp[2], tp[1]);    // T^(S - r)
-    } else {
-      tsel[1] = mx_sel4(r, tp[1], tp[0], 0.0, 0.0);
-      tB = mx_sel4(r, tp[2], tp[1], tp[0], 0.0);
-      TA = mx_sel4(r, tp[3], tp[2], tp[1], 0.0);
-    }
-    double cb[3][2], ye[3];
+    if constexpr (D == 8) tsel[1] = mx_sel4(r, tp[3], tp[2], tp[1], tp[0]);
+    else tsel[1] = mx_sel4(r, tp[1], tp[0], 0.0, 0.0);
+    double cb[3][2];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
       cb[ax][0] = cn[ax][0] * tsel[0];
       cb[ax][1] = has1 ? cn[ax][1] * tsel[1] : 0.0;
-      ye[ax] = cn[ax][0] * tB;
     }
     if (cs + 1 < NCS) fetch_coeffs(cs + 1);
-    const double rT = fast_rcp(Ti), rT2 = rT * rT, step = Ti * inv_res;
-    const double kv = rT * inv_mu, ka = rT2 * inv_mu;
-    const double thr1 = pp.vmax * Ti, thr2 = pp.amax * (Ti * Ti);
-    const double K0 = step * pp.wc, K1 = step * rT * pp.wv, K2 = step * rT2 * pp.wa;
-    // ---- forward, tiles 1 .. 3: velocity and acceleration of this lane's samples (and the position of its fifth) ----
-    // Stage order (registers): limits -> their gradient steps u = 5 .. 14 -> position tile 0 -> corridor rows -> steps u = 0 .. 4;
-    // a weight lives from its sample's penalty to its matrix instruction and no longer.
-    mx_d4 V[3][4];
-    auto forward_tile = [&](const int t) {
-      const double af0 = laf[(t * 64 + lane_o) * 2], af1 = laf[(t * 64 + lane_o) * 2 + 1];
-      const mx_d4 z = {0.0, 0.0, 0.0, 0.0};
+    double gN[3][2], csum, Rs1, Rs2, rT, step;
+    mx_column_set<S>(pp, inv_mu, inv_res, lane_o, lag, laf, lr + col * TST, M, nrb, Ti, cb,
+                     [&](const int rb) {  // the next block on its way: this pair's next, or the next column set's first
+                       const int rbn = rb + 1 < nrb ? rb + 1 : 0, csn = rb + 1 < nrb ? cs : cs + 1;
+                       if (csn < NCS) fetch_rows(csn, rbn);
+                     },
+                     [&](const int rb) {
+                       if ((rb + 1 < nrb ? cs : cs + 1) < NCS) {
 #pragma unroll
-      for (int ax = 0; ax < 3; ++ax) V[ax][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af0, cb[ax][0], z, 0, 0, 0);
+                         for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int ax = 0; ax < 3; ++ax) V[ax][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af1, cb[ax][1], V[ax][t], 0, 0, 0);
-    };
-    forward_tile(1);
-    forward_tile(2);
-    forward_tile(3);
-    auto val = [&](int ax, int u) { return V[ax][u >> 2][u & 3]; };  // (u compile-time after unrolling)
-    const double p4[3] = {val(0, 4), val(1, 4), val(2, 4)};          // (the position of the fifth sample sits in tile 1)
-    double gN[3][2];  // gradient w.r.t. c~: columns r and 4 + r of this lane's pair
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) gN[ax][0] = gN[ax][1] = 0.0;
-    auto grad_step = [&](const int u, const double (&w)[3]) {  // gN += tab[slot u]' w: two 4x4x4 instructions per axis
-      const double ag0 = lag[(u * 64 + lane_o) * 2], ag1 = lag[(u * 64 + lane_o) * 2 + 1];
-#pragma unroll
-      for (int ax = 0; ax < 3; ++ax) {
-        gN[ax][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ag0, w[ax], gN[ax][0], 0, 0, 0);
-        gN[ax][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ag1, w[ax], gN[ax][1], 0, 0, 0);
-      }
-    };
-    double csum = 0.0, Rs1 = 0.0, Rs2 = 0.0;
-    // ---- velocity / acceleration limits (the formulas of piece_penalty_part) ----
-#pragma unroll
-    for (int ii = 0; ii < NSL; ++ii) {
-      double a1[3], a2[3];
-#pragma unroll
-      for (int ax = 0; ax < 3; ++ax) {
-        a1[ax] = val(ax, NSL + ii);
-        a2[ax] = val(ax, 2 * NSL + ii);
-      }
-      // (|a1| kv - cv > 0 <=> |a1| > vmax T: two maxima and two compares instead of six FMAs and five maxima)
-      const double m1 = fmax(fmax(fabs(a1[0]), fabs(a1[1])), fabs(a1[2])), m2 = fmax(fmax(fabs(a2[0]), fabs(a2[1])), fabs(a2[2]));
-      if (__any(m1 > thr1 || m2 > thr2)) {  // only one of +v, -v (+a, -a) can be violated: the slope has the sign of a1 (a2)
-        double cost = 0.0, s1[3], s2[3];
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-          double f, df;
-          smoothed_l1_unit(__builtin_fma(fabs(a1[ax]), kv, -cv), f, df);
-          cost = __builtin_fma(wvm, f, cost);
-          s1[ax] = K1 * copysign(df, a1[ax]);
-          Rs1 = __builtin_fma(s1[ax], a1[ax], Rs1);
-          smoothed_l1_unit(__builtin_fma(fabs(a2[ax]), ka, -ca), f, df);
-          cost = __builtin_fma(wam, f, cost);
-          s2[ax] = K2 * copysign(df, a2[ax]);
-          Rs2 = __builtin_fma(s2[ax], a2[ax], Rs2);
-        }
-        csum += cost;
-        grad_step(NSL + ii, s1);
-        grad_step(2 * NSL + ii, s2);
-      }
-    }
-    // ---- corridor rows: positions and offsets in units of mu, normals as given ----
-    forward_tile(0);
-    double ps[3][NSL];
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii) ps[ax][ii] = V[ax][0][ii];
-      ps[ax][4] = p4[ax];
-    }
-    double Fs[NSL], G[3][NSL];
-#pragma unroll
-    for (int ii = 0; ii < NSL; ++ii) {
-      Fs[ii] = 0.0;
-#pragma unroll
-      for (int ax = 0; ax < 3; ++ax) G[ax][ii] = 0.0;
-    }
-#pragma unroll 1
-    for (int rb = 0; rb < nrb; ++rb) {
-      // the next block on its way -- this pair's next, or the next column set's first -- while this one is walked; it is parked
-      // (the same LDS rows: this block is done with them then) behind the walk
-      const int rbn = rb + 1 < nrb ? rb + 1 : 0, csn = rb + 1 < nrb ? cs : cs + 1;
-      if (csn < NCS) fetch_rows(csn, rbn);
-      const double *src = lr + col * TST;
-      const int nq = M - rb * RB < RB ? M - rb * RB : RB;
-#pragma unroll 1
-      for (int q0 = 0; q0 < nq; q0 += 4) {  // (rows beyond M are zero rows: inside every corridor)
-        double h[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) h[q][e] = src[(q0 + q) * 4 + e];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int ii = 0; ii < NSL; ++ii) {
-            const double u = __builtin_fma(h[q][0], ps[0][ii], __builtin_fma(h[q][1], ps[1][ii], __builtin_fma(h[q][2], ps[2][ii], -h[q][3])));
-            if (__any(u > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
-              const double w = fmax(u, 0.0), uc = fmin(w, 1.0), sq = uc * uc;
-              Fs[ii] += w - uc;
-              Fs[ii] = __builtin_fma(sq * uc, __builtin_fma(-0.5, uc, 1.0), Fs[ii]);
-              const double df = sq * __builtin_fma(-2.0, uc, 3.0);
-              G[0][ii] = __builtin_fma(df, h[q][0], G[0][ii]);
-              G[1][ii] = __builtin_fma(df, h[q][1], G[1][ii]);
-              G[2][ii] = __builtin_fma(df, h[q][2], G[2][ii]);
-            }
-          }
-        }
-      }
-      if (csn < NCS) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) landed(hn[m][e]);
-        park_rows();
-      }
-    }
-#pragma unroll
-    for (int ii = 0; ii < NSL; ++ii) {
-      csum = __builtin_fma(wcm, Fs[ii], csum);
-      if (__any(Fs[ii] > 0.0)) {  // (no violated row at this sample in the whole wave: its weights are zeros)
-        const double w0[3] = {K0 * G[0][ii], K0 * G[1][ii], K0 * G[2][ii]};
-        grad_step(ii, w0);
-      }
-    }
+                           for (int e = 0; e < 4; ++e) landed(hn[m][e]);
+                         park_rows();
+                       }
+                     },
+                     gN, csum, Rs1, Rs2, rT, step);
     // ---- d/dT at fixed c (quadrature weight and sample times, as in piece_penalty_part); the sums over the pair's four lanes as
     //      products with a matrix of ones (every lane receives the sum) ----
     double acc = 0.0;
@@ -353,10 +370,14 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
       g1[ax] = gN[ax][1] * tsel[1];
     }
     if (a.with_energy) {
+      // y_k = c_k T^(S - 1 - k) = c~_k T^-S for the lane's column k = r < S (zero operands A elsewhere); T^(S - r) = tsel[0] T^-(S - 1)
+      const double rTS = S == 4 ? (rT * rT) * (rT * rT) : rT * (rT * rT);
+      const double TA = tsel[0] * (S == 4 ? rT * (rT * rT) : rT * rT);
 #pragma unroll
       for (int ax = 0; ax < 3; ++ax) {
-        const double e = __builtin_amdgcn_mfma_f64_4x4x4f64(AE, ye[ax], 0.0, 0, 0, 0);
-        const double ps = __builtin_amdgcn_mfma_f64_4x4x4f64(AP, ye[ax], 0.0, 0, 0, 0);
+        const double ye = cb[ax][0] * rTS;
+        const double e = __builtin_amdgcn_mfma_f64_4x4x4f64(AE, ye, 0.0, 0, 0, 0);
+        const double ps = __builtin_amdgcn_mfma_f64_4x4x4f64(AP, ye, 0.0, 0, 0, 0);
         g0[ax] = __builtin_fma(e, TA, g0[ax]);  // (e = 0 in the lanes r >= S)
         gT = __builtin_fma(ps, ps, gT);
       }
