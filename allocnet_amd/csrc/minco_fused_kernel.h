@@ -26,6 +26,7 @@
 // streaming kernels remain the better shape (the host picks: allocnet_amd.hip cost_grad_dev_impl).
 #pragma once
 #include "minco_kernels.h"
+#include "piece_grad_mx.h"
 
 namespace anet {
 
@@ -56,14 +57,22 @@ struct FusedShape {
   static constexpr int PST = 130;                              // row stride of the LDS arrays (pairs, padded)
 };
 
-template <int S, int NB, bool NEXACT = false, int NPC = -1>
+// MX (round 6; exact shapes whose groups fill the workgroup, G NB = 128, at 20 samples per piece): phase 2 in k_piece_grad_mx's
+// mapping -- a wave owns 32 (trajectory, piece) pairs as two column sets of 16, four lanes per pair with five samples each, the
+// contractions with the basis table on the FP64 matrix instructions (piece_grad_mx.h: mx_column_set); the piece's coefficients are
+// formed by three of its four lanes (one axis each) and change hands through the LDS rows the adjoint's hand-over uses later.
+template <int S, int NB, bool NEXACT = false, int NPC = -1, bool MX = false>
 __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, const double *__restrict__ tab) {
   constexpr int m = S - 1, D = 2 * S, GM = FusedShape<NB>::G, PST = FusedShape<NB>::PST;
   constexpr int ROW_T = 0, ROW_GX = ROW_T + 1, ROW_GTD = ROW_GX + 3 * D, ROW_GDT = ROW_GTD + 3, ROW_PC = ROW_GDT + 1, ROW_EN = ROW_PC + 1;
   constexpr int NRED = 3 * D + 2;  // values a lane pair hands to the pair that adds up a piece: gC, gT, pc
   __shared__ double lds[(ROW_EN + 1) * PST];
-  __shared__ double lred[NRED * 128];
-  __shared__ double ltab[kFusedMaxRes * 3 * D];
+  __shared__ double lred[MX ? 1 : NRED * 128];
+  __shared__ double ltab[MX ? 1 : kFusedMaxRes * 3 * D];
+  constexpr int MXTST = 16 * 4 + 2;                   // (MX) doubles per pair of a parked row block, as in k_piece_grad_mx
+  __shared__ double mx_lag[MX ? kMxNU * 64 * 2 : 1];  // (MX) gradient A operands [u][lane][ct]
+  __shared__ double mx_laf[MX ? 4 * 64 * 2 : 1];      // (MX) forward A operands [tile][lane][ks]
+  __shared__ double mx_row[MX ? 4 * 16 * MXTST : 1];  // (MX) per wave: the corridor rows of the column set at work
   // What phase 3 needs of phase 1 (factor, node states, durations, energy: ~100 doubles per chain lane) waits in LDS, not in
   // registers across phase 2: with them the sample loop (whose table rows are per-lane values) goes into scratch
   constexpr int nl = Factor<S, NB>::nl > 0 ? Factor<S, NB>::nl : 1;
@@ -95,8 +104,33 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     // the rows of position, velocity and acceleration of every sample (read by other threads behind the barrier); by the waves
     // that have no chain to start: a load-to-store round trip in front of wave 0's chain would be in front of everything
     constexpr int CW = TW ? 2 : 1;  // waves with chain lanes
-    if (wave >= CW)
-      for (int e = tid - 64 * CW; e < a.pp.res * 3 * D; e += 256 - 64 * CW) ltab[e] = tab[(size_t)(e / (3 * D)) * 4 * D + e % (3 * D)];
+    if constexpr (MX) {
+      static_assert(CW == 2, "two idle waves build the operand tables");
+      const int lane = tid & 63, r = lane >> 4, col = lane & 15;
+      const double inv_mu = 1.0 / a.pp.mu;
+      if (wave == 2) {
+#pragma unroll
+        for (int u = 0; u < kMxNU; ++u)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const int ic = lane & 3, j = r + 4 * (u % kMxNSL), d = u / kMxNSL, cc = 4 * ct + ic;
+            mx_lag[(u * 64 + lane) * 2 + ct] = tab[(size_t)(j * 4 + d) * D + (cc < D ? cc : 0)] * (cc < D ? 1.0 : 0.0);
+          }
+      } else if (wave == 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int row = 16 * t + col, u = row >> 2, rr = row & 3, d = u / kMxNSL, j = rr + 4 * (u % kMxNSL), ck = 4 * ks + r;
+            const bool in = u < kMxNU && ck < D;
+            const double v = tab[(size_t)(j * 4 + (in ? d : 0)) * D + (in ? ck : 0)];
+            mx_laf[(t * 64 + lane) * 2 + ks] = in ? (d == 0 ? v * inv_mu : v) : 0.0;
+          }
+      }
+    } else {
+      if (wave >= CW)
+        for (int e = tid - 64 * CW; e < a.pp.res * 3 * D; e += 256 - 64 * CW) ltab[e] = tab[(size_t)(e / (3 * D)) * 4 * D + e % (3 * D)];
+    }
   }
 
   // phase 2's lane mapping
@@ -347,6 +381,217 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   __syncthreads();
   ANET_FP(4);
 
+  // The adjoint's first step for one (trajectory, piece, axis): g_x = Phi' gC for the piece's two node states and the direct
+  // dPhi/dT term (k_minco_propagate's loop over the pieces, minco_kernels.h propagate_axis), from the piece's own coefficients:
+  // x0[j] = j! c_j, x1 = the piece's derivatives at its end; handed to phase 3 through LDS.
+  auto adjoint_first = [&](const int ax, const double (&cfa)[D], const double (&gca)[D], const double Ti, const int pair) {
+    const Pw<S> p(fast_rcp(Ti));
+    double tp[D];
+    tp[0] = 1.0;
+#pragma unroll
+    for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
+    double x0[S], x1[S], gs[S], ge[S], h[S];
+    double fact = 1.0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      if (j > 0) fact *= (double)j;
+      x0[j] = fact * cfa[D - 1 - j];
+      double acc = 0.0;
+#pragma unroll
+      for (int q = j; q < D; ++q) {
+        double f = 1.0;
+#pragma unroll
+        for (int e = 0; e < j; ++e) f *= (double)(q - e);
+        acc = __builtin_fma(f * tp[q - j], cfa[D - 1 - q], acc);
+      }
+      x1[j] = acc;
+      gs[j] = gca[D - 1 - j] * (1.0 / fact);
+      ge[j] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < S; ++q) h[q] = gca[S - 1 - q] * p[q];
+    double dsum = 0.0;
+#pragma unroll
+    for (int bb = 0; bb < 2 * S; ++bb) {
+      const int dg = bb % S;
+      double u = 0.0, qd = 0.0;
+#pragma unroll
+      for (int q = 0; q < S; ++q) {
+        u = __builtin_fma(Tab<S>::BHI[q][bb], h[q], u);
+        qd = __builtin_fma((double)(S + q - dg) * Tab<S>::BHI[q][bb], h[q], qd);
+      }
+      const double sc = p[S - dg];
+      const double xb = (bb < S) ? x0[dg] : x1[dg];
+      if (bb < S) gs[dg] = __builtin_fma(u, sc, gs[dg]);
+      else ge[dg] = u * sc;
+      dsum = __builtin_fma(xb * sc, qd, dsum);
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      lds[(ROW_GX + ax * D + j) * PST + pair] = gs[j];
+      lds[(ROW_GX + ax * D + S + j) * PST + pair] = ge[j];
+    }
+    lds[(ROW_GTD + ax) * PST + pair] = -p[1] * dsum;
+  };
+
+  if constexpr (MX) {
+    // ---- phase 2, MX: four lanes per (trajectory, piece), 32 pairs per wave as two column sets of 16 ---------------------------------
+    static_assert(TW && NEXACT && FusedShape<NB>::G * NB == 128, "an exact shape whose groups fill the workgroup");
+    const int lane = tid & 63, r = lane >> 4, col = lane & 15;
+    const Penalty pp = a.pp;
+    const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
+    const int M = a.hpolys ? pp.M : 0, nrb = (M + 15) / 16;
+    double *const lr = mx_row + wave * 16 * MXTST;
+    double AE, AP;  // energy part: the A operands of k_piece_grad_mx (a row of the energy Hessian's integers, the derivative factors)
+    {
+      const int ie = lane & 3, ke = lane >> 4;
+      double fi = 1.0, fk = 1.0;
+      for (int e = 0; e < S; ++e) {
+        fi *= (double)(D - 1 - ie - e);
+        fk *= (double)(D - 1 - ke - e);
+      }
+      AE = (ie < S && ke < S) ? 2.0 * fi * fk / (double)(2 * S - 1 - ie - ke) : 0.0;
+      AP = ke < S ? fk : 0.0;
+    }
+    const bool has1 = 4 + r < D;
+    double hn[4][4];
+    int hok = 0;
+    auto fetch_rows = [&](const int cs, const int rb) {  // lane (r, col): the rows r, r + 4, r + 8, r + 12 of its pair's block
+      const int pr = 32 * wave + 16 * cs + col, pc_ = pr / G, tt2 = pr % G;
+      const int64_t bb = b0 + tt2 < a.B ? b0 + tt2 : a.B - 1;
+      hok = 0;
+#pragma unroll
+      for (int mm = 0; mm < 4; ++mm) {
+        const int rr = rb * 16 + r + 4 * mm;
+        const bool ok = rr < M;
+        const double *src = a.hpolys + (int64_t)((pc_ * pp.M + (ok ? rr : 0)) * 4) * ld + bb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hn[mm][e] = M > 0 ? src[(int64_t)e * ld] : 0.0;
+        hok |= ok ? (1 << mm) : 0;
+      }
+    };
+    auto park_rows = [&]() {
+#pragma unroll
+      for (int mm = 0; mm < 4; ++mm) {
+        double *dst = lr + col * MXTST + (r + 4 * mm) * 4;
+        const bool ok = (hok >> mm) & 1;
+        dst[0] = ok ? hn[mm][0] : 0.0;
+        dst[1] = ok ? hn[mm][1] : 0.0;
+        dst[2] = ok ? hn[mm][2] : 0.0;
+        dst[3] = ok ? hn[mm][3] * inv_mu : 0.0;
+      }
+    };
+    auto landed = [](double &v) { asm volatile("" : "+v"(v)); };
+    auto wave_sync = []() {  // what one lane of the wave wrote to LDS is read by another behind this (LDS instructions execute in order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (nrb > 0) {
+      fetch_rows(0, 0);
+      park_rows();
+    }
+#pragma unroll 1
+    for (int cs = 0; cs < 2; ++cs) {
+      const int pair = 32 * wave + 16 * cs + col, piece = pair / G, t2m = pair % G;
+      const bool live = b0 + t2m < a.B;
+      const int64_t bbm = live ? b0 + t2m : a.B - 1;
+      const double Ti = lds[ROW_T * PST + pair];
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      double tp[D];
+      tp[0] = 1.0;
+#pragma unroll
+      for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
+      // the piece's coefficients of axis r (lanes r < 3) from its two node states, as solve_axis emits them; c~ to the hand-over rows
+      double cf[D], e_share = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) cf[k] = 0.0;
+      if (r < 3) {
+        const Pw<S> pw(fast_rcp(Ti));
+        double x0[m], x1[m];
+        const double *ns = lxs + 3 * t2m + r;
+#pragma unroll
+        for (int j = 0; j < m; ++j) {
+          x0[j] = ns[(size_t)(piece * (m + 1) + j) * XST];
+          x1[j] = ns[(size_t)((piece + 1) * (m + 1) + j) * XST];
+        }
+        const double P0 = ns[(size_t)(piece * (m + 1) + m) * XST], P1 = ns[(size_t)((piece + 1) * (m + 1) + m) * XST];
+        double *cp = (a.coeffs_out && live) ? a.coeffs_out + (int64_t)(piece * 3 * D + r * D) * ld + bbm : nullptr;
+        e_share = emit_piece<S>(piece, pw, P0, P1, x0, x1, [&](int, int k, double v) {
+          cf[k] = v;
+          if (cp) cp[(int64_t)k * ld] = v;
+        });
+#pragma unroll
+        for (int k = 0; k < D; ++k) lds[(ROW_GX + r * D + k) * PST + pair] = cf[k] * tp[D - 1 - k];
+      }
+      wave_sync();
+      double cb[3][2];
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        cb[ax][0] = lds[(ROW_GX + ax * D + r) * PST + pair];
+        cb[ax][1] = has1 ? lds[(ROW_GX + ax * D + (has1 ? 4 + r : r)) * PST + pair] : 0.0;
+      }
+      {  // the piece's energy share: the three axes' lanes added by a product with ones (every lane receives the sum)
+        const double e_piece = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, e_share, 0.0, 0, 0, 0);
+        if (r == 0) lds[ROW_EN * PST + pair] = e_piece;
+      }
+      ANET_FP(5);
+      double gN[3][2], csum, Rs1, Rs2, rT, step;
+      mx_column_set<S>(pp, inv_mu, inv_res, lane_o, mx_lag, mx_laf, lr + col * MXTST, M, nrb, Ti, cb,
+                       [&](const int rb) {
+                         const int rbn = rb + 1 < nrb ? rb + 1 : 0, csn = rb + 1 < nrb ? cs : cs + 1;
+                         if (csn < 2) fetch_rows(csn, rbn);
+                       },
+                       [&](const int rb) {
+                         if ((rb + 1 < nrb ? cs : cs + 1) < 2) {
+#pragma unroll
+                           for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                             for (int e = 0; e < 4; ++e) landed(hn[mm][e]);
+                           park_rows();
+                         }
+                       },
+                       gN, csum, Rs1, Rs2, rT, step);
+      ANET_FP(6);
+      double acc = 0.0;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        acc = __builtin_fma(cb[ax][0] * (double)(D - 1 - r), gN[ax][0], acc);
+        acc = __builtin_fma(cb[ax][1] * (double)(D - 5 - r), gN[ax][1], acc);
+      }
+      double gT = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, csum * inv_res + rT * (acc - __builtin_fma(2.0, Rs2, Rs1)), 0.0, 0, 0, 0);
+      const double pc = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, step * csum, 0.0, 0, 0, 0);
+      const double tsel0 = mx_sel4(r, tp[D - 1], tp[D - 2], tp[D - 3], tp[D - 4]);
+      const double tsel1 = D == 8 ? mx_sel4(r, tp[3], tp[2], tp[1], tp[0]) : mx_sel4(r, tp[1], tp[0], 0.0, 0.0);
+      // (cb already carries the powers: the columns' d/dc = T^k d/dc~ need them once more)
+      const double rTS = S == 4 ? (rT * rT) * (rT * rT) : rT * (rT * rT);
+      const double TA = tsel0 * (S == 4 ? rT * (rT * rT) : rT * rT);
+      wave_sync();  // (every lane of the pair has read c~ from the hand-over rows: they take d/dc now)
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const double ye = cb[ax][0] * rTS;
+        const double e = __builtin_amdgcn_mfma_f64_4x4x4f64(AE, ye, 0.0, 0, 0, 0);
+        const double ps = __builtin_amdgcn_mfma_f64_4x4x4f64(AP, ye, 0.0, 0, 0, 0);
+        gT = __builtin_fma(ps, ps, gT);
+        lds[(ROW_GX + ax * D + r) * PST + pair] = __builtin_fma(e, TA, gN[ax][0] * tsel0);
+        if (has1) lds[(ROW_GX + ax * D + 4 + r) * PST + pair] = gN[ax][1] * tsel1;
+      }
+      wave_sync();
+      ANET_FP(7);
+      if (r < 3) {
+        double gca[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) gca[k] = lds[(ROW_GX + r * D + k) * PST + pair];
+        adjoint_first(r, cf, gca, Ti, pair);
+      }
+      if (r == 0) {
+        lds[ROW_GDT * PST + pair] = gT;
+        lds[ROW_PC * PST + pair] = pc;
+      }
+      wave_sync();  // (the next column set's hand-over rows are other pairs' columns; the row buffer is this wave's)
+    }
+  } else
   // ---- phase 2 (all waves): two lanes per (trajectory, piece) ------------------------------------------------------------------
   {
     const int q = q2;
@@ -445,56 +690,8 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
         // The adjoint's first step, per piece and in parallel: g_x = Phi' gC for the piece's two node states and the direct
         // dPhi/dT term (k_minco_propagate's loop over the pieces, minco_kernels.h propagate_axis), from the piece's own
         // coefficients: x0[j] = j! c_j, x1 = the piece's derivatives at its end.
-        const Pw<S> p(fast_rcp(Ti));
-        double tp[D];
-        tp[0] = 1.0;
 #pragma unroll
-        for (int e = 1; e < D; ++e) tp[e] = tp[e - 1] * Ti;
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-          double x0[S], x1[S], gs[S], ge[S], h[S];
-          double fact = 1.0;
-#pragma unroll
-          for (int j = 0; j < S; ++j) {
-            if (j > 0) fact *= (double)j;
-            x0[j] = fact * cf[ax][D - 1 - j];
-            double acc = 0.0;
-#pragma unroll
-            for (int q = j; q < D; ++q) {
-              double f = 1.0;
-#pragma unroll
-              for (int e = 0; e < j; ++e) f *= (double)(q - e);
-              acc = __builtin_fma(f * tp[q - j], cf[ax][D - 1 - q], acc);
-            }
-            x1[j] = acc;
-            gs[j] = gC[ax][D - 1 - j] * (1.0 / fact);
-            ge[j] = 0.0;
-          }
-#pragma unroll
-          for (int q = 0; q < S; ++q) h[q] = gC[ax][S - 1 - q] * p[q];
-          double dsum = 0.0;
-#pragma unroll
-          for (int bb = 0; bb < 2 * S; ++bb) {
-            const int dg = bb % S;
-            double u = 0.0, qd = 0.0;
-#pragma unroll
-            for (int q = 0; q < S; ++q) {
-              u = __builtin_fma(Tab<S>::BHI[q][bb], h[q], u);
-              qd = __builtin_fma((double)(S + q - dg) * Tab<S>::BHI[q][bb], h[q], qd);
-            }
-            const double sc = p[S - dg];
-            const double xb = (bb < S) ? x0[dg] : x1[dg];
-            if (bb < S) gs[dg] = __builtin_fma(u, sc, gs[dg]);
-            else ge[dg] = u * sc;
-            dsum = __builtin_fma(xb * sc, qd, dsum);
-          }
-#pragma unroll
-          for (int j = 0; j < S; ++j) {
-            lds[(ROW_GX + ax * D + j) * PST + pair] = gs[j];
-            lds[(ROW_GX + ax * D + S + j) * PST + pair] = ge[j];
-          }
-          lds[(ROW_GTD + ax) * PST + pair] = -p[1] * dsum;
-        }
+        for (int ax = 0; ax < 3; ++ax) adjoint_first(ax, cf[ax], gC[ax], Ti, pair);
         lds[ROW_GDT * PST + pair] = gT;
         lds[ROW_PC * PST + pair] = pc;
       }

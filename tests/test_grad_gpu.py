@@ -171,7 +171,10 @@ def test_large_batch_shapes_agree_with_small_batch_shapes_and_oracle(anet_ctx, s
 
 @pytest.mark.parametrize("s,c,N,M,res", [(4, 3, 8, 16, 20), (4, 4, 8, 50, 7), (4, 3, 5, 20, 64), (4, 2, 3, 6, 1), (4, 3, 1, 6, 3),
                                          (3, 3, 16, 16, 20), (3, 3, 13, 9, 10), (3, 3, 5, 16, 20), (3, 2, 8, 0, 5), (3, 1, 2, 7, 2),
-                                         (4, 3, 8, 16, 65)])
+                                         (4, 3, 8, 16, 65),
+                                         # full groups of 8-piece snap at 20 samples: phase 2 on the matrix instructions (MX) -- two row
+                                         # blocks with a ragged second, a partial group of four rows, no rows
+                                         (4, 3, 8, 21, 20), (4, 3, 8, 7, 20), (4, 3, 8, 0, 20)])
 def test_one_launch_evaluation_at_every_group_size(anet_ctx, s, c, N, M, res):
     """Batches of up to one workgroup per CU (two rounds of them for <= 8 pieces) are evaluated in ONE launch (csrc/minco_fused_kernel.h: solve, penalty / energy
     partial gradients and adjoint of a group of G trajectories in one workgroup, G = 16 ... 1 by batch, the lanes a smaller group
