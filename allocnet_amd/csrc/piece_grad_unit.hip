@@ -77,7 +77,7 @@ static void launch_fused_t(const FusedArgs &a_in, const double *tab, hipStream_t
   const dim3 grid((unsigned)((a.B + G - 1) / G));
   // Full groups of the exact shapes at 20 samples per piece: phase 2 on the matrix instructions (minco_fused_kernel.h, MX).
   // ANET_FUSED_MX=0 keeps the vector sample loop (A-B runs).
-  if constexpr (NEXACT && NPC >= 0 && S == 4 && FusedShape<NB>::G * NB == 128) {
+  if constexpr (NEXACT && NPC >= 0 && FusedShape<NB>::G * NB == 128) {
     static const int mx = [] { const char *e = getenv("ANET_FUSED_MX"); return e ? atoi(e) : 1; }();
     if (mx && G == GM && a.pp.res == kMxRes) {
       hipLaunchKernelGGL((k_minco_cost_grad_fused<S, NB, NEXACT, NPC, true>), grid, dim3(256), 0, st, a, tab);
