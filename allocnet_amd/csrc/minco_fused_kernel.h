@@ -133,6 +133,33 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     }
   }
 
+  // (MX) the corridor rows travel global -> registers -> LDS a block ahead of their use; the FIRST block of a wave's first column set
+  // is requested during phase 1 -- by the idle waves at once, by the chain waves behind their own loads (loads return in order: in
+  // front of them they would delay the chain) -- and parked at the start of phase 2.
+  const int mx_M = (MX && a.hpolys) ? a.pp.M : 0, mx_nrb = (mx_M + 15) / 16;
+  double hn[4][4];
+  int hok = 0;
+  auto fetch_rows = [&](const int cs, const int rb) {  // lane (r, col): the rows r, r + 4, r + 8, r + 12 of its pair's block
+    const int r = (tid & 63) >> 4, col = tid & 15, M = mx_M;
+    const Penalty &pp = a.pp;
+    const int pr = 32 * wave + 16 * cs + col, pc_ = pr / G, tt2 = pr % G;
+    const int64_t bb = b0 + tt2 < a.B ? b0 + tt2 : a.B - 1;
+    hok = 0;
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) {
+      const int rr = rb * 16 + r + 4 * mm;
+      const bool ok = rr < M;
+      const double *src = a.hpolys + (int64_t)((pc_ * pp.M + (ok ? rr : 0)) * 4) * ld + bb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hn[mm][e] = M > 0 ? src[(int64_t)e * ld] : 0.0;
+      hok |= ok ? (1 << mm) : 0;
+    }
+  };
+
+  if constexpr (MX) {
+    if (wave >= 2 && mx_nrb > 0) fetch_rows(0, 0);
+  }
+
   // phase 2's lane mapping
   const int q2 = tid / LPQ;                      // which lane pair of its (trajectory, piece)
   const int pair = (tid % LPQ) >> 1, half = tid & 1;
@@ -265,6 +292,14 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
       }
 #pragma unroll
       for (int i = 0; i < NC; ++i) F.r[i] = fast_rcp(tt[i]);
+      if constexpr (MX) {
+        // (every input of the chain has landed -- they were awaited for the reciprocals -- : the row block flies during the chain)
+#pragma unroll
+        for (int k = 0; k <= NC; ++k) asm volatile("" : "+v"(P[k]));
+#pragma unroll
+        for (int j = 0; j < m; ++j) asm volatile("" : "+v"(hv[j]));
+        if (mx_nrb > 0) fetch_rows(0, 0);
+      }
       ANET_FP(1);
       F.template factorize_chain<true>(Nh, np, meet_block);
       ANET_FP(2);
@@ -454,22 +489,6 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
       AP = ke < S ? fk : 0.0;
     }
     const bool has1 = 4 + r < D;
-    double hn[4][4];
-    int hok = 0;
-    auto fetch_rows = [&](const int cs, const int rb) {  // lane (r, col): the rows r, r + 4, r + 8, r + 12 of its pair's block
-      const int pr = 32 * wave + 16 * cs + col, pc_ = pr / G, tt2 = pr % G;
-      const int64_t bb = b0 + tt2 < a.B ? b0 + tt2 : a.B - 1;
-      hok = 0;
-#pragma unroll
-      for (int mm = 0; mm < 4; ++mm) {
-        const int rr = rb * 16 + r + 4 * mm;
-        const bool ok = rr < M;
-        const double *src = a.hpolys + (int64_t)((pc_ * pp.M + (ok ? rr : 0)) * 4) * ld + bb;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hn[mm][e] = M > 0 ? src[(int64_t)e * ld] : 0.0;
-        hok |= ok ? (1 << mm) : 0;
-      }
-    };
     auto park_rows = [&]() {
 #pragma unroll
       for (int mm = 0; mm < 4; ++mm) {
@@ -487,8 +506,11 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    if (nrb > 0) {
-      fetch_rows(0, 0);
+    if (nrb > 0) {  // (requested during phase 1)
+#pragma unroll
+      for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) landed(hn[mm][e]);
       park_rows();
     }
 #pragma unroll 1
@@ -536,9 +558,9 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
         const double e_piece = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, e_share, 0.0, 0, 0, 0);
         if (r == 0) lds[ROW_EN * PST + pair] = e_piece;
       }
-      ANET_FP(5);
+      if (cs == 0) ANET_FP(5);
       double gN[3][2], csum, Rs1, Rs2, rT, step;
-      mx_column_set<S>(pp, inv_mu, inv_res, lane_o, mx_lag, mx_laf, lr + col * MXTST, M, nrb, Ti, cb,
+      mx_column_set<S, true>(pp, inv_mu, inv_res, lane_o, mx_lag, mx_laf, lr + col * MXTST, M, nrb, Ti, cb,
                        [&](const int rb) {
                          const int rbn = rb + 1 < nrb ? rb + 1 : 0, csn = rb + 1 < nrb ? cs : cs + 1;
                          if (csn < 2) fetch_rows(csn, rbn);
@@ -553,7 +575,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
                          }
                        },
                        gN, csum, Rs1, Rs2, rT, step);
-      ANET_FP(6);
+      if (cs == 0) ANET_FP(6);
       double acc = 0.0;
 #pragma unroll
       for (int ax = 0; ax < 3; ++ax) {
@@ -578,7 +600,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
         if (has1) lds[(ROW_GX + ax * D + 4 + r) * PST + pair] = gN[ax][1] * tsel1;
       }
       wave_sync();
-      ANET_FP(7);
+      if (cs == 0) ANET_FP(7);
       if (r < 3) {
         double gca[D];
 #pragma unroll

@@ -53,7 +53,9 @@ __device__ __forceinline__ double mx_xor_sum(double v) {  // sum over the four l
 // one-launch evaluation (minco_fused_kernel.h, MX) share.  rows: the pair's parked row block in LDS ([row][4], b / mu); before(rb) /
 // after(rb): called around the walk of row block rb (the callers' prefetch of the next block and its parking).  lag / laf: the
 // constant A operands in LDS, read through lane_o (an index the compiler cannot hoist the reads through).
-template <int S, class Before, class After>
+// ROW_FIRST (the one-launch evaluation: one wave per SIMD, where every compare-to-branch is a bubble nothing fills): one
+// wave-uniform test per row over its five samples ahead of the per-sample tests.
+template <int S, bool ROW_FIRST = false, class Before, class After>
 __device__ __forceinline__ void mx_column_set(const Penalty &pp, const double inv_mu, const double inv_res, const int lane_o,
                                               const double *lag, const double *laf, const double *rows, const int M, const int nrb,
                                               const double Ti, const double (&cb)[3][2], Before &&before, After &&after,
@@ -157,9 +159,19 @@ __device__ __forceinline__ void mx_column_set(const Penalty &pp, const double in
         for (int e = 0; e < 4; ++e) h[q][e] = src[(q0 + q) * 4 + e];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        double uq[NSL];
+#pragma unroll
+        for (int ii = 0; ii < NSL; ++ii)
+          uq[ii] = __builtin_fma(h[q][0], ps[0][ii], __builtin_fma(h[q][1], ps[1][ii], __builtin_fma(h[q][2], ps[2][ii], -h[q][3])));
+        if constexpr (ROW_FIRST) {
+          double um = uq[0];
+#pragma unroll
+          for (int ii = 1; ii < NSL; ++ii) um = fmax(um, uq[ii]);
+          if (!__any(um > 0.0)) continue;
+        }
 #pragma unroll
         for (int ii = 0; ii < NSL; ++ii) {
-          const double u = __builtin_fma(h[q][0], ps[0][ii], __builtin_fma(h[q][1], ps[1][ii], __builtin_fma(h[q][2], ps[2][ii], -h[q][3])));
+          const double u = uq[ii];
           if (__any(u > 0.0)) {  // wave-uniform: inside the corridor nothing else is computed
             const double w = fmax(u, 0.0), uc = fmin(w, 1.0), sq = uc * uc;
             Fs[ii] += w - uc;
