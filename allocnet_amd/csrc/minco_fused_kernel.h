@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
       }
       if (cs == 0) ANET_FP(5);
       double gN[3][2], csum, Rs1, Rs2, rT, step;
-      mx_column_set<S, true>(pp, inv_mu, inv_res, lane_o, mx_lag, mx_laf, lr + col * MXTST, M, nrb, Ti, cb,
+      mx_column_set<S>(pp, inv_mu, inv_res, lane_o, mx_lag, mx_laf, lr + col * MXTST, M, nrb, Ti, cb,
                        [&](const int rb) {
                          const int rbn = rb + 1 < nrb ? rb + 1 : 0, csn = rb + 1 < nrb ? cs : cs + 1;
                          if (csn < 2) fetch_rows(csn, rbn);

@@ -53,9 +53,10 @@ __device__ __forceinline__ double mx_xor_sum(double v) {  // sum over the four l
 // one-launch evaluation (minco_fused_kernel.h, MX) share.  rows: the pair's parked row block in LDS ([row][4], b / mu); before(rb) /
 // after(rb): called around the walk of row block rb (the callers' prefetch of the next block and its parking).  lag / laf: the
 // constant A operands in LDS, read through lane_o (an index the compiler cannot hoist the reads through).
-// ROW_FIRST (the one-launch evaluation: one wave per SIMD, where every compare-to-branch is a bubble nothing fills): one
-// wave-uniform test per row over its five samples ahead of the per-sample tests.
-template <int S, bool ROW_FIRST = false, class Before, class After>
+// Corridor rows: one wave-uniform test per row over the lane's five samples ahead of the per-sample tests (a compare-to-branch is
+// a bubble -- one wave per SIMD in the one-launch kernel: 23.8 -> 22.6 us; two here: 311 -> 295 us -- and the zero rows a corridor is
+// padded with never pass the first test).
+template <int S, class Before, class After>
 __device__ __forceinline__ void mx_column_set(const Penalty &pp, const double inv_mu, const double inv_res, const int lane_o,
                                               const double *lag, const double *laf, const double *rows, const int M, const int nrb,
                                               const double Ti, const double (&cb)[3][2], Before &&before, After &&after,
@@ -163,7 +164,7 @@ __device__ __forceinline__ void mx_column_set(const Penalty &pp, const double in
 #pragma unroll
         for (int ii = 0; ii < NSL; ++ii)
           uq[ii] = __builtin_fma(h[q][0], ps[0][ii], __builtin_fma(h[q][1], ps[1][ii], __builtin_fma(h[q][2], ps[2][ii], -h[q][3])));
-        if constexpr (ROW_FIRST) {
+        {
           double um = uq[0];
 #pragma unroll
           for (int ii = 1; ii < NSL; ++ii) um = fmax(um, uq[ii]);
