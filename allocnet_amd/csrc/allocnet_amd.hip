@@ -1037,13 +1037,12 @@ static int basis_table(anet_ctx *ctx, int s, int res, hipStream_t st, const doub
 }
 
 // The large-batch penalty kernel with the basis-table contractions on the FP64 matrix instructions (csrc/piece_grad_mx.h): built for
-// res = 20.  Order 4 takes it by default (131 072 x 8 pieces: 310 us against 344, profiles/r06_piece_grad_mx.txt); order 3 does not
-// (six coefficients fill three quarters of the instructions' k and column tiles: 312 us against 293 for 65 536 x 16 pieces).
-// ANET_PG_MX = 0: never, 1: order 4 (default), 2: orders 3 and 4 (A-B runs).
+// res = 20, orders 3 and 4 (131 072 x 8 snap pieces: 295 us against 344; 65 536 x 16 jerk pieces: 287 against 296 -- six coefficients
+// fill three quarters of the instructions' k and column tiles --, profiles/r06_piece_grad_mx.txt).  ANET_PG_MX=0: never (A-B runs).
 static int anet_piece_grad_mx_res() { return 20; }
-static int piece_grad_mx_level() {
+static bool piece_grad_mx_enabled() {
   static const int v = [] { const char *e = getenv("ANET_PG_MX"); return e ? atoi(e) : 1; }();
-  return v;
+  return v != 0;
 }
 
 // The launch shape of the penalty / energy-gradient kernel (launch_piece_grad): 0 a lane per (trajectory, piece); 1 two lanes per
@@ -1053,8 +1052,7 @@ static int piece_grad_shape(anet_ctx *ctx, int s, int n_pieces, int64_t batch, c
   static const int64_t sw_env = [] { const char *e = getenv("ANET_PIECE_SW_MAX_PAIRS"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
   const int64_t sw_max_pairs = sw_env >= 0 ? sw_env : per_cu(ctx, kPieceSampleSplitMaxPairs);
   if (pen && batch <= axis_variant_max_batch(ctx)) return batch * n_pieces <= sw_max_pairs ? 2 : 1;
-  if (pen && pen->res == anet_piece_grad_mx_res() && (s == 4 ? piece_grad_mx_level() >= 1 : (s == 3 && piece_grad_mx_level() >= 2)))
-    return 3;
+  if (pen && pen->res == anet_piece_grad_mx_res() && (s == 3 || s == 4) && piece_grad_mx_enabled()) return 3;
   return 0;
 }
 

@@ -279,7 +279,7 @@ def minco_cost_grad_launches(s, N, B, penalty=None, ctx=None):
 def minco_piece_grad_shape(s, N, B, penalty=None, ctx=None):
     """anet_minco_piece_grad_shape: the launch shape of the penalty / energy-gradient kernel for this batch -- 0 a lane per
     (trajectory, piece), 1 / 2 the small-batch shapes, 3 k_piece_grad_mx (the basis-table contractions on the FP64 matrix
-    instructions: large batches, order 4, 20 samples per piece)."""
+    instructions: large batches, orders 3 and 4, 20 samples per piece)."""
     ctx = ctx or default_context(0)
     n = ctx.lib.anet_minco_piece_grad_shape(ctx.handle, s, N, B, ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p)
                                             if penalty is not None else None)

@@ -263,7 +263,7 @@ int anet_minco_cost_grad_launches(anet_ctx *ctx, int s, int n_pieces, int64_t ba
 /* The launch shape anet_minco_partial_grads_dev picks for this shape on this context's device: 0 one lane per (trajectory,
  * piece) (k_piece_grad, large batches); 1 two lanes per pair; 2 two lanes and the samples over a workgroup's four waves (the small
  * batches); 3 k_piece_grad_mx -- four lanes per pair, the contractions with the basis table on the FP64 matrix instructions
- * (large batches, order 4, res = 20: the penalty functional of qp_solver.hpp:244-296's rows at planner.yaml:21's sampling);
+ * (large batches, orders 3 and 4, res = 20: the penalty functional of qp_solver.hpp:244-296's rows at planner.yaml:21's sampling);
  * negative = error.  For callers that label a measurement with the kernel that ran (bench.py).                                */
 int anet_minco_piece_grad_shape(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen);
 int anet_minco_cost_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,

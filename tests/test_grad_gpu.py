@@ -120,12 +120,12 @@ def test_random_shapes_against_both_oracles(anet_ctx):
 
 @pytest.mark.parametrize("s,c,N,M,res", [(4, 3, 8, 16, 9), (4, 4, 8, 9, 9), (4, 3, 5, 16, 9), (3, 3, 8, 12, 9), (3, 3, 5, 7, 9),
                                          (4, 3, 1, 6, 9), (4, 3, 2, 6, 9), (3, 2, 3, 0, 9),
-                                         # res = 20, order 4: k_piece_grad_mx (the table contractions on the matrix instructions) --
+                                         # res = 20, orders 3 / 4: k_piece_grad_mx (the table contractions on the matrix instructions) --
                                          # one full row block, two blocks with a ragged second, a partial group of four, no rows
                                          (4, 3, 8, 16, 20), (4, 4, 5, 21, 20), (4, 2, 3, 7, 20), (4, 3, 2, 0, 20), (4, 3, 1, 37, 20),
                                          (3, 3, 8, 12, 20)])
 def test_large_batch_shapes_agree_with_small_batch_shapes_and_oracle(anet_ctx, s, c, N, M, res):
-    """Batches above 16384 run the lane-per-trajectory solve / adjoint and the lane-per-piece penalty kernel (order 4 at 20 samples
+    """Batches above 16384 run the lane-per-trajectory solve / adjoint and the lane-per-piece penalty kernel (orders 3 / 4 at 20 samples
     per piece: four lanes per piece and the FP64 matrix instructions, csrc/piece_grad_mx.h), batches up to
     16384 the lane-per-(trajectory, axis) and two-lanes-per-piece shapes: the same 16384 + 257 trajectories (a ragged last
     workgroup) through both agree to rounding -- whole batch against chunks of 8192 -- and a strided sample agrees with the C

@@ -89,7 +89,7 @@ def main():
         sides = {}
         for mx in (0, 1):
             dump = os.path.join(td, f"mx{mx}.npz")
-            env = dict(os.environ, ANET_PG_MX=str(2 * mx))    # (2: orders 3 and 4)
+            env = dict(os.environ, ANET_PG_MX=str(mx))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", str(args.batch), "--order", str(args.order),
                                 "--pieces", str(args.pieces), "--dump", dump],
                                capture_output=True, text=True, env=env, cwd=ROOT)
@@ -97,7 +97,7 @@ def main():
                 print(r.stderr[-3000:])
                 raise SystemExit(f"ANET_PG_MX={mx} failed")
             sides[mx] = (json.loads(r.stdout.strip().splitlines()[-1]), dict(np.load(dump)))
-            print(f"ANET_PG_MX={2 * mx}:", json.dumps(sides[mx][0]))
+            print(f"ANET_PG_MX={mx}:", json.dumps(sides[mx][0]))
         a, b = sides[0][1], sides[1][1]
         for k in a:
             sc = np.abs(a[k]).max()
