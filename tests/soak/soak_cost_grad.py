@@ -19,7 +19,7 @@ def run(n_cases, seed=12345, ctx=None, verbose=True):
         s = int(rng.choice([3, 4]))
         c = int(rng.integers(2, s + 1))
         N = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16]))
-        M = int(rng.choice([0, 6, 7, 9, 12, 16]))
+        M = int(rng.choice([0, 6, 7, 9, 12, 16, 21]))      # (21: a second, ragged row block in the matrix-instruction kernels)
         res = int(rng.choice([1, 3, 8, 20, 33]))
         B = int(rng.choice([1, 2, 63, 64, 65, 100, 511, 2047, 2048, 2049, 4096, 16384, 16385, 20000]))
         if N >= 12 and B > 4096:
