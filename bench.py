@@ -175,7 +175,7 @@ def with_peak(roof):
     return dict(roof, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
 
 
-COST_GRAD_KERNELS = {1: "k_minco_cost_grad_fused", 3: "k_piece_grad (+ k_minco_solve, k_minco_propagate)"}
+COST_GRAD_KERNELS = {1: "k_minco_cost_grad_fused", 3: "k_piece_grad (+ solve, propagate)"}   # (+ k_minco_solve, k_minco_propagate)
 PIECE_GRAD_KERNELS = {0: "k_piece_grad", 1: "k_piece_grad", 2: "k_piece_grad", 3: "k_piece_grad_mx"}
 
 
@@ -184,7 +184,7 @@ def cost_grad_kernel_label(aa, ctx, s, N, B, pen):
     (anet_minco_cost_grad_launches, anet_minco_piece_grad_shape)"""
     if aa.minco_cost_grad_launches(s, N, B, penalty=pen, ctx=ctx) == 1:
         return COST_GRAD_KERNELS[1]
-    return PIECE_GRAD_KERNELS[aa.minco_piece_grad_shape(s, N, B, penalty=pen, ctx=ctx)] + " (+ k_minco_solve, k_minco_propagate)"
+    return PIECE_GRAD_KERNELS[aa.minco_piece_grad_shape(s, N, B, penalty=pen, ctx=ctx)] + " (+ solve, propagate)"
 
 
 def cost_grad_picks(launches):
