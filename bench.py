@@ -1164,8 +1164,7 @@ def main():
                                                  "hbm_frac": b2 * abytes / (dtg / (NG * reps)) / 1e9 / HBM_PEAK_GBS}
         except Exception as exc:      # (graph capture is an extra, never the headline)
             out["config1_b1024"]["graph64x8"] = {"error": str(exc)[:200]}
-        out["config1_b1024"]["streams8"] = {"value": b2 * K2 * ns / dt8, "ms_per_launch": dt8 / (K2 * ns) * 1e3,
-                                            "hbm_frac": b2 * abytes / (dt8 / (K2 * ns)) / 1e9 / HBM_PEAK_GBS}
+        out["config1_b1024"]["streams8"] = {"ms_per_launch": dt8 / (K2 * ns) * 1e3}    # (the line has a budget: the rate follows)
         # ... and what a sampler of time allocations should call instead of K launches of 1024 replicated problems: ONE
         # launch over K candidate duration vectors of few problems (anet_minco_sample_costs_dev: problem data per problem,
         # durations per sample, only the cost comes back)
@@ -1187,7 +1186,7 @@ def main():
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / 20
                 smp[label] = {"ms_per_launch": ms, "value": Ks / (ms * 1e-3),
-                              "fp64_frac_at_4.1_kflop_per_sample": Ks * 4100.0 / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+                              "fp64_frac": Ks * 4100.0 / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
             # (time-allocation samples/s in one launch of 2^20 samples; 8 (N + 1) bytes per sample: bound by its FP64 work, ~4.1 kFLOP per sample)
             out["config1_b1024"]["sampler"] = smp
         except Exception as exc:
