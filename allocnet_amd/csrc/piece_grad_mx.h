@@ -11,7 +11,7 @@
 // pair 16 cs + col and on the samples j = r + 4 i', i' = 0 .. 4 -- four lanes per pair, five samples each, the assignment both
 // instructions' register layouts ask for:
 //   * forward, v_mfma_f64_16x16x4_f64: D[row][col] = sum_k A[row][k] B[k][col], A[row = lane & 15][k = lane >> 4] = table rows
-//     (constant per lane, kept in registers), B[k = lane >> 4][col = lane & 15] = c~ of pair `col` -- a lane loads just the two
+//     (constants of the lane, read from LDS at their use), B[k = lane >> 4][col = lane & 15] = c~ of pair `col` -- a lane loads just the two
 //     coefficients k = r, 4 + r of its pair --, and result register i of lane (r, col) is row 4 i + r.  The 60 (state, sample)
 //     rows are numbered row = 4 u + r, u = 5 d + i', so lane (r, col) receives exactly ITS samples' states: no transposes;
 //   * gradient, v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks; layout probed on the device, tools/micro/mfma_f64_layout.hip:
@@ -41,11 +41,6 @@ typedef double mx_d4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double mx_sel4(int r, double a0, double a1, double a2, double a3) {
   return r == 0 ? a0 : (r == 1 ? a1 : (r == 2 ? a2 : a3));
-}
-__device__ __forceinline__ double mx_xor_sum(double v) {  // sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
 }
 
 // One column set of 16 pairs on a wave: the states of every lane's five samples from the B operands cb (c~ of the lane's pair, columns r
