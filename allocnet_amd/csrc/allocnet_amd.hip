@@ -1093,7 +1093,7 @@ int anet_minco_partial_grads_dev(anet_ctx *ctx, int s, int n_pieces, int64_t bat
     const dim3 g2((unsigned)((2 * batch + 255) / 256), (unsigned)n_pieces);
     anet::launch_piece_grad(s, 1, g2, block, st, a, tab);
   } else {  // 0: a lane per (trajectory, piece); 3: four lanes per pair and the matrix instructions -- 64 pairs per wave either way
-    anet::launch_piece_grad(s, shape, grid, block, st, a, tab);
+    anet::launch_piece_grad(s, shape, grid, block, st, a, tab, ctx->cus);
   }
   ANET_HIP(ctx, hipGetLastError());
   return ANET_OK;

@@ -738,7 +738,7 @@ __global__ void __launch_bounds__(256, SW > 1 ? ANET_PG_SW_MINB : ANET_PG_MINB) 
 // strategy costs k_minco_solve_axis a third (8.9 -> 12.2 us per launch of 1024) and the interior-point QP 3 %, so it is
 // not a flag of the whole library.  shape: 0 lane per (trajectory, piece); 1 two lanes per pair; 2 two lanes per pair and
 // the samples over the four waves of a workgroup.
-void launch_piece_grad(int s, int shape, dim3 grid, dim3 block, hipStream_t st, const PieceGradArgs &a, const double *tab);
+void launch_piece_grad(int s, int shape, dim3 grid, dim3 block, hipStream_t st, const PieceGradArgs &a, const double *tab, int mx_cus = 0);
 
 struct PropArgs {
   const double *T, *coeffs, *gdC, *gdT;

@@ -36,6 +36,9 @@ namespace anet {
 constexpr int kMxRes = 20;  // samples per piece this kernel is built for: 4 lanes x 5 samples
 constexpr int kMxNSL = 5;   // samples per lane
 constexpr int kMxNU = 15;   // (state, sample-of-the-lane) slots per lane: u = 5 d + i'
+// Column sets of 16 pairs a wave of k_piece_grad_mx walks (template parameter NCS): 4, or 8 where that still leaves four
+// waves per SIMD slot pair -- a wave's first loads are cold, twice the sets per wave halve their share: 131 072 x 8 pieces 292 -> 283 us
+// (16: 288; at 20 000 x 8, where 8 leave SIMDs empty, 61 -> 76: hence the threshold, launch_piece_grad).
 
 typedef double mx_d4 __attribute__((ext_vector_type(4)));
 
@@ -192,10 +195,10 @@ __device__ __forceinline__ void mx_column_set(const Penalty &pp, const double in
   }
 }
 
-template <int S>
+template <int S, int NCS = 4>
 __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGradArgs a, const double *__restrict__ tab) {
   static_assert(S == 3 || S == 4, "orders 3 and 4");
-  constexpr int D = 2 * S, NSL = kMxNSL, NU = kMxNU, NCS = 4, RB = 16;
+  constexpr int D = 2 * S, NSL = kMxNSL, NU = kMxNU, RB = 16;
   constexpr int TST = RB * 4 + 2;              // doubles per trajectory of a row block in LDS (+2: the 16 trajectories' 16-byte reads fall on 16 bank groups)
   __shared__ double lag[NU * 64 * 2];          // gradient A operands: [u][lane][ct]
   __shared__ double laf[4 * 64 * 2];           // forward A operands: [tile][lane][ks]
@@ -245,7 +248,7 @@ __global__ void __launch_bounds__(256, ANET_PGMX_MINB) k_piece_grad_mx(PieceGrad
     AP = ke < S ? fk : 0.0;
   }
   __syncthreads();
-  const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  const int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * NCS);
   if (b0 >= a.B) return;
   const int M = a.hpolys ? pp.M : 0;
   const int nrb = (M + RB - 1) / RB;                       // row blocks of 16 per pair

@@ -11,20 +11,34 @@
 
 namespace anet {
 
-void launch_piece_grad(int s, int shape, dim3 grid, dim3 block, hipStream_t st, const PieceGradArgs &a, const double *tab) {
+void launch_piece_grad(int s, int shape, dim3 grid, dim3 block, hipStream_t st, const PieceGradArgs &a, const double *tab, int mx_cus) {
   if (shape == 3) {  // large batches, res = 20, orders 3 / 4: the table contractions on the matrix instructions (piece_grad_mx.h)
     // (ANET_PGMX_DYNLDS: bytes of unused dynamic LDS per workgroup -- an occupancy probe for tools/, never set otherwise)
     static const int dyn = [] {
       const char *e = getenv("ANET_PGMX_DYNLDS");
       const int v = e ? atoi(e) : 0;
       if (v > 0) {
-        (void)hipFuncSetAttribute((const void *)k_piece_grad_mx<4>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
-        (void)hipFuncSetAttribute((const void *)k_piece_grad_mx<3>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+        (void)hipFuncSetAttribute((const void *)k_piece_grad_mx<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+        (void)hipFuncSetAttribute((const void *)k_piece_grad_mx<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+        (void)hipFuncSetAttribute((const void *)k_piece_grad_mx<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+        (void)hipFuncSetAttribute((const void *)k_piece_grad_mx<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
       }
       return v;
     }();
-    if (s == 3) hipLaunchKernelGGL((k_piece_grad_mx<3>), grid, block, dyn, st, a, tab);
-    else hipLaunchKernelGGL((k_piece_grad_mx<4>), grid, block, dyn, st, a, tab);
+    // a workgroup = four waves x 16 NCS trajectories of one piece index; eight column sets per wave where that leaves >= 4 waves per
+    // SIMD (shape >> 8: the device's compute units, handed down by the caller; 0 = unknown: four sets)
+    const int cus = mx_cus;
+    const int64_t waves8 = (a.B + 127) / 128 * (int64_t)grid.y;
+    const bool eight = cus > 0 && waves8 >= (int64_t)16 * cus;
+    const int ncs = eight ? 8 : 4;
+    const dim3 gmx((unsigned)((a.B + 64 * ncs - 1) / (64 * ncs)), grid.y);
+    if (s == 3) {
+      if (eight) hipLaunchKernelGGL((k_piece_grad_mx<3, 8>), gmx, block, dyn, st, a, tab);
+      else hipLaunchKernelGGL((k_piece_grad_mx<3, 4>), gmx, block, dyn, st, a, tab);
+    } else {
+      if (eight) hipLaunchKernelGGL((k_piece_grad_mx<4, 8>), gmx, block, dyn, st, a, tab);
+      else hipLaunchKernelGGL((k_piece_grad_mx<4, 4>), gmx, block, dyn, st, a, tab);
+    }
   } else if (shape == 2) {
     if (s == 2) hipLaunchKernelGGL((k_piece_grad<2, true, 4>), grid, block, 0, st, a, tab);
     else if (s == 3) hipLaunchKernelGGL((k_piece_grad<3, true, 4>), grid, block, 0, st, a, tab);
