@@ -58,21 +58,24 @@ struct FusedShape {
 };
 
 // MX (round 6; exact shapes whose groups fill the workgroup, G NB = 128, at 20 samples per piece): phase 2 in k_piece_grad_mx's
-// mapping -- a wave owns 32 (trajectory, piece) pairs as two column sets of 16, four lanes per pair with five samples each, the
+// mapping on EIGHT waves (512 lanes: two waves per SIMD in phase 2 -- a lone wave issues an instruction every 6 - 7 cycles, two
+// fill each other's bubbles; the chain phases still run on waves 0 and 1, and at two waves per SIMD the kernel fits 256 registers
+// with 40 - 68 B of scratch outside the hot loops) -- a wave owns one column set of 16 (trajectory, piece) pairs, four lanes per pair with five samples each, the
 // contractions with the basis table on the FP64 matrix instructions (piece_grad_mx.h: mx_column_set); the piece's coefficients are
 // formed by three of its four lanes (one axis each) and change hands through the LDS rows the adjoint's hand-over uses later.
 template <int S, int NB, bool NEXACT = false, int NPC = -1, bool MX = false>
-__global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, const double *__restrict__ tab) {
+__global__ void __launch_bounds__(MX ? 512 : 256, 1) k_minco_cost_grad_fused(FusedArgs a, const double *__restrict__ tab) {
   constexpr int m = S - 1, D = 2 * S, GM = FusedShape<NB>::G, PST = FusedShape<NB>::PST;
   constexpr int ROW_T = 0, ROW_GX = ROW_T + 1, ROW_GTD = ROW_GX + 3 * D, ROW_GDT = ROW_GTD + 3, ROW_PC = ROW_GDT + 1, ROW_EN = ROW_PC + 1;
   constexpr int NRED = 3 * D + 2;  // values a lane pair hands to the pair that adds up a piece: gC, gT, pc
   __shared__ double lds[(ROW_EN + 1) * PST];
   __shared__ double lred[MX ? 1 : NRED * 128];
   __shared__ double ltab[MX ? 1 : kFusedMaxRes * 3 * D];
-  constexpr int MXTST = 16 * 4 + 2;                   // (MX) doubles per pair of a parked row block, as in k_piece_grad_mx
+  constexpr int MXRB = 8, MXW = 8;                    // (MX) rows per parked block, waves of the workgroup
+  constexpr int MXTST = MXRB * 4 + 2;                 // (MX) doubles per pair of a parked row block (+2: 16 pairs' reads on 16 bank groups)
   __shared__ double mx_lag[MX ? kMxNU * 64 * 2 : 1];  // (MX) gradient A operands [u][lane][ct]
   __shared__ double mx_laf[MX ? 4 * 64 * 2 : 1];      // (MX) forward A operands [tile][lane][ks]
-  __shared__ double mx_row[MX ? 4 * 16 * MXTST : 1];  // (MX) per wave: the corridor rows of the column set at work
+  __shared__ double mx_row[MX ? MXW * 16 * MXTST : 1];  // (MX) per wave: the corridor rows of its column set, a block of MXRB at a time
   // What phase 3 needs of phase 1 (factor, node states, durations, energy: ~100 doubles per chain lane) waits in LDS, not in
   // registers across phase 2: with them the sample loop (whose table rows are per-lane values) goes into scratch
   constexpr int nl = Factor<S, NB>::nl > 0 ? Factor<S, NB>::nl : 1;
@@ -136,18 +139,19 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   // (MX) the corridor rows travel global -> registers -> LDS a block ahead of their use; the FIRST block of a wave's first column set
   // is requested during phase 1 -- by the idle waves at once, by the chain waves behind their own loads (loads return in order: in
   // front of them they would delay the chain) -- and parked at the start of phase 2.
-  const int mx_M = (MX && a.hpolys) ? a.pp.M : 0, mx_nrb = (mx_M + 15) / 16;
-  double hn[4][4];
+  const int mx_M = (MX && a.hpolys) ? a.pp.M : 0, mx_nrb = (mx_M + MXRB - 1) / MXRB;
+  constexpr int MXNM = MXRB / 4;  // rows a lane fetches per block
+  double hn[MXNM][4];
   int hok = 0;
-  auto fetch_rows = [&](const int cs, const int rb) {  // lane (r, col): the rows r, r + 4, r + 8, r + 12 of its pair's block
+  auto fetch_rows = [&](const int rb) {  // lane (r, col): the rows r, r + 4 of its pair's block
     const int r = (tid & 63) >> 4, col = tid & 15, M = mx_M;
     const Penalty &pp = a.pp;
-    const int pr = 32 * wave + 16 * cs + col, pc_ = pr / G, tt2 = pr % G;
+    const int pr = 16 * wave + col, pc_ = pr / G, tt2 = pr % G;
     const int64_t bb = b0 + tt2 < a.B ? b0 + tt2 : a.B - 1;
     hok = 0;
 #pragma unroll
-    for (int mm = 0; mm < 4; ++mm) {
-      const int rr = rb * 16 + r + 4 * mm;
+    for (int mm = 0; mm < MXNM; ++mm) {
+      const int rr = rb * MXRB + r + 4 * mm;
       const bool ok = rr < M;
       const double *src = a.hpolys + (int64_t)((pc_ * pp.M + (ok ? rr : 0)) * 4) * ld + bb;
 #pragma unroll
@@ -157,7 +161,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   };
 
   if constexpr (MX) {
-    if (wave >= 2 && mx_nrb > 0) fetch_rows(0, 0);
+    if (wave >= 2 && mx_nrb > 0) fetch_rows(0);
   }
 
   // phase 2's lane mapping
@@ -298,7 +302,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
         for (int k = 0; k <= NC; ++k) asm volatile("" : "+v"(P[k]));
 #pragma unroll
         for (int j = 0; j < m; ++j) asm volatile("" : "+v"(hv[j]));
-        if (mx_nrb > 0) fetch_rows(0, 0);
+        if (mx_nrb > 0) fetch_rows(0);
       }
       ANET_FP(1);
       F.template factorize_chain<true>(Nh, np, meet_block);
@@ -470,12 +474,12 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
   };
 
   if constexpr (MX) {
-    // ---- phase 2, MX: four lanes per (trajectory, piece), 32 pairs per wave as two column sets of 16 ---------------------------------
+    // ---- phase 2, MX: four lanes per (trajectory, piece), one column set of 16 pairs per wave (eight waves) ---------------------------
     static_assert(TW && NEXACT && FusedShape<NB>::G * NB == 128, "an exact shape whose groups fill the workgroup");
     const int lane = tid & 63, r = lane >> 4, col = lane & 15;
     const Penalty pp = a.pp;
     const double inv_mu = 1.0 / pp.mu, inv_res = 1.0 / (double)pp.res;
-    const int M = a.hpolys ? pp.M : 0, nrb = (M + 15) / 16;
+    const int M = mx_M, nrb = mx_nrb;
     double *const lr = mx_row + wave * 16 * MXTST;
     double AE, AP;  // energy part: the A operands of k_piece_grad_mx (a row of the energy Hessian's integers, the derivative factors)
     {
@@ -491,7 +495,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     const bool has1 = 4 + r < D;
     auto park_rows = [&]() {
 #pragma unroll
-      for (int mm = 0; mm < 4; ++mm) {
+      for (int mm = 0; mm < MXNM; ++mm) {
         double *dst = lr + col * MXTST + (r + 4 * mm) * 4;
         const bool ok = (hok >> mm) & 1;
         dst[0] = ok ? hn[mm][0] : 0.0;
@@ -508,14 +512,13 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
     };
     if (nrb > 0) {  // (requested during phase 1)
 #pragma unroll
-      for (int mm = 0; mm < 4; ++mm)
+      for (int mm = 0; mm < MXNM; ++mm)
 #pragma unroll
         for (int e = 0; e < 4; ++e) landed(hn[mm][e]);
       park_rows();
     }
-#pragma unroll 1
-    for (int cs = 0; cs < 2; ++cs) {
-      const int pair = 32 * wave + 16 * cs + col, piece = pair / G, t2m = pair % G;
+    {
+      const int pair = 16 * wave + col, piece = pair / G, t2m = pair % G;
       const bool live = b0 + t2m < a.B;
       const int64_t bbm = live ? b0 + t2m : a.B - 1;
       const double Ti = lds[ROW_T * PST + pair];
@@ -558,24 +561,23 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
         const double e_piece = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, e_share, 0.0, 0, 0, 0);
         if (r == 0) lds[ROW_EN * PST + pair] = e_piece;
       }
-      if (cs == 0) ANET_FP(5);
+      ANET_FP(5);
       double gN[3][2], csum, Rs1, Rs2, rT, step;
-      mx_column_set<S>(pp, inv_mu, inv_res, lane_o, mx_lag, mx_laf, lr + col * MXTST, M, nrb, Ti, cb,
-                       [&](const int rb) {
-                         const int rbn = rb + 1 < nrb ? rb + 1 : 0, csn = rb + 1 < nrb ? cs : cs + 1;
-                         if (csn < 2) fetch_rows(csn, rbn);
-                       },
-                       [&](const int rb) {
-                         if ((rb + 1 < nrb ? cs : cs + 1) < 2) {
+      mx_column_set<S, MXRB>(pp, inv_mu, inv_res, lane_o, mx_lag, mx_laf, lr + col * MXTST, M, nrb, Ti, cb,
+                             [&](const int rb) {  // the pair's next row block on its way while this one is walked
+                               if (rb + 1 < nrb) fetch_rows(rb + 1);
+                             },
+                             [&](const int rb) {
+                               if (rb + 1 < nrb) {
 #pragma unroll
-                           for (int mm = 0; mm < 4; ++mm)
+                                 for (int mm = 0; mm < MXNM; ++mm)
 #pragma unroll
-                             for (int e = 0; e < 4; ++e) landed(hn[mm][e]);
-                           park_rows();
-                         }
-                       },
-                       gN, csum, Rs1, Rs2, rT, step);
-      if (cs == 0) ANET_FP(6);
+                                   for (int e = 0; e < 4; ++e) landed(hn[mm][e]);
+                                 park_rows();
+                               }
+                             },
+                             gN, csum, Rs1, Rs2, rT, step);
+      ANET_FP(6);
       double acc = 0.0;
 #pragma unroll
       for (int ax = 0; ax < 3; ++ax) {
@@ -600,7 +602,7 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
         if (has1) lds[(ROW_GX + ax * D + 4 + r) * PST + pair] = gN[ax][1] * tsel1;
       }
       wave_sync();
-      if (cs == 0) ANET_FP(7);
+      ANET_FP(7);
       if (r < 3) {
         double gca[D];
 #pragma unroll
@@ -611,7 +613,6 @@ __global__ void __launch_bounds__(256, 1) k_minco_cost_grad_fused(FusedArgs a, c
         lds[ROW_GDT * PST + pair] = gT;
         lds[ROW_PC * PST + pair] = pc;
       }
-      wave_sync();  // (the next column set's hand-over rows are other pairs' columns; the row buffer is this wave's)
     }
   } else
   // ---- phase 2 (all waves): two lanes per (trajectory, piece) ------------------------------------------------------------------

@@ -54,12 +54,12 @@ __device__ __forceinline__ double mx_sel4(int r, double a0, double a1, double a2
 // Corridor rows: one wave-uniform test per row over the lane's five samples ahead of the per-sample tests (a compare-to-branch is
 // a bubble -- one wave per SIMD in the one-launch kernel: 23.8 -> 22.6 us; two here: 311 -> 295 us -- and the zero rows a corridor is
 // padded with never pass the first test).
-template <int S, class Before, class After>
+template <int S, int RB = 16, class Before, class After>
 __device__ __forceinline__ void mx_column_set(const Penalty &pp, const double inv_mu, const double inv_res, const int lane_o,
                                               const double *lag, const double *laf, const double *rows, const int M, const int nrb,
                                               const double Ti, const double (&cb)[3][2], Before &&before, After &&after,
                                               double (&gN)[3][2], double &csum, double &Rs1, double &Rs2, double &rT, double &step) {
-  constexpr int NSL = kMxNSL, RB = 16;
+  constexpr int NSL = kMxNSL;  // (RB: rows of a parked block, 16 or 8)
   const double wcm = pp.wc * pp.mu, wvm = pp.wv * pp.mu, wam = pp.wa * pp.mu;
   const double cv = pp.vmax * inv_mu, ca = pp.amax * inv_mu;
   rT = fast_rcp(Ti);

@@ -94,7 +94,7 @@ static void launch_fused_t(const FusedArgs &a_in, const double *tab, hipStream_t
   if constexpr (NEXACT && NPC >= 0 && FusedShape<NB>::G * NB == 128) {
     static const int mx = [] { const char *e = getenv("ANET_FUSED_MX"); return e ? atoi(e) : 1; }();
     if (mx && G == GM && a.pp.res == kMxRes) {
-      hipLaunchKernelGGL((k_minco_cost_grad_fused<S, NB, NEXACT, NPC, true>), grid, dim3(256), 0, st, a, tab);
+      hipLaunchKernelGGL((k_minco_cost_grad_fused<S, NB, NEXACT, NPC, true>), grid, dim3(512), 0, st, a, tab);  // (eight waves)
       return;
     }
   }
