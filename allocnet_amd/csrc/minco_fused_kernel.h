@@ -137,8 +137,8 @@ __global__ void __launch_bounds__(MX ? 512 : 256, 1) k_minco_cost_grad_fused(Fus
   }
 
   // (MX) the corridor rows travel global -> registers -> LDS a block ahead of their use; the FIRST block of a wave's first column set
-  // is requested during phase 1 -- by the idle waves at once, by the chain waves behind their own loads (loads return in order: in
-  // front of them they would delay the chain) -- and parked at the start of phase 2.
+  // is requested during phase 1 -- by the idle waves at once, by the chain waves behind their chain -- and parked at the start of
+  // phase 2.
   const int mx_M = (MX && a.hpolys) ? a.pp.M : 0, mx_nrb = (mx_M + MXRB - 1) / MXRB;
   constexpr int MXNM = MXRB / 4;  // rows a lane fetches per block
   double hn[MXNM][4];
@@ -296,14 +296,6 @@ __global__ void __launch_bounds__(MX ? 512 : 256, 1) k_minco_cost_grad_fused(Fus
       }
 #pragma unroll
       for (int i = 0; i < NC; ++i) F.r[i] = fast_rcp(tt[i]);
-      if constexpr (MX) {
-        // (every input of the chain has landed -- they were awaited for the reciprocals -- : the row block flies during the chain)
-#pragma unroll
-        for (int k = 0; k <= NC; ++k) asm volatile("" : "+v"(P[k]));
-#pragma unroll
-        for (int j = 0; j < m; ++j) asm volatile("" : "+v"(hv[j]));
-        if (mx_nrb > 0) fetch_rows(0);
-      }
       ANET_FP(1);
       F.template factorize_chain<true>(Nh, np, meet_block);
       ANET_FP(2);
@@ -318,6 +310,12 @@ __global__ void __launch_bounds__(MX ? 512 : 256, 1) k_minco_cost_grad_fused(Fus
         sweep_backward_chain<true, S, NC>(F, Nh, np, rr, X, [&](int, const Pw<S> &) {}, meet_solution);
       }
       ANET_FP(3);
+      if constexpr (MX) {
+        // (the chain waves' first row block: behind the chain -- in front of it the chain's own loads would wait behind these,
+        //  loads return in order, and a forced wait for the chain's inputs there cost 1.8 k cycles of phase 1 -- ; it flies while
+        //  the factor is parked and the barrier is reached)
+        if (mx_nrb > 0) fetch_rows(0);
+      }
       if (chain_lane) {
         if (ax1 == 0) {
 #pragma unroll
