@@ -62,7 +62,7 @@ PROTOTYPES = {
     "anet_minco_propagate_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "anet_minco_cost_grad_workspace": (c_int64, [c_int, c_int, c_int64]),
-    "anet_minco_cost_grad_launches": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "anet_minco_cost_grad_launches": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "anet_minco_piece_grad_shape": (c_int, [c_void_p, c_int, c_int, c_int64, c_void_p]),
     "anet_minco_cost_grad_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int64] + [c_void_p] * 12),
     "anet_minco_cost_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_int64] + [c_void_p] * 10),

@@ -1118,15 +1118,23 @@ int64_t anet_minco_cost_grad_workspace(int s, int n_pieces, int64_t ld) {
   return ((int64_t)n_pieces * 3 * 2 * s * 2 + 2 * (int64_t)n_pieces + 1) * ld;
 }
 
-// Does this evaluation run as ONE launch (k_minco_cost_grad_fused) or as solve -> piece gradients -> adjoint?
-static bool cost_grad_in_one_launch(const anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen) {
+// Does this evaluation run as ONE launch (k_minco_cost_grad_fused) or as solve -> piece gradients -> adjoint?  (c: the boundary
+// count, or -1 when the caller does not know it: the thresholds of the vector phase 2 then)
+static bool cost_grad_in_one_launch(const anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const anet_penalty *pen) {
   // Small batches in ONE launch (minco_fused_kernel.h): up to THREE rounds of one workgroup per CU for problems of up to eight pieces,
   // two rounds for longer ones (measured with the chains eliminated from both ends, one launch against three: 8192 x 8-seg snap 54.0
   // against 64.9 us, 12000: 79.5 / 83.8, 16384 = four rounds: 105.5 / 102.4 -- not taken; 4096 x 16-seg jerk 51.8 / 61.0, 2500: 48.7 /
-  // 59.3) -- beyond that the three streaming kernels have the chip full anyway and are the better shape
-  // (ANET_FUSED_MAX_GROUPS overrides; 0 disables).
+  // 59.3) -- beyond that the three streaming kernels have the chip full anyway and are the better shape.
+  // Round 6: where phase 2 runs on the matrix instructions and eight waves (the exact shapes at 20 samples per piece: launch_fused_t)
+  // a round of groups costs 17 us instead of 27 and the crossover moves out -- 16 384 x 8-seg snap (four rounds) 68.7 us against 102.9,
+  // 24 576 (six) 100.5 / 107.4, 32 768 (eight) 133.4 / 125.5: SIX rounds; 16 384 x 16-seg jerk (eight rounds of groups of 8) 131.4 / 150.6:
+  // EIGHT.  (ANET_FUSED_MAX_GROUPS overrides; 0 disables.)
   static const int64_t fused_groups_env = [] { const char *e = getenv("ANET_FUSED_MAX_GROUPS"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
-  const int64_t fused_max_groups = fused_groups_env >= 0 ? fused_groups_env : (n_pieces <= 8 ? 3 : 2) * (int64_t)ctx->cus;
+  static const int fused_mx_env = [] { const char *e = getenv("ANET_FUSED_MX"); return e ? atoi(e) : 1; }();
+  const bool mx = fused_mx_env && pen && pen->res == anet_piece_grad_mx_res() && c == 3 &&
+                  ((s == 4 && n_pieces == 8) || (s == 3 && n_pieces == 16));
+  const int rounds = mx ? (n_pieces <= 8 ? 6 : 8) : (n_pieces <= 8 ? 3 : 2);
+  const int64_t fused_max_groups = fused_groups_env >= 0 ? fused_groups_env : rounds * (int64_t)ctx->cus;
   const int fg = pen ? anet::cost_grad_fused_group(s, n_pieces) : 0;
   return fg > 0 && (batch + fg - 1) / fg <= fused_max_groups && pen->res <= anet::kFusedMaxRes;
 }
@@ -1144,7 +1152,7 @@ static int cost_grad_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t
   if (batch == 0) return ANET_OK;
   if (!work || !cost || !gradT || (n_pieces > 1 && !gradP))
     return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad_dev: NULL output or workspace");
-  if (cost_grad_in_one_launch(ctx, s, n_pieces, batch, pen)) {
+  if (cost_grad_in_one_launch(ctx, s, c, n_pieces, batch, pen)) {
     if (!head || !tail || !T || (n_pieces > 1 && !wps) || ld < batch)
       return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad_dev: NULL input or ld < batch");
     const double *tab = nullptr;
@@ -1190,11 +1198,11 @@ static int cost_grad_dev_impl(anet_ctx *ctx, int s, int c, int n_pieces, int64_t
   return do_propagate(ctx, s, a, (hipStream_t)stream);
 }
 
-int anet_minco_cost_grad_launches(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen) {
+int anet_minco_cost_grad_launches(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const anet_penalty *pen) {
   if (!ctx) return fail(nullptr, ANET_ERR_INVALID, "ctx is NULL");
-  if (s < 2 || s > 4 || n_pieces < 1 || n_pieces > ANET_MAX_PIECES || batch < 0)
+  if (s < 2 || s > 4 || c < 1 || c > s || n_pieces < 1 || n_pieces > ANET_MAX_PIECES || batch < 0)
     return fail(ctx, ANET_ERR_INVALID, "anet_minco_cost_grad_launches: bad shape");
-  return cost_grad_in_one_launch(ctx, s, n_pieces, batch, pen) ? 1 : 3;
+  return cost_grad_in_one_launch(ctx, s, c, n_pieces, batch, pen) ? 1 : 3;
 }
 
 int anet_minco_cost_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, int64_t ld,

@@ -265,11 +265,11 @@ def _tptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def minco_cost_grad_launches(s, N, B, penalty=None, ctx=None):
-    """anet_minco_cost_grad_launches: 1 if a cost + gradient evaluation of this shape runs as ONE launch
-    (k_minco_cost_grad_fused) on this context's device, 3 for solve -> piece gradients -> adjoint."""
+def minco_cost_grad_launches(s, N, B, penalty=None, ctx=None, c=3):
+    """anet_minco_cost_grad_launches: 1 if a cost + gradient evaluation of this shape (order s, boundary count c, N pieces) runs
+    as ONE launch (k_minco_cost_grad_fused) on this context's device, 3 for solve -> piece gradients -> adjoint."""
     ctx = ctx or default_context(0)
-    n = ctx.lib.anet_minco_cost_grad_launches(ctx.handle, s, N, B, ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p)
+    n = ctx.lib.anet_minco_cost_grad_launches(ctx.handle, s, c, N, B, ctypes.cast(ctypes.pointer(penalty), ctypes.c_void_p)
                                               if penalty is not None else None)
     if n < 0:
         ctx.check(n)

@@ -256,10 +256,12 @@ int anet_minco_propagate_grad_dev(anet_ctx *ctx, int s, int c, int n_pieces, int
  * work: device scratch of anet_minco_cost_grad_workspace(s, N, ld) doubles.
  * coeffs_out may be NULL.  cost: [batch].                                                     */
 int64_t anet_minco_cost_grad_workspace(int s, int n_pieces, int64_t ld);
-/* Kernel launches anet_minco_cost_grad_dev makes for this shape on this context's device: 1 (k_minco_cost_grad_fused: batches
- * of up to three rounds of one workgroup per compute unit, orders 3 and 4, res <= 64) or 3 (k_minco_solve -> k_piece_grad ->
- * k_minco_propagate); negative = error.  For callers that label a measurement with the kernel that ran (bench.py).          */
-int anet_minco_cost_grad_launches(anet_ctx *ctx, int s, int n_pieces, int64_t batch, const anet_penalty *pen);
+/* Kernel launches anet_minco_cost_grad_dev makes for this shape (order s, boundary count c) on this context's device: 1
+ * (k_minco_cost_grad_fused: batches of up to three rounds of one workgroup per compute unit, orders 3 and 4, res <= 64 -- six /
+ * eight rounds for 8-piece snap / 16-piece jerk with c = 3 at res = 20, whose phase 2 runs on the FP64 matrix instructions) or 3
+ * (k_minco_solve -> k_piece_grad[_mx] -> k_minco_propagate); negative = error.  For callers that label a measurement with the
+ * kernel that ran (bench.py).                                                                                                  */
+int anet_minco_cost_grad_launches(anet_ctx *ctx, int s, int c, int n_pieces, int64_t batch, const anet_penalty *pen);
 /* The launch shape anet_minco_partial_grads_dev picks for this shape on this context's device: 0 one lane per (trajectory,
  * piece) (k_piece_grad, large batches); 1 two lanes per pair; 2 two lanes and the samples over a workgroup's four waves (the small
  * batches); 3 k_piece_grad_mx -- four lanes per pair, the contractions with the basis table on the FP64 matrix instructions

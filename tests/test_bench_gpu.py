@@ -126,8 +126,15 @@ def test_launch_shapes_follow_the_devices_compute_units():
     cus = ctx.compute_units
     assert cus == torch.cuda.get_device_properties(0).multi_processor_count and cus > 0
     pen = aa.make_penalty(rho=50.0, w_corridor=1e4, w_vel=1e3, w_acc=1e3, smooth_mu=1e-2, max_vel=4.0, max_acc=6.0, res=20, poly_rows=16)
-    assert aa.minco_cost_grad_launches(4, 8, 16 * 3 * cus, penalty=pen, ctx=ctx) == 1
-    assert aa.minco_cost_grad_launches(4, 8, 16 * 3 * cus + 1, penalty=pen, ctx=ctx) == 3
+    # (8-piece snap with c = 3 at 20 samples: phase 2 on the matrix instructions and eight waves -- six rounds; any other boundary
+    #  count or sample count: the vector phase 2, three rounds)
+    mx = os.environ.get("ANET_FUSED_MX", "1") != "0"
+    assert aa.minco_cost_grad_launches(4, 8, 16 * (6 if mx else 3) * cus, penalty=pen, ctx=ctx) == 1
+    assert aa.minco_cost_grad_launches(4, 8, 16 * (6 if mx else 3) * cus + 1, penalty=pen, ctx=ctx) == 3
+    assert aa.minco_cost_grad_launches(4, 8, 16 * 3 * cus, penalty=pen, ctx=ctx, c=4) == 1
+    assert aa.minco_cost_grad_launches(4, 8, 16 * 3 * cus + 1, penalty=pen, ctx=ctx, c=4) == 3
+    assert aa.minco_cost_grad_launches(3, 16, 8 * (8 if mx else 2) * cus, penalty=pen, ctx=ctx) == 1
+    assert aa.minco_cost_grad_launches(3, 16, 8 * (8 if mx else 2) * cus + 1, penalty=pen, ctx=ctx) == 3
     assert aa.minco_cost_grad_launches(4, 8, 64, penalty=None, ctx=ctx) == 3          # no penalty: the streaming kernels
     # the penalty kernel's launch shape: the small-batch shapes by pairs per compute unit, above them the matrix-instruction
     # kernel for orders 3 / 4 at 20 samples per piece (k_piece_grad_mx), the lane-per-pair kernel otherwise
@@ -138,4 +145,4 @@ def test_launch_shapes_follow_the_devices_compute_units():
     assert aa.minco_piece_grad_shape(4, 8, big, penalty=pen9, ctx=ctx) == 0
     assert aa.minco_piece_grad_shape(2, 8, big, penalty=pen, ctx=ctx) == 0
     assert aa.minco_piece_grad_shape(4, 8, 4 * cus, penalty=pen, ctx=ctx) == 2 and aa.minco_piece_grad_shape(4, 8, 32 * cus, penalty=pen, ctx=ctx) == 1
-    assert aa.minco_cost_grad_launches(2, 8, 64, penalty=pen, ctx=ctx) == 3           # order 2 has no one-launch instantiation
+    assert aa.minco_cost_grad_launches(2, 8, 64, penalty=pen, ctx=ctx, c=2) == 3      # order 2 has no one-launch instantiation
