@@ -57,8 +57,8 @@ struct FusedShape {
   static constexpr int PST = 130;                              // row stride of the LDS arrays (pairs, padded)
 };
 
-// MX (round 6; exact shapes whose groups fill the workgroup, G NB = 128, at 20 samples per piece): phase 2 in k_piece_grad_mx's
-// mapping on EIGHT waves (512 lanes: two waves per SIMD in phase 2 -- a lone wave issues an instruction every 6 - 7 cycles, two
+// MX (round 6; the exact shapes at 20 samples per piece, groups of at least 16 (trajectory, piece) pairs): phase 2 in k_piece_grad_mx's
+// mapping on a wave per column set of 16 pairs -- for full groups (G NB = 128) EIGHT waves (512 lanes: two waves per SIMD in phase 2 -- a lone wave issues an instruction every 6 - 7 cycles, two
 // fill each other's bubbles; the chain phases still run on waves 0 and 1, and at two waves per SIMD the kernel fits 256 registers
 // with 40 - 68 B of scratch outside the hot loops) -- a wave owns one column set of 16 (trajectory, piece) pairs, four lanes per pair with five samples each, the
 // contractions with the basis table on the FP64 matrix instructions (piece_grad_mx.h: mx_column_set); the piece's coefficients are
@@ -146,9 +146,10 @@ __global__ void __launch_bounds__(MX ? 512 : 256, 1) k_minco_cost_grad_fused(Fus
   auto fetch_rows = [&](const int rb) {  // lane (r, col): the rows r, r + 4 of its pair's block
     const int r = (tid & 63) >> 4, col = tid & 15, M = mx_M;
     const Penalty &pp = a.pp;
+    hok = 0;
+    if (16 * wave >= G * NB) return;  // (a smaller group: fewer column sets than waves -- wave-uniform)
     const int pr = 16 * wave + col, pc_ = pr / G, tt2 = pr % G;
     const int64_t bb = b0 + tt2 < a.B ? b0 + tt2 : a.B - 1;
-    hok = 0;
 #pragma unroll
     for (int mm = 0; mm < MXNM; ++mm) {
       const int rr = rb * MXRB + r + 4 * mm;
@@ -508,14 +509,16 @@ __global__ void __launch_bounds__(MX ? 512 : 256, 1) k_minco_cost_grad_fused(Fus
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    if (nrb > 0) {  // (requested during phase 1)
+    // (a group of G < 16 trajectories has G NB / 16 column sets: the workgroup is launched with that many waves, four at least --
+    //  two chain waves, two for the operand tables --, and a wave without a column set has nothing to do here)
+    if (16 * wave < G * NB) {
+      if (nrb > 0) {  // (requested during phase 1)
 #pragma unroll
-      for (int mm = 0; mm < MXNM; ++mm)
+        for (int mm = 0; mm < MXNM; ++mm)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) landed(hn[mm][e]);
-      park_rows();
-    }
-    {
+          for (int e = 0; e < 4; ++e) landed(hn[mm][e]);
+        park_rows();
+      }
       const int pair = 16 * wave + col, piece = pair / G, t2m = pair % G;
       const bool live = b0 + t2m < a.B;
       const int64_t bbm = live ? b0 + t2m : a.B - 1;

@@ -93,8 +93,10 @@ static void launch_fused_t(const FusedArgs &a_in, const double *tab, hipStream_t
   // ANET_FUSED_MX=0 keeps the vector sample loop (A-B runs).
   if constexpr (NEXACT && NPC >= 0 && FusedShape<NB>::G * NB == 128) {
     static const int mx = [] { const char *e = getenv("ANET_FUSED_MX"); return e ? atoi(e) : 1; }();
-    if (mx && G == GM && a.pp.res == kMxRes) {
-      hipLaunchKernelGGL((k_minco_cost_grad_fused<S, NB, NEXACT, NPC, true>), grid, dim3(512), 0, st, a, tab);  // (eight waves)
+    // (groups of at least two column sets of 16 pairs: G NB >= 32; a wave per column set, four waves at least)
+    if (mx && G * NB >= 16 && a.pp.res == kMxRes) {
+      const int waves = G * NB / 16 < 4 ? 4 : G * NB / 16;
+      hipLaunchKernelGGL((k_minco_cost_grad_fused<S, NB, NEXACT, NPC, true>), grid, dim3(64 * waves), 0, st, a, tab);
       return;
     }
   }
