@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(MX ? 512 : 256, 1) k_minco_cost_grad_fused(Fus
   };
 
   if constexpr (MX) {
-    // ---- phase 2, MX: four lanes per (trajectory, piece), one column set of 16 pairs per wave (eight waves) ---------------------------
+    // ---- phase 2, MX: four lanes per (trajectory, piece), one column set of 16 pairs per wave (eight waves for a full group) ----------
     static_assert(TW && NEXACT && FusedShape<NB>::G * NB == 128, "an exact shape whose groups fill the workgroup");
     const int lane = tid & 63, r = lane >> 4, col = lane & 15;
     const Penalty pp = a.pp;
