@@ -234,3 +234,46 @@ def test_time_reversal_is_a_symmetry_of_the_evaluation(anet_ctx, s, N):
         if N > 1:
             sp = np.maximum(1.0, np.abs(gP).reshape(B, -1).max(axis=1))[:, None, None]
             assert (np.abs(rgP[:, ::-1] - gP) <= 1e-9 * sp).all(), (B, (np.abs(rgP[:, ::-1] - gP) / sp).max())
+
+
+def test_matrix_instruction_kernels_agree_with_the_vector_kernels(anet_ctx, tmp_path):
+    """The matrix-instruction forms of the penalty arithmetic (round 6: k_piece_grad_mx, phase 2 of the one-launch kernel on a wave
+    per column set) against the vector forms they replace, same inputs: the vector side runs in a process of its own with
+    ANET_PG_MX=0 ANET_FUSED_MX=0 (the library reads the switches once).  Batches that take every matrix-instruction shape: groups
+    of 2 / 8 / 16 trajectories in one launch (300, 2047, 4096 + 3 ragged), six rounds of groups (20 000), the streaming kernel with
+    four and with eight column sets per wave (33 000, 70 001), 8-piece snap and 16-piece jerk.  Cost to 1e-12, gradients to 1e-10
+    of their scale -- two orders inside the parity bar against the C restatement, which both sides meet on their own."""
+    import subprocess
+    import sys
+    import os
+    import allocnet_amd as aa
+    from tests.util import corridor_problem
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(4, 8, 300), (4, 8, 2047), (4, 8, 4099), (4, 8, 20000), (4, 8, 33000), (4, 8, 70001), (3, 16, 1024), (3, 16, 9000), (3, 16, 40000)]
+    script = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import allocnet_amd as aa
+from tests.util import corridor_problem
+out = {{}}
+for k, (s, N, B) in enumerate({cases!r}):
+    head, tail, wps, T, hp = corridor_problem(np.random.default_rng(500 + k), B, N, 3, 16)
+    pen = aa.make_penalty(rho=3.0, w_corridor=1e3, w_vel=40.0, w_acc=15.0, smooth_mu=0.03, max_vel=2.5, max_acc=3.5, res=20, poly_rows=16)
+    c, gP, gT = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen)
+    out[f"c{{k}}"], out[f"p{{k}}"], out[f"t{{k}}"] = c, gP, gT
+np.savez({str(tmp_path / 'vector.npz')!r}, **out)
+"""
+    env = dict(os.environ, ANET_PG_MX="0", ANET_FUSED_MX="0")
+    res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    ref = np.load(tmp_path / "vector.npz")
+    for k, (s, N, B) in enumerate(cases):
+        head, tail, wps, T, hp = corridor_problem(np.random.default_rng(500 + k), B, N, 3, 16)
+        pen = aa.make_penalty(rho=3.0, w_corridor=1e3, w_vel=40.0, w_acc=15.0, smooth_mu=0.03, max_vel=2.5, max_acc=3.5, res=20, poly_rows=16)
+        c, gP, gT = aa.minco_cost_grad(head, tail, wps, T, s, hpolys=hp, penalty=pen, ctx=anet_ctx)
+        assert np.abs(c - ref[f"c{k}"]).max() <= 1e-12 * np.abs(c).max(), (s, N, B)
+        assert np.abs(gT - ref[f"t{k}"]).max() <= 1e-10 * max(1.0, np.abs(gT).max()), (s, N, B)
+        assert np.abs(gP - ref[f"p{k}"]).max() <= 1e-10 * max(1.0, np.abs(gP).max()), (s, N, B)
+    # (the switches are honoured: the default side really took the matrix-instruction shapes)
+    if os.environ.get("ANET_PG_MX", "1") != "0":
+        assert aa.minco_piece_grad_shape(4, 8, 70001, penalty=pen, ctx=anet_ctx) == 3
